@@ -1,0 +1,308 @@
+"""ctypes binding of the C ABI in include/vgicp_hip.h (libvgicp_hip.so).
+
+This is plumbing for tests and bench.py: it adds no compute and no fallback.  If the HIP module has
+not been built, importing the library raises; if there is no gfx950 device, `Context()` raises
+`VgicpError` carrying the library's message.  Nothing here imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvgicp_hip.so")
+
+OK, ERR_BAD_ARGUMENT, ERR_HIP, ERR_RCCL, ERR_TABLE_FULL, ERR_DEGENERATE, ERR_NO_DEVICE, ERR_NOT_READY = range(8)
+FLAG_PROFILE = 1
+FLAG_NO_GRAPH = 2
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/vgicp_hip.h declares
+EXPORTS = (
+    "vgicp_abi_version", "vgicp_create", "vgicp_destroy", "vgicp_last_error", "vgicp_device_info",
+    "vgicp_map_reset", "vgicp_map_upsert", "vgicp_map_erase", "vgicp_map_size",
+    "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
+    "vgicp_accumulate", "vgicp_match", "vgicp_voxel_index",
+    "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
+)
+
+
+class VgicpError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"vgicp status {code}: {message}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("max_iteration", C.c_int32), ("chunk_iterations", C.c_int32),
+                ("translation_sq_threshold", C.c_double), ("cosine_threshold", C.c_double),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("world_size", C.c_int32),
+                ("launches", C.c_int32), ("seconds", C.c_double), ("device_seconds", C.c_double),
+                ("corr_count", C.POINTER(C.c_uint64)), ("normal_eq", C.POINTER(C.c_double)),
+                ("kernel_ms", C.POINTER(C.c_float))]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libvgicp_hip.so and declare its prototypes. Raises if the module is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP module first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C eskf_lio_amd/csrc). "
+            "There is no CPU fallback for this path.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    sz = C.c_size_t
+    lib.vgicp_abi_version.restype = C.c_int
+    lib.vgicp_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.vgicp_destroy.argtypes = [vp]
+    lib.vgicp_last_error.argtypes = [vp]
+    lib.vgicp_last_error.restype = C.c_char_p
+    lib.vgicp_device_info.argtypes = [vp, C.c_char_p, sz, ip, C.POINTER(C.c_uint64)]
+    lib.vgicp_map_reset.argtypes = [vp, C.c_double, sz]
+    lib.vgicp_map_upsert.argtypes = [vp, sz, ip, dp, dp]
+    lib.vgicp_map_erase.argtypes = [vp, sz, ip]
+    lib.vgicp_map_size.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    lib.vgicp_align.argtypes = [vp, sz, dp, dp, dp, C.POINTER(Params), dp, C.POINTER(Stats)]
+    lib.vgicp_scan_upload.argtypes = [vp, sz, dp, dp]
+    lib.vgicp_align_resident.argtypes = [vp, dp, C.POINTER(Params), dp, C.POINTER(Stats)]
+    lib.vgicp_accumulate.argtypes = [vp, sz, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64)]
+    lib.vgicp_match.argtypes = [vp, sz, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64), C.POINTER(sz)]
+    lib.vgicp_voxel_index.argtypes = [vp, sz, dp, ip]
+    lib.vgicp_comm_unique_id.argtypes = [vp, vp]
+    lib.vgicp_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.vgicp_comm_destroy.argtypes = [vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("vgicp_last_error",):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _f64(a, shape_tail) -> np.ndarray:
+    out = np.ascontiguousarray(a, dtype=np.float64)
+    if out.size and (out.ndim != 2 or out.shape[1] != shape_tail):
+        out = out.reshape(-1, shape_tail)
+    return out
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def pose_to_abi(T: np.ndarray) -> np.ndarray:
+    """4x4 (row, col) numpy pose -> 16 doubles column-major."""
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).T).reshape(16)
+
+
+def pose_from_abi(v: np.ndarray) -> np.ndarray:
+    return np.asarray(v, dtype=np.float64).reshape(4, 4).T.copy()
+
+
+@dataclass
+class AlignResult:
+    pose: np.ndarray  # 4x4
+    iterations: int
+    converged: bool
+    world_size: int
+    launches: int
+    seconds: float
+    device_seconds: float
+    corr_count: np.ndarray  # per executed iteration
+    normal_eq: np.ndarray  # iterations x 27
+    kernel_ms: Optional[np.ndarray] = None
+    status: int = OK
+    message: str = ""
+    JTJ: np.ndarray = field(default=None, repr=False)  # iterations x 6 x 6 (mirrored)
+    JTr: np.ndarray = field(default=None, repr=False)  # iterations x 6
+
+
+def expand_normal_eq(rows: np.ndarray):
+    """iterations x 27 packed rows -> (iterations x 6 x 6 symmetric JTJ, iterations x 6 JTr)."""
+    rows = np.asarray(rows, dtype=np.float64).reshape(-1, 27)
+    JTJ = np.zeros((rows.shape[0], 6, 6))
+    k = 0
+    for r in range(6):
+        for c in range(r + 1):
+            JTJ[:, r, c] = rows[:, k]
+            JTJ[:, c, r] = rows[:, k]
+            k += 1
+    return JTJ, rows[:, 21:27].copy()
+
+
+class Context:
+    """One vgicp_ctx bound to one HIP device (one process per GPU)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.vgicp_create(int(device_id), C.byref(self._h))
+        if rc != OK:
+            msg = self._lib.vgicp_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise VgicpError(rc, msg)
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.vgicp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int, allow=()):
+        if rc != OK and rc not in allow:
+            raise VgicpError(rc, self._lib.vgicp_last_error(self._h).decode())
+        return rc
+
+    def last_error(self) -> str:
+        return self._lib.vgicp_last_error(self._h).decode()
+
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        cu = C.c_int32()
+        hbm = C.c_uint64()
+        self._check(self._lib.vgicp_device_info(self._h, name, 64, C.byref(cu), C.byref(hbm)))
+        return name.value.decode(), cu.value, hbm.value
+
+    # -- map mirror --
+    def map_reset(self, voxel_size: float, capacity_hint: int = 0):
+        self._check(self._lib.vgicp_map_reset(self._h, float(voxel_size), int(capacity_hint)))
+
+    def map_upsert(self, keys, means, covs):
+        keys = np.ascontiguousarray(keys, dtype=np.int32).reshape(-1, 3)
+        means = _f64(means, 3)
+        covs = _f64(covs, 9)
+        n = keys.shape[0]
+        if means.shape[0] != n or covs.shape[0] != n:
+            raise ValueError("keys / means / covs disagree in length")
+        self._check(self._lib.vgicp_map_upsert(self._h, n, keys.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               _dp(means), _dp(covs)))
+
+    def map_erase(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int32).reshape(-1, 3)
+        self._check(self._lib.vgicp_map_erase(self._h, keys.shape[0],
+                                              keys.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def map_size(self):
+        v, s = C.c_size_t(), C.c_size_t()
+        self._check(self._lib.vgicp_map_size(self._h, C.byref(v), C.byref(s)))
+        return v.value, s.value
+
+    # -- registration --
+    def scan_upload(self, points, covs):
+        points, covs = _f64(points, 3), _f64(covs, 9)
+        if points.shape[0] != covs.shape[0]:
+            raise ValueError("points / covs disagree in length")
+        self._check(self._lib.vgicp_scan_upload(self._h, points.shape[0], _dp(points), _dp(covs)))
+
+    def _run(self, call, max_iteration, translation_sq_threshold, cosine_threshold, chunk, flags,
+             allow_degenerate):
+        p = Params(int(max_iteration), int(chunk), float(translation_sq_threshold),
+                   float(cosine_threshold), int(flags), 0)
+        cap = max(int(max_iteration), 1)
+        counts = np.zeros(cap, dtype=np.uint64)
+        neq = np.zeros((cap, 27))
+        kms = np.zeros(cap, dtype=np.float32)
+        st = Stats()
+        st.corr_count = counts.ctypes.data_as(C.POINTER(C.c_uint64))
+        st.normal_eq = _dp(neq)
+        st.kernel_ms = kms.ctypes.data_as(C.POINTER(C.c_float))
+        out = np.zeros(16)
+        rc = call(p, out, st)
+        allow = (ERR_DEGENERATE,) if allow_degenerate else ()
+        self._check(rc, allow)
+        it = st.iterations
+        JTJ, JTr = expand_normal_eq(neq[:it])
+        return AlignResult(pose=pose_from_abi(out), iterations=it, converged=bool(st.converged),
+                           world_size=st.world_size, launches=st.launches, seconds=st.seconds,
+                           device_seconds=st.device_seconds, corr_count=counts[:it].copy(),
+                           normal_eq=neq[:it].copy(),
+                           kernel_ms=kms[:st.launches].copy() if flags & FLAG_PROFILE else None,
+                           status=rc, message=self.last_error() if rc else "", JTJ=JTJ, JTr=JTr)
+
+    def align(self, points, covs, guess, max_iteration, translation_sq_threshold, cosine_threshold,
+              chunk_iterations: int = 0, flags: int = 0, allow_degenerate: bool = False) -> AlignResult:
+        points, covs = _f64(points, 3), _f64(covs, 9)
+        if points.shape[0] != covs.shape[0]:
+            raise ValueError("points / covs disagree in length")
+        g = pose_to_abi(guess)
+        return self._run(lambda p, out, st: self._lib.vgicp_align(
+            self._h, points.shape[0], _dp(points), _dp(covs), _dp(g), C.byref(p), _dp(out), C.byref(st)),
+            max_iteration, translation_sq_threshold, cosine_threshold, chunk_iterations, flags,
+            allow_degenerate)
+
+    def align_resident(self, guess, max_iteration, translation_sq_threshold, cosine_threshold,
+                       chunk_iterations: int = 0, flags: int = 0,
+                       allow_degenerate: bool = False) -> AlignResult:
+        g = pose_to_abi(guess)
+        return self._run(lambda p, out, st: self._lib.vgicp_align_resident(
+            self._h, _dp(g), C.byref(p), _dp(out), C.byref(st)),
+            max_iteration, translation_sq_threshold, cosine_threshold, chunk_iterations, flags,
+            allow_degenerate)
+
+    # -- hooks --
+    def accumulate(self, points, covs, pose):
+        points, covs = _f64(points, 3), _f64(covs, 9)
+        g = pose_to_abi(pose)
+        JTJ, JTr, cnt = np.zeros(36), np.zeros(6), C.c_uint64()
+        self._check(self._lib.vgicp_accumulate(self._h, points.shape[0], _dp(points), _dp(covs), _dp(g),
+                                               _dp(JTJ), _dp(JTr), C.byref(cnt)))
+        return JTJ.reshape(6, 6).T.copy(), JTr, cnt.value
+
+    def match(self, points, covs):
+        points, covs = _f64(points, 3), _f64(covs, 9)
+        n = points.shape[0]
+        sp, sc, mp, mc = np.zeros((n, 3)), np.zeros((n, 9)), np.zeros((n, 3)), np.zeros((n, 9))
+        ix = np.zeros(n, dtype=np.uint64)
+        m = C.c_size_t()
+        self._check(self._lib.vgicp_match(self._h, n, _dp(points), _dp(covs), _dp(sp), _dp(sc), _dp(mp),
+                                          _dp(mc), ix.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(m)))
+        k = m.value
+        return sp[:k], sc[:k], mp[:k], mc[:k], ix[:k]
+
+    def voxel_index(self, points) -> np.ndarray:
+        points = _f64(points, 3)
+        keys = np.zeros((points.shape[0], 3), dtype=np.int32)
+        self._check(self._lib.vgicp_voxel_index(self._h, points.shape[0], _dp(points),
+                                                keys.ctypes.data_as(C.POINTER(C.c_int32))))
+        return keys
+
+    # -- multi-GPU --
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        self._check(self._lib.vgicp_comm_unique_id(self._h, buf))
+        return buf.raw
+
+    def comm_init(self, world_size: int, rank: int, unique_id: bytes):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        self._check(self._lib.vgicp_comm_init(self._h, int(world_size), int(rank), buf))
+
+    def comm_destroy(self):
+        self._check(self._lib.vgicp_comm_destroy(self._h))

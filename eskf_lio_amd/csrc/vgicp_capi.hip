@@ -1,0 +1,738 @@
+// vgicp_capi.hip — the C ABI declared in include/vgicp_hip.h (host side of the HIP module).
+//
+// Owns: the device context, the voxel-table mirror of LocalMap (growth / rehash policy), the resident
+// scan, the iteration launch schedule of ICP::align (reference src/Registration.cpp:15-28) and the
+// optional RCCL communicator that merges the normal equations across GPUs (the cross-device form of
+// the thread merge at reference src/Registration.cpp:71-75).
+// No PyTorch, no oracle, no CPU fallback: without a gfx950 device every compute entry point fails
+// with VGICP_ERR_NO_DEVICE / VGICP_ERR_HIP.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vgicp_hip.h"
+#include "vgicp_device.h"
+
+using namespace vgicp;
+
+namespace {
+
+// ---- the few RCCL entry points used, bound at run time so the library loads without RCCL ----
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[VGICP_UNIQUE_ID_BYTES]; } ncclUniqueId;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclDouble = 8;  // ncclFloat64, rccl.h
+constexpr int kNcclSum = 0;
+
+thread_local std::string g_create_error;
+
+double now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+uint64_t next_pow2(uint64_t v) {
+  uint64_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+constexpr uint64_t kMinSlots = 1024;
+constexpr int kDefaultChunk = 4;
+constexpr int kMaxChunksInFlight = 2;
+
+}  // namespace
+
+struct vgicp_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  mutable std::string err;
+  int cu_count = 0;
+  uint64_t hbm_bytes = 0;
+  std::string arch;
+
+  // voxel table
+  double voxel_size = 0.0;
+  VoxelRecord* table = nullptr;
+  uint64_t slots = 0;
+  uint64_t voxels = 0;      // FULL records
+  uint64_t tombstones = 0;
+  uint32_t* d_counters = nullptr;  // 4 words
+  uint32_t* h_counters = nullptr;  // pinned
+
+  // batch staging (upsert / erase / hooks)
+  void* d_stage = nullptr;
+  size_t stage_bytes = 0;
+
+  // resident scan
+  double* d_scan_aos = nullptr;  // points (3n) then covs (9n)
+  double* d_scan = nullptr;      // SoA planes
+  size_t scan_capacity = 0;      // points
+  uint32_t n = 0;
+  uint64_t stride = 0;
+  bool scan_ready = false;
+
+  // align state
+  AlignState* d_state = nullptr;
+  AlignState* h_state = nullptr;  // pinned, kMaxChunksInFlight + 1 slots
+  double* d_partials = nullptr;
+  double* d_sums = nullptr;
+  double* d_log = nullptr;
+  double* h_log = nullptr;  // pinned
+  int log_capacity = 0;     // iterations
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_chunk[kMaxChunksInFlight] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev_prof;
+
+  // RCCL
+  RcclApi rccl;
+  ncclComm_t comm = nullptr;
+  int world_size = 1;
+  int rank = 0;
+};
+
+namespace {
+
+int fail(const vgicp_ctx* ctx, int code, const std::string& text) {
+  if (ctx) ctx->err = text; else g_create_error = text;
+  return code;
+}
+int fail_hip(const vgicp_ctx* ctx, hipError_t e, const char* what) {
+  return fail(ctx, VGICP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define VG_HIP(ctx, call)                                              \
+  do {                                                                 \
+    hipError_t e__ = (call);                                           \
+    if (e__ != hipSuccess) return fail_hip((ctx), e__, #call);         \
+  } while (0)
+
+int ensure_stage(vgicp_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->stage_bytes) return VGICP_OK;
+  if (ctx->d_stage) VG_HIP(ctx, hipFree(ctx->d_stage));
+  ctx->d_stage = nullptr;
+  ctx->stage_bytes = 0;
+  const size_t want = bytes + bytes / 2;
+  VG_HIP(ctx, hipMalloc(&ctx->d_stage, want));
+  ctx->stage_bytes = want;
+  return VGICP_OK;
+}
+
+int alloc_table(vgicp_ctx* ctx, uint64_t slots, VoxelRecord** out) {
+  if (slots > (1ull << 32)) return fail(ctx, VGICP_ERR_TABLE_FULL, "voxel table would exceed 2^32 slots");
+  VoxelRecord* t = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&t), slots * sizeof(VoxelRecord));
+  if (e != hipSuccess)
+    return fail(ctx, VGICP_ERR_TABLE_FULL, std::string("hipMalloc(voxel table): ") + hipGetErrorString(e));
+  VG_HIP(ctx, launch_table_clear(ctx->stream, t, slots));
+  *out = t;
+  return VGICP_OK;
+}
+
+// Keep load (FULL + TOMB + incoming) <= 1/2 at all times; size new tables for load <= 1/4.
+int ensure_table(vgicp_ctx* ctx, uint64_t incoming) {
+  const uint64_t used = ctx->voxels + ctx->tombstones + incoming;
+  if (ctx->table && used * 2 <= ctx->slots) return VGICP_OK;
+  const uint64_t slots = next_pow2(std::max<uint64_t>(kMinSlots, (ctx->voxels + incoming) * 4));
+  VoxelRecord* fresh = nullptr;
+  int rc = alloc_table(ctx, slots, &fresh);
+  if (rc != VGICP_OK) return rc;
+  if (ctx->table) {
+    if (ctx->voxels > 0) {
+      VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+      VG_HIP(ctx, launch_rehash(ctx->stream, ctx->table, ctx->slots, fresh, (uint32_t)(slots - 1),
+                                ctx->d_counters));
+    }
+    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VG_HIP(ctx, hipFree(ctx->table));
+  }
+  ctx->table = fresh;
+  ctx->slots = slots;
+  ctx->tombstones = 0;
+  return VGICP_OK;
+}
+
+int ensure_scan(vgicp_ctx* ctx, size_t n) {
+  if (n <= ctx->scan_capacity && ctx->d_scan) return VGICP_OK;
+  if (ctx->d_scan) VG_HIP(ctx, hipFree(ctx->d_scan));
+  if (ctx->d_scan_aos) VG_HIP(ctx, hipFree(ctx->d_scan_aos));
+  ctx->d_scan = ctx->d_scan_aos = nullptr;
+  ctx->scan_capacity = 0;
+  size_t cap = std::max<size_t>(n + n / 4, 1024);
+  cap = (cap + 63) & ~size_t(63);  // planes stay 512-byte aligned
+  VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_scan), cap * kScanPlanes * sizeof(double)));
+  VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_scan_aos), cap * kScanPlanes * sizeof(double)));
+  ctx->scan_capacity = cap;
+  return VGICP_OK;
+}
+
+int ensure_log(vgicp_ctx* ctx, int iterations) {
+  if (iterations <= ctx->log_capacity) return VGICP_OK;
+  if (ctx->d_log) VG_HIP(ctx, hipFree(ctx->d_log));
+  if (ctx->h_log) VG_HIP(ctx, hipHostFree(ctx->h_log));
+  ctx->d_log = ctx->h_log = nullptr;
+  ctx->log_capacity = 0;
+  const int cap = std::max(iterations, 128);
+  VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_log), (size_t)cap * kSlots * sizeof(double)));
+  VG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_log), (size_t)cap * kSlots * sizeof(double), 0));
+  ctx->log_capacity = cap;
+  return VGICP_OK;
+}
+
+uint32_t iterate_grid(uint32_t n) {
+  const uint32_t want = (n + kIterBlock - 1) / kIterBlock;
+  return std::min<uint32_t>(std::max<uint32_t>(want, 1), kMaxIterBlocks);
+}
+
+IterArgs make_args(const vgicp_ctx* ctx) {
+  IterArgs a;
+  a.scan = ctx->d_scan;
+  a.stride = ctx->stride;
+  a.n = ctx->n;
+  a.mask = (uint32_t)(ctx->slots - 1);
+  a.table = ctx->table;
+  a.voxel_size = ctx->voxel_size;
+  a.partials = ctx->d_partials;
+  a.sums = ctx->d_sums;
+  a.state = ctx->d_state;
+  a.log = ctx->d_log;
+  return a;
+}
+
+int load_rccl(vgicp_ctx* ctx) {
+  if (ctx->rccl.lib) return VGICP_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* nm : names) {
+    lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(ctx, VGICP_ERR_RCCL, std::string("cannot load librccl: ") + dlerror());
+  RcclApi api;
+  api.lib = lib;
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce)
+    return fail(ctx, VGICP_ERR_RCCL, "librccl lacks a required symbol");
+  ctx->rccl = api;
+  return VGICP_OK;
+}
+
+int fail_rccl(const vgicp_ctx* ctx, int code, const char* what) {
+  const char* txt = ctx->rccl.GetErrorString ? ctx->rccl.GetErrorString(code) : "?";
+  return fail(ctx, VGICP_ERR_RCCL, std::string(what) + ": " + txt);
+}
+
+bool finite16(const double* m) {
+  for (int i = 0; i < 16; ++i)
+    if (!std::isfinite(m[i])) return false;
+  return true;
+}
+
+// Enqueue one VGICP round on the context's stream.
+int enqueue_round(vgicp_ctx* ctx, const IterArgs& args, uint32_t grid) {
+  if (ctx->comm == nullptr) {
+    VG_HIP(ctx, launch_iterate(ctx->stream, args, grid, /*fused_tail=*/true));
+    return VGICP_OK;
+  }
+  VG_HIP(ctx, launch_iterate(ctx->stream, args, grid, /*fused_tail=*/false));
+  const int rc = ctx->rccl.AllReduce(ctx->d_sums, ctx->d_sums, kSlots, kNcclDouble, kNcclSum,
+                                     ctx->comm, ctx->stream);
+  if (rc != 0) return fail_rccl(ctx, rc, "ncclAllReduce");
+  VG_HIP(ctx, launch_tail(ctx->stream, args));
+  return VGICP_OK;
+}
+
+int check_params(const vgicp_ctx* ctx, const vgicp_params* p) {
+  if (!p) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "params is NULL");
+  if (p->max_iteration < 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "max_iteration < 0");
+  return VGICP_OK;
+}
+
+void pose_to_state(const double* m16, double* pose12) {
+  Pose T;
+  pose_from_mat4(m16, T);
+  for (int k = 0; k < 9; ++k) pose12[k] = T.R[k];
+  for (int k = 0; k < 3; ++k) pose12[9 + k] = T.t[k];
+}
+void state_to_pose(const double* pose12, double* m16) {
+  Pose T;
+  for (int k = 0; k < 9; ++k) T.R[k] = pose12[k];
+  for (int k = 0; k < 3; ++k) T.t[k] = pose12[9 + k];
+  pose_to_mat4(T, m16);
+}
+
+int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, double* out_pose,
+              vgicp_stats* stats) {
+  const double t0 = now_seconds();
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload first");
+  int rc = check_params(ctx, params);
+  if (rc != VGICP_OK) return rc;
+  const int max_it = params->max_iteration;
+  rc = ensure_log(ctx, max_it);
+  if (rc != VGICP_OK) return rc;
+  const bool profile = (params->flags & VGICP_FLAG_PROFILE) != 0;
+  int chunk = params->chunk_iterations > 0 ? params->chunk_iterations : kDefaultChunk;
+  if (profile) chunk = 1;
+
+  AlignState* h0 = &ctx->h_state[0];
+  std::memset(h0, 0, sizeof(AlignState));
+  pose_to_state(guess, h0->pose);
+  h0->cosine_threshold = params->cosine_threshold;
+  h0->translation_sq_threshold = params->translation_sq_threshold;
+  h0->max_iteration = max_it;
+  h0->done = (max_it == 0) ? 1 : 0;
+  VG_HIP(ctx, hipMemcpyAsync(ctx->d_state, h0, sizeof(AlignState), hipMemcpyHostToDevice, ctx->stream));
+
+  const IterArgs args = make_args(ctx);
+  const uint32_t grid = iterate_grid(ctx->n);
+  if (profile && (int)ctx->ev_prof.size() < 2 * max_it) {
+    const size_t old = ctx->ev_prof.size();
+    ctx->ev_prof.resize(2 * (size_t)max_it, nullptr);
+    for (size_t k = old; k < ctx->ev_prof.size(); ++k) VG_HIP(ctx, hipEventCreate(&ctx->ev_prof[k]));
+  }
+
+  VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+  int launched = 0;           // rounds enqueued
+  int chunks_enqueued = 0, chunks_checked = 0;
+  bool finished = false;
+  // Keep up to two chunks in flight: enqueue chunk k+1 before looking at chunk k's status, so the
+  // device never idles behind the host; rounds enqueued past convergence exit at their first load.
+  while (!finished) {
+    while (launched < max_it && chunks_enqueued - chunks_checked < kMaxChunksInFlight) {
+      const int todo = std::min(chunk, max_it - launched);
+      for (int j = 0; j < todo; ++j) {
+        if (profile) VG_HIP(ctx, hipEventRecord(ctx->ev_prof[2 * (launched + j)], ctx->stream));
+        rc = enqueue_round(ctx, args, grid);
+        if (rc != VGICP_OK) return rc;
+        if (profile) VG_HIP(ctx, hipEventRecord(ctx->ev_prof[2 * (launched + j) + 1], ctx->stream));
+      }
+      launched += todo;
+      const int slot = chunks_enqueued % kMaxChunksInFlight;
+      VG_HIP(ctx, hipMemcpyAsync(&ctx->h_state[1 + slot], ctx->d_state, sizeof(AlignState),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+      VG_HIP(ctx, hipEventRecord(ctx->ev_chunk[slot], ctx->stream));
+      ++chunks_enqueued;
+    }
+    if (chunks_checked == chunks_enqueued) break;  // max_iteration == 0
+    const int slot = chunks_checked % kMaxChunksInFlight;
+    VG_HIP(ctx, hipEventSynchronize(ctx->ev_chunk[slot]));
+    ++chunks_checked;
+    if (ctx->h_state[1 + slot].done || (launched >= max_it && chunks_checked == chunks_enqueued))
+      finished = true;
+  }
+  VG_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+  AlignState* hf = &ctx->h_state[0];
+  VG_HIP(ctx, hipMemcpyAsync(hf, ctx->d_state, sizeof(AlignState), hipMemcpyDeviceToHost, ctx->stream));
+  const bool want_log = stats && (stats->corr_count || stats->normal_eq);
+  if (want_log && max_it > 0)
+    VG_HIP(ctx, hipMemcpyAsync(ctx->h_log, ctx->d_log, (size_t)max_it * kSlots * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+  state_to_pose(hf->pose, out_pose);
+  if (stats) {
+    stats->iterations = hf->iteration;
+    stats->converged = hf->converged;
+    stats->world_size = ctx->world_size;
+    stats->launches = launched;
+    float ms = 0.f;
+    VG_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+    stats->device_seconds = ms * 1e-3;
+    for (int it = 0; it < hf->iteration; ++it) {
+      const double* row = ctx->h_log + (size_t)it * kSlots;
+      if (stats->corr_count) stats->corr_count[it] = (uint64_t)row[kCountSlot];
+      if (stats->normal_eq) std::memcpy(stats->normal_eq + (size_t)it * kNormalEq, row, kNormalEq * sizeof(double));
+    }
+    if (profile && stats->kernel_ms) {
+      for (int it = 0; it < launched; ++it) {
+        float k = 0.f;
+        VG_HIP(ctx, hipEventElapsedTime(&k, ctx->ev_prof[2 * it], ctx->ev_prof[2 * it + 1]));
+        stats->kernel_ms[it] = k;
+      }
+    }
+    stats->seconds = now_seconds() - t0;
+  }
+  if (!finite16(out_pose)) return fail(ctx, VGICP_ERR_DEGENERATE, "solved pose is not finite (singular normal equations)");
+  return VGICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vgicp_abi_version(void) { return VGICP_ABI_VERSION; }
+
+int vgicp_create(int device_id, vgicp_ctx** out) {
+  if (!out) return fail(nullptr, VGICP_ERR_BAD_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(nullptr, VGICP_ERR_NO_DEVICE,
+                std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+  if (device_id < 0 || device_id >= count)
+    return fail(nullptr, VGICP_ERR_BAD_ARGUMENT, "device_id out of range");
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device_id);
+  if (e != hipSuccess) return fail_hip(nullptr, e, "hipGetDeviceProperties");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, VGICP_ERR_NO_DEVICE,
+                std::string("device is ") + prop.gcnArchName + ", this module is built for gfx950 only");
+  vgicp_ctx* ctx = new vgicp_ctx;
+  ctx->device = device_id;
+  ctx->cu_count = prop.multiProcessorCount;
+  ctx->hbm_bytes = prop.totalGlobalMem;
+  ctx->arch = prop.gcnArchName;
+  auto bail = [&](hipError_t err, const char* what) {
+    int rc = fail_hip(nullptr, err, what);
+    delete ctx;
+    return rc;
+  };
+#define VG_CREATE(call)                                  \
+  do {                                                   \
+    hipError_t e__ = (call);                             \
+    if (e__ != hipSuccess) return bail(e__, #call);      \
+  } while (0)
+  VG_CREATE(hipSetDevice(device_id));
+  VG_CREATE(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), 4 * sizeof(uint32_t)));
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), 4 * sizeof(uint32_t), 0));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_state), sizeof(AlignState)));
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state),
+                          (1 + kMaxChunksInFlight) * sizeof(AlignState), 0));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_partials),
+                      (size_t)kMaxIterBlocks * kSlots * sizeof(double)));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sums), kSlots * sizeof(double)));
+  VG_CREATE(hipMemset(ctx->d_state, 0, sizeof(AlignState)));
+  VG_CREATE(hipEventCreate(&ctx->ev_begin));
+  VG_CREATE(hipEventCreate(&ctx->ev_end));
+  for (int k = 0; k < kMaxChunksInFlight; ++k)
+    VG_CREATE(hipEventCreateWithFlags(&ctx->ev_chunk[k], hipEventDisableTiming));
+#undef VG_CREATE
+  *out = ctx;
+  return VGICP_OK;
+}
+
+int vgicp_destroy(vgicp_ctx* ctx) {
+  if (!ctx) return VGICP_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
+  (void)hipFree(ctx->table);
+  (void)hipFree(ctx->d_counters);
+  (void)hipHostFree(ctx->h_counters);
+  (void)hipFree(ctx->d_stage);
+  (void)hipFree(ctx->d_scan);
+  (void)hipFree(ctx->d_scan_aos);
+  (void)hipFree(ctx->d_state);
+  (void)hipHostFree(ctx->h_state);
+  (void)hipFree(ctx->d_partials);
+  (void)hipFree(ctx->d_sums);
+  (void)hipFree(ctx->d_log);
+  (void)hipHostFree(ctx->h_log);
+  if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+  if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+  for (auto& e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev_prof) if (e) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return VGICP_OK;
+}
+
+const char* vgicp_last_error(const vgicp_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int vgicp_device_info(const vgicp_ctx* ctx, char* name, size_t name_len, int32_t* cu_count,
+                      uint64_t* hbm_bytes) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (name && name_len) {
+    std::strncpy(name, ctx->arch.c_str(), name_len - 1);
+    name[name_len - 1] = '\0';
+  }
+  if (cu_count) *cu_count = ctx->cu_count;
+  if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+  return VGICP_OK;
+}
+
+int vgicp_map_reset(vgicp_ctx* ctx, double voxel_size, size_t capacity_hint) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!(voxel_size > 0.0) || !std::isfinite(voxel_size))
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "voxel_size must be positive and finite");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->table) VG_HIP(ctx, hipFree(ctx->table));
+  ctx->table = nullptr;
+  ctx->slots = ctx->voxels = ctx->tombstones = 0;
+  ctx->voxel_size = voxel_size;
+  const uint64_t slots = next_pow2(std::max<uint64_t>(kMinSlots, (uint64_t)capacity_hint * 4));
+  int rc = alloc_table(ctx, slots, &ctx->table);
+  if (rc != VGICP_OK) return rc;
+  ctx->slots = slots;
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VGICP_OK;
+}
+
+int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double* means,
+                     const double* covs) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (n == 0) return VGICP_OK;
+  if (!keys || !means || !covs) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL batch pointer");
+  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "batch too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_table(ctx, n);
+  if (rc != VGICP_OK) return rc;
+  const size_t kb = n * 3 * sizeof(int32_t), mb = n * 3 * sizeof(double), cb = n * 9 * sizeof(double);
+  const size_t koff = 0, moff = (kb + 255) & ~size_t(255), coff = moff + mb;
+  rc = ensure_stage(ctx, coff + cb);
+  if (rc != VGICP_OK) return rc;
+  char* base = static_cast<char*>(ctx->d_stage);
+  VG_HIP(ctx, hipMemcpyAsync(base + koff, keys, kb, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(base + moff, means, mb, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(base + coff, covs, cb, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, launch_upsert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), (uint32_t)n,
+                            reinterpret_cast<const int32_t*>(base + koff),
+                            reinterpret_cast<const double*>(base + moff),
+                            reinterpret_cast<const double*>(base + coff), ctx->d_counters));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->voxels += ctx->h_counters[0];
+  if (ctx->h_counters[1] != 0) return fail(ctx, VGICP_ERR_TABLE_FULL, "voxel table probe sequence exhausted");
+  return VGICP_OK;
+}
+
+int vgicp_map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (n == 0) return VGICP_OK;
+  if (!keys) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL batch pointer");
+  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "batch too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t kb = n * 3 * sizeof(int32_t);
+  int rc = ensure_stage(ctx, kb);
+  if (rc != VGICP_OK) return rc;
+  VG_HIP(ctx, hipMemcpyAsync(ctx->d_stage, keys, kb, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, launch_erase(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), (uint32_t)n,
+                           static_cast<const int32_t*>(ctx->d_stage), ctx->d_counters));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->voxels -= ctx->h_counters[0];
+  ctx->tombstones += ctx->h_counters[0];
+  return VGICP_OK;
+}
+
+int vgicp_map_size(const vgicp_ctx* ctx, size_t* voxels, size_t* table_slots) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (voxels) *voxels = ctx->voxels;
+  if (table_slots) *table_slots = ctx->slots;
+  return VGICP_OK;
+}
+
+int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const double* covs) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (n > 0 && (!points || !covs)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
+  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_scan(ctx, n);
+  if (rc != VGICP_OK) return rc;
+  ctx->scan_ready = false;
+  ctx->n = (uint32_t)n;
+  ctx->stride = ctx->scan_capacity;
+  if (n > 0) {
+    double* aos_pts = ctx->d_scan_aos;
+    double* aos_cov = ctx->d_scan_aos + 3 * ctx->scan_capacity;
+    VG_HIP(ctx, hipMemcpyAsync(aos_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VG_HIP(ctx, hipMemcpyAsync(aos_cov, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, (uint32_t)n, ctx->d_scan, ctx->stride));
+    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->scan_ready = true;
+  return VGICP_OK;
+}
+
+int vgicp_align_resident(vgicp_ctx* ctx, const double guess[16], const vgicp_params* params,
+                         double out_pose[16], vgicp_stats* stats) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!guess || !out_pose) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pose pointer");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  return run_align(ctx, guess, params, out_pose, stats);
+}
+
+int vgicp_align(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
+                const double guess[16], const vgicp_params* params, double out_pose[16],
+                vgicp_stats* stats) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  const double t0 = now_seconds();
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  int rc = vgicp_scan_upload(ctx, n, points, covs);
+  if (rc != VGICP_OK) return rc;
+  rc = vgicp_align_resident(ctx, guess, params, out_pose, stats);
+  if (stats) stats->seconds = now_seconds() - t0;
+  return rc;
+}
+
+int vgicp_accumulate(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
+                     const double pose[16], double JTJ[36], double JTr[6], uint64_t* count) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!pose || !JTJ || !JTr) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL output pointer");
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  int rc = vgicp_scan_upload(ctx, n, points, covs);
+  if (rc != VGICP_OK) return rc;
+  rc = ensure_log(ctx, 1);
+  if (rc != VGICP_OK) return rc;
+  AlignState* h0 = &ctx->h_state[0];
+  std::memset(h0, 0, sizeof(AlignState));
+  pose_to_state(pose, h0->pose);
+  h0->cosine_threshold = 2.0;
+  h0->max_iteration = 1;
+  VG_HIP(ctx, hipMemcpyAsync(ctx->d_state, h0, sizeof(AlignState), hipMemcpyHostToDevice, ctx->stream));
+  // local rank only: always the fused single-device round
+  VG_HIP(ctx, launch_iterate(ctx->stream, make_args(ctx), iterate_grid(ctx->n), true));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_log, ctx->d_log, kSlots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const double* row = ctx->h_log;
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c <= r; ++c) {
+      JTJ[r + 6 * c] = row[tri6(r, c)];
+      JTJ[c + 6 * r] = row[tri6(r, c)];
+    }
+  for (int k = 0; k < 6; ++k) JTr[k] = row[21 + k];
+  if (count) *count = (uint64_t)row[kCountSlot];
+  return VGICP_OK;
+}
+
+int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
+                double* src_points, double* src_covs, double* map_points, double* map_covs,
+                uint64_t* src_index, size_t* matched) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!matched) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "matched is NULL");
+  *matched = 0;
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (n == 0) return VGICP_OK;
+  if (!points || !covs || !src_points || !src_covs || !map_points || !map_covs)
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL array pointer");
+  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t nb = match_blocks((uint32_t)n);
+  // staging layout: in_pts | in_cov | out src_pts | src_cov | map_pts | map_cov | index | counts
+  const size_t pb = n * 3 * sizeof(double), cb = n * 9 * sizeof(double), ib = n * sizeof(uint64_t);
+  const size_t nbb = ((size_t)nb * sizeof(uint32_t) + 255) & ~size_t(255);
+  const size_t total = 3 * pb + 3 * cb + ib + nbb + 256;
+  int rc = ensure_stage(ctx, total);
+  if (rc != VGICP_OK) return rc;
+  char* b = static_cast<char*>(ctx->d_stage);
+  double* in_pts = reinterpret_cast<double*>(b);
+  double* in_cov = reinterpret_cast<double*>(b + pb);
+  double* o_sp = reinterpret_cast<double*>(b + pb + cb);
+  double* o_sc = reinterpret_cast<double*>(b + 2 * pb + cb);
+  double* o_mp = reinterpret_cast<double*>(b + 2 * pb + 2 * cb);
+  double* o_mc = reinterpret_cast<double*>(b + 3 * pb + 2 * cb);
+  uint64_t* o_ix = reinterpret_cast<uint64_t*>(b + 3 * pb + 3 * cb);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(b + 3 * pb + 3 * cb + ib);
+  uint32_t* d_total = reinterpret_cast<uint32_t*>(b + 3 * pb + 3 * cb + ib + nbb);
+  VG_HIP(ctx, hipMemcpyAsync(in_pts, points, pb, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(in_cov, covs, cb, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, launch_match(ctx->stream, in_pts, in_cov, (uint32_t)n, ctx->table,
+                           (uint32_t)(ctx->slots - 1), ctx->voxel_size, counts, d_total, o_sp, o_sc,
+                           o_mp, o_mc, o_ix));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t m = ctx->h_counters[0];
+  if (m > 0) {
+    VG_HIP(ctx, hipMemcpyAsync(src_points, o_sp, m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VG_HIP(ctx, hipMemcpyAsync(src_covs, o_sc, m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VG_HIP(ctx, hipMemcpyAsync(map_points, o_mp, m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VG_HIP(ctx, hipMemcpyAsync(map_covs, o_mc, m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (src_index)
+      VG_HIP(ctx, hipMemcpyAsync(src_index, o_ix, m * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *matched = m;
+  return VGICP_OK;
+}
+
+int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* keys) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (n == 0) return VGICP_OK;
+  if (!points || !keys) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL array pointer");
+  if (!(ctx->voxel_size > 0.0)) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel size: call vgicp_map_reset first");
+  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t pb = n * 3 * sizeof(double), kb = n * 3 * sizeof(int32_t);
+  int rc = ensure_stage(ctx, pb + kb);
+  if (rc != VGICP_OK) return rc;
+  char* b = static_cast<char*>(ctx->d_stage);
+  VG_HIP(ctx, hipMemcpyAsync(b, points, pb, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, launch_voxel_index(ctx->stream, reinterpret_cast<const double*>(b), (uint32_t)n,
+                                 ctx->voxel_size, reinterpret_cast<int32_t*>(b + pb)));
+  VG_HIP(ctx, hipMemcpyAsync(keys, b + pb, kb, hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VGICP_OK;
+}
+
+int vgicp_comm_unique_id(vgicp_ctx* ctx, void* id128) {
+  if (!ctx || !id128) return VGICP_ERR_BAD_ARGUMENT;
+  int rc = load_rccl(ctx);
+  if (rc != VGICP_OK) return rc;
+  ncclUniqueId id;
+  const int e = ctx->rccl.GetUniqueId(&id);
+  if (e != 0) return fail_rccl(ctx, e, "ncclGetUniqueId");
+  std::memcpy(id128, id.internal, VGICP_UNIQUE_ID_BYTES);
+  return VGICP_OK;
+}
+
+int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128) {
+  if (!ctx || !id128) return VGICP_ERR_BAD_ARGUMENT;
+  if (world_size < 1 || rank < 0 || rank >= world_size)
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "bad world_size / rank");
+  if (ctx->comm) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "communicator already initialised");
+  int rc = load_rccl(ctx);
+  if (rc != VGICP_OK) return rc;
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(id.internal, id128, VGICP_UNIQUE_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  const int e = ctx->rccl.CommInitRank(&comm, world_size, id, rank);
+  if (e != 0) return fail_rccl(ctx, e, "ncclCommInitRank");
+  ctx->comm = comm;
+  ctx->world_size = world_size;
+  ctx->rank = rank;
+  return VGICP_OK;
+}
+
+int vgicp_comm_destroy(vgicp_ctx* ctx) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->comm) {
+    VG_HIP(ctx, hipSetDevice(ctx->device));
+    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+  }
+  ctx->world_size = 1;
+  ctx->rank = 0;
+  return VGICP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// vgicp_device.h — device-side data layout and kernel launch entry points (gfx950 only).
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   scan      12 SoA planes of `stride` doubles: x y z c00 c10 c20 c01 c11 c21 c02 c12 c22
+//             (a point costs 96 B per iteration, every load is a coalesced 512-B wave access)
+//   table     open-addressing hash table of 128-byte voxel records, power-of-two slot count,
+//             linear probing, load <= 1/4: a lookup is one cache line, a hit needs no second hop
+//   partials  one 256-byte row of 32 doubles per workgroup (21 JTJ + 6 JTr + count + 4 pad)
+//   state     one AlignState: total pose, thresholds, iteration counter, done/converged flags
+//   log       per-iteration 32-double rows (reduced normal equations + count), read back once
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vgicp_math.h"
+
+namespace vgicp {
+
+constexpr int kSlots = 32;      // doubles per partial row
+constexpr int kNormalEq = 27;   // 21 lower-triangle JTJ entries + 6 JTr entries
+constexpr int kCountSlot = 27;  // match count travels as an exact double
+constexpr int kScanPlanes = 12;
+constexpr int kIterBlock = 256;       // threads per workgroup of the iteration kernel
+constexpr int kMaxIterBlocks = 2048;  // grid cap; larger scans grid-stride
+
+enum : int32_t { SLOT_EMPTY = 0, SLOT_FULL = 1, SLOT_TOMB = 2, SLOT_LOCKED = 3 };
+
+// One voxel of the reference's LocalMap::Voxel as the path reads it: key, mean, covariance
+// (reference include/ESKF_LIO/LocalMap.hpp:63-70; numPoints / points stay on the host).
+struct alignas(128) VoxelRecord {
+  int32_t key[3];
+  int32_t state;
+  double mean[3];
+  double cov[9];  // column-major
+  double pad[2];
+};
+static_assert(sizeof(VoxelRecord) == 128, "one voxel = one 128-byte line");
+
+struct AlignState {
+  double pose[12];  // total transform: R column-major (9) then t (3)
+  double step[12];  // last increment
+  double cosine_threshold;
+  double translation_sq_threshold;
+  int32_t max_iteration;
+  int32_t iteration;  // rounds executed so far
+  int32_t done;       // set on convergence or when iteration == max_iteration
+  int32_t converged;
+  uint32_t ticket;    // workgroup arrival counter of the running launch
+  uint32_t pad[3];
+};
+
+struct IterArgs {
+  const double* scan;  // SoA planes
+  uint64_t stride;
+  uint32_t n;
+  uint32_t mask;  // slots - 1
+  const VoxelRecord* table;
+  double voxel_size;
+  double* partials;   // [grid][kSlots]
+  double* sums;       // [kSlots]: reduced row handed to the all-reduce (multi-GPU path)
+  AlignState* state;
+  double* log;        // [max_iteration][kSlots]
+};
+
+// ---- launchers (defined in vgicp_kernels.hip) ----
+// One VGICP iteration over the resident scan. fused_tail: the last workgroup also solves the 6x6
+// system and advances the pose (single GPU); otherwise it leaves the reduced row in args.sums.
+hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, bool fused_tail);
+// Multi-GPU tail: solve from args.sums (already all-reduced) and advance the pose.
+hipError_t launch_tail(hipStream_t s, const IterArgs& args);
+hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
+                            uint32_t n, double* soa, uint64_t stride);
+hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots);
+hipError_t launch_upsert(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
+                         const int32_t* keys, const double* means, const double* covs,
+                         uint32_t* counters /* [0] new inserts, [1] failures */);
+hipError_t launch_erase(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
+                        const int32_t* keys, uint32_t* counters /* [0] erased */);
+hipError_t launch_rehash(hipStream_t s, const VoxelRecord* old_table, uint64_t old_slots,
+                         VoxelRecord* table, uint32_t mask, uint32_t* counters);
+hipError_t launch_voxel_index(hipStream_t s, const double* points_aos, uint32_t n, double voxel_size,
+                              int32_t* keys);
+// Correspondence materialisation in ascending point order (three small passes).
+hipError_t launch_match(hipStream_t s, const double* points_aos, const double* covs_aos, uint32_t n,
+                        const VoxelRecord* table, uint32_t mask, double voxel_size,
+                        uint32_t* block_counts, uint32_t* total, double* src_points,
+                        double* src_covs, double* map_points, double* map_covs, uint64_t* src_index);
+uint32_t match_blocks(uint32_t n);
+
+}  // namespace vgicp

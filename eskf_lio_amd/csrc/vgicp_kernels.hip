@@ -1,0 +1,534 @@
+// vgicp_kernels.hip — hand-written CDNA4 (gfx950) kernels of the VGICP registration path.
+//
+// Reference behaviour each kernel reproduces (paths relative to the reference checkout):
+//   iterate_kernel  one round of the loop in ICP::align (src/Registration.cpp:15-28):
+//                   Open3D PointCloud::Transform of point + covariance (call sites :13,27),
+//                   LocalMap::getVoxelIndex + voxelGrid_.find (src/LocalMap.cpp:94-100,114-118),
+//                   ICP::computeJTJAndJTr (src/Registration.cpp:83-102), the accumulation and merge
+//                   of ICP::computeTransform (:60-76), and in its last workgroup the LDLT solve,
+//                   se3ToSE3, pose composition and convergence test (:78-79, :20-25, :37-50)
+//   upsert/erase    the effect of LocalMap::updateLocalMap's insert and evict loops on the data the
+//                   path reads (src/LocalMap.cpp:47-72), mirrored from host-computed voxel values
+//   match kernels   LocalMap::correspondenceMatching with materialised output (src/LocalMap.cpp:78-112)
+//
+// Design notes (DESIGN.md has the numbers):
+//   * The scan is never written back: the TOTAL pose is applied to the original point in registers
+//     each round (the reference transforms a copy incrementally), so a point costs 96 B of reads.
+//   * MFMA is not used: this is a gather plus a 27-value reduction at ~2 fp64 flop per byte.
+//   * Reduction: 32-slot halving butterfly inside a 64-lane wave (32 exchanges instead of 6 x 28),
+//     LDS across the waves of a workgroup, one 256-byte partial row per workgroup written through to
+//     memory (sc1), an arrival ticket, and a fixed-order final sum in the last workgroup to arrive —
+//     bit-reproducible whichever workgroup that is.
+#include "vgicp_device.h"
+
+namespace vgicp {
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+// Write-through (sc1) store / L1-bypassing (sc1) load: the in-launch hand-off of partial rows to
+// the last workgroup (cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md visibility table).
+__device__ __forceinline__ void store_through(double* p, double v) {
+  __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_through(const double* p) {
+  return __longlong_as_double(
+      (long long)__hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t voxel_hash(int32_t x, int32_t y, int32_t z) {
+  uint32_t h = fmix32((uint32_t)x * 0x9E3779B1u + 0x7F4A7C15u);
+  h = fmix32(h ^ ((uint32_t)y * 0x85EBCA77u));
+  h = fmix32(h ^ ((uint32_t)z * 0xC2B2AE3Du));
+  return h;
+}
+
+// LocalMap::getVoxelIndex: IEEE division, floor, double -> int32.
+__device__ __forceinline__ int32_t voxel_coord(double x, double voxel_size) {
+  return (int32_t)floor(x / voxel_size);
+}
+
+// q = R p + t evaluated as Open3D's homogeneous product does (left to right, no FMA contraction),
+// so the first round reproduces the CPU path's voxel keys bit for bit.
+__device__ __forceinline__ void transform_point(const double* R, const double* t, double x, double y,
+                                                double z, double* q) {
+#pragma clang fp contract(off)
+  q[0] = ((R[0] * x + R[3] * y) + R[6] * z) + t[0];
+  q[1] = ((R[1] * x + R[4] * y) + R[7] * z) + t[1];
+  q[2] = ((R[2] * x + R[5] * y) + R[8] * z) + t[2];
+}
+
+// Probe for the voxel that contains the key. Returns the record or nullptr.
+__device__ __forceinline__ const VoxelRecord* find_voxel(const VoxelRecord* table, uint32_t mask,
+                                                         int32_t kx, int32_t ky, int32_t kz) {
+  uint32_t slot = voxel_hash(kx, ky, kz) & mask;
+  for (;;) {
+    const VoxelRecord* rec = table + slot;
+    const int4 ks = *reinterpret_cast<const int4*>(rec);
+    if (ks.w == SLOT_EMPTY) return nullptr;
+    if (ks.w == SLOT_FULL && ks.x == kx && ks.y == ky && ks.z == kz) return rec;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// One halving step of the wave butterfly: N live values -> N/2, exchanging with lane ^ MASK.
+template <int N, int MASK>
+__device__ __forceinline__ void fold(double (&v)[kSlots], bool upper) {
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j) {
+    const double keep = upper ? v[j + N / 2] : v[j];
+    const double send = upper ? v[j] : v[j + N / 2];
+    v[j] = keep + __shfl_xor(send, MASK, 64);
+  }
+}
+
+// The serial tail of one round: LDLT solve, se(3) exponential, pose update, convergence.
+__device__ void solve_and_advance(const double* totals, AlignState* st, double* log, double* work) {
+  const int it = st->iteration;
+  double* row = log + (size_t)it * kSlots;
+  for (int k = 0; k < kSlots; ++k) row[k] = totals[k];
+  double rhs[6], xi[6];
+  for (int k = 0; k < 6; ++k) rhs[k] = -totals[21 + k];
+  ldlt6_solve(totals, rhs, xi, work);
+  Pose step, total, next;
+  se3_exp(xi, step);
+  for (int k = 0; k < 9; ++k) total.R[k] = st->pose[k];
+  for (int k = 0; k < 3; ++k) total.t[k] = st->pose[9 + k];
+  pose_compose(step, total, next);
+  for (int k = 0; k < 9; ++k) { st->pose[k] = next.R[k]; st->step[k] = step.R[k]; }
+  for (int k = 0; k < 3; ++k) { st->pose[9 + k] = next.t[k]; st->step[9 + k] = step.t[k]; }
+  const bool conv = converged(step, st->cosine_threshold, st->translation_sq_threshold);
+  st->iteration = it + 1;
+  if (conv) {
+    st->converged = 1;
+    st->done = 1;
+  } else if (it + 1 >= st->max_iteration) {
+    st->done = 1;
+  }
+}
+
+template <bool FUSED_TAIL>
+__global__ __launch_bounds__(kIterBlock) void iterate_kernel(IterArgs a) {
+  constexpr int kWaves = kIterBlock / 64;
+  constexpr int kGroups = kIterBlock / kSlots;
+  __shared__ double red[kWaves][kSlots];
+  __shared__ double fin[kGroups][kSlots];
+  __shared__ double totals[kSlots];
+  __shared__ double work[kLdltWork];
+  __shared__ uint32_t is_last;
+
+  AlignState* st = a.state;
+  if (st->done) return;  // uniform: converged (or exhausted) in an earlier launch
+
+  double R[9], t[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = st->pose[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = st->pose[9 + k];
+
+  double v[kSlots];
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) v[k] = 0.0;
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t step = gridDim.x * kIterBlock;
+  for (uint32_t i = blockIdx.x * kIterBlock + tid; i < a.n; i += step) {
+    const double* s = a.scan + i;
+    const double x = s[0], y = s[a.stride], z = s[2 * a.stride];
+    double C[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) C[k] = s[(3 + k) * a.stride];
+
+    double p[3];
+    transform_point(R, t, x, y, z, p);
+    const int32_t kx = voxel_coord(p[0], a.voxel_size);
+    const int32_t ky = voxel_coord(p[1], a.voxel_size);
+    const int32_t kz = voxel_coord(p[2], a.voxel_size);
+    const VoxelRecord* rec = find_voxel(a.table, a.mask, kx, ky, kz);
+    if (rec == nullptr) continue;
+
+    double mu[3], S[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mu[k] = rec->mean[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S[k] = rec->cov[k];
+
+    // S = R C R^T + C_voxel
+    double RC[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        RC[r + 3 * c] = R[r] * C[3 * c] + R[r + 3] * C[1 + 3 * c] + R[r + 6] * C[2 + 3 * c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        S[r + 3 * c] += RC[r] * R[c] + RC[r + 3] * R[c + 3] + RC[r + 6] * R[c + 6];
+
+    double W[9];
+    inv3(S, W);
+    const double e0 = p[0] - mu[0], e1 = p[1] - mu[1], e2 = p[2] - mu[2];
+    // Q = [p]x W  (rows 3..5, columns 0..2 of J^T Sigma^-1 J)
+    double Q[9];  // Q[r + 3c]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Q[0 + 3 * c] = p[1] * W[2 + 3 * c] - p[2] * W[1 + 3 * c];
+      Q[1 + 3 * c] = p[2] * W[0 + 3 * c] - p[0] * W[2 + 3 * c];
+      Q[2 + 3 * c] = p[0] * W[1 + 3 * c] - p[1] * W[0 + 3 * c];
+    }
+    // lower triangle of J^T Sigma^-1 J, row by row
+    v[0] += W[0];
+    v[1] += W[1]; v[2] += W[4];
+    v[3] += W[2]; v[4] += W[5]; v[5] += W[8];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int base = (3 + r) * (4 + r) / 2;
+      const double q0 = Q[r], q1 = Q[r + 3], q2 = Q[r + 6];
+      v[base + 0] += q0; v[base + 1] += q1; v[base + 2] += q2;
+      v[base + 3] += q2 * p[1] - q1 * p[2];
+      if (r >= 1) v[base + 4] += q0 * p[2] - q2 * p[0];
+      if (r >= 2) v[base + 5] += q1 * p[0] - q0 * p[1];
+    }
+    // J^T Sigma^-1 r
+    v[21] += W[0] * e0 + W[3] * e1 + W[6] * e2;
+    v[22] += W[1] * e0 + W[4] * e1 + W[7] * e2;
+    v[23] += W[2] * e0 + W[5] * e1 + W[8] * e2;
+    v[24] += Q[0] * e0 + Q[3] * e1 + Q[6] * e2;
+    v[25] += Q[1] * e0 + Q[4] * e1 + Q[7] * e2;
+    v[26] += Q[2] * e0 + Q[5] * e1 + Q[8] * e2;
+    v[kCountSlot] += 1.0;
+  }
+
+  // ---- wave: 32-slot halving butterfly; lane l ends with slot (l >> 1) summed over 64 lanes ----
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  fold<32, 32>(v, (lane & 32) != 0);
+  fold<16, 16>(v, (lane & 16) != 0);
+  fold<8, 8>(v, (lane & 8) != 0);
+  fold<4, 4>(v, (lane & 4) != 0);
+  fold<2, 2>(v, (lane & 2) != 0);
+  const double wsum = v[0] + __shfl_xor(v[0], 1, 64);
+  if ((lane & 1) == 0) red[wave][lane >> 1] = wsum;
+  __syncthreads();
+
+  // ---- workgroup: fixed-order sum over waves, one write-through row per workgroup ----
+  const uint32_t nblk = gridDim.x;
+  if (wave == 0) {
+    if (lane < kSlots) {
+      double tot = red[0][lane];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) tot += red[w][lane];
+      store_through(a.partials + (size_t)blockIdx.x * kSlots + lane, tot);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has left this CU before the ticket
+    if (lane == 0) {
+      const uint32_t prev = __hip_atomic_fetch_add((gu32*)&st->ticket, 1u, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+      is_last = (prev == nblk - 1) ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  if (!is_last) return;
+
+  // ---- last workgroup to arrive: deterministic final sum over all rows ----
+  {
+    const uint32_t slot = tid & (kSlots - 1), group = tid / kSlots;
+    double s = 0.0;
+    for (uint32_t b = group; b < nblk; b += kGroups)
+      s += load_through(a.partials + (size_t)b * kSlots + slot);
+    fin[group][slot] = s;
+  }
+  __syncthreads();
+  if (tid < kSlots) {
+    double tot = fin[0][tid];
+#pragma unroll
+    for (int g = 1; g < kGroups; ++g) tot += fin[g][tid];
+    totals[tid] = tot;
+    if (!FUSED_TAIL) a.sums[tid] = tot;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store((gu32*)&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (FUSED_TAIL) solve_and_advance(totals, st, a.log, work);
+  }
+}
+
+// Multi-GPU tail: sums[] holds the all-reduced row; every rank runs the same arithmetic.
+__global__ void tail_kernel(IterArgs a) {
+  __shared__ double totals[kSlots];
+  __shared__ double work[kLdltWork];
+  if (threadIdx.x != 0 || a.state->done) return;
+  for (int k = 0; k < kSlots; ++k) totals[k] = a.sums[k];
+  solve_and_advance(totals, a.state, a.log, work);
+}
+
+// AoS (the caller's Eigen memory) -> 12 SoA planes.
+__global__ void pack_scan_kernel(const double* __restrict__ pts, const double* __restrict__ covs,
+                                 uint32_t n, double* __restrict__ soa, uint64_t stride) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) soa[k * stride + i] = pts[3 * (size_t)i + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) soa[(3 + k) * stride + i] = covs[9 * (size_t)i + k];
+}
+
+__global__ void table_clear_kernel(VoxelRecord* table, uint64_t slots) {
+  // 8 threads per record, 16 B each
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= slots * 8) return;
+  reinterpret_cast<int4*>(table)[g] = make_int4(0, 0, 0, 0);
+}
+
+// Claim-or-update insert. Keys are unique within a batch, so a LOCKED slot always belongs to a
+// different key and is skipped; tombstones are never reused (rehash reclaims them).
+__device__ __forceinline__ bool insert_voxel(VoxelRecord* table, uint32_t mask, int32_t kx,
+                                             int32_t ky, int32_t kz, const double* mean,
+                                             const double* cov, uint32_t* counters) {
+  uint32_t slot = voxel_hash(kx, ky, kz) & mask;
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
+    VoxelRecord* rec = table + slot;
+    int32_t state = __hip_atomic_load(&rec->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (state == SLOT_EMPTY) {
+      int32_t expected = SLOT_EMPTY;
+      if (__hip_atomic_compare_exchange_strong(&rec->state, &expected, SLOT_LOCKED, __ATOMIC_RELAXED,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        rec->key[0] = kx; rec->key[1] = ky; rec->key[2] = kz;
+        for (int k = 0; k < 3; ++k) rec->mean[k] = mean[k];
+        for (int k = 0; k < 9; ++k) rec->cov[k] = cov[k];
+        __hip_atomic_store(&rec->state, SLOT_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&counters[0], 1u);
+        return true;
+      }
+      state = expected;  // lost the race: look at what the winner left
+    }
+    if (state == SLOT_FULL && rec->key[0] == kx && rec->key[1] == ky && rec->key[2] == kz) {
+      for (int k = 0; k < 3; ++k) rec->mean[k] = mean[k];
+      for (int k = 0; k < 9; ++k) rec->cov[k] = cov[k];
+      return true;
+    }
+    slot = (slot + 1) & mask;
+  }
+  atomicAdd(&counters[1], 1u);
+  return false;
+}
+
+__global__ void upsert_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
+                              const int32_t* __restrict__ keys, const double* __restrict__ means,
+                              const double* __restrict__ covs, uint32_t* counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double mean[3], cov[9];
+  for (int k = 0; k < 3; ++k) mean[k] = means[3 * (size_t)i + k];
+  for (int k = 0; k < 9; ++k) cov[k] = covs[9 * (size_t)i + k];
+  insert_voxel(table, mask, keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2],
+               mean, cov, counters);
+}
+
+__global__ void rehash_kernel(const VoxelRecord* __restrict__ old_table, uint64_t old_slots,
+                              VoxelRecord* table, uint32_t mask, uint32_t* counters) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= old_slots) return;
+  const VoxelRecord* rec = old_table + i;
+  if (rec->state != SLOT_FULL) return;
+  double mean[3], cov[9];
+  for (int k = 0; k < 3; ++k) mean[k] = rec->mean[k];
+  for (int k = 0; k < 9; ++k) cov[k] = rec->cov[k];
+  insert_voxel(table, mask, rec->key[0], rec->key[1], rec->key[2], mean, cov, counters);
+}
+
+__global__ void erase_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
+                             const int32_t* __restrict__ keys, uint32_t* counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t kx = keys[3 * (size_t)i], ky = keys[3 * (size_t)i + 1], kz = keys[3 * (size_t)i + 2];
+  uint32_t slot = voxel_hash(kx, ky, kz) & mask;
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
+    VoxelRecord* rec = table + slot;
+    const int32_t state = rec->state;
+    if (state == SLOT_EMPTY) return;
+    if (state == SLOT_FULL && rec->key[0] == kx && rec->key[1] == ky && rec->key[2] == kz) {
+      // duplicates in the batch race here: exactly one CAS wins and counts
+      int32_t expected = SLOT_FULL;
+      if (__hip_atomic_compare_exchange_strong(&rec->state, &expected, SLOT_TOMB, __ATOMIC_RELAXED,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicAdd(&counters[0], 1u);
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+__global__ void voxel_index_kernel(const double* __restrict__ pts, uint32_t n, double voxel_size,
+                                   int32_t* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) keys[3 * (size_t)i + k] = voxel_coord(pts[3 * (size_t)i + k], voxel_size);
+}
+
+// ---- correspondence materialisation: count per block, scan block counts, compact ----
+constexpr int kMatchBlock = 256;
+
+__device__ __forceinline__ const VoxelRecord* match_point(const double* pts, uint32_t i, uint32_t n,
+                                                          const VoxelRecord* table, uint32_t mask,
+                                                          double voxel_size) {
+  if (i >= n) return nullptr;
+  const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+  return find_voxel(table, mask, voxel_coord(x, voxel_size), voxel_coord(y, voxel_size),
+                    voxel_coord(z, voxel_size));
+}
+
+__global__ __launch_bounds__(kMatchBlock) void match_count_kernel(
+    const double* __restrict__ pts, uint32_t n, const VoxelRecord* __restrict__ table, uint32_t mask,
+    double voxel_size, uint32_t* __restrict__ block_counts) {
+  const uint32_t i = blockIdx.x * kMatchBlock + threadIdx.x;
+  const bool hit = match_point(pts, i, n, table, mask, voxel_size) != nullptr;
+  const int total = __syncthreads_count(hit ? 1 : 0);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = (uint32_t)total;
+}
+
+// Exclusive scan of block_counts in place by one workgroup; total -> *total_out.
+__global__ __launch_bounds__(1024) void match_scan_kernel(uint32_t* counts, uint32_t nb,
+                                                          uint32_t* total_out) {
+  __shared__ uint32_t wave_sum[16];
+  __shared__ uint32_t carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += 1024) {
+    const uint32_t idx = base + tid;
+    const uint32_t val = idx < nb ? counts[idx] : 0u;
+    uint32_t incl = val;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t before = carry;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_sum[w];
+    if (idx < nb) counts[idx] = before + incl - val;
+    __syncthreads();
+    if (tid == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(kMatchBlock) void match_write_kernel(
+    const double* __restrict__ pts, const double* __restrict__ covs, uint32_t n,
+    const VoxelRecord* __restrict__ table, uint32_t mask, double voxel_size,
+    const uint32_t* __restrict__ block_offsets, double* __restrict__ src_points,
+    double* __restrict__ src_covs, double* __restrict__ map_points, double* __restrict__ map_covs,
+    uint64_t* __restrict__ src_index) {
+  __shared__ uint32_t wave_hits[kMatchBlock / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t i = blockIdx.x * kMatchBlock + tid;
+  const VoxelRecord* rec = match_point(pts, i, n, table, mask, voxel_size);
+  const unsigned long long ballot = __ballot(rec != nullptr);
+  if (lane == 0) wave_hits[wave] = (uint32_t)__popcll(ballot);
+  __syncthreads();
+  if (rec == nullptr) return;
+  uint32_t pos = block_offsets[blockIdx.x] + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+  for (uint32_t w = 0; w < wave; ++w) pos += wave_hits[w];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    src_points[3 * (size_t)pos + k] = pts[3 * (size_t)i + k];
+    map_points[3 * (size_t)pos + k] = rec->mean[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    src_covs[9 * (size_t)pos + k] = covs[9 * (size_t)i + k];
+    map_covs[9 * (size_t)pos + k] = rec->cov[k];
+  }
+  if (src_index) src_index[pos] = i;
+}
+
+inline uint32_t blocks_for(uint64_t work, uint32_t block) { return (uint32_t)((work + block - 1) / block); }
+
+}  // namespace
+
+hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, bool fused_tail) {
+  if (fused_tail)
+    hipLaunchKernelGGL(iterate_kernel<true>, dim3(grid), dim3(kIterBlock), 0, s, args);
+  else
+    hipLaunchKernelGGL(iterate_kernel<false>, dim3(grid), dim3(kIterBlock), 0, s, args);
+  return hipGetLastError();
+}
+
+hipError_t launch_tail(hipStream_t s, const IterArgs& args) {
+  hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(64), 0, s, args);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
+                            uint32_t n, double* soa, uint64_t stride) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_scan_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, points_aos,
+                     covs_aos, n, soa, stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots) {
+  hipLaunchKernelGGL(table_clear_kernel, dim3(blocks_for(slots * 8, 256)), dim3(256), 0, s, table,
+                     slots);
+  return hipGetLastError();
+}
+
+hipError_t launch_upsert(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
+                         const int32_t* keys, const double* means, const double* covs,
+                         uint32_t* counters) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(upsert_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask, n, keys,
+                     means, covs, counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_erase(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
+                        const int32_t* keys, uint32_t* counters) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(erase_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask, n, keys,
+                     counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_rehash(hipStream_t s, const VoxelRecord* old_table, uint64_t old_slots,
+                         VoxelRecord* table, uint32_t mask, uint32_t* counters) {
+  hipLaunchKernelGGL(rehash_kernel, dim3(blocks_for(old_slots, 256)), dim3(256), 0, s, old_table,
+                     old_slots, table, mask, counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_voxel_index(hipStream_t s, const double* points_aos, uint32_t n, double voxel_size,
+                              int32_t* keys) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(voxel_index_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, points_aos, n,
+                     voxel_size, keys);
+  return hipGetLastError();
+}
+
+uint32_t match_blocks(uint32_t n) { return blocks_for(n, kMatchBlock); }
+
+hipError_t launch_match(hipStream_t s, const double* points_aos, const double* covs_aos, uint32_t n,
+                        const VoxelRecord* table, uint32_t mask, double voxel_size,
+                        uint32_t* block_counts, uint32_t* total, double* src_points,
+                        double* src_covs, double* map_points, double* map_covs, uint64_t* src_index) {
+  const uint32_t nb = match_blocks(n);
+  hipLaunchKernelGGL(match_count_kernel, dim3(nb), dim3(kMatchBlock), 0, s, points_aos, n, table,
+                     mask, voxel_size, block_counts);
+  hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nb, total);
+  hipLaunchKernelGGL(match_write_kernel, dim3(nb), dim3(kMatchBlock), 0, s, points_aos, covs_aos, n,
+                     table, mask, voxel_size, block_counts, src_points, src_covs, map_points,
+                     map_covs, src_index);
+  return hipGetLastError();
+}
+
+}  // namespace vgicp

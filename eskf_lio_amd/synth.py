@@ -1,0 +1,226 @@
+"""Synthetic voxel maps and scans for the VGICP registration path.
+
+Everything here is generated from a counter-based splitmix64 stream using only IEEE-exact
+operations (+, -, *, /, sqrt) on the per-element path, so the same seed produces the same bits on
+any host: fixtures under tests/golden/ store only *outputs* and regenerate their inputs from seeds.
+
+Shapes follow the reference's boundary types: points are N x 3 float64 rows (the memory of a
+std::vector<Eigen::Vector3d>), covariances are N x 9 float64 rows holding a COLUMN-major 3x3 each
+(the memory of a std::vector<Eigen::Matrix3d>) — reference include/ESKF_LIO/Registration.hpp:18-21.
+Covariances are `R diag(1, 1, 1e-2) R^T` for a uniformly random rotation R, the family the
+reference's preprocessing emits (reference include/ESKF_LIO/CloudPreprocessor.hpp:30-31,
+src/CloudPreprocessor.cpp:121-123); that equals `I - 0.99 n n^T` for a uniform unit vector n.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+MAP_SEED = 0x4D41505F31  # "MAP_1"
+SCAN_SEED = 0x5343414E5F31  # "SCAN_1"
+VOXEL_SIZE = 0.3  # reference config/hilti_config.yaml:37
+OCCUPANCY = 0.5
+
+_U64 = np.uint64
+_GAMMA = _U64(0x9E3779B97F4A7C15)
+_M1 = _U64(0xBF58476D1CE4E5B9)
+_M2 = _U64(0x94D049BB133111EB)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """One splitmix64 output step applied element-wise to uint64 counters."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(x, dtype=_U64) + _GAMMA).astype(_U64)
+        z = (z ^ (z >> _U64(30))) * _M1
+        z = (z ^ (z >> _U64(27))) * _M2
+        return z ^ (z >> _U64(31))
+
+
+def rand_u64(seed: int, stream: int, index: np.ndarray) -> np.ndarray:
+    """u64(seed, stream, i) = splitmix64(splitmix64(seed + stream) + i)."""
+    base = splitmix64(np.array([(seed + stream) & 0xFFFFFFFFFFFFFFFF], dtype=_U64))[0]
+    with np.errstate(over="ignore"):
+        return splitmix64(base + np.asarray(index, dtype=_U64))
+
+
+def rand_unit(seed: int, stream: int, index: np.ndarray) -> np.ndarray:
+    """Uniform doubles in [0, 1): top 53 bits scaled by 2^-53."""
+    return (rand_u64(seed, stream, index) >> _U64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _unit_vectors(seed: int, stream0: int, index: np.ndarray, tries: int = 24) -> np.ndarray:
+    """Marsaglia (1972) uniform points on S^2 without trigonometry: first accepted of `tries` draws."""
+    n = index.shape[0]
+    out = np.zeros((n, 3))
+    out[:, 2] = 1.0
+    pending = np.ones(n, dtype=bool)
+    for k in range(tries):
+        if not pending.any():
+            break
+        idx = index[pending]
+        a = 2.0 * rand_unit(seed, stream0 + 2 * k, idx) - 1.0
+        b = 2.0 * rand_unit(seed, stream0 + 2 * k + 1, idx) - 1.0
+        s = a * a + b * b
+        ok = (s < 1.0) & (s > 0.0)
+        root = np.sqrt(np.maximum(1.0 - s, 0.0))
+        vec = np.stack([2.0 * a * root, 2.0 * b * root, 1.0 - 2.0 * s], axis=1)
+        where = np.flatnonzero(pending)[ok]
+        out[where] = vec[ok]
+        pending[where] = False
+    return out
+
+
+def disc_covariances(seed: int, stream0: int, index: np.ndarray) -> np.ndarray:
+    """N x 9 exactly symmetric covariances I - 0.99 n n^T (column-major == row-major here)."""
+    nrm = _unit_vectors(seed, stream0, index)
+    cov = np.empty((index.shape[0], 9))
+    for r in range(3):
+        for c in range(r, 3):
+            v = (1.0 if r == c else 0.0) - 0.99 * (nrm[:, r] * nrm[:, c])
+            cov[:, r + 3 * c] = v
+            cov[:, c + 3 * r] = v
+    return cov
+
+
+def se3_to_SE3(xi) -> np.ndarray:
+    """4x4 pose from [rho; phi] by the reference's rule (reference src/Utils.cpp:40-63).
+
+    Scalar libm calls only; used to build guesses / ground-truth poses, not per-point data."""
+    rho = [float(v) for v in xi[:3]]
+    phi = [float(v) for v in xi[3:]]
+    sq = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]
+    angle = math.sqrt(sq)
+    k = phi if sq == 0.0 else [p / angle for p in phi]
+    s, c = math.sin(angle), math.cos(angle)
+    T = np.eye(4)
+    ck = [(1.0 - c) * v for v in k]
+    sk = [s * v for v in k]
+    T[0, 1] = ck[0] * k[1] - sk[2]
+    T[1, 0] = ck[0] * k[1] + sk[2]
+    T[0, 2] = ck[0] * k[2] + sk[1]
+    T[2, 0] = ck[0] * k[2] - sk[1]
+    T[1, 2] = ck[1] * k[2] - sk[0]
+    T[2, 1] = ck[1] * k[2] + sk[0]
+    for i in range(3):
+        T[i, i] = ck[i] * k[i] + c
+    if angle < 1e-6:
+        J = np.eye(3)
+    else:
+        f1 = s / angle
+        f2 = (1.0 - c) / angle
+        K = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
+        J = f1 * np.eye(3) + (1.0 - f1) * np.outer(k, k) + f2 * K
+    T[:3, 3] = J @ np.array(rho)
+    return T
+
+
+GUESS_XI = (0.05, -0.03, 0.02, 0.004, -0.003, 0.005)  # 5 cm / ~0.4 deg
+TRUE_XI = (0.06, -0.04, 0.03, 0.003, -0.002, 0.004)
+
+
+def default_guess() -> np.ndarray:
+    return se3_to_SE3(GUESS_XI)
+
+
+@dataclass
+class VoxelMap:
+    voxel_size: float
+    side: int  # cells per axis of the occupied cube
+    keys: np.ndarray  # V x 3 int32
+    means: np.ndarray  # V x 3 float64
+    covs: np.ndarray  # V x 9 float64, column-major 3x3
+
+    @property
+    def lo(self) -> float:
+        return -(self.side // 2) * self.voxel_size
+
+    @property
+    def hi(self) -> float:
+        return (self.side - self.side // 2) * self.voxel_size
+
+
+def map_side(num_voxels: int, occupancy: float = OCCUPANCY) -> int:
+    side = int(math.ceil((num_voxels / occupancy) ** (1.0 / 3.0)))
+    while side ** 3 < num_voxels / occupancy:
+        side += 1
+    return side
+
+
+def make_map(num_voxels: int, seed: int = MAP_SEED, voxel_size: float = VOXEL_SIZE) -> VoxelMap:
+    """The 'fixed synthetic voxel map': the `num_voxels` cells of a centred side^3 cube whose
+    splitmix64 hash is smallest are occupied; one mean inside each cell, one disc covariance."""
+    side = map_side(num_voxels)
+    cells = np.arange(side ** 3, dtype=np.uint64)
+    order = np.argsort(rand_u64(seed, 0, cells), kind="stable")[:num_voxels]
+    cell = np.sort(order).astype(np.int64)
+    half = side // 2
+    keys = np.stack([cell % side - half, (cell // side) % side - half, cell // (side * side) - half],
+                    axis=1).astype(np.int32)
+    idx = cell.astype(np.uint64)
+    u = np.stack([0.1 + 0.8 * rand_unit(seed, 1 + a, idx) for a in range(3)], axis=1)
+    means = (keys.astype(np.float64) + u) * voxel_size
+    covs = disc_covariances(seed, 16, idx)
+    return VoxelMap(voxel_size, side, keys, np.ascontiguousarray(means), covs)
+
+
+def make_uniform_scan(num_points: int, vmap: VoxelMap, seed: int = SCAN_SEED):
+    """The headline 'uniform-random' scan: points ~ U[lo, hi)^3 over the map extent."""
+    idx = np.arange(num_points, dtype=np.uint64)
+    span = vmap.hi - vmap.lo
+    pts = np.stack([vmap.lo + span * rand_unit(seed, 1 + a, idx) for a in range(3)], axis=1)
+    return np.ascontiguousarray(pts), disc_covariances(seed, 16, idx)
+
+
+def _apply(T: np.ndarray, pts: np.ndarray) -> np.ndarray:
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    return np.stack([T[r, 0] * x + T[r, 1] * y + T[r, 2] * z + T[r, 3] for r in range(3)], axis=1)
+
+
+def _conjugate(R: np.ndarray, covs: np.ndarray) -> np.ndarray:
+    """R C R^T on N x 9 column-major covariances with a fixed evaluation order."""
+    C = covs.reshape(-1, 3, 3).transpose(0, 2, 1)  # C[n, r, c]
+    RC = np.stack([np.stack([R[r, 0] * C[:, 0, c] + R[r, 1] * C[:, 1, c] + R[r, 2] * C[:, 2, c]
+                             for c in range(3)], axis=1) for r in range(3)], axis=1)
+    out = np.stack([np.stack([RC[:, r, 0] * R[c, 0] + RC[:, r, 1] * R[c, 1] + RC[:, r, 2] * R[c, 2]
+                              for c in range(3)], axis=1) for r in range(3)], axis=1)
+    return np.ascontiguousarray(out.transpose(0, 2, 1).reshape(-1, 9))
+
+
+def invert_pose(T: np.ndarray) -> np.ndarray:
+    Ti = np.eye(4)
+    Ti[:3, :3] = T[:3, :3].T
+    Ti[:3, 3] = -(T[:3, :3].T @ T[:3, 3])
+    return Ti
+
+
+def make_structured_scan(num_points: int, vmap: VoxelMap, seed: int = SCAN_SEED,
+                         noise: float = 0.01, true_xi=TRUE_XI):
+    """Parity/KAT scan: p_i = T_true^-1 (mean_v(i) + eps), C_i = R_true^T cov_v(i) R_true, with
+    v(i) drawn without replacement (num_points <= V) and eps ~ Irwin-Hall(12) * noise."""
+    V = vmap.keys.shape[0]
+    if num_points > V:
+        raise ValueError("structured scan needs num_points <= number of voxels")
+    vid = np.arange(V, dtype=np.uint64)
+    pick = np.sort(np.argsort(rand_u64(seed, 64, vid), kind="stable")[:num_points])
+    idx = np.arange(num_points, dtype=np.uint64)
+    eps = np.zeros((num_points, 3))
+    for a in range(3):
+        acc = np.zeros(num_points)
+        for k in range(12):
+            acc = acc + rand_unit(seed, 100 + 12 * a + k, idx)
+        eps[:, a] = (acc - 6.0) * noise
+    T_true = se3_to_SE3(true_xi)
+    T_inv = invert_pose(T_true)
+    pts = _apply(T_inv, vmap.means[pick] + eps)
+    covs = _conjugate(T_inv[:3, :3], vmap.covs[pick])
+    return np.ascontiguousarray(pts), covs, T_true
+
+
+# The configurations BASELINE.json names (C1, C2, C5): points, voxels.
+CONFIGS = {
+    "C1": (5_000, 50_000),
+    "C2": (100_000, 1_000_000),
+    "C5": (1_000_000, 10_000_000),
+}

@@ -1,0 +1,152 @@
+/* vgicp_hip.h — C ABI of the MI355X (gfx950) Voxelized-GICP registration module.
+ *
+ * This is the drop-in boundary for ONE path of LimHaeryong/ESKF_LIO (reference @ 2024_10_08):
+ * the scan-to-local-map registration ICP::align() and the hash-voxel lookup it drives.  Every
+ * entry point names the reference interface it replaces (file:line relative to the reference
+ * checkout).  Plain C: opaque handle, raw pointers and sizes, int status codes; no C++ types, no
+ * exceptions, nothing from PyTorch.  The C++ shim that keeps the reference's class signatures on top
+ * of this ABI is include/eskf_lio_shim/; the binding recipe is INTEGRATION.md.
+ *
+ * Memory conventions (identical to what the reference's containers expose through .data()):
+ *   points   n x 3 doubles, xyz per point            (std::vector<Eigen::Vector3d>)
+ *   covs     n x 9 doubles, COLUMN-major 3x3 each     (std::vector<Eigen::Matrix3d>)
+ *   pose     16 doubles, COLUMN-major 4x4            (Eigen::Isometry3d::matrix().data())
+ *   keys     n x 3 int32 voxel indices               (Eigen::Vector3i)
+ * The caller owns every host buffer, for the duration of the call only.  The context owns all
+ * device memory.  A context serves one caller thread at a time (the reference's align/update are
+ * never concurrent: src/main.cpp:68-70); distinct contexts are independent.
+ */
+#ifndef VGICP_HIP_H_
+#define VGICP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGICP_ABI_VERSION 1
+
+typedef struct vgicp_ctx vgicp_ctx;
+
+/* Status codes. The reference has no error reporting at all (no exceptions, no status; M == 0 and
+ * singular systems are unguarded: src/Registration.cpp:78), so every code but OK is an addition.
+ * Non-convergence is NOT an error (stats.converged = 0, pose still returned), as in the reference
+ * (src/Registration.cpp:30-34). */
+enum {
+  VGICP_OK = 0,
+  VGICP_ERR_BAD_ARGUMENT = 1,
+  VGICP_ERR_HIP = 2,          /* a HIP runtime call failed; text in vgicp_last_error() */
+  VGICP_ERR_RCCL = 3,         /* RCCL missing or a collective failed */
+  VGICP_ERR_TABLE_FULL = 4,   /* the device voxel table could not grow */
+  VGICP_ERR_DEGENERATE = 5,   /* the solved pose is not finite (singular normal equations) */
+  VGICP_ERR_NO_DEVICE = 6,    /* no usable gfx950 device */
+  VGICP_ERR_NOT_READY = 7     /* align before a map / scan exists */
+};
+
+/* Replaces the three YAML keys ICP's constructor reads (include/ESKF_LIO/Registration.hpp:23-28,
+ * config/hilti_config.yaml:50-53). */
+typedef struct vgicp_params {
+  int32_t max_iteration;
+  int32_t chunk_iterations;          /* iterations enqueued between host convergence checks;
+                                        0 = library default; >= max_iteration = never look */
+  double translation_sq_threshold;
+  double cosine_threshold;
+  uint32_t flags;                    /* VGICP_FLAG_* */
+  uint32_t reserved;
+} vgicp_params;
+
+#define VGICP_FLAG_PROFILE 1u        /* bracket every iteration launch with HIP events (kernel_ms) */
+#define VGICP_FLAG_NO_GRAPH 2u       /* enqueue plain launches instead of replaying a hipGraph */
+
+/* What the reference only prints or drops: per-call convergence (its converged_ member is sticky,
+ * include/ESKF_LIO/Registration.hpp:50) and the per-iteration correspondence counts. */
+typedef struct vgicp_stats {
+  int32_t iterations;        /* rounds executed, the converging round included */
+  int32_t converged;         /* this call only */
+  int32_t world_size;        /* ranks that contributed (1 without a communicator) */
+  int32_t launches;          /* iteration kernels enqueued (>= iterations with chunking) */
+  double seconds;            /* host wall time of the call */
+  double device_seconds;     /* HIP events on the module's stream around all iteration launches */
+  uint64_t* corr_count;      /* optional, max_iteration entries: matched points per iteration,
+                                summed over all ranks */
+  double* normal_eq;         /* optional, max_iteration x 27: 21 lower-triangle entries of JTJ
+                                (row by row) then the 6 entries of JTr, summed over all ranks */
+  float* kernel_ms;          /* optional, max_iteration entries, filled under VGICP_FLAG_PROFILE */
+} vgicp_stats;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int vgicp_abi_version(void);
+/* Bind a context to one HIP device (one process per GPU; device_id is the LOCAL ordinal). */
+int vgicp_create(int device_id, vgicp_ctx** out);
+int vgicp_destroy(vgicp_ctx* ctx);
+/* Text of the last failure on this context (never NULL; "" when none). ctx may be NULL for
+ * failures of vgicp_create itself. */
+const char* vgicp_last_error(const vgicp_ctx* ctx);
+/* name[0..name_len) receives the device's gcnArchName; cu_count its compute units. */
+int vgicp_device_info(const vgicp_ctx* ctx, char* name, size_t name_len, int32_t* cu_count,
+                      uint64_t* hbm_bytes);
+
+/* ---- device mirror of LocalMap's voxel grid -------------------------------------------------
+ * Replaces the read side of LocalMap::VoxelGrid (include/ESKF_LIO/LocalMap.hpp:25-26,63-89).  The
+ * host LocalMap stays authoritative for save()/visualise; after each updateLocalMap
+ * (src/LocalMap.cpp:47-72) it forwards the touched voxels as ONE upsert batch and the evicted keys
+ * as ONE erase batch so the mirror is current before the next align. */
+int vgicp_map_reset(vgicp_ctx* ctx, double voxel_size, size_t capacity_hint);
+/* Insert or overwrite voxels {key -> (mean, covariance)}.  Keys must be unique inside one batch. */
+int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double* means,
+                     const double* covs);
+/* Remove voxels (src/LocalMap.cpp:60-72); absent keys are ignored. */
+int vgicp_map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys);
+int vgicp_map_size(const vgicp_ctx* ctx, size_t* voxels, size_t* table_slots);
+
+/* ---- registration ---------------------------------------------------------------------------
+ * vgicp_align replaces ICP::align(cloud, localMap, guess) (src/Registration.cpp:7-35; declared
+ * include/ESKF_LIO/Registration.hpp:30-32) including the hot loop it drives:
+ * LocalMap::correspondenceMatching (src/LocalMap.cpp:78-118), ICP::computeTransform and
+ * computeJTJAndJTr (src/Registration.cpp:52-102), Open3D PointCloud::Transform (call sites
+ * src/Registration.cpp:13,27), Utils::se3ToSE3 (src/Utils.cpp:40-63) and ICP::convergenceCheck
+ * (src/Registration.cpp:37-50).  Inputs are not modified (the reference deep-copies the cloud,
+ * src/Registration.cpp:11; here the scan is copied to the device instead).
+ * With a communicator (below) every rank passes ITS shard of the scan and all ranks return the same
+ * pose. */
+int vgicp_align(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
+                const double guess[16], const vgicp_params* params, double out_pose[16],
+                vgicp_stats* stats);
+/* The same in two steps, for callers that keep a scan resident across several aligns (and for
+ * timing the path with its inputs already in HBM). */
+int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const double* covs);
+int vgicp_align_resident(vgicp_ctx* ctx, const double guess[16], const vgicp_params* params,
+                         double out_pose[16], vgicp_stats* stats);
+
+/* ---- single-step hooks (API parity + tests) -------------------------------------------------
+ * One iteration's normal equations at a given total pose, no solve: what the accumulation loop of
+ * ICP::computeTransform (src/Registration.cpp:60-76) leaves in JTJ / JTr, plus the match count.
+ * JTJ is written as a full column-major 6x6 (mirrored from its lower triangle). Local rank only. */
+int vgicp_accumulate(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
+                     const double pose[16], double JTJ[36], double JTr[6], uint64_t* count);
+/* LocalMap::correspondenceMatching (src/LocalMap.cpp:78-112) on points/covs given in the MAP frame:
+ * materialises (srcPoints, srcCovs, mapPoints, mapCovs) in ascending point order. Output arrays hold
+ * n entries each; src_index (optional) receives the matched point indices. */
+int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
+                double* src_points, double* src_covs, double* map_points, double* map_covs,
+                uint64_t* src_index, size_t* matched);
+/* LocalMap::getVoxelIndex (src/LocalMap.cpp:114-118) evaluated on the device. */
+int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* keys);
+
+/* ---- multi-GPU: one process per GPU, RCCL all-reduce of the normal equations ----------------
+ * Replaces the thread merge of ICP::computeTransform (src/Registration.cpp:71-75) across devices:
+ * per iteration one all-reduce (sum) of 28 doubles (21 + 6 + match count) over xGMI.  Rank 0 calls
+ * vgicp_comm_unique_id, the host side ships the 128 bytes to every rank (any transport), then every
+ * rank calls vgicp_comm_init.  The voxel map is replicated: every rank applies the same
+ * upsert/erase batches. */
+#define VGICP_UNIQUE_ID_BYTES 128
+int vgicp_comm_unique_id(vgicp_ctx* ctx, void* id128);
+int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128);
+int vgicp_comm_destroy(vgicp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGICP_HIP_H_ */

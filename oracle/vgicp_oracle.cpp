@@ -1,0 +1,617 @@
+// vgicp_oracle.cpp — CPU restatement of the reference's VGICP scan-to-map registration.
+//
+// TEST INFRASTRUCTURE ONLY (see vgicp_oracle.h).  PARITY UNPINNED: the reference holds no tests or
+// golden vectors for this path and cannot be built here; this file is pinned by analytic
+// known-answer tests and by an independent numpy restatement.
+//
+// What is restated, and from where (paths relative to the reference checkout):
+//   align loop            src/Registration.cpp:7-35
+//   convergence rule      src/Registration.cpp:37-50
+//   normal equations      src/Registration.cpp:52-81 (loop + LDLT solve), :83-102 (one residual)
+//   voxel lookup          src/LocalMap.cpp:78-118
+//   voxel statistics      include/ESKF_LIO/LocalMap.hpp:63-89, insertion loop src/LocalMap.cpp:47-58
+//   so(3)/se(3) helpers   src/Utils.cpp:5-11, 28-32, 40-63
+// Third-party arithmetic the reference calls but does not vendor (no pinned version; Eigen must be
+// >= 3.4, Open3D >= 0.13), restated from the published algorithms:
+//   Eigen  Matrix3d::inverse (cofactors), LDLT<6x6> with diagonal pivoting + pseudo-inverse of D,
+//          AngleAxisd::toRotationMatrix, normalized() (no-op on the zero vector), Isometry product
+//   Open3D PointCloud::Transform (homogeneous product then /w; covariance R C R^T; serial loops),
+//          utility::hash_eigen (boost-style combiner; affects iteration order only)
+//
+// Built by oracle/Makefile with the reference's flags: -O3, OpenMP, no -march (CMakeLists.txt:6,19,41),
+// so there is no FMA contraction on x86-64 and every product/sum below rounds once, as in Eigen.
+#include "vgicp_oracle.h"
+
+#include <omp.h>
+
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace {
+
+struct V3 {
+  double x, y, z;
+};
+struct M3 {
+  double a[9];  // column-major: a[r + 3c]
+  double& operator()(int r, int c) { return a[r + 3 * c]; }
+  double operator()(int r, int c) const { return a[r + 3 * c]; }
+};
+struct M4 {
+  double a[16];  // column-major: a[r + 4c]
+  double& operator()(int r, int c) { return a[r + 4 * c]; }
+  double operator()(int r, int c) const { return a[r + 4 * c]; }
+};
+using M6 = std::array<double, 36>;  // column-major 6x6
+using V6 = std::array<double, 6>;
+
+static_assert(sizeof(V3) == 24 && sizeof(M3) == 72, "layout must match Eigen's dense storage");
+
+inline M3 mul(const M3& A, const M3& B) {
+  M3 C;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) {
+      double s = A(r, 0) * B(0, c);
+      s += A(r, 1) * B(1, c);
+      s += A(r, 2) * B(2, c);
+      C(r, c) = s;
+    }
+  return C;
+}
+inline M3 transpose(const M3& A) {
+  M3 T;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) T(r, c) = A(c, r);
+  return T;
+}
+inline M3 add(const M3& A, const M3& B) {
+  M3 C;
+  for (int i = 0; i < 9; ++i) C.a[i] = A.a[i] + B.a[i];
+  return C;
+}
+inline V3 mul(const M3& A, const V3& v) {
+  return {A(0, 0) * v.x + A(0, 1) * v.y + A(0, 2) * v.z,
+          A(1, 0) * v.x + A(1, 1) * v.y + A(1, 2) * v.z,
+          A(2, 0) * v.x + A(2, 1) * v.y + A(2, 2) * v.z};
+}
+inline M3 identity3() { return M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+inline M4 identity4() {
+  M4 I{};
+  I(0, 0) = I(1, 1) = I(2, 2) = I(3, 3) = 1.0;
+  return I;
+}
+inline M3 rotation_of(const M4& T) {
+  M3 R;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) R(r, c) = T(r, c);
+  return R;
+}
+
+// Utils::skewSymmetric — src/Utils.cpp:5-11
+inline M3 hat(const V3& v) {
+  M3 S{};
+  S(0, 1) = -v.z; S(0, 2) = v.y;
+  S(1, 0) = v.z;  S(1, 2) = -v.x;
+  S(2, 0) = -v.y; S(2, 1) = v.x;
+  return S;
+}
+
+// Eigen fixed-size 3x3 inverse: adjugate times 1/det, det expanded along column 0.
+inline double cof(const M3& m, int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m(i1, j1) * m(i2, j2) - m(i1, j2) * m(i2, j1);
+}
+inline M3 inverse(const M3& m) {
+  const double k0 = cof(m, 0, 0), k1 = cof(m, 1, 0), k2 = cof(m, 2, 0);
+  const double det = k0 * m(0, 0) + k1 * m(1, 0) + k2 * m(2, 0);
+  const double invdet = 1.0 / det;
+  M3 R;
+  R(0, 0) = k0 * invdet; R(0, 1) = k1 * invdet; R(0, 2) = k2 * invdet;
+  R(1, 0) = cof(m, 0, 1) * invdet; R(1, 1) = cof(m, 1, 1) * invdet; R(1, 2) = cof(m, 2, 1) * invdet;
+  R(2, 0) = cof(m, 0, 2) * invdet; R(2, 1) = cof(m, 1, 2) * invdet; R(2, 2) = cof(m, 2, 2) * invdet;
+  return R;
+}
+
+// Isometry3d * Isometry3d (affine-compact product, last row stays 0 0 0 1).
+inline M4 compose(const M4& A, const M4& B) {
+  M4 C = identity4();
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 3; ++r) {
+      double s = A(r, 0) * B(0, c);
+      s += A(r, 1) * B(1, c);
+      s += A(r, 2) * B(2, c);
+      if (c == 3) s += A(r, 3);
+      C(r, c) = s;
+    }
+  return C;
+}
+
+// AngleAxisd(r.norm(), r.normalized()).toRotationMatrix() — src/Utils.cpp:28-32
+inline M3 rotation_from_vector(const V3& r) {
+  const double sq = r.x * r.x + r.y * r.y + r.z * r.z;
+  const double angle = std::sqrt(sq);
+  V3 k = r;
+  if (sq > 0.0) k = {r.x / angle, r.y / angle, r.z / angle};
+  const double s = std::sin(angle), c = std::cos(angle);
+  const V3 sk = {s * k.x, s * k.y, s * k.z};
+  const V3 ck = {(1.0 - c) * k.x, (1.0 - c) * k.y, (1.0 - c) * k.z};
+  M3 R;
+  double t;
+  t = ck.x * k.y; R(0, 1) = t - sk.z; R(1, 0) = t + sk.z;
+  t = ck.x * k.z; R(0, 2) = t + sk.y; R(2, 0) = t - sk.y;
+  t = ck.y * k.z; R(1, 2) = t - sk.x; R(2, 1) = t + sk.x;
+  R(0, 0) = ck.x * k.x + c;
+  R(1, 1) = ck.y * k.y + c;
+  R(2, 2) = ck.z * k.z + c;
+  return R;
+}
+
+// Utils::computeJ — src/Utils.cpp:40-54
+inline M3 so3_left_jacobian(const V3& r) {
+  const double sq = r.x * r.x + r.y * r.y + r.z * r.z;
+  const double angle = std::sqrt(sq);
+  if (angle < 1e-6) return identity3();
+  const V3 k = {r.x / angle, r.y / angle, r.z / angle};
+  const double f1 = std::sin(angle) / angle;
+  const double f2 = (1.0 - std::cos(angle)) / angle;
+  const double kk[3] = {k.x, k.y, k.z};
+  const M3 K = hat(k);
+  M3 J;
+  for (int c = 0; c < 3; ++c)
+    for (int rr = 0; rr < 3; ++rr)
+      J(rr, c) = f1 * (rr == c ? 1.0 : 0.0) + ((1.0 - f1) * kk[rr]) * kk[c] + f2 * K(rr, c);
+  return J;
+}
+
+// Utils::se3ToSE3 — src/Utils.cpp:56-63; se3 = [rho; phi]
+inline M4 exp_se3(const V6& xi) {
+  const V3 rho = {xi[0], xi[1], xi[2]}, phi = {xi[3], xi[4], xi[5]};
+  const M3 J = so3_left_jacobian(phi);
+  const V3 t = mul(J, rho);
+  const M3 R = rotation_from_vector(phi);
+  M4 T = identity4();
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) T(r, c) = R(r, c);
+  T(0, 3) = t.x; T(1, 3) = t.y; T(2, 3) = t.z;
+  return T;
+}
+
+// Eigen LDLT<Matrix<double,6,6>, Lower>::compute + solve (unblocked, diagonal pivoting).
+V6 ldlt_solve(const M6& Ain, const V6& rhs) {
+  constexpr int n = 6;
+  double A[n][n];
+  for (int c = 0; c < n; ++c)
+    for (int r = 0; r < n; ++r) A[r][c] = Ain[r + 6 * c];
+  int tr[n];
+  for (int i = 0; i < n; ++i) tr[i] = i;
+  for (int k = 0; k < n; ++k) {
+    int big = k;
+    double bigv = std::fabs(A[k][k]);
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(A[i][i]) > bigv) { bigv = std::fabs(A[i][i]); big = i; }
+    tr[k] = big;
+    if (big != k) {
+      for (int j = 0; j < k; ++j) std::swap(A[k][j], A[big][j]);
+      for (int i = big + 1; i < n; ++i) std::swap(A[i][k], A[i][big]);
+      std::swap(A[k][k], A[big][big]);
+      for (int i = k + 1; i < big; ++i) std::swap(A[i][k], A[big][i]);
+    }
+    if (k > 0) {
+      double temp[n];
+      for (int j = 0; j < k; ++j) temp[j] = A[j][j] * A[k][j];
+      double dot = 0.0;
+      for (int j = 0; j < k; ++j) dot += A[k][j] * temp[j];
+      A[k][k] -= dot;
+      for (int i = k + 1; i < n; ++i) {
+        double d = 0.0;
+        for (int j = 0; j < k; ++j) d += A[i][j] * temp[j];
+        A[i][k] -= d;
+      }
+    }
+    const double pivot = A[k][k];
+    const bool ok = std::fabs(pivot) > 0.0;
+    if (k == 0 && !ok) {
+      for (int j = 0; j < n; ++j) tr[j] = j;
+      break;
+    }
+    if (ok)
+      for (int i = k + 1; i < n; ++i) A[i][k] /= pivot;
+  }
+  V6 x = rhs;
+  for (int k = 0; k < n; ++k) std::swap(x[k], x[tr[k]]);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j) x[i] -= A[i][j] * x[j];
+  const double tol = std::numeric_limits<double>::min();
+  for (int i = 0; i < n; ++i) x[i] = std::fabs(A[i][i]) > tol ? x[i] / A[i][i] : 0.0;
+  for (int i = n - 1; i >= 0; --i)
+    for (int j = i + 1; j < n; ++j) x[i] -= A[j][i] * x[j];
+  for (int k = n - 1; k >= 0; --k) std::swap(x[k], x[tr[k]]);
+  return x;
+}
+
+// ICP::computeJTJAndJTr — src/Registration.cpp:83-102.  J = [I | -hat(p)], dense products as Eigen
+// evaluates them: JT = J^T * inv(cov) (6x3), JTJ = JT * J (6x6), JTr = JT * (p - mu).
+void residual_blocks(const V3& p, const V3& mu, const M3& cov, M6& JTJ, V6& JTr) {
+  double J[3][6] = {};
+  const M3 S = hat(p);
+  for (int r = 0; r < 3; ++r) {
+    J[r][r] = 1.0;
+    for (int c = 0; c < 3; ++c) J[r][3 + c] = -S(r, c);
+  }
+  const M3 W = inverse(cov);
+  double JT[6][3];
+  for (int i = 0; i < 6; ++i)
+    for (int c = 0; c < 3; ++c) {
+      double s = J[0][i] * W(0, c);
+      s += J[1][i] * W(1, c);
+      s += J[2][i] * W(2, c);
+      JT[i][c] = s;
+    }
+  const double res[3] = {p.x - mu.x, p.y - mu.y, p.z - mu.z};
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) {
+      double s = JT[i][0] * J[0][j];
+      s += JT[i][1] * J[1][j];
+      s += JT[i][2] * J[2][j];
+      JTJ[i + 6 * j] = s;
+    }
+    double s = JT[i][0] * res[0];
+    s += JT[i][1] * res[1];
+    s += JT[i][2] * res[2];
+    JTr[i] = s;
+  }
+}
+
+// ICP::convergenceCheck — src/Registration.cpp:37-50
+bool step_converged(const M4& step, double cosine_threshold, double translation_sq_threshold) {
+  const double cosine = 0.5 * ((step(0, 0) + step(1, 1) + step(2, 2)) - 1.0);
+  if (cosine < cosine_threshold) return false;
+  const double tsq = step(0, 3) * step(0, 3) + step(1, 3) * step(1, 3) + step(2, 3) * step(2, 3);
+  if (tsq > translation_sq_threshold) return false;
+  return true;
+}
+
+// Open3D PointCloud::Transform, serial as upstream.
+void transform_cloud(std::vector<V3>& pts, std::vector<M3>& covs, const M4& T) {
+  for (auto& p : pts) {
+    double q[4];
+    for (int r = 0; r < 4; ++r) q[r] = T(r, 0) * p.x + T(r, 1) * p.y + T(r, 2) * p.z + T(r, 3) * 1.0;
+    p = {q[0] / q[3], q[1] / q[3], q[2] / q[3]};
+  }
+  const M3 R = rotation_of(T), Rt = transpose(R);
+  for (auto& C : covs) C = mul(mul(R, C), Rt);
+}
+
+struct Key {
+  int32_t i, j, k;
+  bool operator==(const Key& o) const { return i == o.i && j == o.j && k == o.k; }
+};
+// open3d::utility::hash_eigen<Vector3i>: boost-style combine of std::hash<int> over the 3 entries.
+struct KeyHash {
+  size_t operator()(const Key& key) const {
+    size_t seed = 0;
+    const int32_t e[3] = {key.i, key.j, key.k};
+    for (int n = 0; n < 3; ++n)
+      seed ^= std::hash<int>()(e[n]) + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+    return seed;
+  }
+};
+
+// LocalMap::Voxel — include/ESKF_LIO/LocalMap.hpp:63-89
+struct Voxel {
+  size_t cap, count;
+  std::vector<V3> samples;
+  V3 mean;
+  M3 cov;
+  Voxel(size_t cap_, const V3& p, const M3& C) : cap(cap_), count(1), mean(p), cov(C) {
+    samples.reserve(cap);
+    samples.push_back(p);
+  }
+  void add(const V3& p, const M3& C) {
+    if (count >= cap) return;
+    samples.push_back(p);
+    const double n = static_cast<double>(count), n1 = static_cast<double>(count + 1);
+    mean = {(n * mean.x + p.x) / n1, (n * mean.y + p.y) / n1, (n * mean.z + p.z) / n1};
+    for (int e = 0; e < 9; ++e) cov.a[e] = (n * cov.a[e] + C.a[e]) / n1;
+    ++count;
+  }
+};
+
+inline Key voxel_key(const V3& p, double voxel_size) {
+  return {static_cast<int32_t>(std::floor(p.x / voxel_size)),
+          static_cast<int32_t>(std::floor(p.y / voxel_size)),
+          static_cast<int32_t>(std::floor(p.z / voxel_size))};
+}
+
+}  // namespace
+
+struct oracle_map {
+  double voxel_size;
+  size_t cap;
+  std::unordered_map<Key, Voxel, KeyHash> grid;
+};
+
+namespace {
+
+struct Matches {
+  std::vector<V3> src_pts, map_pts;
+  std::vector<M3> src_covs, map_covs;
+};
+
+// LocalMap::correspondenceMatching as the reference runs it (thread-private buffers, arrival-order
+// concatenation under a critical section).
+Matches match_faithful(const oracle_map& map, const std::vector<V3>& pts, const std::vector<M3>& covs) {
+  Matches out;
+  out.src_pts.reserve(pts.size());
+  out.src_covs.reserve(pts.size());
+  out.map_pts.reserve(pts.size());
+  out.map_covs.reserve(pts.size());
+#pragma omp parallel
+  {
+    Matches mine;
+#pragma omp for nowait
+    for (size_t i = 0; i < pts.size(); ++i) {
+      auto it = map.grid.find(voxel_key(pts[i], map.voxel_size));
+      if (it == map.grid.cend()) continue;
+      mine.src_pts.push_back(pts[i]);
+      mine.src_covs.push_back(covs[i]);
+      mine.map_pts.push_back(it->second.mean);
+      mine.map_covs.push_back(it->second.cov);
+    }
+#pragma omp critical
+    {
+      out.src_pts.insert(out.src_pts.end(), mine.src_pts.begin(), mine.src_pts.end());
+      out.src_covs.insert(out.src_covs.end(), mine.src_covs.begin(), mine.src_covs.end());
+      out.map_pts.insert(out.map_pts.end(), mine.map_pts.begin(), mine.map_pts.end());
+      out.map_covs.insert(out.map_covs.end(), mine.map_covs.begin(), mine.map_covs.end());
+    }
+  }
+  return out;
+}
+
+void sum_faithful(const Matches& m, M6& JTJ, V6& JTr) {
+  JTJ.fill(0.0);
+  JTr.fill(0.0);
+  const size_t count = m.src_pts.size();
+#pragma omp parallel
+  {
+    M6 accJ;
+    V6 accr;
+    accJ.fill(0.0);
+    accr.fill(0.0);
+#pragma omp for nowait
+    for (size_t i = 0; i < count; ++i) {
+      M6 Ji;
+      V6 ri;
+      residual_blocks(m.src_pts[i], m.map_pts[i], add(m.src_covs[i], m.map_covs[i]), Ji, ri);
+      for (int e = 0; e < 36; ++e) accJ[e] += Ji[e];
+      for (int e = 0; e < 6; ++e) accr[e] += ri[e];
+    }
+#pragma omp critical
+    {
+      for (int e = 0; e < 36; ++e) JTJ[e] += accJ[e];
+      for (int e = 0; e < 6; ++e) JTr[e] += accr[e];
+    }
+  }
+}
+
+// Same arithmetic, one pass in ascending point order, nothing materialised.
+size_t sum_deterministic(const oracle_map& map, const V3* pts, const M3* covs, size_t n, M6& JTJ,
+                         V6& JTr) {
+  JTJ.fill(0.0);
+  JTr.fill(0.0);
+  size_t hits = 0;
+  for (size_t i = 0; i < n; ++i) {
+    auto it = map.grid.find(voxel_key(pts[i], map.voxel_size));
+    if (it == map.grid.cend()) continue;
+    M6 Ji;
+    V6 ri;
+    residual_blocks(pts[i], it->second.mean, add(covs[i], it->second.cov), Ji, ri);
+    for (int e = 0; e < 36; ++e) JTJ[e] += Ji[e];
+    for (int e = 0; e < 6; ++e) JTr[e] += ri[e];
+    ++hits;
+  }
+  return hits;
+}
+
+M4 solve_step(const M6& JTJ, const V6& JTr, V6* se3_out) {
+  V6 neg;
+  for (int e = 0; e < 6; ++e) neg[e] = -JTr[e];
+  const V6 se3 = ldlt_solve(JTJ, neg);
+  if (se3_out) *se3_out = se3;
+  return exp_se3(se3);
+}
+
+M4 load4(const double* p) {
+  M4 T;
+  std::memcpy(T.a, p, sizeof T.a);
+  return T;
+}
+
+}  // namespace
+
+extern "C" {
+
+oracle_map* oracle_map_create(double voxel_size, size_t max_points_per_voxel) {
+  auto* m = new oracle_map;
+  m->voxel_size = voxel_size;
+  m->cap = max_points_per_voxel;
+  return m;
+}
+void oracle_map_destroy(oracle_map* map) { delete map; }
+size_t oracle_map_size(const oracle_map* map) { return map->grid.size(); }
+
+void oracle_map_insert(oracle_map* map, size_t n, const double* points, const double* covs) {
+  const V3* P = reinterpret_cast<const V3*>(points);
+  const M3* C = reinterpret_cast<const M3*>(covs);
+  for (size_t i = 0; i < n; ++i) {
+    const Key key = voxel_key(P[i], map->voxel_size);
+    auto it = map->grid.find(key);
+    if (it == map->grid.end()) {
+      map->grid.emplace(key, Voxel(map->cap, P[i], C[i]));
+    } else {
+      it->second.add(P[i], C[i]);
+    }
+  }
+}
+
+size_t oracle_map_export(const oracle_map* map, size_t capacity, int32_t* keys, double* means,
+                         double* covs, uint64_t* counts) {
+  size_t w = 0;
+  for (const auto& kv : map->grid) {
+    if (w == capacity) break;
+    keys[3 * w + 0] = kv.first.i;
+    keys[3 * w + 1] = kv.first.j;
+    keys[3 * w + 2] = kv.first.k;
+    std::memcpy(means + 3 * w, &kv.second.mean, 24);
+    std::memcpy(covs + 9 * w, kv.second.cov.a, 72);
+    if (counts) counts[w] = kv.second.count;
+    ++w;
+  }
+  return w;
+}
+
+void oracle_voxel_index(double voxel_size, size_t n, const double* points, int32_t* keys) {
+  const V3* P = reinterpret_cast<const V3*>(points);
+  for (size_t i = 0; i < n; ++i) {
+    const Key k = voxel_key(P[i], voxel_size);
+    keys[3 * i] = k.i;
+    keys[3 * i + 1] = k.j;
+    keys[3 * i + 2] = k.k;
+  }
+}
+
+size_t oracle_match(const oracle_map* map, size_t n, const double* points, const double* covs,
+                    double* src_points, double* src_covs, double* map_points, double* map_covs,
+                    uint64_t* src_index) {
+  const V3* P = reinterpret_cast<const V3*>(points);
+  const M3* C = reinterpret_cast<const M3*>(covs);
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i) {
+    auto it = map->grid.find(voxel_key(P[i], map->voxel_size));
+    if (it == map->grid.cend()) continue;
+    std::memcpy(src_points + 3 * m, &P[i], 24);
+    std::memcpy(src_covs + 9 * m, &C[i], 72);
+    std::memcpy(map_points + 3 * m, &it->second.mean, 24);
+    std::memcpy(map_covs + 9 * m, it->second.cov.a, 72);
+    if (src_index) src_index[m] = i;
+    ++m;
+  }
+  return m;
+}
+
+void oracle_jtj_jtr(const double src_point[3], const double map_point[3], const double cov[9],
+                    double JTJ[36], double JTr[6]) {
+  V3 p, mu;
+  M3 C;
+  std::memcpy(&p, src_point, 24);
+  std::memcpy(&mu, map_point, 24);
+  std::memcpy(C.a, cov, 72);
+  M6 J;
+  V6 r;
+  residual_blocks(p, mu, C, J, r);
+  std::memcpy(JTJ, J.data(), sizeof(double) * 36);
+  std::memcpy(JTr, r.data(), sizeof(double) * 6);
+}
+
+size_t oracle_accumulate(const oracle_map* map, size_t n, const double* points, const double* covs,
+                         double JTJ[36], double JTr[6]) {
+  M6 J;
+  V6 r;
+  const size_t m = sum_deterministic(*map, reinterpret_cast<const V3*>(points),
+                                     reinterpret_cast<const M3*>(covs), n, J, r);
+  std::memcpy(JTJ, J.data(), sizeof(double) * 36);
+  std::memcpy(JTr, r.data(), sizeof(double) * 6);
+  return m;
+}
+
+void oracle_solve_step(const double JTJ[36], const double JTr[6], double se3[6], double step16[16]) {
+  M6 J;
+  V6 r, xi;
+  std::memcpy(J.data(), JTJ, sizeof(double) * 36);
+  std::memcpy(r.data(), JTr, sizeof(double) * 6);
+  const M4 T = solve_step(J, r, &xi);
+  if (se3) std::memcpy(se3, xi.data(), sizeof(double) * 6);
+  std::memcpy(step16, T.a, sizeof T.a);
+}
+
+void oracle_se3_to_SE3(const double se3[6], double out16[16]) {
+  V6 xi;
+  std::memcpy(xi.data(), se3, sizeof(double) * 6);
+  const M4 T = exp_se3(xi);
+  std::memcpy(out16, T.a, sizeof T.a);
+}
+
+int oracle_convergence_check(const double step16[16], double cosine_threshold,
+                             double translation_sq_threshold) {
+  return step_converged(load4(step16), cosine_threshold, translation_sq_threshold) ? 1 : 0;
+}
+
+void oracle_transform(size_t n, double* points, double* covs, const double T16[16]) {
+  std::vector<V3> P(n);
+  std::vector<M3> C(n);
+  std::memcpy(P.data(), points, n * 24);
+  std::memcpy(C.data(), covs, n * 72);
+  transform_cloud(P, C, load4(T16));
+  std::memcpy(points, P.data(), n * 24);
+  std::memcpy(covs, C.data(), n * 72);
+}
+
+int oracle_align(const oracle_map* map, size_t n, const double* points, const double* covs,
+                 const double guess16[16], int max_iteration, double translation_sq_threshold,
+                 double cosine_threshold, int mode, double out_pose16[16],
+                 oracle_align_stats* stats) {
+  const double t0 = omp_get_wtime();
+  // working copy of the scan, moved by the guess first
+  std::vector<V3> pts(n);
+  std::vector<M3> cvs(n);
+  std::memcpy(pts.data(), points, n * 24);
+  std::memcpy(cvs.data(), covs, n * 72);
+  M4 total = load4(guess16);
+  transform_cloud(pts, cvs, total);
+
+  bool done = false;
+  int rounds = 0;
+  for (int it = 0; it < max_iteration; ++it) {
+    M6 JTJ;
+    V6 JTr;
+    size_t hits;
+    if (mode == ORACLE_FAITHFUL) {
+      Matches m = match_faithful(*map, pts, cvs);
+      hits = m.src_pts.size();
+      sum_faithful(m, JTJ, JTr);
+    } else {
+      hits = sum_deterministic(*map, pts.data(), cvs.data(), n, JTJ, JTr);
+    }
+    if (stats) {
+      if (stats->corr_count) stats->corr_count[it] = hits;
+      if (stats->JTJ) std::memcpy(stats->JTJ + 36 * it, JTJ.data(), sizeof(double) * 36);
+      if (stats->JTr) std::memcpy(stats->JTr + 6 * it, JTr.data(), sizeof(double) * 6);
+    }
+    const M4 step = solve_step(JTJ, JTr, nullptr);
+    total = compose(step, total);
+    rounds = it + 1;
+    if (step_converged(step, cosine_threshold, translation_sq_threshold)) {
+      done = true;
+      break;
+    }
+    transform_cloud(pts, cvs, step);
+  }
+  std::memcpy(out_pose16, total.a, sizeof total.a);
+  if (stats) {
+    stats->iterations = rounds;
+    stats->converged = done ? 1 : 0;
+    stats->threads = (mode == ORACLE_FAITHFUL) ? omp_get_max_threads() : 1;
+    stats->seconds = omp_get_wtime() - t0;
+  }
+  return 0;
+}
+
+int oracle_max_threads(void) { return omp_get_max_threads(); }
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+/* vgicp_oracle.h — C interface of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a CPU restatement of the reference's VGICP hot path, used as
+ * the checker in tests/, in __graft_entry__.smoke() and as bench.py's `cpu_baseline` leg.  The
+ * product (eskf_lio_amd/, include/) never includes, links or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference (LimHaeryong/ESKF_LIO @ 2024_10_08) ships no tests, golden
+ * vectors or fixtures for this path, and it cannot be compiled here (Eigen, Open3D, yaml-cpp and
+ * ROS 2 are absent; no network), so the oracle is pinned only by analytic known-answer tests and by
+ * an independent numpy restatement (oracle/vgicp_numpy.py); see DESIGN.md "Oracle".
+ *
+ * All matrices are column-major, all points are xyz triples of doubles, exactly the memory the
+ * reference's std::vector<Eigen::Vector3d> / std::vector<Eigen::Matrix3d> expose through .data().
+ */
+#ifndef VGICP_ORACLE_H_
+#define VGICP_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_map oracle_map;
+
+/* reference: LocalMap(double voxelSize, size_t maxNumPointsPerVoxel, bool) — LocalMap.hpp:54-61 */
+oracle_map* oracle_map_create(double voxel_size, size_t max_points_per_voxel);
+void oracle_map_destroy(oracle_map* map);
+size_t oracle_map_size(const oracle_map* map);
+
+/* The insertion loop of LocalMap::updateLocalMap (LocalMap.cpp:47-58) with Voxel's constructor and
+ * Voxel::addPoint (LocalMap.hpp:72-87): points are taken as already in the world frame. */
+void oracle_map_insert(oracle_map* map, size_t n, const double* points, const double* covs);
+
+/* Dump every voxel: keys n x 3 int32, means n x 3, covs n x 9, counts n (numPoints). Order is the
+ * container's iteration order (unspecified). Returns the number of voxels written (<= capacity). */
+size_t oracle_map_export(const oracle_map* map, size_t capacity, int32_t* keys, double* means,
+                         double* covs, uint64_t* counts);
+
+/* LocalMap::getVoxelIndex (LocalMap.cpp:114-118): floor(point / voxelSize) cast to int32. */
+void oracle_voxel_index(double voxel_size, size_t n, const double* points, int32_t* keys);
+
+/* LocalMap::correspondenceMatching (LocalMap.cpp:78-112), results in ascending point order.
+ * Output arrays must hold n entries; returns M. src_index (optional) receives the point indices. */
+size_t oracle_match(const oracle_map* map, size_t n, const double* points, const double* covs,
+                    double* src_points, double* src_covs, double* map_points, double* map_covs,
+                    uint64_t* src_index);
+
+/* ICP::computeJTJAndJTr (Registration.cpp:83-102) for one correspondence; cov = srcCov + mapCov. */
+void oracle_jtj_jtr(const double src_point[3], const double map_point[3], const double cov[9],
+                    double JTJ[36], double JTr[6]);
+
+/* One iteration's normal equations for points/covs ALREADY transformed into the map frame:
+ * correspondenceMatching + the accumulation loop of ICP::computeTransform (Registration.cpp:52-76),
+ * summed in ascending point order (deterministic). Returns M. */
+size_t oracle_accumulate(const oracle_map* map, size_t n, const double* points, const double* covs,
+                         double JTJ[36], double JTr[6]);
+
+/* JTJ.ldlt().solve(-JTr) then Utils::se3ToSE3 (Registration.cpp:78-79, Utils.cpp:40-63). */
+void oracle_solve_step(const double JTJ[36], const double JTr[6], double se3[6], double step16[16]);
+void oracle_se3_to_SE3(const double se3[6], double out16[16]);
+int oracle_convergence_check(const double step16[16], double cosine_threshold,
+                             double translation_sq_threshold);
+/* Open3D PointCloud::Transform: p <- (T [p;1]).xyz / w, C <- R C R^T, in place. */
+void oracle_transform(size_t n, double* points, double* covs, const double T16[16]);
+
+typedef struct oracle_align_stats {
+  int32_t iterations;       /* rounds executed (the converging round included) */
+  int32_t converged;        /* per call, not sticky */
+  int32_t threads;          /* OpenMP threads used */
+  int32_t reserved;
+  double seconds;           /* omp_get_wtime() around the whole align */
+  uint64_t* corr_count;     /* optional, max_iteration entries */
+  double* JTJ;              /* optional, max_iteration x 36 */
+  double* JTr;              /* optional, max_iteration x 6 */
+} oracle_align_stats;
+
+enum { ORACLE_DETERMINISTIC = 0, ORACLE_FAITHFUL = 1 };
+
+/* ICP::align (Registration.cpp:7-35).
+ * mode ORACLE_DETERMINISTIC: single pass in point order (bit-reproducible, thread-count free).
+ * mode ORACLE_FAITHFUL: the reference's structure — OpenMP regions with thread-private buffers and
+ *   critical-section merges, materialised correspondences, serial in-place transforms. */
+int oracle_align(const oracle_map* map, size_t n, const double* points, const double* covs,
+                 const double guess16[16], int max_iteration, double translation_sq_threshold,
+                 double cosine_threshold, int mode, double out_pose16[16],
+                 oracle_align_stats* stats);
+
+int oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGICP_ORACLE_H_ */
