@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -85,13 +86,15 @@ struct vgicp_ctx {
   bool scan_ready = false;
 
   // align state
-  AlignState* d_state = nullptr;
+  AlignState* d_state = nullptr;  // two, ping-pong: launch j reads [j&1], writes [(j+1)&1]
   AlignState* h_state = nullptr;  // pinned, kMaxChunksInFlight + 1 slots
-  double* d_partials = nullptr;
-  double* d_sums = nullptr;
+  double* d_rows[2] = {nullptr, nullptr};  // partial rows, ping-pong like the state
+  double* d_sums = nullptr;       // one row: the all-reduce message (multi-GPU)
+  int iter_block = 512;           // threads per workgroup of the iteration kernel (measured best at C2)
   double* d_log = nullptr;
   double* h_log = nullptr;  // pinned
   int log_capacity = 0;     // iterations
+  uint64_t* d_stamps = nullptr;  // only with VGICP_DEBUG_STAMPS=1
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_chunk[kMaxChunksInFlight] = {nullptr, nullptr};
   std::vector<hipEvent_t> ev_prof;
@@ -191,23 +194,23 @@ int ensure_log(vgicp_ctx* ctx, int iterations) {
   return VGICP_OK;
 }
 
-uint32_t iterate_grid(uint32_t n) {
-  const uint32_t want = (n + kIterBlock - 1) / kIterBlock;
+uint32_t iterate_grid(const vgicp_ctx* ctx) {
+  const uint32_t block = (uint32_t)ctx->iter_block;
+  const uint32_t want = (ctx->n + block - 1) / block;
   return std::min<uint32_t>(std::max<uint32_t>(want, 1), kMaxIterBlocks);
 }
 
-IterArgs make_args(const vgicp_ctx* ctx) {
+IterArgs base_args(const vgicp_ctx* ctx) {
   IterArgs a;
+  std::memset(&a, 0, sizeof a);
   a.scan = ctx->d_scan;
   a.stride = ctx->stride;
   a.n = ctx->n;
   a.mask = (uint32_t)(ctx->slots - 1);
   a.table = ctx->table;
   a.voxel_size = ctx->voxel_size;
-  a.partials = ctx->d_partials;
-  a.sums = ctx->d_sums;
-  a.state = ctx->d_state;
   a.log = ctx->d_log;
+  a.stamps = ctx->d_stamps;
   return a;
 }
 
@@ -244,17 +247,30 @@ bool finite16(const double* m) {
   return true;
 }
 
-// Enqueue one VGICP round on the context's stream.
-int enqueue_round(vgicp_ctx* ctx, const IterArgs& args, uint32_t grid) {
-  if (ctx->comm == nullptr) {
-    VG_HIP(ctx, launch_iterate(ctx->stream, args, grid, /*fused_tail=*/true));
-    return VGICP_OK;
+// Enqueue launch j of an align on the context's stream.  Launch j's prologue closes round j-1 (fold
+// its rows, solve, advance the pose) and its body accumulates round j; the launch after the last
+// round is prologue-only and runs as a single workgroup (`closing`).  With a communicator each body
+// launch is followed by this rank's row fold and the 256-byte all-reduce the next prologue reads.
+int enqueue_launch(vgicp_ctx* ctx, const IterArgs& base, int j, uint32_t body_grid, bool closing,
+                   bool use_comm) {
+  IterArgs a = base;
+  a.state_in = ctx->d_state + (j & 1);
+  a.state_out = ctx->d_state + ((j + 1) & 1);
+  a.rows = ctx->d_rows[j & 1];
+  if (use_comm) {
+    a.prev = ctx->d_sums;
+    a.prev_rows = j > 0 ? 1u : 0u;
+  } else {
+    a.prev = ctx->d_rows[(j + 1) & 1];
+    a.prev_rows = j > 0 ? body_grid : 0u;
   }
-  VG_HIP(ctx, launch_iterate(ctx->stream, args, grid, /*fused_tail=*/false));
-  const int rc = ctx->rccl.AllReduce(ctx->d_sums, ctx->d_sums, kSlots, kNcclDouble, kNcclSum,
-                                     ctx->comm, ctx->stream);
-  if (rc != 0) return fail_rccl(ctx, rc, "ncclAllReduce");
-  VG_HIP(ctx, launch_tail(ctx->stream, args));
+  VG_HIP(ctx, launch_iterate(ctx->stream, a, closing ? 1u : body_grid, ctx->iter_block));
+  if (use_comm && !closing) {
+    VG_HIP(ctx, launch_fold_rows(ctx->stream, a.rows, body_grid, a.state_out, ctx->d_sums));
+    const int rc = ctx->rccl.AllReduce(ctx->d_sums, ctx->d_sums, kSlots, kNcclDouble, kNcclSum,
+                                       ctx->comm, ctx->stream);
+    if (rc != 0) return fail_rccl(ctx, rc, "ncclAllReduce");
+  }
   return VGICP_OK;
 }
 
@@ -300,46 +316,50 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
   h0->done = (max_it == 0) ? 1 : 0;
   VG_HIP(ctx, hipMemcpyAsync(ctx->d_state, h0, sizeof(AlignState), hipMemcpyHostToDevice, ctx->stream));
 
-  const IterArgs args = make_args(ctx);
-  const uint32_t grid = iterate_grid(ctx->n);
-  if (profile && (int)ctx->ev_prof.size() < 2 * max_it) {
+  const IterArgs base = base_args(ctx);
+  const uint32_t grid = iterate_grid(ctx);
+  const bool use_comm = ctx->comm != nullptr;
+  const int total_launches = max_it > 0 ? max_it + 1 : 0;  // max_it bodies + the closing prologue
+  if (profile && (int)ctx->ev_prof.size() < 2 * total_launches) {
     const size_t old = ctx->ev_prof.size();
-    ctx->ev_prof.resize(2 * (size_t)max_it, nullptr);
+    ctx->ev_prof.resize(2 * (size_t)total_launches, nullptr);
     for (size_t k = old; k < ctx->ev_prof.size(); ++k) VG_HIP(ctx, hipEventCreate(&ctx->ev_prof[k]));
   }
 
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
-  int launched = 0;           // rounds enqueued
+  int launched = 0;
   int chunks_enqueued = 0, chunks_checked = 0;
-  bool finished = false;
+  bool finished = total_launches == 0;
   // Keep up to two chunks in flight: enqueue chunk k+1 before looking at chunk k's status, so the
-  // device never idles behind the host; rounds enqueued past convergence exit at their first load.
+  // device never idles behind the host; launches enqueued past convergence exit at their first load.
   while (!finished) {
-    while (launched < max_it && chunks_enqueued - chunks_checked < kMaxChunksInFlight) {
-      const int todo = std::min(chunk, max_it - launched);
-      for (int j = 0; j < todo; ++j) {
-        if (profile) VG_HIP(ctx, hipEventRecord(ctx->ev_prof[2 * (launched + j)], ctx->stream));
-        rc = enqueue_round(ctx, args, grid);
+    while (launched < total_launches && chunks_enqueued - chunks_checked < kMaxChunksInFlight) {
+      // the first chunk carries one extra launch: launch j closes round j-1
+      const int todo = std::min(chunk + (launched == 0 ? 1 : 0), total_launches - launched);
+      for (int k = 0; k < todo; ++k) {
+        const int j = launched + k;
+        if (profile) VG_HIP(ctx, hipEventRecord(ctx->ev_prof[2 * j], ctx->stream));
+        rc = enqueue_launch(ctx, base, j, grid, /*closing=*/j == max_it, use_comm);
         if (rc != VGICP_OK) return rc;
-        if (profile) VG_HIP(ctx, hipEventRecord(ctx->ev_prof[2 * (launched + j) + 1], ctx->stream));
+        if (profile) VG_HIP(ctx, hipEventRecord(ctx->ev_prof[2 * j + 1], ctx->stream));
       }
       launched += todo;
       const int slot = chunks_enqueued % kMaxChunksInFlight;
-      VG_HIP(ctx, hipMemcpyAsync(&ctx->h_state[1 + slot], ctx->d_state, sizeof(AlignState),
-                                 hipMemcpyDeviceToHost, ctx->stream));
+      VG_HIP(ctx, hipMemcpyAsync(&ctx->h_state[1 + slot], ctx->d_state + (launched & 1),
+                                 sizeof(AlignState), hipMemcpyDeviceToHost, ctx->stream));
       VG_HIP(ctx, hipEventRecord(ctx->ev_chunk[slot], ctx->stream));
       ++chunks_enqueued;
     }
-    if (chunks_checked == chunks_enqueued) break;  // max_iteration == 0
     const int slot = chunks_checked % kMaxChunksInFlight;
     VG_HIP(ctx, hipEventSynchronize(ctx->ev_chunk[slot]));
     ++chunks_checked;
-    if (ctx->h_state[1 + slot].done || (launched >= max_it && chunks_checked == chunks_enqueued))
+    if (ctx->h_state[1 + slot].done || (launched >= total_launches && chunks_checked == chunks_enqueued))
       finished = true;
   }
   VG_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
   AlignState* hf = &ctx->h_state[0];
-  VG_HIP(ctx, hipMemcpyAsync(hf, ctx->d_state, sizeof(AlignState), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(hf, ctx->d_state + (launched & 1), sizeof(AlignState),
+                             hipMemcpyDeviceToHost, ctx->stream));
   const bool want_log = stats && (stats->corr_count || stats->normal_eq);
   if (want_log && max_it > 0)
     VG_HIP(ctx, hipMemcpyAsync(ctx->h_log, ctx->d_log, (size_t)max_it * kSlots * sizeof(double),
@@ -361,7 +381,8 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
       if (stats->normal_eq) std::memcpy(stats->normal_eq + (size_t)it * kNormalEq, row, kNormalEq * sizeof(double));
     }
     if (profile && stats->kernel_ms) {
-      for (int it = 0; it < launched; ++it) {
+      // one entry per body launch (the closing single-workgroup launch is not a round)
+      for (int it = 0; it < std::min(launched, max_it); ++it) {
         float k = 0.f;
         VG_HIP(ctx, hipEventElapsedTime(&k, ctx->ev_prof[2 * it], ctx->ev_prof[2 * it + 1]));
         stats->kernel_ms[it] = k;
@@ -414,13 +435,22 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   VG_CREATE(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), 4 * sizeof(uint32_t)));
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), 4 * sizeof(uint32_t), 0));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_state), sizeof(AlignState)));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_state), 2 * sizeof(AlignState)));
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state),
                           (1 + kMaxChunksInFlight) * sizeof(AlignState), 0));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_partials),
-                      (size_t)kMaxIterBlocks * kSlots * sizeof(double)));
+  for (int k = 0; k < 2; ++k)
+    VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows[k]),
+                        (size_t)kMaxIterBlocks * kSlots * sizeof(double)));
+  if (const char* blk = std::getenv("VGICP_ITER_BLOCK")) {
+    const int b = std::atoi(blk);
+    if (b == 256 || b == 512 || b == 1024) ctx->iter_block = b;
+  }
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sums), kSlots * sizeof(double)));
-  VG_CREATE(hipMemset(ctx->d_state, 0, sizeof(AlignState)));
+  VG_CREATE(hipMemset(ctx->d_state, 0, 2 * sizeof(AlignState)));
+  if (const char* dbg = std::getenv("VGICP_DEBUG_STAMPS"); dbg && dbg[0] == '1') {
+    VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_stamps), 8 * sizeof(uint64_t)));
+    VG_CREATE(hipMemset(ctx->d_stamps, 0, 8 * sizeof(uint64_t)));
+  }
   VG_CREATE(hipEventCreate(&ctx->ev_begin));
   VG_CREATE(hipEventCreate(&ctx->ev_end));
   for (int k = 0; k < kMaxChunksInFlight; ++k)
@@ -435,6 +465,16 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
+  if (ctx->d_stamps) {
+    uint64_t h[8] = {0};
+    if (hipMemcpy(h, ctx->d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[4] > 0) {
+      const double k = 0.01 / (double)h[4];  // 100 MHz ticks -> us per launch
+      std::fprintf(stderr, "[vgicp stamps] body launches %llu | workgroup 0: prologue (fold+solve) %.2f us, "
+                   "gather+accumulate loop %.2f us, butterfly+row store %.2f us\n", (unsigned long long)h[4],
+                   h[0] * k, h[1] * k, h[2] * k);
+    }
+    (void)hipFree(ctx->d_stamps);
+  }
   (void)hipFree(ctx->table);
   (void)hipFree(ctx->d_counters);
   (void)hipHostFree(ctx->h_counters);
@@ -443,7 +483,8 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipFree(ctx->d_scan_aos);
   (void)hipFree(ctx->d_state);
   (void)hipHostFree(ctx->h_state);
-  (void)hipFree(ctx->d_partials);
+  (void)hipFree(ctx->d_rows[0]);
+  (void)hipFree(ctx->d_rows[1]);
   (void)hipFree(ctx->d_sums);
   (void)hipFree(ctx->d_log);
   (void)hipHostFree(ctx->h_log);
@@ -608,8 +649,13 @@ int vgicp_accumulate(vgicp_ctx* ctx, size_t n, const double* points, const doubl
   h0->cosine_threshold = 2.0;
   h0->max_iteration = 1;
   VG_HIP(ctx, hipMemcpyAsync(ctx->d_state, h0, sizeof(AlignState), hipMemcpyHostToDevice, ctx->stream));
-  // local rank only: always the fused single-device round
-  VG_HIP(ctx, launch_iterate(ctx->stream, make_args(ctx), iterate_grid(ctx->n), true));
+  // local rank only (never the communicator): one body launch, then the closing prologue
+  const IterArgs base = base_args(ctx);
+  const uint32_t grid = iterate_grid(ctx);
+  rc = enqueue_launch(ctx, base, 0, grid, false, false);
+  if (rc != VGICP_OK) return rc;
+  rc = enqueue_launch(ctx, base, 1, grid, true, false);
+  if (rc != VGICP_OK) return rc;
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_log, ctx->d_log, kSlots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const double* row = ctx->h_log;

@@ -5,8 +5,10 @@
 //             (a point costs 96 B per iteration, every load is a coalesced 512-B wave access)
 //   table     open-addressing hash table of 128-byte voxel records, power-of-two slot count,
 //             linear probing, load <= 1/4: a lookup is one cache line, a hit needs no second hop
-//   partials  one 256-byte row of 32 doubles per workgroup (21 JTJ + 6 JTr + count + 4 pad)
-//   state     one AlignState: total pose, thresholds, iteration counter, done/converged flags
+//   rows      two buffers of one 256-byte row of 32 doubles per workgroup (21 JTJ + 6 JTr + count +
+//             4 pad): launch j writes buffer j&1 and folds buffer (j+1)&1 in its prologue
+//   state     two AlignStates (ping-pong like the rows): total pose, thresholds, iteration counter,
+//             done/converged flags
 //   log       per-iteration 32-double rows (reduced normal equations + count), read back once
 #pragma once
 
@@ -21,7 +23,6 @@ constexpr int kSlots = 32;      // doubles per partial row
 constexpr int kNormalEq = 27;   // 21 lower-triangle JTJ entries + 6 JTr entries
 constexpr int kCountSlot = 27;  // match count travels as an exact double
 constexpr int kScanPlanes = 12;
-constexpr int kIterBlock = 256;       // threads per workgroup of the iteration kernel
 constexpr int kMaxIterBlocks = 2048;  // grid cap; larger scans grid-stride
 
 enum : int32_t { SLOT_EMPTY = 0, SLOT_FULL = 1, SLOT_TOMB = 2, SLOT_LOCKED = 3 };
@@ -46,8 +47,6 @@ struct AlignState {
   int32_t iteration;  // rounds executed so far
   int32_t done;       // set on convergence or when iteration == max_iteration
   int32_t converged;
-  uint32_t ticket;    // workgroup arrival counter of the running launch
-  uint32_t pad[3];
 };
 
 struct IterArgs {
@@ -57,18 +56,24 @@ struct IterArgs {
   uint32_t mask;  // slots - 1
   const VoxelRecord* table;
   double voxel_size;
-  double* partials;   // [grid][kSlots]
-  double* sums;       // [kSlots]: reduced row handed to the all-reduce (multi-GPU path)
-  AlignState* state;
+  double* rows;        // [grid][kSlots]: partial rows this launch writes
+  const double* prev;  // rows the previous launch wrote (or the all-reduced single row)
+  uint32_t prev_rows;  // how many; 0 = first round, nothing to solve yet
+  uint32_t pad;
+  const AlignState* state_in;
+  AlignState* state_out;
   double* log;        // [max_iteration][kSlots]
+  uint64_t* stamps;   // diagnostic aid (VGICP_DEBUG_STAMPS=1): phase times of workgroup 0 in 10 ns
+                      // ticks, summed over launches; nullptr in normal operation
 };
 
 // ---- launchers (defined in vgicp_kernels.hip) ----
-// One VGICP iteration over the resident scan. fused_tail: the last workgroup also solves the 6x6
-// system and advances the pose (single GPU); otherwise it leaves the reduced row in args.sums.
-hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, bool fused_tail);
-// Multi-GPU tail: solve from args.sums (already all-reduced) and advance the pose.
-hipError_t launch_tail(hipStream_t s, const IterArgs& args);
+// One VGICP round over the resident scan: prologue folds args.prev and advances the pose, body
+// accumulates this round's rows. block = 256 / 512 / 1024 threads per workgroup.
+hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, int block);
+// Multi-GPU: fold nrows rows into sums[kSlots] (the 256-byte message of the all-reduce).
+hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, const AlignState* state,
+                            double* sums);
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
                             uint32_t n, double* soa, uint64_t stride);
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots);

@@ -1,12 +1,13 @@
 // vgicp_kernels.hip — hand-written CDNA4 (gfx950) kernels of the VGICP registration path.
 //
 // Reference behaviour each kernel reproduces (paths relative to the reference checkout):
-//   iterate_kernel  one round of the loop in ICP::align (src/Registration.cpp:15-28):
+//   iterate_kernel  one round of the loop in ICP::align (src/Registration.cpp:15-28). Prologue: the
+//                   merge of the previous round's partial sums, the LDLT solve, se3ToSE3, pose
+//                   composition and convergence test (:71-79, :20-25, :37-50). Body:
 //                   Open3D PointCloud::Transform of point + covariance (call sites :13,27),
 //                   LocalMap::getVoxelIndex + voxelGrid_.find (src/LocalMap.cpp:94-100,114-118),
-//                   ICP::computeJTJAndJTr (src/Registration.cpp:83-102), the accumulation and merge
-//                   of ICP::computeTransform (:60-76), and in its last workgroup the LDLT solve,
-//                   se3ToSE3, pose composition and convergence test (:78-79, :20-25, :37-50)
+//                   ICP::computeJTJAndJTr (src/Registration.cpp:83-102) and the accumulation of
+//                   ICP::computeTransform (:60-70)
 //   upsert/erase    the effect of LocalMap::updateLocalMap's insert and evict loops on the data the
 //                   path reads (src/LocalMap.cpp:47-72), mirrored from host-computed voxel values
 //   match kernels   LocalMap::correspondenceMatching with materialised output (src/LocalMap.cpp:78-112)
@@ -16,27 +17,15 @@
 //     each round (the reference transforms a copy incrementally), so a point costs 96 B of reads.
 //   * MFMA is not used: this is a gather plus a 27-value reduction at ~2 fp64 flop per byte.
 //   * Reduction: 32-slot halving butterfly inside a 64-lane wave (32 exchanges instead of 6 x 28),
-//     LDS across the waves of a workgroup, one 256-byte partial row per workgroup written through to
-//     memory (sc1), an arrival ticket, and a fixed-order final sum in the last workgroup to arrive —
-//     bit-reproducible whichever workgroup that is.
+//     LDS across the waves of a workgroup, one plain 256-byte partial row per workgroup.  Nothing in a
+//     launch waits for another workgroup: the NEXT launch's prologue folds the rows (every workgroup,
+//     redundantly, in one fixed order — bit-reproducible) while its own scan loads are in flight, so
+//     the kernel boundary is the only grid-wide synchronisation and no workgroup runs a serial tail
+//     alone (the first version's ticket + write-through + last-workgroup tail cost 13 us per round).
 #include "vgicp_device.h"
 
 namespace vgicp {
 namespace {
-
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-typedef __attribute__((address_space(1))) unsigned int gu32;
-
-// Write-through (sc1) store / L1-bypassing (sc1) load: the in-launch hand-off of partial rows to
-// the last workgroup (cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md visibility table).
-__device__ __forceinline__ void store_through(double* p, double v) {
-  __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_through(const double* p) {
-  return __longlong_as_double(
-      (long long)__hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
 
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -88,62 +77,224 @@ __device__ __forceinline__ void fold(double (&v)[kSlots], bool upper) {
   }
 }
 
-// The serial tail of one round: LDLT solve, se(3) exponential, pose update, convergence.
-__device__ void solve_and_advance(const double* totals, AlignState* st, double* log, double* work) {
-  const int it = st->iteration;
-  double* row = log + (size_t)it * kSlots;
-  for (int k = 0; k < kSlots; ++k) row[k] = totals[k];
-  double rhs[6], xi[6];
-  for (int k = 0; k < 6; ++k) rhs[k] = -totals[21 + k];
-  ldlt6_solve(totals, rhs, xi, work);
-  Pose step, total, next;
-  se3_exp(xi, step);
-  for (int k = 0; k < 9; ++k) total.R[k] = st->pose[k];
-  for (int k = 0; k < 3; ++k) total.t[k] = st->pose[9 + k];
-  pose_compose(step, total, next);
-  for (int k = 0; k < 9; ++k) { st->pose[k] = next.R[k]; st->step[k] = step.R[k]; }
-  for (int k = 0; k < 3; ++k) { st->pose[9 + k] = next.t[k]; st->step[9 + k] = step.t[k]; }
-  const bool conv = converged(step, st->cosine_threshold, st->translation_sq_threshold);
-  st->iteration = it + 1;
-  if (conv) {
-    st->converged = 1;
-    st->done = 1;
-  } else if (it + 1 >= st->max_iteration) {
-    st->done = 1;
-  }
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
 }
 
-template <bool FUSED_TAIL>
-__global__ __launch_bounds__(kIterBlock) void iterate_kernel(IterArgs a) {
-  constexpr int kWaves = kIterBlock / 64;
-  constexpr int kGroups = kIterBlock / kSlots;
-  __shared__ double red[kWaves][kSlots];
+// Pivoted LDL^T solve of the 6x6 normal equations by ONE wave (all 64 lanes must call it).
+// Same algorithm as vgicp_math.h's ldlt6_solve — Eigen's LDLT: largest remaining |diagonal| first,
+// symmetric swap, invalid (zero) pivots leave their column untouched, D pseudo-inverted — but laid
+// out across lanes: lane 6r + c holds A(r, c) of the full symmetric matrix, the pivot search reads
+// the diagonal through v_readlane (uniform), the swap and the rank-1 update are lane shuffles. The
+// serial form costs ~10 us of dependent LDS traffic on one lane; this one is a few hundred cycles.
+// totals: 21 lower-triangle entries then the 6 entries of J^T r. Every lane returns x = A^-1 (-J^T r).
+__device__ __forceinline__ void ldlt6_solve_wave(const double* totals, uint32_t lane, double (&x)[6]) {
+  const int cell = lane < 36 ? (int)lane : 0;
+  const int r = cell / 6, c = cell % 6;
+  double a = totals[r >= c ? tri6(r, c) : tri6(c, r)];
+  int perm[6] = {0, 1, 2, 3, 4, 5};
+  bool zero_diag = false;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (zero_diag) break;
+    int p = k;
+    double best = fabs(readlane_f64(a, 7 * k));
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const double d = fabs(readlane_f64(a, 7 * i));
+      if (d > best) { best = d; p = i; }
+    }
+    perm[k] = p;
+    if (p != k) {  // uniform: symmetric row/column swap k <-> p
+      const int sr = (r == k) ? p : (r == p) ? k : r;
+      const int sc = (c == k) ? p : (c == p) ? k : c;
+      a = __shfl(a, 6 * sr + sc, 64);
+    }
+    const double akk = readlane_f64(a, 7 * k);
+    const bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) {  // the whole diagonal is zero: identity transpositions, nothing to do
+      perm[0] = 0;
+      zero_diag = true;
+    } else if (valid) {
+      const double a_rk = __shfl(a, 6 * r + k, 64);
+      const double a_kc = __shfl(a, 6 * k + c, 64);
+      const double l_rk = a_rk / akk;
+      if (r > k && c > k) a -= l_rk * a_kc;
+      else if (r > k && c == k) a = l_rk;
+    }
+  }
+  double L[6][6], D[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    D[i] = readlane_f64(a, 7 * i);
+#pragma unroll
+    for (int j = 0; j < i; ++j) L[i][j] = readlane_f64(a, 6 * i + j);
+  }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] = -totals[21 + i];
+  if (!zero_diag) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int q = k + 1; q < 6; ++q)
+        if (perm[k] == q) { const double t = y[k]; y[k] = y[q]; y[q] = t; }
+  }
+#pragma unroll
+  for (int i = 1; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < i; ++j) y[i] -= L[i][j] * y[j];
+  const double tol = 2.2250738585072014e-308;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] = (fabs(D[i]) > tol) ? y[i] / D[i] : 0.0;
+#pragma unroll
+  for (int i = 4; i >= 0; --i)
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) y[i] -= L[j][i] * y[j];
+  if (!zero_diag) {
+#pragma unroll
+    for (int k = 5; k >= 0; --k)
+#pragma unroll
+      for (int q = k + 1; q < 6; ++q)
+        if (perm[k] == q) { const double t = y[k]; y[k] = y[q]; y[q] = t; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = y[i];
+}
+
+// What every wave needs to run a round: the total pose, or the news that the loop has ended.
+struct RoundHead {
+  Pose total;
+  bool stop;
+};
+
+// Prologue of a round, run redundantly by EVERY wave of EVERY workgroup (identical arithmetic on
+// identical inputs, so identical bits everywhere): fold the previous round's partial rows in a fixed
+// order, solve the 6x6 system, advance the pose, test convergence. Workgroup 0 also publishes the
+// new state and the log row for the next launch / the host.  Reference: the merge, solve, compose and
+// convergence test of src/Registration.cpp:71-79, :20-25.
+template <int BLOCK>
+__device__ __forceinline__ RoundHead round_prologue(const IterArgs& a, double (*fin)[kSlots],
+                                                    double* totals) {
+  constexpr int kGroups = BLOCK / kSlots;
+  constexpr int kBatch = 8;  // independent loads in flight per thread; the add order stays fixed
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const AlignState* in = a.state_in;
+  AlignState* out = a.state_out;
+  const bool publish = blockIdx.x == 0 && tid == 0;
+
+  RoundHead head;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) head.total.R[k] = in->pose[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) head.total.t[k] = in->pose[9 + k];
+  const int it = in->iteration;
+  const int max_it = in->max_iteration;
+  head.stop = in->done != 0;
+  if (head.stop || a.prev_rows == 0) {
+    // nothing to fold: either the loop ended in an earlier launch, or this is the first round
+    if (publish) *out = *in;
+    return head;
+  }
+
+  {
+    const uint32_t slot = tid & (kSlots - 1), group = tid / kSlots;
+    double s = 0.0;
+    for (uint32_t b0 = group; b0 < a.prev_rows; b0 += kGroups * kBatch) {
+      double row[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const uint32_t b = b0 + u * kGroups;
+        row[u] = b < a.prev_rows ? a.prev[(size_t)b * kSlots + slot] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) s += row[u];
+    }
+    fin[group][slot] = s;
+  }
+  __syncthreads();
+  if (tid < kSlots) {
+    double tot = fin[0][tid];
+#pragma unroll
+    for (int g = 1; g < kGroups; ++g) tot += fin[g][tid];
+    totals[tid] = tot;
+  }
+  __syncthreads();
+
+  double xi[6];
+  ldlt6_solve_wave(totals, lane, xi);
+  Pose step, next;
+  se3_exp(xi, step);
+  pose_compose(step, head.total, next);
+  const double cos_thr = in->cosine_threshold, tsq_thr = in->translation_sq_threshold;
+  const bool conv = converged(step, cos_thr, tsq_thr);
+  head.total = next;
+  head.stop = conv || (it + 1 >= max_it);
+  if (blockIdx.x == 0 && tid < kSlots) a.log[(size_t)it * kSlots + tid] = totals[tid];
+  if (publish) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { out->pose[k] = next.R[k]; out->step[k] = step.R[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { out->pose[9 + k] = next.t[k]; out->step[9 + k] = step.t[k]; }
+    out->cosine_threshold = cos_thr;
+    out->translation_sq_threshold = tsq_thr;
+    out->max_iteration = max_it;
+    out->iteration = it + 1;
+    out->converged = conv ? 1 : 0;
+    out->done = head.stop ? 1 : 0;
+  }
+  return head;
+}
+
+__device__ __forceinline__ void load_point(const IterArgs& a, uint32_t i, double (&q)[kScanPlanes]) {
+  const double* s = a.scan + i;
+#pragma unroll
+  for (int k = 0; k < kScanPlanes; ++k) q[k] = s[k * a.stride];
+}
+
+// One VGICP round.  Launch j reads state j&1 and the rows launch j-1 wrote, writes state (j+1)&1
+// and its own rows; the host alternates the buffers.  Order inside a workgroup: issue the first
+// point's loads (they do not depend on the pose), run the prologue while they fly, then the gather
+// + accumulate loop, then reduce to one 256-byte row with plain stores — the kernel boundary is the
+// only synchronisation between workgroups.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
+  constexpr int kWaves = BLOCK / 64;
+  constexpr int kGroups = BLOCK / kSlots;
   __shared__ double fin[kGroups][kSlots];
   __shared__ double totals[kSlots];
-  __shared__ double work[kLdltWork];
-  __shared__ uint32_t is_last;
+  __shared__ double red[kWaves][kSlots];
 
-  AlignState* st = a.state;
-  if (st->done) return;  // uniform: converged (or exhausted) in an earlier launch
+  const uint64_t t_begin = a.stamps ? wall_clock64() : 0;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t stride_pts = gridDim.x * BLOCK;
+  uint32_t i = blockIdx.x * BLOCK + tid;
 
-  double R[9], t[3];
+  double q[kScanPlanes];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) R[k] = st->pose[k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) t[k] = st->pose[9 + k];
+  for (int k = 0; k < kScanPlanes; ++k) q[k] = 0.0;
+  if (i < a.n) load_point(a, i, q);
+
+  const RoundHead head = round_prologue<BLOCK>(a, fin, totals);
+  if (head.stop) return;  // uniform across the grid
+  const uint64_t t_head = a.stamps ? wall_clock64() : 0;
+  const double* R = head.total.R;
+  const double* t = head.total.t;
 
   double v[kSlots];
 #pragma unroll
   for (int k = 0; k < kSlots; ++k) v[k] = 0.0;
 
-  const uint32_t tid = threadIdx.x;
-  const uint32_t step = gridDim.x * kIterBlock;
-  for (uint32_t i = blockIdx.x * kIterBlock + tid; i < a.n; i += step) {
-    const double* s = a.scan + i;
-    const double x = s[0], y = s[a.stride], z = s[2 * a.stride];
+  while (i < a.n) {
+    const double x = q[0], y = q[1], z = q[2];
     double C[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) C[k] = s[(3 + k) * a.stride];
+    for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
+    const uint32_t inext = i + stride_pts;
+    if (inext < a.n) load_point(a, inext, q);  // prefetch the next point under this one's gather
+    i = inext;
 
     double p[3];
     transform_point(R, t, x, y, z, p);
@@ -205,6 +356,7 @@ __global__ __launch_bounds__(kIterBlock) void iterate_kernel(IterArgs a) {
     v[26] += Q[2] * e0 + Q[5] * e1 + Q[8] * e2;
     v[kCountSlot] += 1.0;
   }
+  const uint64_t t_loop = a.stamps ? wall_clock64() : 0;
 
   // ---- wave: 32-slot halving butterfly; lane l ends with slot (l >> 1) summed over 64 lanes ----
   const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -216,56 +368,40 @@ __global__ __launch_bounds__(kIterBlock) void iterate_kernel(IterArgs a) {
   const double wsum = v[0] + __shfl_xor(v[0], 1, 64);
   if ((lane & 1) == 0) red[wave][lane >> 1] = wsum;
   __syncthreads();
-
-  // ---- workgroup: fixed-order sum over waves, one write-through row per workgroup ----
-  const uint32_t nblk = gridDim.x;
-  if (wave == 0) {
-    if (lane < kSlots) {
-      double tot = red[0][lane];
+  // ---- workgroup: fixed-order sum over waves, one plain 256-byte row per workgroup ----
+  if (tid < kSlots) {
+    double tot = red[0][tid];
 #pragma unroll
-      for (int w = 1; w < kWaves; ++w) tot += red[w][lane];
-      store_through(a.partials + (size_t)blockIdx.x * kSlots + lane, tot);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has left this CU before the ticket
-    if (lane == 0) {
-      const uint32_t prev = __hip_atomic_fetch_add((gu32*)&st->ticket, 1u, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-      is_last = (prev == nblk - 1) ? 1u : 0u;
-    }
+    for (int w = 1; w < kWaves; ++w) tot += red[w][tid];
+    a.rows[(size_t)blockIdx.x * kSlots + tid] = tot;
   }
-  __syncthreads();
-  if (!is_last) return;
+  if (a.stamps && blockIdx.x == 0 && tid == 0) {
+    const uint64_t t_end = wall_clock64();
+    atomicAdd((unsigned long long*)&a.stamps[0], (unsigned long long)(t_head - t_begin));
+    atomicAdd((unsigned long long*)&a.stamps[1], (unsigned long long)(t_loop - t_head));
+    atomicAdd((unsigned long long*)&a.stamps[2], (unsigned long long)(t_end - t_loop));
+    atomicAdd((unsigned long long*)&a.stamps[4], 1ull);
+  }
+}
 
-  // ---- last workgroup to arrive: deterministic final sum over all rows ----
-  {
-    const uint32_t slot = tid & (kSlots - 1), group = tid / kSlots;
-    double s = 0.0;
-    for (uint32_t b = group; b < nblk; b += kGroups)
-      s += load_through(a.partials + (size_t)b * kSlots + slot);
-    fin[group][slot] = s;
-  }
+// Multi-GPU only: fold this rank's rows into one row (fixed order) so the all-reduce moves 256 B.
+__global__ __launch_bounds__(1024) void fold_rows_kernel(const double* __restrict__ rows,
+                                                         uint32_t nrows, const AlignState* state,
+                                                         double* __restrict__ sums) {
+  constexpr int kGroups = 1024 / kSlots;
+  __shared__ double fin[kGroups][kSlots];
+  if (state->done) return;  // rows are stale once the loop has ended; the value is never used
+  const uint32_t tid = threadIdx.x, slot = tid & (kSlots - 1), group = tid / kSlots;
+  double s = 0.0;
+  for (uint32_t b = group; b < nrows; b += kGroups) s += rows[(size_t)b * kSlots + slot];
+  fin[group][slot] = s;
   __syncthreads();
   if (tid < kSlots) {
     double tot = fin[0][tid];
 #pragma unroll
     for (int g = 1; g < kGroups; ++g) tot += fin[g][tid];
-    totals[tid] = tot;
-    if (!FUSED_TAIL) a.sums[tid] = tot;
+    sums[tid] = tot;
   }
-  __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_store((gu32*)&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (FUSED_TAIL) solve_and_advance(totals, st, a.log, work);
-  }
-}
-
-// Multi-GPU tail: sums[] holds the all-reduced row; every rank runs the same arithmetic.
-__global__ void tail_kernel(IterArgs a) {
-  __shared__ double totals[kSlots];
-  __shared__ double work[kLdltWork];
-  if (threadIdx.x != 0 || a.state->done) return;
-  for (int k = 0; k < kSlots; ++k) totals[k] = a.sums[k];
-  solve_and_advance(totals, a.state, a.log, work);
 }
 
 // AoS (the caller's Eigen memory) -> 12 SoA planes.
@@ -456,16 +592,19 @@ inline uint32_t blocks_for(uint64_t work, uint32_t block) { return (uint32_t)((w
 
 }  // namespace
 
-hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, bool fused_tail) {
-  if (fused_tail)
-    hipLaunchKernelGGL(iterate_kernel<true>, dim3(grid), dim3(kIterBlock), 0, s, args);
-  else
-    hipLaunchKernelGGL(iterate_kernel<false>, dim3(grid), dim3(kIterBlock), 0, s, args);
+hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, int block) {
+  switch (block) {
+    case 256: hipLaunchKernelGGL(iterate_kernel<256>, dim3(grid), dim3(256), 0, s, args); break;
+    case 512: hipLaunchKernelGGL(iterate_kernel<512>, dim3(grid), dim3(512), 0, s, args); break;
+    case 1024: hipLaunchKernelGGL(iterate_kernel<1024>, dim3(grid), dim3(1024), 0, s, args); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
-hipError_t launch_tail(hipStream_t s, const IterArgs& args) {
-  hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(64), 0, s, args);
+hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, const AlignState* state,
+                            double* sums) {
+  hipLaunchKernelGGL(fold_rows_kernel, dim3(1), dim3(1024), 0, s, rows, nrows, state, sums);
   return hipGetLastError();
 }
 
