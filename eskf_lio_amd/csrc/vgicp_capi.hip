@@ -264,7 +264,8 @@ int enqueue_launch(vgicp_ctx* ctx, const IterArgs& base, int j, uint32_t body_gr
     a.prev = ctx->d_rows[(j + 1) & 1];
     a.prev_rows = j > 0 ? body_grid : 0u;
   }
-  VG_HIP(ctx, launch_iterate(ctx->stream, a, closing ? 1u : body_grid, ctx->iter_block));
+  if (closing) VG_HIP(ctx, launch_close(ctx->stream, a));
+  else VG_HIP(ctx, launch_iterate(ctx->stream, a, body_grid, ctx->iter_block));
   if (use_comm && !closing) {
     VG_HIP(ctx, launch_fold_rows(ctx->stream, a.rows, body_grid, a.state_out, ctx->d_sums));
     const int rc = ctx->rccl.AllReduce(ctx->d_sums, ctx->d_sums, kSlots, kNcclDouble, kNcclSum,
@@ -472,6 +473,8 @@ int vgicp_destroy(vgicp_ctx* ctx) {
       std::fprintf(stderr, "[vgicp stamps] body launches %llu | workgroup 0: prologue (fold+solve) %.2f us, "
                    "gather+accumulate loop %.2f us, butterfly+row store %.2f us\n", (unsigned long long)h[4],
                    h[0] * k, h[1] * k, h[2] * k);
+      std::fprintf(stderr, "[vgicp stamps] prologue split: barrier after fold %.2f us, wave-0 solve %.2f us, "
+                   "publish+barrier %.2f us (the rest is row/state loads + fold)\n", h[5] * k, h[6] * k, h[7] * k);
     }
     (void)hipFree(ctx->d_stamps);
   }

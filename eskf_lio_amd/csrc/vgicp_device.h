@@ -71,6 +71,8 @@ struct IterArgs {
 // One VGICP round over the resident scan: prologue folds args.prev and advances the pose, body
 // accumulates this round's rows. block = 256 / 512 / 1024 threads per workgroup.
 hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, int block);
+// The prologue-only launch that closes the last round (single workgroup).
+hipError_t launch_close(hipStream_t s, const IterArgs& args);
 // Multi-GPU: fold nrows rows into sums[kSlots] (the 256-byte message of the all-reduce).
 hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, const AlignState* state,
                             double* sums);

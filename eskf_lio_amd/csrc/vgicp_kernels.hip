@@ -89,11 +89,12 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 // out across lanes: lane 6r + c holds A(r, c) of the full symmetric matrix, the pivot search reads
 // the diagonal through v_readlane (uniform), the swap and the rank-1 update are lane shuffles. The
 // serial form costs ~10 us of dependent LDS traffic on one lane; this one is a few hundred cycles.
-// totals: 21 lower-triangle entries then the 6 entries of J^T r. Every lane returns x = A^-1 (-J^T r).
-__device__ __forceinline__ void ldlt6_solve_wave(const double* totals, uint32_t lane, double (&x)[6]) {
+// tot: lane l < 27 holds entry l of the packed row (21 lower-triangle entries of J^T S^-1 J, then
+// the 6 entries of J^T S^-1 r). Every lane returns x = A^-1 (-J^T r).
+__device__ __forceinline__ void ldlt6_solve_wave(double tot, uint32_t lane, double (&x)[6]) {
   const int cell = lane < 36 ? (int)lane : 0;
   const int r = cell / 6, c = cell % 6;
-  double a = totals[r >= c ? tri6(r, c) : tri6(c, r)];
+  double a = __shfl(tot, r >= c ? tri6(r, c) : tri6(c, r), 64);
   int perm[6] = {0, 1, 2, 3, 4, 5};
   bool zero_diag = false;
 #pragma unroll
@@ -134,7 +135,7 @@ __device__ __forceinline__ void ldlt6_solve_wave(const double* totals, uint32_t 
   }
   double y[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] = -totals[21 + i];
+  for (int i = 0; i < 6; ++i) y[i] = -readlane_f64(tot, 21 + i);
   if (!zero_diag) {
 #pragma unroll
     for (int k = 0; k < 6; ++k)
@@ -164,27 +165,79 @@ __device__ __forceinline__ void ldlt6_solve_wave(const double* totals, uint32_t 
   for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
+// se(3) exponential as vgicp_math.h's se3_exp (reference src/Utils.cpp:28-32,40-63) with the sine
+// and cosine of the one angle taken from a single sincos call.
+__device__ __forceinline__ void se3_exp_device(const double* xi, Pose& T) {
+  const double* r = xi + 3;
+  const double n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  const double angle = sqrt(n2);
+  double s, c;
+  sincos(angle, &s, &c);
+  double k[3] = {r[0], r[1], r[2]};
+  if (n2 > 0.0) { k[0] = r[0] / angle; k[1] = r[1] / angle; k[2] = r[2] / angle; }
+  const double sx = s * k[0], sy = s * k[1], sz = s * k[2];
+  const double cx = (1.0 - c) * k[0], cy = (1.0 - c) * k[1], cz = (1.0 - c) * k[2];
+  double tmp;
+  tmp = cx * k[1]; T.R[3] = tmp - sz; T.R[1] = tmp + sz;
+  tmp = cx * k[2]; T.R[6] = tmp + sy; T.R[2] = tmp - sy;
+  tmp = cy * k[2]; T.R[7] = tmp - sx; T.R[5] = tmp + sx;
+  T.R[0] = cx * k[0] + c;
+  T.R[4] = cy * k[1] + c;
+  T.R[8] = cz * k[2] + c;
+  if (angle < 1e-6) {
+    T.t[0] = xi[0]; T.t[1] = xi[1]; T.t[2] = xi[2];
+    return;
+  }
+  const double f1 = s / angle, f2 = (1.0 - c) / angle;
+  double J[9];
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) J[rr + 3 * cc] = (1.0 - f1) * k[rr] * k[cc];
+  J[0] += f1; J[4] += f1; J[8] += f1;
+  J[3] += -f2 * k[2]; J[6] += f2 * k[1];
+  J[1] += f2 * k[2];  J[7] += -f2 * k[0];
+  J[2] += -f2 * k[1]; J[5] += f2 * k[0];
+  mat3_vec(J, xi, T.t);
+}
+
 // What every wave needs to run a round: the total pose, or the news that the loop has ended.
 struct RoundHead {
   Pose total;
   bool stop;
 };
 
-// Prologue of a round, run redundantly by EVERY wave of EVERY workgroup (identical arithmetic on
-// identical inputs, so identical bits everywhere): fold the previous round's partial rows in a fixed
-// order, solve the 6x6 system, advance the pose, test convergence. Workgroup 0 also publishes the
-// new state and the log row for the next launch / the host.  Reference: the merge, solve, compose and
-// convergence test of src/Registration.cpp:71-79, :20-25.
+// LDS a workgroup of BLOCK threads needs for the prologue.
 template <int BLOCK>
-__device__ __forceinline__ RoundHead round_prologue(const IterArgs& a, double (*fin)[kSlots],
-                                                    double* totals) {
+struct PrologueShared {
+  double fin[BLOCK / kSlots][kSlots];
+  double pose[12];
+  int stop;
+};
+
+// Prologue of a round, run by EVERY workgroup (identical arithmetic on identical inputs, so every
+// workgroup derives the same pose): fold the previous round's partial rows in a fixed order, solve
+// the 6x6 system, advance the pose, test convergence.  All global loads (rows and state) are issued
+// before the first wait; wave 0 alone runs the solve while the other waves park at the barrier, so
+// they do not steal its issue slots.  Workgroup 0 also publishes the new state and the log row for
+// the next launch / the host.  Reference: the merge, solve, compose and convergence test of
+// src/Registration.cpp:71-79, :20-25.
+template <int BLOCK>
+__device__ __forceinline__ RoundHead round_prologue(const IterArgs& a, PrologueShared<BLOCK>& sh) {
   constexpr int kGroups = BLOCK / kSlots;
-  constexpr int kBatch = 8;  // independent loads in flight per thread; the add order stays fixed
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  constexpr int kBatch = 16;  // independent loads in flight per thread; the add order stays fixed
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const AlignState* in = a.state_in;
   AlignState* out = a.state_out;
-  const bool publish = blockIdx.x == 0 && tid == 0;
 
+  // rows first (the long pole), then the state, all in flight together
+  const uint32_t slot = tid & (kSlots - 1), group = tid / kSlots;
+  double row[kBatch];
+#pragma unroll
+  for (int u = 0; u < kBatch; ++u) {
+    const uint32_t b = group + u * kGroups;
+    row[u] = b < a.prev_rows ? a.prev[(size_t)b * kSlots + slot] : 0.0;
+  }
   RoundHead head;
 #pragma unroll
   for (int k = 0; k < 9; ++k) head.total.R[k] = in->pose[k];
@@ -192,59 +245,80 @@ __device__ __forceinline__ RoundHead round_prologue(const IterArgs& a, double (*
   for (int k = 0; k < 3; ++k) head.total.t[k] = in->pose[9 + k];
   const int it = in->iteration;
   const int max_it = in->max_iteration;
+  const double cos_thr = in->cosine_threshold, tsq_thr = in->translation_sq_threshold;
   head.stop = in->done != 0;
   if (head.stop || a.prev_rows == 0) {
     // nothing to fold: either the loop ended in an earlier launch, or this is the first round
-    if (publish) *out = *in;
+    if (blockIdx.x == 0 && tid == 0) *out = *in;
     return head;
   }
 
-  {
-    const uint32_t slot = tid & (kSlots - 1), group = tid / kSlots;
-    double s = 0.0;
-    for (uint32_t b0 = group; b0 < a.prev_rows; b0 += kGroups * kBatch) {
-      double row[kBatch];
+  double s = 0.0;
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
-        const uint32_t b = b0 + u * kGroups;
-        row[u] = b < a.prev_rows ? a.prev[(size_t)b * kSlots + slot] : 0.0;
-      }
+  for (int u = 0; u < kBatch; ++u) s += row[u];
+  for (uint32_t b0 = group + kBatch * kGroups; b0 < a.prev_rows; b0 += kGroups * kBatch) {
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u) s += row[u];
+    for (int u = 0; u < kBatch; ++u) {
+      const uint32_t b = b0 + u * kGroups;
+      row[u] = b < a.prev_rows ? a.prev[(size_t)b * kSlots + slot] : 0.0;
     }
-    fin[group][slot] = s;
-  }
-  __syncthreads();
-  if (tid < kSlots) {
-    double tot = fin[0][tid];
 #pragma unroll
-    for (int g = 1; g < kGroups; ++g) tot += fin[g][tid];
-    totals[tid] = tot;
+    for (int u = 0; u < kBatch; ++u) s += row[u];
   }
+  sh.fin[group][slot] = s;
+  const uint64_t p1 = a.stamps ? wall_clock64() : 0;
   __syncthreads();
+  const uint64_t p2 = a.stamps ? wall_clock64() : 0;
+  uint64_t p3 = 0;
 
-  double xi[6];
-  ldlt6_solve_wave(totals, lane, xi);
-  Pose step, next;
-  se3_exp(xi, step);
-  pose_compose(step, head.total, next);
-  const double cos_thr = in->cosine_threshold, tsq_thr = in->translation_sq_threshold;
-  const bool conv = converged(step, cos_thr, tsq_thr);
-  head.total = next;
-  head.stop = conv || (it + 1 >= max_it);
-  if (blockIdx.x == 0 && tid < kSlots) a.log[(size_t)it * kSlots + tid] = totals[tid];
-  if (publish) {
+  if (wave == 0) {
+    double tot = 0.0;
+    if (lane < kSlots) {
+      tot = sh.fin[0][lane];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { out->pose[k] = next.R[k]; out->step[k] = step.R[k]; }
+      for (int g = 1; g < kGroups; ++g) tot += sh.fin[g][lane];
+    }
+    double xi[6];
+    ldlt6_solve_wave(tot, lane, xi);
+    Pose step, next;
+    se3_exp_device(xi, step);
+    pose_compose(step, head.total, next);
+    const bool conv = converged(step, cos_thr, tsq_thr);
+    const bool stop = conv || (it + 1 >= max_it);
+    p3 = a.stamps ? wall_clock64() : 0;
+    // static register indices only: a dynamically indexed private array would go to scratch
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { out->pose[9 + k] = next.t[k]; out->step[9 + k] = step.t[k]; }
-    out->cosine_threshold = cos_thr;
-    out->translation_sq_threshold = tsq_thr;
-    out->max_iteration = max_it;
-    out->iteration = it + 1;
-    out->converged = conv ? 1 : 0;
-    out->done = head.stop ? 1 : 0;
+    for (int k = 0; k < 9; ++k) if (lane == (uint32_t)k) sh.pose[k] = next.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (lane == (uint32_t)(9 + k)) sh.pose[9 + k] = next.t[k];
+    if (lane == 0) sh.stop = stop ? 1 : 0;
+    if (blockIdx.x == 0) {
+      if (lane < kSlots) a.log[(size_t)it * kSlots + lane] = tot;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { out->pose[k] = next.R[k]; out->step[k] = step.R[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { out->pose[9 + k] = next.t[k]; out->step[9 + k] = step.t[k]; }
+        out->cosine_threshold = cos_thr;
+        out->translation_sq_threshold = tsq_thr;
+        out->max_iteration = max_it;
+        out->iteration = it + 1;
+        out->converged = conv ? 1 : 0;
+        out->done = stop ? 1 : 0;
+      }
+    }
   }
+  __syncthreads();
+  if (a.stamps && blockIdx.x == 0 && tid == 0) {
+    atomicAdd((unsigned long long*)&a.stamps[5], (unsigned long long)(p2 - p1));
+    atomicAdd((unsigned long long*)&a.stamps[6], (unsigned long long)(p3 - p2));
+    atomicAdd((unsigned long long*)&a.stamps[7], (unsigned long long)(wall_clock64() - p3));
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) head.total.R[k] = sh.pose[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) head.total.t[k] = sh.pose[9 + k];
+  head.stop = sh.stop != 0;
   return head;
 }
 
@@ -262,9 +336,7 @@ __device__ __forceinline__ void load_point(const IterArgs& a, uint32_t i, double
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
   constexpr int kWaves = BLOCK / 64;
-  constexpr int kGroups = BLOCK / kSlots;
-  __shared__ double fin[kGroups][kSlots];
-  __shared__ double totals[kSlots];
+  __shared__ PrologueShared<BLOCK> sh;
   __shared__ double red[kWaves][kSlots];
 
   const uint64_t t_begin = a.stamps ? wall_clock64() : 0;
@@ -277,7 +349,7 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
   for (int k = 0; k < kScanPlanes; ++k) q[k] = 0.0;
   if (i < a.n) load_point(a, i, q);
 
-  const RoundHead head = round_prologue<BLOCK>(a, fin, totals);
+  const RoundHead head = round_prologue<BLOCK>(a, sh);
   if (head.stop) return;  // uniform across the grid
   const uint64_t t_head = a.stamps ? wall_clock64() : 0;
   const double* R = head.total.R;
@@ -382,6 +454,14 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
     atomicAdd((unsigned long long*)&a.stamps[2], (unsigned long long)(t_end - t_loop));
     atomicAdd((unsigned long long*)&a.stamps[4], 1ull);
   }
+}
+
+// The launch after the last round: prologue only (fold the last rows, solve, publish the final
+// state), one workgroup.  A kernel of its own so per-kernel profiles of iterate_kernel hold rounds only.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void close_kernel(IterArgs a) {
+  __shared__ PrologueShared<BLOCK> sh;
+  (void)round_prologue<BLOCK>(a, sh);
 }
 
 // Multi-GPU only: fold this rank's rows into one row (fixed order) so the all-reduce moves 256 B.
@@ -599,6 +679,11 @@ hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, in
     case 1024: hipLaunchKernelGGL(iterate_kernel<1024>, dim3(grid), dim3(1024), 0, s, args); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_close(hipStream_t s, const IterArgs& args) {
+  hipLaunchKernelGGL(close_kernel<1024>, dim3(1), dim3(1024), 0, s, args);
   return hipGetLastError();
 }
 
