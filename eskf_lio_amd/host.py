@@ -1,0 +1,154 @@
+"""Python handles on the C++ host mirror (libvgicp_host.so = include/eskf_lio_shim/ compiled).
+
+`LocalMap` and `ICP` here are thin ctypes proxies of the C++ classes ESKF_LIO::LocalMap and
+ESKF_LIO::ICP that keep the reference's method names and argument meaning (reference
+include/ESKF_LIO/LocalMap.hpp:91-98, include/ESKF_LIO/Registration.hpp:23-32), so parity tests read
+like tests of the reference would: build a map with updateLocalMap(), register with align().
+No compute happens in Python and there is no fallback: errors of the HIP module surface as
+RuntimeError with the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvgicp_host.so")
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    capi.load_library()  # libvgicp_hip.so first (RTLD_GLOBAL), the host layer links against it
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() / make -C eskf_lio_amd/host")
+    lib = C.CDLL(LIB_PATH)
+    vp, dp, sz = C.c_void_p, C.POINTER(C.c_double), C.c_size_t
+    lib.host_last_error.restype = C.c_char_p
+    lib.host_localmap_create_config.restype = vp
+    lib.host_localmap_create_config.argtypes = [C.c_double, sz, C.c_double, C.c_double, C.c_int, C.c_double,
+                                                C.c_double]
+    lib.host_localmap_create.restype = vp
+    lib.host_localmap_create.argtypes = [C.c_double, sz]
+    lib.host_localmap_destroy.argtypes = [vp]
+    lib.host_localmap_size.restype = sz
+    lib.host_localmap_size.argtypes = [vp]
+    lib.host_localmap_update.argtypes = [vp, sz, dp, dp, dp, C.c_int]
+    lib.host_localmap_match.argtypes = [vp, sz, dp, dp, dp, dp, dp, dp, C.POINTER(sz)]
+    lib.host_localmap_export.restype = sz
+    lib.host_localmap_export.argtypes = [vp, sz, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_uint64)]
+    lib.host_localmap_save.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.host_icp_create.restype = vp
+    lib.host_icp_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int]
+    lib.host_icp_destroy.argtypes = [vp]
+    lib.host_icp_align.argtypes = [vp, sz, dp, dp, vp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_uint64), sz]
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise RuntimeError(lib.host_last_error().decode())
+
+
+class LocalMap:
+    """ESKF_LIO::LocalMap: host-authoritative voxel grid + device mirror."""
+
+    def __init__(self, voxelSize: float, maxNumPointsPerVoxel: int, config: Optional[dict] = None):
+        self._lib = load_library()
+        if config is None:
+            self._h = self._lib.host_localmap_create(float(voxelSize), int(maxNumPointsPerVoxel))
+        else:
+            self._h = self._lib.host_localmap_create_config(
+                float(voxelSize), int(maxNumPointsPerVoxel), float(config["translation_sq_threshold"]),
+                float(config["cosine_threshold"]), int(bool(config["remove_distant_points"])),
+                float(config["distance_threshold"]), float(config["removing_period"]))
+        if not self._h:
+            raise RuntimeError(self._lib.host_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.host_localmap_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        return self._lib.host_localmap_size(self._h)
+
+    def updateLocalMap(self, points, covs, transform, initialize: bool = False):
+        """Returns the cloud moved into the world frame (the reference mutates it in place)."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3).copy()
+        cvs = np.ascontiguousarray(covs, dtype=np.float64).reshape(-1, 9).copy()
+        T = capi.pose_to_abi(transform)
+        _check(self._lib, self._lib.host_localmap_update(self._h, pts.shape[0], _dp(pts), _dp(cvs), _dp(T),
+                                                         int(initialize)))
+        return pts, cvs
+
+    def correspondenceMatching(self, points, covs):
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        cvs = np.ascontiguousarray(covs, dtype=np.float64).reshape(-1, 9)
+        n = pts.shape[0]
+        sp, sc, mp, mc = np.zeros((n, 3)), np.zeros((n, 9)), np.zeros((n, 3)), np.zeros((n, 9))
+        m = C.c_size_t()
+        _check(self._lib, self._lib.host_localmap_match(self._h, n, _dp(pts), _dp(cvs), _dp(sp), _dp(sc),
+                                                        _dp(mp), _dp(mc), C.byref(m)))
+        k = m.value
+        return sp[:k], sc[:k], mp[:k], mc[:k]
+
+    def export(self):
+        n = len(self)
+        keys = np.zeros((n, 3), dtype=np.int32)
+        means, covs = np.zeros((n, 3)), np.zeros((n, 9))
+        counts = np.zeros(n, dtype=np.uint64)
+        w = self._lib.host_localmap_export(self._h, n, keys.ctypes.data_as(C.POINTER(C.c_int32)), _dp(means),
+                                           _dp(covs), counts.ctypes.data_as(C.POINTER(C.c_uint64)))
+        assert w == n
+        return keys, means, covs, counts
+
+    def save(self, cloud_path: str, trajectory_path: str):
+        _check(self._lib, self._lib.host_localmap_save(self._h, cloud_path.encode(), trajectory_path.encode()))
+
+
+class ICP:
+    """ESKF_LIO::ICP: config keys as in registration.* of the reference's YAML."""
+
+    def __init__(self, max_iteration: int, translation_sq_threshold: float, cosine_threshold: float,
+                 chunk_iterations: int = 0):
+        self._lib = load_library()
+        self.max_iteration = int(max_iteration)
+        self._h = self._lib.host_icp_create(self.max_iteration, float(translation_sq_threshold),
+                                            float(cosine_threshold), int(chunk_iterations))
+        self.iterations = 0
+        self.converged = False
+        self.correspondence_counts = np.zeros(0, dtype=np.uint64)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.host_icp_destroy(self._h)
+            self._h = None
+
+    def align(self, points, covs, localMap: LocalMap, guess) -> np.ndarray:
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        cvs = np.ascontiguousarray(covs, dtype=np.float64).reshape(-1, 9)
+        g = capi.pose_to_abi(guess)
+        out = np.zeros(16)
+        it, conv = C.c_int32(), C.c_int32()
+        cap = max(self.max_iteration, 1)
+        counts = np.zeros(cap, dtype=np.uint64)
+        _check(self._lib, self._lib.host_icp_align(self._h, pts.shape[0], _dp(pts), _dp(cvs), localMap._h, _dp(g),
+                                                   _dp(out), C.byref(it), C.byref(conv),
+                                                   counts.ctypes.data_as(C.POINTER(C.c_uint64)), cap))
+        self.iterations, self.converged = it.value, bool(conv.value)
+        self.correspondence_counts = counts[:it.value].copy()
+        return capi.pose_from_abi(out)

@@ -1,0 +1,178 @@
+// vgicp_host.cpp — builds the C++ host mirror (include/eskf_lio_shim/: ESKF_LIO::LocalMap and
+// ESKF_LIO::ICP with the reference's method signatures) into libvgicp_host.so and gives it a small
+// C surface so the Python parity tests can drive the SAME C++ objects a patched Odometry.cpp would
+// (reference call sites: src/Odometry.cpp:61,86, src/ErrorStateKF.cpp:130).
+// Compiled with plain g++ against the dependency-free stand-in types (no Eigen / Open3D here); all
+// compute goes through libvgicp_hip.so.
+#define ESKF_LIO_SHIM_FORCE_POD 1
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "../../include/eskf_lio_shim/Registration.hpp"
+
+using ESKF_LIO::ICP;
+using ESKF_LIO::Isometry3d;
+using ESKF_LIO::LocalMap;
+using ESKF_LIO::PointCloud;
+
+namespace
+{
+thread_local std::string g_error;
+
+PointCloud makeCloud(size_t n, const double * points, const double * covs)
+{
+  PointCloud cloud;
+  cloud.points_.resize(n);
+  cloud.covariances_.resize(n);
+  if (n) {
+    std::memcpy(cloud.points_.data(), points, n * 24);
+    std::memcpy(cloud.covariances_.data(), covs, n * 72);
+  }
+  return cloud;
+}
+
+template<typename F>
+int guarded(F && f)
+{
+  try {
+    f();
+    return 0;
+  } catch (const std::exception & e) {
+    g_error = e.what();
+    return 1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char * host_last_error(void) {return g_error.c_str();}
+
+// LocalMap(config) — the YAML constructor's keys as plain arguments.
+LocalMap * host_localmap_create_config(
+  double voxel_size, size_t max_points_per_voxel, double translation_sq_threshold,
+  double cosine_threshold, int remove_distant_points, double distance_threshold,
+  double remove_period)
+{
+  LocalMap * out = nullptr;
+  guarded(
+    [&] {
+      ESKF_LIO::LocalMapConfig c;
+      c.voxelSize = voxel_size;
+      c.maxNumPointsPerVoxel = max_points_per_voxel;
+      c.translationSquaredThreshold = translation_sq_threshold;
+      c.cosineThreshold = cosine_threshold;
+      c.removeDistantPoints = remove_distant_points != 0;
+      c.distanceThreshold = distance_threshold;
+      c.removePeriod = remove_period;
+      out = new LocalMap(c);
+    });
+  return out;
+}
+
+// LocalMap(double voxelSize, size_t maxNumPointsPerVoxel, bool visualize = false)
+LocalMap * host_localmap_create(double voxel_size, size_t max_points_per_voxel)
+{
+  LocalMap * out = nullptr;
+  guarded([&] {out = new LocalMap(voxel_size, max_points_per_voxel);});
+  return out;
+}
+
+void host_localmap_destroy(LocalMap * map) {delete map;}
+size_t host_localmap_size(const LocalMap * map) {return map->size();}
+
+// updateLocalMap(cloud, transform, initialize); the transformed cloud is written back to
+// points/covs, as the reference mutates the shared cloud in place (src/LocalMap.cpp:15).
+int host_localmap_update(
+  LocalMap * map, size_t n, double * points, double * covs, const double transform[16],
+  int initialize)
+{
+  return guarded(
+    [&] {
+      auto cloud = std::make_shared<PointCloud>(makeCloud(n, points, covs));
+      map->updateLocalMap(cloud, ESKF_LIO::shim::poseFromData(transform), initialize != 0);
+      if (n) {
+        std::memcpy(points, cloud->points_.data(), n * 24);
+        std::memcpy(covs, cloud->covariances_.data(), n * 72);
+      }
+    });
+}
+
+// correspondenceMatching(points, covariances) -> the four arrays, M returned through *matched.
+int host_localmap_match(
+  const LocalMap * map, size_t n, const double * points, const double * covs, double * src_points,
+  double * src_covs, double * map_points, double * map_covs, size_t * matched)
+{
+  return guarded(
+    [&] {
+      PointCloud cloud = makeCloud(n, points, covs);
+      auto [sp, sc, mp, mc] = map->correspondenceMatching(cloud.points_, cloud.covariances_);
+      *matched = sp.size();
+      if (!sp.empty()) {
+        std::memcpy(src_points, sp.data(), sp.size() * 24);
+        std::memcpy(src_covs, sc.data(), sc.size() * 72);
+        std::memcpy(map_points, mp.data(), mp.size() * 24);
+        std::memcpy(map_covs, mc.data(), mc.size() * 72);
+      }
+    });
+}
+
+// Host-authoritative voxel statistics (order = container iteration order).
+size_t host_localmap_export(
+  const LocalMap * map, size_t capacity, int32_t * keys, double * means, double * covs,
+  uint64_t * counts)
+{
+  size_t w = 0;
+  for (const auto & kv : map->grid()) {
+    if (w == capacity) {break;}
+    keys[3 * w] = kv.first.i;
+    keys[3 * w + 1] = kv.first.j;
+    keys[3 * w + 2] = kv.first.k;
+    std::memcpy(means + 3 * w, kv.second.mean.data(), 24);
+    std::memcpy(covs + 9 * w, kv.second.covariance.data(), 72);
+    counts[w] = kv.second.numPoints;
+    ++w;
+  }
+  return w;
+}
+
+int host_localmap_save(const LocalMap * map, const char * cloud_path, const char * trajectory_path)
+{
+  return guarded([&] {map->save(cloud_path, trajectory_path);});
+}
+
+// ICP(config) — registration.max_iteration / translation_sq_threshold / cosine_threshold
+ICP * host_icp_create(
+  int max_iteration, double translation_sq_threshold, double cosine_threshold, int chunk_iterations)
+{
+  ESKF_LIO::RegistrationConfig c;
+  c.maxIteration = max_iteration;
+  c.translationSquaredThreshold = translation_sq_threshold;
+  c.cosineThreshold = cosine_threshold;
+  c.chunkIterations = chunk_iterations;
+  return new ICP(c);
+}
+void host_icp_destroy(ICP * icp) {delete icp;}
+
+// icp->align(cloud, localMap, guess)
+int host_icp_align(
+  ICP * icp, size_t n, const double * points, const double * covs, const LocalMap * map,
+  const double guess[16], double out_pose[16], int32_t * iterations, int32_t * converged,
+  uint64_t * corr_count, size_t corr_capacity)
+{
+  return guarded(
+    [&] {
+      const PointCloud cloud = makeCloud(n, points, covs);
+      const Isometry3d T = icp->align(cloud, *map, ESKF_LIO::shim::poseFromData(guess));
+      std::memcpy(out_pose, ESKF_LIO::shim::poseData(T), 16 * sizeof(double));
+      const auto & st = icp->lastStats();
+      if (iterations) {*iterations = st.iterations;}
+      if (converged) {*converged = st.converged ? 1 : 0;}
+      for (size_t k = 0; k < st.correspondenceCounts.size() && k < corr_capacity; ++k) {
+        corr_count[k] = st.correspondenceCounts[k];
+      }
+    });
+}
+
+}  // extern "C"

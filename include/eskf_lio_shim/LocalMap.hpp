@@ -1,0 +1,412 @@
+// LocalMap.hpp — drop-in for the reference's include/ESKF_LIO/LocalMap.hpp + src/LocalMap.cpp.
+//
+// Same class name, namespace and public methods as the reference (include/ESKF_LIO/LocalMap.hpp:
+// 28-61 constructors, :91-98 methods), so src/Odometry.cpp:61,86 and src/ErrorStateKF.cpp:115-130
+// compile against it unchanged.  What differs is where the data lives:
+//   * the host std::unordered_map stays authoritative (save() and the running-mean insertion rule of
+//     Voxel::addPoint, LocalMap.hpp:79-87, need it) and is updated exactly as
+//     LocalMap::updateLocalMap does (src/LocalMap.cpp:10-76);
+//   * every voxel touched by an update is forwarded to the device mirror as ONE vgicp_map_upsert
+//     batch, every evicted voxel as ONE vgicp_map_erase batch, so the HIP registration path reads a
+//     table that is current before the next ICP::align;
+//   * correspondenceMatching() (src/LocalMap.cpp:78-112) runs on the device through vgicp_match and
+//     returns the reference's tuple (srcPoints, srcCovs, mapPoints, mapCovs) in ascending point order
+//     (the reference's order is thread-arrival order, i.e. unspecified).
+// Deviations, both documented in DESIGN.md: prevTransform_ is initialised (the reference reads it
+// uninitialised on the first frame, LocalMap.hpp:113 / LocalMap.cpp:39,134) so the first update
+// always inserts; Open3D GUI calls are dropped (visualizeLocalMap() returns true without a window).
+// There is no CPU fallback: every method that needs the device throws std::runtime_error with the
+// library's message when the HIP module reports an error.
+#ifndef ESKF_LIO_SHIM_LOCAL_MAP_HPP_
+#define ESKF_LIO_SHIM_LOCAL_MAP_HPP_
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../vgicp_hip.h"
+#include "Types.hpp"
+
+#if defined(ESKF_LIO_SHIM_NATIVE_TYPES) && __has_include(<yaml-cpp/yaml.h>)
+#include <yaml-cpp/yaml.h>
+#define ESKF_LIO_SHIM_HAVE_YAML 1
+#endif
+
+namespace ESKF_LIO
+{
+
+// The keys LocalMap's YAML constructor reads (config/hilti_config.yaml:36-45).
+struct LocalMapConfig
+{
+  double voxelSize = 0.3;
+  size_t maxNumPointsPerVoxel = 1000;
+  double translationSquaredThreshold = 1.0e-2;
+  double cosineThreshold = 0.985;
+  bool removeDistantPoints = true;
+  double distanceThreshold = 100.0;
+  double removePeriod = 10.0;
+};
+
+namespace shim
+{
+inline void check(vgicp_ctx * ctx, int rc, const char * what)
+{
+  if (rc != VGICP_OK) {
+    throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " +
+            vgicp_last_error(ctx));
+  }
+}
+
+// One device context per process, created on first use (device = $VGICP_DEVICE or 0).
+inline vgicp_ctx * defaultContext()
+{
+  static vgicp_ctx * ctx = [] {
+      int dev = 0;
+      if (const char * env = std::getenv("VGICP_DEVICE")) {dev = std::atoi(env);}
+      vgicp_ctx * c = nullptr;
+      const int rc = vgicp_create(dev, &c);
+      if (rc != VGICP_OK) {
+        throw std::runtime_error(std::string("vgicp_create failed: ") + vgicp_last_error(nullptr));
+      }
+      return c;
+    }();
+  return ctx;
+}
+}  // namespace shim
+
+class LocalMap
+{
+public:
+  struct Voxel;
+
+  using PointVector = typename std::vector<Vector3d>;
+  using CovarianceVector = typename std::vector<Matrix3d>;
+  using Correspondence = typename std::tuple<PointVector, CovarianceVector, PointVector,
+      CovarianceVector>;
+
+  struct Key
+  {
+    int32_t i, j, k;
+    bool operator==(const Key & o) const {return i == o.i && j == o.j && k == o.k;}
+  };
+  // open3d::utility::hash_eigen<Eigen::Vector3i> (boost-style combine); only iteration order
+  // depends on it.
+  struct VoxelHash
+  {
+    size_t operator()(const Key & key) const
+    {
+      size_t seed = 0;
+      const int32_t e[3] = {key.i, key.j, key.k};
+      for (int n = 0; n < 3; ++n) {
+        seed ^= std::hash<int>()(e[n]) + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+      }
+      return seed;
+    }
+  };
+  using VoxelGrid = typename std::unordered_map<Key, Voxel, VoxelHash>;
+
+  struct Voxel
+  {
+    size_t maxNumPoints;
+    size_t numPoints;
+    PointVector points;
+    Vector3d mean;
+    Matrix3d covariance;
+    bool dirty = false;  // touched since the last device sync
+
+    Voxel(size_t maxNumPoints_, const Vector3d & point, const Matrix3d & covariance_)
+    : maxNumPoints(maxNumPoints_), numPoints(1), mean(point), covariance(covariance_)
+    {
+      points.reserve(maxNumPoints);
+      points.push_back(point);
+    }
+
+    // returns true when the voxel changed
+    bool addPoint(const Vector3d & point, const Matrix3d & covariance_)
+    {
+      if (numPoints >= maxNumPoints) {return false;}
+      points.push_back(point);
+      const double n = static_cast<double>(numPoints), n1 = static_cast<double>(numPoints + 1);
+      for (int a = 0; a < 3; ++a) {mean(a) = (n * mean(a) + point(a)) / n1;}
+      for (int c = 0; c < 3; ++c) {
+        for (int r = 0; r < 3; ++r) {
+          covariance(r, c) = (n * covariance(r, c) + covariance_(r, c)) / n1;
+        }
+      }
+      ++numPoints;
+      return true;
+    }
+  };
+
+  explicit LocalMap(const LocalMapConfig & config, bool visualize = false, vgicp_ctx * ctx = nullptr)
+  : voxelSize_(config.voxelSize)
+    , maxNumPointsPerVoxel_(config.maxNumPointsPerVoxel)
+    , translationSquaredThreshold_(config.translationSquaredThreshold)
+    , cosineThreshold_(config.cosineThreshold)
+    , removeDistantPoints_(config.removeDistantPoints)
+    , distanceThreshold_(config.distanceThreshold)
+    , removePeriod_(config.removePeriod)
+    , visualize_(visualize)
+    , ctx_(ctx ? ctx : shim::defaultContext())
+  {
+    shim::check(ctx_, vgicp_map_reset(ctx_, voxelSize_, 0), "vgicp_map_reset");
+  }
+
+  // reference: LocalMap(double voxelSize, size_t maxNumPointsPerVoxel, bool visualize = false).
+  // The reference leaves the update thresholds uninitialised here (LocalMap.hpp:54-61); this one
+  // disables the motion gate and the eviction instead, i.e. every update inserts.
+  LocalMap(double voxelSize, size_t maxNumPointsPerVoxel, bool visualize = false,
+    vgicp_ctx * ctx = nullptr)
+  : voxelSize_(voxelSize)
+    , maxNumPointsPerVoxel_(maxNumPointsPerVoxel)
+    , translationSquaredThreshold_(-1.0)
+    , cosineThreshold_(2.0)
+    , removeDistantPoints_(false)
+    , distanceThreshold_(std::numeric_limits<double>::infinity())
+    , removePeriod_(std::numeric_limits<double>::infinity())
+    , visualize_(visualize)
+    , ctx_(ctx ? ctx : shim::defaultContext())
+  {
+    shim::check(ctx_, vgicp_map_reset(ctx_, voxelSize_, 0), "vgicp_map_reset");
+  }
+
+#if defined(ESKF_LIO_SHIM_HAVE_YAML)
+  // reference: LocalMap(const YAML::Node &, const PinholeCameraParameters &, bool visualize = true)
+  LocalMap(
+    const YAML::Node & config, const open3d::camera::PinholeCameraParameters &,
+    bool visualize = true)
+  : LocalMap(fromYaml(config), visualize) {}
+
+  static LocalMapConfig fromYaml(const YAML::Node & config)
+  {
+    LocalMapConfig c;
+    const auto & m = config["local_map"];
+    c.voxelSize = m["voxel_size"].as<double>();
+    c.maxNumPointsPerVoxel = m["max_num_points_per_voxel"].as<size_t>();
+    c.translationSquaredThreshold = m["update"]["translation_sq_threshold"].as<double>();
+    c.cosineThreshold = m["update"]["cosine_threshold"].as<double>();
+    c.removeDistantPoints = m["remove_distant_points"]["enabled"].as<bool>();
+    c.distanceThreshold = m["remove_distant_points"]["distance_threshold"].as<double>();
+    c.removePeriod = m["remove_distant_points"]["removing_period"].as<double>();
+    return c;
+  }
+#endif
+
+  // reference: src/LocalMap.cpp:10-76. The cloud is moved into the world frame in place, as there.
+  void updateLocalMap(PointCloudPtr cloud, const Isometry3d & transform, bool initialize = false)
+  {
+    cloud->Transform(transform.matrix());
+    trajectory_.push_back(transform);
+
+    if (initialize == false && hasPrevTransform_ && needsMapUpdate(transform) == false) {
+      prevTransform_ = transform;
+      return;
+    }
+
+    const auto & points = cloud->points_;
+    const auto & covariances = cloud->covariances_;
+    std::vector<Voxel *> touched;
+    std::vector<Key> touchedKeys;
+    for (size_t i = 0; i < points.size(); ++i) {
+      const Key key = toKey(getVoxelIndex(points[i]));
+      auto found = voxelGrid_.find(key);
+      Voxel * voxel = nullptr;
+      bool changed = true;
+      if (found == voxelGrid_.end()) {
+        voxel = &voxelGrid_.emplace(key, Voxel(maxNumPointsPerVoxel_, points[i], covariances[i]))
+          .first->second;
+      } else {
+        voxel = &found->second;
+        changed = voxel->addPoint(points[i], covariances[i]);
+      }
+      if (changed && !voxel->dirty) {
+        voxel->dirty = true;
+        touched.push_back(voxel);
+        touchedKeys.push_back(key);
+      }
+    }
+
+    std::vector<int32_t> erased;
+    if (removeDistantPoints_ && now() - currentRemoveTime_ > removePeriod_) {
+      size_t numRemovedVoxels = 0;
+      const Vector3d position = transform.translation();
+      for (auto it = voxelGrid_.begin(); it != voxelGrid_.end(); ) {
+        if (needsPointRemoval(it->first, position)) {
+          erased.push_back(it->first.i);
+          erased.push_back(it->first.j);
+          erased.push_back(it->first.k);
+          it->second.dirty = false;
+          it = voxelGrid_.erase(it);
+          ++numRemovedVoxels;
+        } else {
+          ++it;
+        }
+      }
+      currentRemoveTime_ = now();
+      std::cout << "removed " << numRemovedVoxels << " voxels\n";
+    }
+
+    syncDevice(touched, touchedKeys, erased);
+    prevTransform_ = transform;
+    hasPrevTransform_ = true;
+  }
+
+  // reference: src/LocalMap.cpp:78-112 (device lookup; ascending point order).
+  Correspondence correspondenceMatching(
+    const PointVector & points, const CovarianceVector & covariances) const
+  {
+    Correspondence correspondence;
+    auto & [srcPoints, srcCovs, mapPoints, mapCovs] = correspondence;
+    const size_t n = points.size();
+    srcPoints.resize(n);
+    srcCovs.resize(n);
+    mapPoints.resize(n);
+    mapCovs.resize(n);
+    size_t matched = 0;
+    if (n > 0) {
+      shim::check(
+        ctx_, vgicp_match(
+          ctx_, n, points.data()->data(), covariances.data()->data(),
+          srcPoints.data()->data(), srcCovs.data()->data(), mapPoints.data()->data(),
+          mapCovs.data()->data(), nullptr, &matched), "vgicp_match");
+    }
+    srcPoints.resize(matched);
+    srcCovs.resize(matched);
+    mapPoints.resize(matched);
+    mapCovs.resize(matched);
+    return correspondence;
+  }
+
+  // reference: src/LocalMap.cpp:120-130 polls an Open3D window; there is none here.
+  bool visualizeLocalMap() const {return true;}
+
+  // reference: src/LocalMap.cpp:156-167 writes a .pcd through Open3D and a PinholeCameraTrajectory
+  // JSON. Written here without Open3D: ASCII PCD v0.7 of every stored point, and the 4x4 poses as a
+  // JSON array of column-major "extrinsic" arrays (the field Open3D's trajectory reader uses).
+  void save(const std::string & cloud_path, const std::string & trajectory_path) const
+  {
+    size_t total = 0;
+    for (const auto & kv : voxelGrid_) {total += kv.second.points.size();}
+    std::ofstream pcd(cloud_path);
+    pcd << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 8 8 8\n"
+        << "TYPE F F F\nCOUNT 1 1 1\nWIDTH " << total << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\n"
+        << "POINTS " << total << "\nDATA ascii\n";
+    pcd.precision(17);
+    for (const auto & kv : voxelGrid_) {
+      for (const auto & p : kv.second.points) {pcd << p(0) << ' ' << p(1) << ' ' << p(2) << '\n';}
+    }
+    std::ofstream traj(trajectory_path);
+    traj.precision(17);
+    traj << "{\n\"class_name\" : \"PinholeCameraTrajectory\",\n\"parameters\" : [\n";
+    for (size_t t = 0; t < trajectory_.size(); ++t) {
+      const double * m = shim::poseData(trajectory_[t]);
+      traj << "{ \"extrinsic\" : [";
+      for (int e = 0; e < 16; ++e) {traj << (e ? ", " : " ") << m[e];}
+      traj << " ] }" << (t + 1 < trajectory_.size() ? ",\n" : "\n");
+    }
+    traj << "],\n\"version_major\" : 1,\n\"version_minor\" : 0\n}\n";
+  }
+
+  // ---- additions (not in the reference) ----
+  size_t size() const {return voxelGrid_.size();}
+  double voxelSize() const {return voxelSize_;}
+  vgicp_ctx * context() const {return ctx_;}
+  const VoxelGrid & grid() const {return voxelGrid_;}
+
+private:
+  static Key toKey(const Vector3i & v) {return Key{v(0), v(1), v(2)};}
+  static double now()
+  {
+    return std::chrono::duration<double>(
+      std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+
+  // reference: src/LocalMap.cpp:114-118
+  Vector3i getVoxelIndex(const Vector3d & point) const
+  {
+    Vector3i idx;
+    for (int a = 0; a < 3; ++a) {idx(a) = static_cast<int>(std::floor(point(a) / voxelSize_));}
+    return idx;
+  }
+
+  // reference: src/LocalMap.cpp:132-147
+  bool needsMapUpdate(const Isometry3d & transform) const
+  {
+    const Isometry3d moved = prevTransform_.inverse() * transform;
+    const auto R = moved.linear();
+    const double cosine = 0.5 * (R(0, 0) + R(1, 1) + R(2, 2) - 1.0);
+    if (cosine < cosineThreshold_) {return true;}
+    const auto t = moved.translation();
+    const double translationSq = t(0) * t(0) + t(1) * t(1) + t(2) * t(2);
+    if (translationSq > translationSquaredThreshold_) {return true;}
+    return false;
+  }
+
+  // reference: src/LocalMap.cpp:149-154
+  bool needsPointRemoval(const Key & key, const Vector3d & currentPos) const
+  {
+    const double c[3] = {(key.i + 0.5) * voxelSize_, (key.j + 0.5) * voxelSize_,
+      (key.k + 0.5) * voxelSize_};
+    const double d0 = c[0] - currentPos(0), d1 = c[1] - currentPos(1), d2 = c[2] - currentPos(2);
+    return std::sqrt(d0 * d0 + d1 * d1 + d2 * d2) > distanceThreshold_;
+  }
+
+  void syncDevice(
+    const std::vector<Voxel *> & touched, const std::vector<Key> & keys,
+    const std::vector<int32_t> & erased)
+  {
+    // a voxel both touched and evicted in this update is gone: its Voxel* is dangling, skip by key
+    std::vector<int32_t> k;
+    std::vector<double> means, covs;
+    k.reserve(3 * touched.size());
+    means.reserve(3 * touched.size());
+    covs.reserve(9 * touched.size());
+    for (size_t n = 0; n < touched.size(); ++n) {
+      if (!erased.empty() && voxelGrid_.find(keys[n]) == voxelGrid_.end()) {continue;}
+      Voxel * v = touched[n];
+      v->dirty = false;
+      k.push_back(keys[n].i);
+      k.push_back(keys[n].j);
+      k.push_back(keys[n].k);
+      for (int a = 0; a < 3; ++a) {means.push_back(v->mean(a));}
+      for (int e = 0; e < 9; ++e) {covs.push_back(v->covariance.data()[e]);}
+    }
+    if (!erased.empty()) {
+      shim::check(ctx_, vgicp_map_erase(ctx_, erased.size() / 3, erased.data()), "vgicp_map_erase");
+    }
+    if (!k.empty()) {
+      shim::check(
+        ctx_, vgicp_map_upsert(ctx_, k.size() / 3, k.data(), means.data(), covs.data()),
+        "vgicp_map_upsert");
+    }
+  }
+
+  double voxelSize_;
+  size_t maxNumPointsPerVoxel_;
+  double translationSquaredThreshold_;
+  double cosineThreshold_;
+  bool removeDistantPoints_;
+  double distanceThreshold_;
+  double removePeriod_;
+  double currentRemoveTime_ = std::numeric_limits<double>::lowest();
+  Isometry3d prevTransform_ = Isometry3d::Identity();
+  bool hasPrevTransform_ = false;
+
+  VoxelGrid voxelGrid_;
+
+  bool visualize_;
+  std::vector<Isometry3d> trajectory_;
+  vgicp_ctx * ctx_;
+};
+}  // namespace ESKF_LIO
+
+#endif  // ESKF_LIO_SHIM_LOCAL_MAP_HPP_

@@ -1,0 +1,113 @@
+// Registration.hpp — drop-in for the reference's include/ESKF_LIO/Registration.hpp +
+// src/Registration.cpp: class ESKF_LIO::ICP with the same constructor keys and the same
+//   Eigen::Isometry3d align(const PointCloud & cloud, const LocalMap & localMap,
+//                           const Eigen::Isometry3d & guess)
+// (reference include/ESKF_LIO/Registration.hpp:23-32), so src/ErrorStateKF.cpp:9,130 compiles
+// against it unchanged.  align() forwards the raw buffers of the cloud to vgicp_align(): the whole
+// loop of src/Registration.cpp:7-35 then runs on the MI355X (see include/vgicp_hip.h).
+// Behaviour kept: inputs are not modified; non-convergence only prints "ICP not converged!"
+// (src/Registration.cpp:30-32) and still returns the pose.  Behaviour changed on purpose: the
+// reference's converged_ member is sticky across calls (Registration.hpp:50, set at
+// Registration.cpp:23 and never reset), so after the first converged frame its message can never
+// print again; here convergence is per call and readable through lastStats().  A HIP / argument
+// error throws std::runtime_error (the reference has no error path at all).
+#ifndef ESKF_LIO_SHIM_REGISTRATION_HPP_
+#define ESKF_LIO_SHIM_REGISTRATION_HPP_
+
+#include <cstdint>
+#include <iostream>
+#include <vector>
+
+#include "LocalMap.hpp"
+
+namespace ESKF_LIO
+{
+
+// The keys ICP's YAML constructor reads (config/hilti_config.yaml:50-53).
+struct RegistrationConfig
+{
+  int maxIteration = 100;
+  double translationSquaredThreshold = 1.0e-6;
+  double cosineThreshold = 0.9999;
+  int chunkIterations = 0;  // vgicp_params.chunk_iterations; 0 = library default
+};
+
+class ICP
+{
+public:
+  using PointVector = typename std::vector<Vector3d>;
+  using CovarianceVector = typename std::vector<Matrix3d>;
+  using Correspondence = typename std::tuple<PointVector, CovarianceVector, PointVector,
+      CovarianceVector>;
+
+  struct Stats
+  {
+    int iterations = 0;
+    bool converged = false;
+    double seconds = 0.0;
+    double deviceSeconds = 0.0;
+    std::vector<uint64_t> correspondenceCounts;
+  };
+
+  explicit ICP(const RegistrationConfig & config)
+  : maxIteration_(config.maxIteration)
+    , translationSquaredThreshold_(config.translationSquaredThreshold)
+    , cosineThreshold_(config.cosineThreshold)
+    , chunkIterations_(config.chunkIterations)
+  {
+  }
+
+#if defined(ESKF_LIO_SHIM_HAVE_YAML)
+  ICP(const YAML::Node & config)
+  : maxIteration_(config["registration"]["max_iteration"].as<int>())
+    , translationSquaredThreshold_(config["registration"]["translation_sq_threshold"].as<double>())
+    , cosineThreshold_(config["registration"]["cosine_threshold"].as<double>())
+  {
+  }
+#endif
+
+  Isometry3d align(const PointCloud & cloud, const LocalMap & localMap, const Isometry3d & guess)
+  {
+    vgicp_ctx * ctx = localMap.context();
+    vgicp_params params{};
+    params.max_iteration = maxIteration_;
+    params.chunk_iterations = chunkIterations_;
+    params.translation_sq_threshold = translationSquaredThreshold_;
+    params.cosine_threshold = cosineThreshold_;
+    std::vector<uint64_t> counts(static_cast<size_t>(maxIteration_ > 0 ? maxIteration_ : 1), 0);
+    vgicp_stats stats{};
+    stats.corr_count = counts.data();
+    double pose[16];
+    const size_t n = cloud.points_.size();
+    const double * pts = n ? cloud.points_.data()->data() : nullptr;
+    const double * covs = n ? cloud.covariances_.data()->data() : nullptr;
+    const int rc = vgicp_align(ctx, n, pts, covs, shim::poseData(guess), &params, pose, &stats);
+    if (rc != VGICP_OK && rc != VGICP_ERR_DEGENERATE) {shim::check(ctx, rc, "vgicp_align");}
+
+    lastStats_.iterations = stats.iterations;
+    lastStats_.converged = stats.converged != 0;
+    lastStats_.seconds = stats.seconds;
+    lastStats_.deviceSeconds = stats.device_seconds;
+    counts.resize(static_cast<size_t>(stats.iterations));
+    lastStats_.correspondenceCounts = counts;
+    if (!lastStats_.converged) {
+      std::cout << "ICP not converged!\n";
+    }
+    return shim::poseFromData(pose);
+  }
+
+  const Stats & lastStats() const {return lastStats_;}
+
+private:
+  ICP() = delete;
+
+  int maxIteration_;
+  double translationSquaredThreshold_;
+  double cosineThreshold_;
+  int chunkIterations_ = 0;
+  Stats lastStats_;
+};
+
+}  // namespace ESKF_LIO
+
+#endif  // ESKF_LIO_SHIM_REGISTRATION_HPP_

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures in this directory from the CPU oracle (deterministic mode).
+
+The reference ships no tests or golden vectors for this path and cannot be built or imported here
+(C++ needing Eigen / Open3D / yaml-cpp / ROS 2), so these fixtures are outputs of oracle/ — itself
+pinned by analytic known-answer tests and an independent numpy restatement (tests/test_oracle.py).
+PARITY UNPINNED by the reference's own tests; see DESIGN.md "Oracle".
+
+Inputs of the C1-sized cases are NOT stored: eskf_lio_amd.synth regenerates them bit-for-bit from
+seeds (IEEE-exact arithmetic only). The tiny case stores its inputs too, so it is hermetic.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from eskf_lio_amd import synth  # noqa: E402
+from oracle import binding as oracle  # noqa: E402
+
+
+def run(vmap, pts, covs, guess, max_it, tsq, cos):
+    om = oracle.OracleMap(vmap.voxel_size, 1)
+    om.insert(vmap.means, vmap.covs)
+    r = om.align(pts, covs, guess, max_it, tsq, cos)
+    return dict(pose=r.pose, iterations=np.int32(r.iterations), converged=np.bool_(r.converged),
+                corr_count=r.corr_count, JTJ=r.JTJ, JTr=r.JTr, guess=guess,
+                params=np.array([max_it, tsq, cos], dtype=np.float64))
+
+
+def checksum(*arrays):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest()[:8], dtype=np.uint64)[0]
+
+
+def main():
+    vmap = synth.make_map(50_000)
+    pts, covs = synth.make_uniform_scan(5_000, vmap)
+    out = run(vmap, pts, covs, synth.default_guess(), 20, 1e-6, 2.0)
+    out["input_checksum"] = checksum(vmap.keys, vmap.means, vmap.covs, pts, covs)
+    np.savez(os.path.join(HERE, "c1_uniform.npz"), **out)
+
+    spts, scovs, T_true = synth.make_structured_scan(5_000, vmap)
+    out = run(vmap, spts, scovs, np.eye(4), 100, 1e-6, 0.9999)
+    out["T_true"] = T_true
+    out["input_checksum"] = checksum(spts, scovs)
+    np.savez(os.path.join(HERE, "c1_structured.npz"), **out)
+
+    tmap = synth.make_map(400, seed=0x54494E59)
+    tpts, tcovs = synth.make_uniform_scan(96, tmap, seed=0x54494E5A)
+    out = run(tmap, tpts, tcovs, synth.default_guess(), 8, 1e-6, 2.0)
+    out.update(keys=tmap.keys, means=tmap.means, covs=tmap.covs, points=tpts, point_covs=tcovs,
+               voxel_size=np.float64(tmap.voxel_size))
+    np.savez(os.path.join(HERE, "tiny.npz"), **out)
+    for f in ("c1_uniform.npz", "c1_structured.npz", "tiny.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, and refuses to compute without a gfx950 device (no fallback). No GPU needed."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAS_GPU = torch.cuda.device_count() > 0  # device_count() does not initialise the GPU
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "vgicp_hip.h")).read()
+    return sorted(set(re.findall(r"\b(vgicp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_build_entry_point_compiles_everything():
+    import __graft_entry__ as g
+    g.build()
+    for rel in ("eskf_lio_amd/lib/libvgicp_hip.so", "eskf_lio_amd/lib/libvgicp_host.so",
+                "oracle/libvgicp_oracle.so"):
+        assert os.path.exists(os.path.join(ROOT, rel)), rel
+
+
+def test_library_exports_every_declared_symbol():
+    from eskf_lio_amd import capi
+    lib = capi.load_library()
+    declared = header_symbols()
+    assert len(declared) == 18 and set(declared) == set(capi.EXPORTS)
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True,
+                         check=True).stdout
+    exported = set(re.findall(r" T (vgicp_[a-z_0-9]+)", out))
+    assert set(declared) <= exported
+    assert lib.vgicp_abi_version() == 1
+
+
+def test_library_is_a_gfx950_code_object_without_torch_or_oracle():
+    from eskf_lio_amd import capi
+    needed = subprocess.run(["readelf", "-d", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    libs = re.findall(r"NEEDED.*\[(.*)\]", needed)
+    assert any("amdhip64" in n for n in libs)
+    assert not any("torch" in n or "c10" in n or "oracle" in n or "rccl" in n for n in libs)  # RCCL is dlopen'ed
+    raw = open(capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in raw and b"gfx942" not in raw and b"sm_" not in raw
+
+
+def test_struct_layouts_match_the_header():
+    from eskf_lio_amd import capi
+    assert C.sizeof(capi.Params) == 32
+    assert capi.Params.translation_sq_threshold.offset == 8 and capi.Params.flags.offset == 24
+    assert C.sizeof(capi.Stats) == 56 and capi.Stats.corr_count.offset == 32
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-device behaviour")
+def test_no_device_means_loud_failure_not_fallback():
+    from eskf_lio_amd import capi
+    with pytest.raises(capi.VgicpError) as e:
+        capi.Context(0)
+    assert e.value.code == capi.ERR_NO_DEVICE
+    lib = capi.load_library()
+    # NULL context: every entry point rejects it instead of crashing
+    assert lib.vgicp_map_reset(None, 0.3, 0) == capi.ERR_BAD_ARGUMENT
+    assert lib.vgicp_destroy(None) == capi.OK
+    from eskf_lio_amd import host
+    with pytest.raises(RuntimeError):
+        host.LocalMap(0.3, 1)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "eskf_lio_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "vgicp_oracle" not in text, f
+    for base, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            assert "oracle" not in open(os.path.join(base, f)).read().lower(), f
+
+
+def test_shard_bounds_tile_the_scan():
+    from eskf_lio_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 8, 9, 100_000, 1_000_003):
+        for w in (1, 2, 3, 4, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def test_pose_abi_roundtrip():
+    from eskf_lio_amd import capi, synth
+    T = synth.se3_to_SE3([1, 2, 3, 0.1, 0.2, 0.3])
+    v = capi.pose_to_abi(T)
+    assert v[12] == T[0, 3] and v[1] == T[1, 0] and v[15] == 1.0      # column-major, as Eigen
+    assert np.array_equal(capi.pose_from_abi(v), T)
+    rows = np.arange(27.0)[None]
+    JTJ, JTr = capi.expand_normal_eq(rows)
+    assert JTJ[0, 3, 1] == 7 and JTJ[0, 1, 3] == 7 and JTJ[0, 5, 5] == 20 and JTr[0, 0] == 21

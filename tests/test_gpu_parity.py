@@ -1,0 +1,386 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes -> libvgicp_hip.so, and through
+the C++ host mirror libvgicp_host.so), against the CPU oracle and the committed golden fixtures.
+
+Bar (BASELINE.json north_star): final pose within 1e-4 m / 1e-4 rad of the CPU path and IDENTICAL
+per-iteration correspondence counts.  The tests also assert the much tighter bound the fp64 kernels
+actually reach (1e-9), so drift is caught early.  Integer work (voxel keys, match indices, counts)
+is compared bit-exactly.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import POSE_TOL_M, POSE_TOL_RAD, TIGHT_POSE_TOL, NORMAL_EQ_RTOL, pose_error
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def assert_align_parity(got, ref, tight=TIGHT_POSE_TOL):
+    assert got.iterations == ref.iterations
+    assert got.converged == ref.converged
+    assert np.array_equal(got.corr_count, ref.corr_count)          # identical correspondence counts
+    dt, dr = pose_error(got.pose, ref.pose)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD                 # contractual tolerance
+    assert dt <= tight and dr <= tight                             # what the HIP path achieves
+
+
+# ---- device / table ---------------------------------------------------------------------------
+def test_device_is_gfx950(gpu_ctx):
+    name, cus, hbm = gpu_ctx.device_info()
+    assert name.startswith("gfx950") and cus >= 200 and hbm > 200e9
+
+
+def test_map_upsert_overwrite_erase_and_growth(gpu_ctx, c1_inputs, oracle):
+    vmap, pts, covs = c1_inputs
+    V = vmap.keys.shape[0]
+    gpu_ctx.map_reset(vmap.voxel_size, 0)                          # no hint: forces growth + rehash
+    for lo in range(0, V, 7_000):                                  # ragged batches
+        gpu_ctx.map_upsert(vmap.keys[lo:lo + 7_000], vmap.means[lo:lo + 7_000], vmap.covs[lo:lo + 7_000])
+    voxels, slots = gpu_ctx.map_size()
+    assert voxels == V and slots >= 2 * V and slots & (slots - 1) == 0
+    gpu_ctx.map_upsert(vmap.keys[:100], vmap.means[:100], vmap.covs[:100])   # pure overwrite
+    assert gpu_ctx.map_size()[0] == V
+    # lookups see exactly the inserted voxels
+    sp, sc, mp, mc, ix = gpu_ctx.match(vmap.means, vmap.covs)
+    assert len(ix) == V and np.array_equal(ix, np.arange(V, dtype=np.uint64))
+    assert np.array_equal(mp, vmap.means) and np.array_equal(mc, vmap.covs)
+    # erase half (with duplicates and absent keys in the batch), lookups follow
+    gone = vmap.keys[::2]
+    batch = np.concatenate([gone, gone[:50], np.full((10, 3), 10_000, dtype=np.int32)])
+    gpu_ctx.map_erase(batch)
+    assert gpu_ctx.map_size()[0] == V - gone.shape[0]
+    _, _, _, _, ix = gpu_ctx.match(vmap.means, vmap.covs)
+    assert np.array_equal(ix, np.arange(1, V, 2, dtype=np.uint64))
+    # re-insert with new values: tombstones do not hide or duplicate them
+    gpu_ctx.map_upsert(gone, vmap.means[::2] + 0.001, vmap.covs[::2])
+    assert gpu_ctx.map_size()[0] == V
+    _, _, mp, _, ix = gpu_ctx.match(vmap.means, vmap.covs)
+    assert len(ix) == V and np.array_equal(mp[::2], vmap.means[::2] + 0.001) and np.array_equal(mp[1::2], vmap.means[1::2])
+    gpu_ctx.map_upsert(np.zeros((0, 3), np.int32), np.zeros((0, 3)), np.zeros((0, 9)))   # empty batch
+
+
+def test_voxel_index_is_bit_exact(gpu_ctx, oracle):
+    gpu_ctx.map_reset(0.3, 0)
+    rng = np.random.default_rng(5)
+    rnd = rng.uniform(-50, 50, size=(60_000, 3))
+    on_face = np.round(rnd / 0.3) * 0.3
+    edge = np.array([[-0.1, 0.0, 0.3], [-0.3, 0.29999999999999993, 0.6], [-0.30000000000000004, 0.9, -1e-300],
+                     [1e-300, -0.0, 299.99999999999994]])
+    for p in (rnd, on_face, edge):
+        assert np.array_equal(gpu_ctx.voxel_index(p), oracle.voxel_index(0.3, p))
+    assert gpu_ctx.voxel_index(edge)[0].tolist() == [-1, 0, 1]     # floor, not truncation
+
+
+def test_match_equals_oracle_correspondences(c1_gpu, c1_inputs, c1_oracle_map, oracle):
+    from eskf_lio_amd import synth
+    _, pts, covs = c1_inputs
+    tp, tc = oracle.transform(pts, covs, synth.default_guess())
+    got = c1_gpu.match(tp, tc)
+    ref = c1_oracle_map.match(tp, tc)
+    assert len(got[4]) == len(ref[4]) > 2000
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)                                # bit-exact, ascending point order
+    # ragged sizes around the workgroup width, and the empty scan
+    for n in (0, 1, 63, 64, 65, 255, 256, 257, 1000):
+        g = c1_gpu.match(tp[:n], tc[:n])
+        r = c1_oracle_map.match(tp[:n], tc[:n])
+        assert all(np.array_equal(a, b) for a, b in zip(g, r))
+
+
+# ---- one iteration ----------------------------------------------------------------------------
+def test_k1_single_correspondence_on_device(gpu_ctx, oracle):
+    gpu_ctx.map_reset(0.3, 0)
+    mu = np.array([[0.95, 2.05, 3.1]])
+    gpu_ctx.map_upsert(np.floor(mu / 0.3).astype(np.int32), mu, 0.5 * np.eye(3).reshape(1, 9))
+    p = np.array([[1.0, 2.0, 3.0]])
+    JTJ, JTr, cnt = gpu_ctx.accumulate(p, 0.5 * np.eye(3).reshape(1, 9), np.eye(4))
+    assert cnt == 1
+    oJ, oR = oracle.jtj_jtr(p[0], mu[0], np.eye(3))
+    assert np.allclose(JTJ, oJ, rtol=0, atol=1e-14) and np.allclose(JTr, oR, rtol=0, atol=1e-14)
+    assert JTJ[3, 3] == 13.0 and JTJ[0, 4] == 3.0                  # hand-written entries for p = (1,2,3)
+
+
+def test_accumulate_matches_oracle(c1_gpu, c1_inputs, c1_oracle_map, oracle):
+    from eskf_lio_amd import synth
+    _, pts, covs = c1_inputs
+    for pose in (np.eye(4), synth.default_guess(), synth.se3_to_SE3([0.5, -0.4, 0.3, 0.2, -0.1, 0.3])):
+        JTJ, JTr, cnt = c1_gpu.accumulate(pts, covs, pose)
+        tp, tc = oracle.transform(pts, covs, pose)
+        oJ, oR, oc = c1_oracle_map.accumulate(tp, tc)
+        assert cnt == oc
+        assert np.abs(JTJ - oJ).max() <= NORMAL_EQ_RTOL * np.abs(oJ).max()
+        assert np.abs(JTr - oR).max() <= NORMAL_EQ_RTOL * max(np.abs(oR).max(), 1.0)
+
+
+def test_accumulate_is_linear_over_shards(c1_gpu, c1_inputs):
+    """Point sharding is exact up to summation order: the multi-GPU path's premise."""
+    from eskf_lio_amd import synth
+    _, pts, covs = c1_inputs
+    g = synth.default_guess()
+    J, r, c = c1_gpu.accumulate(pts, covs, g)
+    parts = [c1_gpu.accumulate(pts[lo:hi], covs[lo:hi], g) for lo, hi in ((0, 1700), (1700, 1701), (1701, 5000))]
+    assert sum(p[2] for p in parts) == c
+    assert np.abs(sum(p[0] for p in parts) - J).max() <= 1e-12 * np.abs(J).max()
+    assert np.abs(sum(p[1] for p in parts) - r).max() <= 1e-12 * np.abs(J).max()
+
+
+# ---- the whole loop ---------------------------------------------------------------------------
+def test_align_c1_forced_20_iterations(c1_gpu, c1_inputs, c1_oracle_map):
+    from eskf_lio_amd import synth
+    _, pts, covs = c1_inputs
+    guess = synth.default_guess()
+    ref = c1_oracle_map.align(pts, covs, guess, 20, 1e-6, 2.0)
+    got = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0)
+    assert got.iterations == 20 and not got.converged
+    assert_align_parity(got, ref)
+    scale = np.abs(ref.JTJ).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(got.JTJ - ref.JTJ) <= 1e-8 * scale).all()
+
+
+def test_align_structured_converges_like_the_reference(c1_gpu, c1_inputs, c1_oracle_map):
+    from eskf_lio_amd import synth
+    vmap, _, _ = c1_inputs
+    pts, covs, T_true = synth.make_structured_scan(5_000, vmap)
+    ref = c1_oracle_map.align(pts, covs, np.eye(4), 100, 1e-6, 0.9999)   # shipped thresholds
+    got = c1_gpu.align(pts, covs, np.eye(4), 100, 1e-6, 0.9999)
+    assert got.converged and got.iterations == 3
+    assert_align_parity(got, ref)
+    dt, dr = pose_error(got.pose, T_true)
+    assert dt < 2e-3 and dr < 1e-3
+
+
+@pytest.mark.parametrize("name", ["c1_uniform", "c1_structured"])
+def test_align_against_golden_fixture(c1_gpu, c1_inputs, name):
+    from eskf_lio_amd import synth
+    vmap, pts, covs = c1_inputs
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    if name == "c1_structured":
+        pts, covs, _ = synth.make_structured_scan(5_000, vmap)
+    max_it, tsq, cos = g["params"]
+    got = c1_gpu.align(pts, covs, g["guess"], int(max_it), tsq, cos)
+    assert got.iterations == int(g["iterations"]) and got.converged == bool(g["converged"])
+    assert np.array_equal(got.corr_count, g["corr_count"])
+    dt, dr = pose_error(got.pose, g["pose"])
+    assert dt <= TIGHT_POSE_TOL and dr <= TIGHT_POSE_TOL
+
+
+def test_align_tiny_hermetic_fixture(gpu_ctx):
+    g = np.load(os.path.join(GOLDEN, "tiny.npz"))
+    gpu_ctx.map_reset(float(g["voxel_size"]), 0)
+    gpu_ctx.map_upsert(g["keys"], g["means"], g["covs"])
+    max_it, tsq, cos = g["params"]
+    got = gpu_ctx.align(g["points"], g["point_covs"], g["guess"], int(max_it), tsq, cos)
+    assert np.array_equal(got.corr_count, g["corr_count"])
+    dt, dr = pose_error(got.pose, g["pose"])
+    assert dt <= TIGHT_POSE_TOL and dr <= TIGHT_POSE_TOL
+
+
+def test_chunking_and_workgroup_schedule_do_not_change_results(c1_gpu, c1_inputs):
+    from eskf_lio_amd import capi, synth
+    vmap, pts, covs = c1_inputs
+    guess = synth.default_guess()
+    base = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, chunk_iterations=20)
+    for chunk in (1, 3, 7, 64):
+        r = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, chunk_iterations=chunk)
+        assert np.array_equal(r.pose, base.pose) and np.array_equal(r.corr_count, base.corr_count)
+    r = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, flags=capi.FLAG_PROFILE)
+    assert np.array_equal(r.pose, base.pose) and r.kernel_ms is not None and (r.kernel_ms[:20] > 0).all()
+    # early exit: converging run, every chunk size reports the same iteration count and pose
+    spts, scovs, _ = synth.make_structured_scan(5_000, vmap)
+    ref = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999, chunk_iterations=100)
+    for chunk in (1, 2, 4, 5):
+        r = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999, chunk_iterations=chunk)
+        assert r.iterations == ref.iterations == 3 and r.converged
+        assert np.array_equal(r.pose, ref.pose) and r.launches < 100
+    # bit-reproducible run to run (the reference is not: SURVEY.md F10)
+    again = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, chunk_iterations=20)
+    assert np.array_equal(again.pose, base.pose) and np.array_equal(again.normal_eq, base.normal_eq)
+
+
+def test_resident_scan_is_not_modified_by_align(c1_gpu, c1_inputs):
+    from eskf_lio_amd import synth
+    _, pts, covs = c1_inputs
+    p0, c0 = pts.copy(), covs.copy()
+    c1_gpu.scan_upload(pts, covs)
+    a = c1_gpu.align_resident(synth.default_guess(), 5, 1e-6, 2.0)
+    b = c1_gpu.align_resident(synth.default_guess(), 5, 1e-6, 2.0)   # same resident scan again
+    assert np.array_equal(a.pose, b.pose) and np.array_equal(pts, p0) and np.array_equal(covs, c0)
+
+
+# ---- edge cases the reference leaves unguarded ------------------------------------------------
+def test_k3_no_correspondences_returns_guess_converged(c1_gpu, c1_inputs, c1_oracle_map):
+    from eskf_lio_amd import synth
+    _, pts, covs = c1_inputs
+    g = synth.default_guess()
+    far = pts[:500] + 1.0e4
+    ref = c1_oracle_map.align(far, covs[:500], g, 10, 1e-6, 0.9999)
+    got = c1_gpu.align(far, covs[:500], g, 10, 1e-6, 0.9999)
+    assert got.iterations == ref.iterations == 1 and got.converged and got.corr_count[0] == 0
+    assert np.array_equal(got.pose, g)
+
+
+def test_empty_scan_empty_map_and_zero_iterations(gpu_ctx, c1_inputs):
+    from eskf_lio_amd import capi, synth
+    vmap, pts, covs = c1_inputs
+    g = synth.default_guess()
+    with pytest.raises(capi.VgicpError) as e:                      # no map yet
+        gpu_ctx.align(pts[:10], covs[:10], g, 5, 1e-6, 0.9999)
+    assert e.value.code == capi.ERR_NOT_READY
+    gpu_ctx.map_reset(vmap.voxel_size, 0)                          # empty map: zero system
+    r = gpu_ctx.align(pts[:100], covs[:100], g, 5, 1e-6, 0.9999)
+    assert r.iterations == 1 and r.converged and np.array_equal(r.pose, g)
+    gpu_ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+    r = gpu_ctx.align(np.zeros((0, 3)), np.zeros((0, 9)), g, 5, 1e-6, 0.9999)   # empty scan
+    assert r.iterations == 1 and r.converged and np.array_equal(r.pose, g)
+    r = gpu_ctx.align(pts, covs, g, 0, 1e-6, 0.9999)               # max_iteration = 0: loop never runs
+    assert r.iterations == 0 and not r.converged and np.array_equal(r.pose, g)
+    with pytest.raises(capi.VgicpError) as e:
+        gpu_ctx.align(pts, covs, g, -1, 1e-6, 0.9999)
+    assert e.value.code == capi.ERR_BAD_ARGUMENT
+    with pytest.raises(capi.VgicpError):
+        gpu_ctx.map_reset(-1.0, 0)
+
+
+def test_degenerate_system_is_reported_not_thrown(gpu_ctx):
+    """One correspondence: JTJ has rank 3. The reference is unguarded here (Registration.cpp:78); the
+    module returns whatever the pivoted LDLT yields and flags a non-finite pose with a status code."""
+    from eskf_lio_amd import capi
+    gpu_ctx.map_reset(0.3, 0)
+    mu = np.array([[0.95, 2.05, 3.1]])
+    gpu_ctx.map_upsert(np.floor(mu / 0.3).astype(np.int32), mu, np.eye(3).reshape(1, 9))
+    r = gpu_ctx.align(np.array([[1.0, 2.0, 3.0]]), np.eye(3).reshape(1, 9), np.eye(4), 3, 1e-6, 0.9999,
+                      allow_degenerate=True)
+    assert r.status in (capi.OK, capi.ERR_DEGENERATE)
+    if r.status == capi.OK:
+        assert np.isfinite(r.pose).all()
+
+
+def test_ragged_scan_sizes(c1_gpu, c1_inputs, c1_oracle_map):
+    from eskf_lio_amd import synth
+    _, pts, covs = c1_inputs
+    g = synth.default_guess()
+    for n in (1, 2, 63, 64, 65, 511, 512, 513, 1025, 4999):
+        ref = c1_oracle_map.align(pts[:n], covs[:n], g, 4, 1e-6, 2.0)
+        got = c1_gpu.align(pts[:n], covs[:n], g, 4, 1e-6, 2.0, allow_degenerate=True)
+        assert np.array_equal(got.corr_count, ref.corr_count)
+        if ref.corr_count.min() >= 50:                             # well-posed: compare poses too
+            dt, dr = pose_error(got.pose, ref.pose)
+            assert dt <= 1e-8 and dr <= 1e-8
+
+
+# ---- through the C++ host mirror (the reference's interface) ----------------------------------
+def test_host_mirror_localmap_and_icp(c1_inputs, oracle):
+    from eskf_lio_amd import host, synth
+    vmap, pts, covs = c1_inputs
+    rng = np.random.default_rng(21)
+    # a map built by the reference's insertion rule: several scans, several points per voxel
+    scans = [(vmap.means[rng.choice(50_000, 8_000, replace=False)] + rng.normal(scale=0.02, size=(8_000, 3)),
+              covs[rng.choice(5_000, 8_000)]) for _ in range(3)]
+    poses = [np.eye(4), synth.se3_to_SE3([0.2, 0.1, 0.0, 0.0, 0.0, 0.02]), synth.se3_to_SE3([0.4, 0.2, 0.0, 0.0, 0.0, 0.04])]
+    lmap = host.LocalMap(0.3, 20)
+    omap = oracle.OracleMap(0.3, 20)
+    for (p, c), T in zip(scans, poses):
+        world_p, world_c = lmap.updateLocalMap(p, c, T)            # cloud->Transform(T) then insert
+        op, oc = oracle.transform(p, c, T)
+        assert np.array_equal(world_p, op) and np.array_equal(world_c, oc)
+        omap.insert(op, oc)
+    assert len(lmap) == len(omap)
+    hk, hm, hc, hn = lmap.export()
+    ok, om_, oc_, on = omap.export()
+    order_h, order_o = np.lexsort(hk.T), np.lexsort(ok.T)
+    assert np.array_equal(hk[order_h], ok[order_o]) and np.array_equal(hn[order_h], on[order_o])
+    assert np.array_equal(hm[order_h], om_[order_o]) and np.array_equal(hc[order_h], oc_[order_o])
+    assert hn.max() > 1                                            # the running mean was exercised
+    # correspondenceMatching: the reference's tuple, device-served
+    tp, tc = oracle.transform(pts, covs, synth.default_guess())
+    got = lmap.correspondenceMatching(tp, tc)
+    ref = omap.match(tp, tc)
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref[:4]))
+    # ICP::align through the C++ class
+    icp = host.ICP(20, 1e-6, 2.0)
+    T = icp.align(pts, covs, lmap, synth.default_guess())
+    ref = omap.align(pts, covs, synth.default_guess(), 20, 1e-6, 2.0)
+    assert icp.iterations == 20 and not icp.converged
+    assert np.array_equal(icp.correspondence_counts, ref.corr_count)
+    dt, dr = pose_error(T, ref.pose)
+    assert dt <= TIGHT_POSE_TOL and dr <= TIGHT_POSE_TOL
+
+
+def test_host_mirror_motion_gate_and_eviction(oracle, tmp_path):
+    from eskf_lio_amd import host, synth
+    cfg = dict(translation_sq_threshold=1e-2, cosine_threshold=0.985, remove_distant_points=True,
+               distance_threshold=5.0, removing_period=0.0)
+    lmap = host.LocalMap(0.3, 1000, cfg)
+    rng = np.random.default_rng(2)
+    near = rng.uniform(-2, 2, size=(500, 3))
+    cov = np.tile(np.eye(3).reshape(1, 9), (500, 1))
+    lmap.updateLocalMap(near, cov, np.eye(4))                      # first frame always inserts
+    n0 = len(lmap)
+    assert n0 > 100
+    lmap.updateLocalMap(rng.uniform(-2, 2, size=(500, 3)), cov, synth.se3_to_SE3([0.01, 0, 0, 0, 0, 0]))
+    assert len(lmap) == n0                                         # moved 1 cm: gated (LocalMap.cpp:39-42)
+    T_far = synth.se3_to_SE3([20.0, 0, 0, 0, 0, 0])
+    lmap.updateLocalMap(rng.uniform(-2, 2, size=(500, 3)), cov, T_far)   # inserts around x=20, evicts the old
+    keys, means, _, _ = lmap.export()
+    centre = (keys + 0.5) * 0.3
+    assert (np.linalg.norm(centre - T_far[:3, 3], axis=1) <= 5.0).all() and len(lmap) > 100
+    # the device mirror followed: old voxels are gone, new ones are there
+    sp, *_ = lmap.correspondenceMatching(near, cov)
+    assert len(sp) == 0
+    sp, _, mp, _ = lmap.correspondenceMatching(means, np.tile(np.eye(3).reshape(1, 9), (len(means), 1)))
+    assert len(sp) == len(means) and np.array_equal(mp, means)
+    lmap.save(str(tmp_path / "map.pcd"), str(tmp_path / "traj.json"))
+    assert "POINTS" in open(tmp_path / "map.pcd").read() and "extrinsic" in open(tmp_path / "traj.json").read()
+
+
+# ---- multi-GPU code path on one device: RCCL communicator of size 1 ---------------------------
+def test_rccl_path_world_size_one(c1_gpu, c1_inputs):
+    from eskf_lio_amd import synth
+    _, pts, covs = c1_inputs
+    g = synth.default_guess()
+    single = c1_gpu.align(pts, covs, g, 20, 1e-6, 2.0)
+    c1_gpu.comm_init(1, 0, c1_gpu.comm_unique_id())
+    try:
+        viacomm = c1_gpu.align(pts, covs, g, 20, 1e-6, 2.0)        # fold kernel + ncclAllReduce + prologue
+        assert viacomm.world_size == 1 and viacomm.iterations == 20
+        assert np.array_equal(viacomm.corr_count, single.corr_count)
+        dt, dr = pose_error(viacomm.pose, single.pose)
+        assert dt <= 1e-12 and dr <= 1e-12
+        spts, scovs, _ = synth.make_structured_scan(5_000, c1_inputs[0])
+        r = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999)
+        assert r.converged and r.iterations == 3
+    finally:
+        c1_gpu.comm_destroy()
+
+
+# ---- BASELINE's full size (C2): size-independent properties ------------------------------------
+def test_c2_full_size_properties(gpu_ctx, oracle):
+    from eskf_lio_amd import synth
+    vmap = synth.make_map(1_000_000)
+    pts, covs = synth.make_uniform_scan(100_000, vmap)
+    gpu_ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+    gpu_ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+    assert gpu_ctx.map_size()[0] == 1_000_000
+    g = synth.default_guess()
+    a = gpu_ctx.align(pts, covs, g, 20, 1e-6, 2.0, chunk_iterations=20)
+    assert a.iterations == 20 and 0.45 < a.corr_count.mean() / 1e5 < 0.55
+    b = gpu_ctx.align(pts, covs, g, 20, 1e-6, 2.0, chunk_iterations=20)
+    assert np.array_equal(a.pose, b.pose) and np.array_equal(a.normal_eq, b.normal_eq)   # deterministic
+    perm = np.random.default_rng(8).permutation(100_000)
+    c = gpu_ctx.align(pts[perm], covs[perm], g, 20, 1e-6, 2.0, chunk_iterations=20)
+    assert np.array_equal(c.corr_count, a.corr_count)              # order-free counts
+    assert np.abs(c.pose - a.pose).max() < 1e-11
+    # first-iteration counts equal an independent count of occupied voxels hit (integer work, exact)
+    tp, _ = oracle.transform(pts, covs, g)
+    keys = oracle.voxel_index(vmap.voxel_size, tp)
+    def pack(k):
+        k = k.astype(np.int64)
+        return ((k[:, 0] + 2048) << 24) | ((k[:, 1] + 2048) << 12) | (k[:, 2] + 2048)
+    assert int(np.isin(pack(keys), pack(vmap.keys)).sum()) == int(a.corr_count[0])
+    # the oracle on the full size (deterministic mode, ~1 s): contractual parity at BASELINE's config
+    om = oracle.OracleMap(vmap.voxel_size, 1)
+    om.insert(vmap.means, vmap.covs)
+    ref = om.align(pts, covs, g, 20, 1e-6, 2.0)
+    assert_align_parity(a, ref)

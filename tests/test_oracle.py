@@ -1,0 +1,268 @@
+"""Pins the CPU oracle (the checker of every GPU parity test) — runs without a GPU.
+
+The reference has no tests, golden vectors or fixtures for this path and cannot be
+built here, so the oracle is pinned by (1) analytic known-answer tests K1-K6,
+(2) an independently written numpy restatement, (3) committed golden outputs (regression).
+PARITY UNPINNED by the reference's own tests.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import pose_error
+from eskf_lio_amd import synth
+from oracle import vgicp_numpy as npo
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def skew(p):
+    return np.array([[0, -p[2], p[1]], [p[2], 0, -p[0]], [-p[1], p[0], 0.0]])
+
+
+# ---- K1: one correspondence, Sigma = I ------------------------------------------------------
+def test_k1_single_residual_blocks(oracle):
+    p = np.array([1.0, 2.0, 3.0])
+    e = np.array([0.1, -0.2, 0.05])
+    JTJ, JTr = oracle.jtj_jtr(p, p - e, np.eye(3))      # r = p - mu = e
+    J = np.hstack([np.eye(3), -skew(p)])                # [I | -[p]x], state [translation; rotation]
+    assert np.allclose(JTJ, J.T @ J, rtol=0, atol=1e-14)
+    assert np.allclose(JTr, J.T @ e, rtol=0, atol=1e-14)
+    # written out by hand for p = (1,2,3):
+    assert JTJ[0, 4] == 3.0 and JTJ[0, 5] == -2.0 and JTJ[1, 3] == -3.0 and JTJ[2, 4] == -1.0
+    assert JTJ[3, 3] == 13.0 and JTJ[4, 4] == 10.0 and JTJ[5, 5] == 5.0 and JTJ[3, 4] == -2.0
+
+
+def test_k1_general_covariance_matches_dense_formula(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        p, mu = rng.normal(size=3) * 5, rng.normal(size=3) * 5
+        A = rng.normal(size=(3, 3))
+        cov = A @ A.T + 0.1 * np.eye(3)
+        JTJ, JTr = oracle.jtj_jtr(p, mu, cov)
+        J = np.hstack([np.eye(3), -skew(p)])
+        W = np.linalg.inv(cov)
+        assert np.allclose(JTJ, J.T @ W @ J, rtol=1e-11, atol=1e-11)
+        assert np.allclose(JTr, J.T @ W @ (p - mu), rtol=1e-11, atol=1e-11)
+
+
+# ---- K2: exact structured scan recovers the motion ------------------------------------------
+def test_k2_noise_free_structured_scan_recovers_pose(oracle):
+    vmap = synth.make_map(4_000, seed=11)
+    pts, covs, T_true = synth.make_structured_scan(1_500, vmap, seed=12, noise=0.0)
+    om = oracle.OracleMap(vmap.voxel_size, 1)
+    om.insert(vmap.means, vmap.covs)
+    r = om.align(pts, covs, np.eye(4), 50, 1e-12, 1.0 - 1e-12)
+    dt, dr = pose_error(r.pose, T_true)
+    assert dt < 1e-9 and dr < 1e-9
+    assert r.corr_count[-1] == 1_500                       # every point lands in its own voxel
+    # one Gauss-Newton step from identity is already O(|phi|^2) close
+    one = om.align(pts, covs, np.eye(4), 1, 1e-12, 2.0)
+    dt1, dr1 = pose_error(one.pose, T_true)
+    assert dt1 < 5e-3 and dr1 < 5e-4
+
+
+# ---- K3: no correspondences -----------------------------------------------------------------
+def test_k3_zero_matches_returns_guess_and_converges(oracle):
+    vmap = synth.make_map(500, seed=3)
+    om = oracle.OracleMap(vmap.voxel_size, 1)
+    om.insert(vmap.means, vmap.covs)
+    pts, covs = synth.make_uniform_scan(64, vmap, seed=4)
+    far = pts + 1.0e4                                      # entirely outside the map
+    g = synth.default_guess()
+    r = om.align(far, covs, g, 10, 1e-6, 0.9999)
+    assert r.iterations == 1 and r.converged and r.corr_count[0] == 0
+    assert np.array_equal(r.pose, g)                       # zero system -> zero step -> pose = guess
+    empty = oracle.OracleMap(0.3, 1)
+    r = empty.align(pts, covs, g, 10, 1e-6, 0.9999)
+    assert r.iterations == 1 and r.converged and np.array_equal(r.pose, g)
+    se3, step = oracle.solve_step(np.zeros((6, 6)), np.zeros(6))
+    assert not se3.any() and np.array_equal(step, np.eye(4))
+
+
+# ---- K4: se3ToSE3 -----------------------------------------------------------------------------
+def test_k4_se3_exponential(oracle):
+    assert np.array_equal(oracle.se3_to_SE3(np.zeros(6)), np.eye(4))
+    T = oracle.se3_to_SE3([1.0, 2.0, 3.0, 0.0, 0.0, 0.0])
+    assert np.array_equal(T[:3, :3], np.eye(3)) and np.array_equal(T[:3, 3], [1.0, 2.0, 3.0])
+    # below the 1e-6 branch: J = I exactly, R is still a proper small rotation
+    T = oracle.se3_to_SE3([1.0, 2.0, 3.0, 1e-7, 0.0, 0.0])
+    assert np.array_equal(T[:3, 3], [1.0, 2.0, 3.0])
+    assert abs(T[2, 1] - 1e-7) < 1e-20 and abs(T[1, 2] + 1e-7) < 1e-20
+    # 90 degrees about z
+    T = oracle.se3_to_SE3([0.0, 0.0, 0.0, 0.0, 0.0, np.pi / 2])
+    assert np.allclose(T[:3, :3], [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15)
+    # general: against the independent numpy restatement and scipy
+    from scipy.spatial.transform import Rotation
+    xi = np.array([0.3, -0.2, 0.5, 0.4, -0.7, 0.2])
+    T = oracle.se3_to_SE3(xi)
+    assert np.allclose(T[:3, :3], Rotation.from_rotvec(xi[3:]).as_matrix(), atol=1e-15)
+    assert np.allclose(T, npo.se3_to_SE3(xi), atol=1e-15)
+    assert np.allclose(T, synth.se3_to_SE3(xi), atol=1e-15)
+
+
+# ---- K5: convergence thresholds are non-strict on the converged side -----------------------
+def test_k5_convergence_check_boundaries(oracle):
+    step = np.eye(4)
+    step[:3, 3] = [1e-3, 0.0, 0.0]                         # |t|^2 == 1e-6 exactly? (1e-3)^2 rounds
+    tsq = float(step[0, 3] ** 2)
+    assert oracle.convergence_check(step, 1.0, tsq)        # equality counts as converged
+    assert not oracle.convergence_check(step, 1.0, np.nextafter(tsq, 0.0))
+    R = oracle.se3_to_SE3([0, 0, 0, 0, 0, 0.01])
+    cosine = 0.5 * (np.trace(R[:3, :3]) - 1.0)
+    assert oracle.convergence_check(R, cosine, 1.0)
+    assert not oracle.convergence_check(R, np.nextafter(cosine, 2.0), 1.0)
+    assert not oracle.convergence_check(np.eye(4), 2.0, 1.0)   # cosine_threshold > 1 never converges
+
+
+# ---- K6: voxel keys: floor of a true division ------------------------------------------------
+def test_k6_voxel_index_floor_semantics(oracle):
+    pts = np.array([[-0.1, 0.0, 0.3], [-0.3, 0.29999999999999993, 0.6], [-0.30000000000000004, 0.9, -1e-300],
+                    [1e-300, -0.0, 299.99999999999994]])
+    keys = oracle.voxel_index(0.3, pts)
+    expect = np.floor(pts / 0.3).astype(np.int32)
+    assert np.array_equal(keys, expect)
+    assert keys[0].tolist() == [-1, 0, 1]                  # floor, not truncation
+    assert keys[1].tolist() == [-1, 0, 2] and keys[2].tolist() == [-2, 3, -1]
+    rng = np.random.default_rng(5)
+    rnd = rng.uniform(-50, 50, size=(20000, 3))
+    on_face = np.round(rnd / 0.3) * 0.3                    # exact multiples of the voxel size
+    for p in (rnd, on_face):
+        assert np.array_equal(oracle.voxel_index(0.3, p), np.floor(p / 0.3).astype(np.int32))
+
+
+# ---- voxel statistics: the reference's running-mean insertion rule ---------------------------
+def test_map_insertion_rule(oracle):
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-1.0, 1.0, size=(400, 3))
+    A = rng.normal(size=(400, 3, 3))
+    covs = (A @ A.transpose(0, 2, 1)).transpose(0, 2, 1).reshape(400, 9)
+    for cap in (1, 3, 1000):
+        om = oracle.OracleMap(0.3, cap)
+        om.insert(pts, covs)
+        nm = npo.NumpyMap(0.3, cap)
+        nm.insert(pts, covs)
+        keys, means, mcovs, counts = om.export()
+        assert len(om) == len(nm) == len({tuple(k) for k in np.floor(pts / 0.3).astype(int)})
+        for k, m, c, n in zip(map(tuple, keys), means, mcovs, counts):
+            cnt, mean, cov = nm._dict[k]
+            assert n == cnt and n <= cap
+            assert np.allclose(m, mean, atol=1e-15) and np.allclose(c.reshape(3, 3).T, cov, atol=1e-14)
+    # cap = 1 freezes the first point of each voxel
+    om = oracle.OracleMap(0.3, 1)
+    om.insert(pts, covs)
+    keys, means, _, counts = om.export()
+    first = {}
+    for p, k in zip(pts, map(tuple, np.floor(pts / 0.3).astype(int))):
+        first.setdefault(k, p)
+    assert all(np.array_equal(first[tuple(k)], m) for k, m in zip(keys, means)) and (counts == 1).all()
+
+
+# ---- open3d Transform semantics ---------------------------------------------------------------
+def test_transform_semantics(oracle):
+    rng = np.random.default_rng(9)
+    pts = rng.normal(size=(50, 3))
+    A = rng.normal(size=(50, 3, 3))
+    C = A @ A.transpose(0, 2, 1)
+    T = synth.se3_to_SE3([0.5, -1.0, 2.0, 0.3, 0.2, -0.4])
+    tp, tc = oracle.transform(pts, C.transpose(0, 2, 1).reshape(50, 9), T)
+    assert np.allclose(tp, pts @ T[:3, :3].T + T[:3, 3], atol=1e-14)
+    assert np.allclose(tc.reshape(50, 3, 3).transpose(0, 2, 1), T[:3, :3] @ C @ T[:3, :3].T, atol=1e-13)
+
+
+# ---- cross-implementation: C++ oracle vs numpy restatement ------------------------------------
+def test_oracle_matches_numpy_restatement_c1(oracle, c1_inputs, c1_oracle_map):
+    vmap, pts, covs = c1_inputs
+    nm = npo.NumpyMap(vmap.voxel_size, 1)
+    nm.insert(vmap.means, vmap.covs)
+    g = synth.default_guess()
+    r = c1_oracle_map.align(pts, covs, g, 20, 1e-6, 2.0)
+    T, counts, JTJs, JTrs, conv = npo.align(nm, pts, covs, g, 20, 1e-6, 2.0)
+    assert r.iterations == 20 and not r.converged and not conv
+    assert np.array_equal(counts, r.corr_count)
+    assert np.abs(T - r.pose).max() < 1e-12
+    scale = np.abs(r.JTJ).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(JTJs - r.JTJ) <= 1e-9 * scale).all()
+    assert np.abs(JTrs - r.JTr).max() <= 1e-9 * np.abs(r.JTr).max()
+    # hit rate ~ occupancy 0.5, loop does not converge within 20 rounds
+    assert 0.45 < r.corr_count.mean() / 5000 < 0.55
+
+
+def test_oracle_matches_numpy_restatement_structured(oracle, c1_inputs, c1_oracle_map):
+    vmap, _, _ = c1_inputs
+    pts, covs, T_true = synth.make_structured_scan(5_000, vmap)
+    nm = npo.NumpyMap(vmap.voxel_size, 1)
+    nm.insert(vmap.means, vmap.covs)
+    r = c1_oracle_map.align(pts, covs, np.eye(4), 100, 1e-6, 0.9999)
+    T, counts, _, _, conv = npo.align(nm, pts, covs, np.eye(4), 100, 1e-6, 0.9999)
+    assert r.converged and conv and r.iterations == len(counts) == 3
+    assert np.array_equal(counts, r.corr_count) and r.corr_count[-1] == 5000
+    assert np.abs(T - r.pose).max() < 1e-12
+    dt, dr = pose_error(r.pose, T_true)
+    assert dt < 2e-3 and dr < 1e-3                         # noise 1 cm / sqrt(N)
+
+
+def test_faithful_mode_equals_deterministic_mode(oracle, c1_inputs, c1_oracle_map):
+    """The reference-structured OpenMP mode differs only by summation order."""
+    _, pts, covs = c1_inputs
+    g = synth.default_guess()
+    d = c1_oracle_map.align(pts, covs, g, 20, 1e-6, 2.0)
+    f = c1_oracle_map.align(pts, covs, g, 20, 1e-6, 2.0, mode=oracle.FAITHFUL)
+    assert np.array_equal(d.corr_count, f.corr_count)
+    assert np.abs(d.pose - f.pose).max() < 1e-12
+
+
+def test_point_order_does_not_matter(oracle, c1_inputs, c1_oracle_map):
+    _, pts, covs = c1_inputs
+    g = synth.default_guess()
+    perm = np.random.default_rng(3).permutation(pts.shape[0])
+    a = c1_oracle_map.align(pts, covs, g, 20, 1e-6, 2.0)
+    b = c1_oracle_map.align(pts[perm], covs[perm], g, 20, 1e-6, 2.0)
+    assert np.array_equal(a.corr_count, b.corr_count) and np.abs(a.pose - b.pose).max() < 1e-12
+
+
+# ---- golden fixtures ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["c1_uniform", "c1_structured"])
+def test_golden_regression(oracle, c1_inputs, c1_oracle_map, name):
+    vmap, pts, covs = c1_inputs
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    if name == "c1_structured":
+        pts, covs, _ = synth.make_structured_scan(5_000, vmap)
+    max_it, tsq, cos = g["params"]
+    r = c1_oracle_map.align(pts, covs, g["guess"], int(max_it), tsq, cos)
+    assert r.iterations == int(g["iterations"]) and r.converged == bool(g["converged"])
+    assert np.array_equal(r.corr_count, g["corr_count"])
+    assert np.abs(r.pose - g["pose"]).max() < 1e-13
+    assert np.allclose(r.JTJ, g["JTJ"], rtol=1e-12, atol=0)
+
+
+def test_golden_tiny_is_hermetic(oracle):
+    g = np.load(os.path.join(GOLDEN, "tiny.npz"))
+    om = oracle.OracleMap(float(g["voxel_size"]), 1)
+    om.insert(g["means"], g["covs"])
+    max_it, tsq, cos = g["params"]
+    r = om.align(g["points"], g["point_covs"], g["guess"], int(max_it), tsq, cos)
+    assert np.array_equal(r.corr_count, g["corr_count"]) and np.abs(r.pose - g["pose"]).max() < 1e-13
+    nm = npo.NumpyMap(float(g["voxel_size"]), 1)
+    nm.insert(g["means"], g["covs"])
+    T, counts, *_ = npo.align(nm, g["points"], g["point_covs"], g["guess"], int(max_it), tsq, cos)
+    assert np.array_equal(counts, g["corr_count"]) and np.abs(T - g["pose"]).max() < 1e-11
+
+
+def test_synthetic_inputs_are_reproducible(c1_inputs):
+    """Seeds regenerate the exact bits the fixtures were made from (IEEE-exact generator)."""
+    import hashlib
+    vmap, pts, covs = c1_inputs
+    g = np.load(os.path.join(GOLDEN, "c1_uniform.npz"))
+    h = hashlib.sha256()
+    for a in (vmap.keys, vmap.means, vmap.covs, pts, covs):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert np.frombuffer(h.digest()[:8], dtype=np.uint64)[0] == g["input_checksum"]
+    assert vmap.side == 47 and vmap.keys.shape == (50_000, 3)
+    assert len({tuple(k) for k in vmap.keys}) == 50_000
+    assert np.array_equal(np.floor(vmap.means / 0.3).astype(np.int32), vmap.keys)
+    C = covs.reshape(-1, 3, 3)
+    assert np.array_equal(C, C.transpose(0, 2, 1))
+    ev = np.linalg.eigvalsh(C[:100])
+    assert np.allclose(ev, [0.01, 1.0, 1.0], atol=1e-12)   # R diag(1,1,1e-2) R^T
