@@ -34,7 +34,7 @@
 #include <vector>
 
 #include "../vgicp_hip.h"
-#include "Types.hpp"
+#include "ShimTypes.hpp"
 
 #if defined(ESKF_LIO_SHIM_NATIVE_TYPES) && __has_include(<yaml-cpp/yaml.h>)
 #include <yaml-cpp/yaml.h>

@@ -1,4 +1,4 @@
-// Types.hpp — boundary types of the drop-in shim.
+// ShimTypes.hpp — boundary types of the drop-in shim.
 //
 // With Eigen and Open3D installed (the reference's own build environment) the shim uses the
 // reference's types unchanged: ESKF_LIO::PointCloud = open3d::geometry::PointCloud and Eigen's
@@ -6,8 +6,8 @@
 // absent — this repository's build and GPU hosts have neither — it falls back to layout-identical
 // plain structs exposing the few members the path touches (points_, covariances_, Transform(),
 // matrix().data(), linear(), translation()), so the same LocalMap / ICP code compiles and is tested.
-#ifndef ESKF_LIO_SHIM_TYPES_HPP_
-#define ESKF_LIO_SHIM_TYPES_HPP_
+#ifndef ESKF_LIO_SHIM_SHIMTYPES_HPP_
+#define ESKF_LIO_SHIM_SHIMTYPES_HPP_
 
 #include <cstring>
 #include <memory>
@@ -183,4 +183,4 @@ using PointCloudPtr = std::shared_ptr<PointCloud>;
 
 }  // namespace ESKF_LIO
 
-#endif  // ESKF_LIO_SHIM_TYPES_HPP_
+#endif  // ESKF_LIO_SHIM_SHIMTYPES_HPP_
