@@ -195,7 +195,7 @@ int ensure_log(vgicp_ctx* ctx, int iterations) {
 }
 
 uint32_t iterate_grid(const vgicp_ctx* ctx) {
-  const uint32_t block = (uint32_t)ctx->iter_block;
+  const uint32_t block = (uint32_t)ctx->iter_block - 64;  // wave 0 of a workgroup solves, the rest own points
   const uint32_t want = (ctx->n + block - 1) / block;
   return std::min<uint32_t>(std::max<uint32_t>(want, 1), kMaxIterBlocks);
 }
@@ -470,11 +470,10 @@ int vgicp_destroy(vgicp_ctx* ctx) {
     uint64_t h[8] = {0};
     if (hipMemcpy(h, ctx->d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[4] > 0) {
       const double k = 0.01 / (double)h[4];  // 100 MHz ticks -> us per launch
-      std::fprintf(stderr, "[vgicp stamps] body launches %llu | workgroup 0: prologue (fold+solve) %.2f us, "
-                   "gather+accumulate loop %.2f us, butterfly+row store %.2f us\n", (unsigned long long)h[4],
-                   h[0] * k, h[1] * k, h[2] * k);
-      std::fprintf(stderr, "[vgicp stamps] prologue split: barrier after fold %.2f us, wave-0 solve %.2f us, "
-                   "publish+barrier %.2f us (the rest is row/state loads + fold)\n", h[5] * k, h[6] * k, h[7] * k);
+      std::fprintf(stderr, "[vgicp stamps] body launches %llu | workgroup 0, first worker lane: loads+fold+barrier %.2f us, "
+                   "speculative probe || solve, to 2nd barrier %.2f us, verify+accumulate loop %.2f us, "
+                   "butterfly+row store %.2f us | solver wave: solve+publish %.2f us\n", (unsigned long long)h[4], h[0] * k,
+                   h[5] * k, h[1] * k, h[2] * k, h[6] * k);
     }
     (void)hipFree(ctx->d_stamps);
   }

@@ -66,7 +66,25 @@ __device__ __forceinline__ const VoxelRecord* find_voxel(const VoxelRecord* tabl
   }
 }
 
-// One halving step of the wave butterfly: N live values -> N/2, exchanging with lane ^ MASK.
+// Lookup + payload: probe the key word(s), then fetch the 96-byte payload of the matching record as
+// six 16-byte loads (same 128-byte line as the key, so they are L1/L2 hits).  Requesting key and
+// payload together was measured slower: every lane addresses its own line, so each extra wave-level
+// load costs 64 tag lookups whether or not the lane ends up matching.
+__device__ __forceinline__ bool find_and_load(const VoxelRecord* table, uint32_t mask, int32_t kx,
+                                              int32_t ky, int32_t kz, double (&mu)[3],
+                                              double (&S)[9]) {
+  const VoxelRecord* rec = find_voxel(table, mask, kx, ky, kz);
+  if (rec == nullptr) return false;
+  const double2* pay = reinterpret_cast<const double2*>(rec->mean);  // 16-byte aligned
+  const double2 a0 = pay[0], a1 = pay[1], a2 = pay[2], a3 = pay[3], a4 = pay[4], a5 = pay[5];
+  mu[0] = a0.x; mu[1] = a0.y; mu[2] = a1.x;
+  S[0] = a1.y; S[1] = a2.x; S[2] = a2.y; S[3] = a3.x; S[4] = a3.y; S[5] = a4.x;
+  S[6] = a4.y; S[7] = a5.x; S[8] = a5.y;
+  return true;
+}
+
+// One halving step of the wave butterfly through the LDS crossbar (ds_bpermute): N live values ->
+// N/2, exchanging with lane ^ MASK.
 template <int N, int MASK>
 __device__ __forceinline__ void fold(double (&v)[kSlots], bool upper) {
 #pragma unroll
@@ -74,6 +92,24 @@ __device__ __forceinline__ void fold(double (&v)[kSlots], bool upper) {
     const double keep = upper ? v[j + N / 2] : v[j];
     const double send = upper ? v[j] : v[j + N / 2];
     v[j] = keep + __shfl_xor(send, MASK, 64);
+  }
+}
+
+// The two widest halving steps without LDS and without selects: v_permlane32_swap / v_permlane16_swap
+// (gfx950) exchange the upper half (odd 16-lane rows) of one register with the lower half (even rows)
+// of another, which is exactly "keep my half of the slots, receive the partner's": 3 instructions per
+// pair of slots instead of 7.
+template <int N, bool ROW16>
+__device__ __forceinline__ void fold_swap(double (&v)[kSlots]) {
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j) {
+    const unsigned alo = (unsigned)__double2loint(v[j]), ahi = (unsigned)__double2hiint(v[j]);
+    const unsigned blo = (unsigned)__double2loint(v[j + N / 2]), bhi = (unsigned)__double2hiint(v[j + N / 2]);
+    const auto lo = ROW16 ? __builtin_amdgcn_permlane16_swap(alo, blo, false, false)
+                          : __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto hi = ROW16 ? __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false)
+                          : __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    v[j] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
   }
 }
 
@@ -165,6 +201,51 @@ __device__ __forceinline__ void ldlt6_solve_wave(double tot, uint32_t lane, doub
   for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
+// Fast path of the 6x6 solve: LDL^T in natural order, fully unrolled, everything in registers with
+// static indices (about 130 fp64 operations and 6 reciprocals; every lane of the wave runs the same
+// scalar program).  For a symmetric positive definite system any elimination order is backward
+// stable, so x differs from the pivoted solve only by rounding (~cond * 1e-16).  Returns false when a
+// pivot is not safely positive — singular or indefinite normal equations, the all-zero system of
+// "no correspondences" included — and the caller then runs the pivoted, Eigen-faithful solve above.
+// A: 21 lower-triangle entries row by row; g: right-hand side (already negated J^T r).
+__device__ __forceinline__ bool ldlt6_solve_spd(const double (&A)[21], const double (&g)[6],
+                                                double (&x)[6]) {
+  double L[6][6], W[6][6], inv[6];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[tri6(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j][k] * W[j][k];
+    ok = ok && (d > 1e-13 * A[tri6(j, j)]) && (d < 1.0e300);  // also false for NaN
+    inv[j] = 1.0 / d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double t = A[tri6(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i][k] * W[j][k];
+      W[i][j] = t;           // L(i,j) * D(j)
+      L[i][j] = t * inv[j];
+    }
+  }
+  double z[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double t = g[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) t -= L[i][k] * z[k];
+    z[i] = t;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double t = z[i] * inv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) t -= L[k][i] * x[k];
+    x[i] = t;
+  }
+  return ok;
+}
+
 // se(3) exponential as vgicp_math.h's se3_exp (reference src/Utils.cpp:28-32,40-63) with the sine
 // and cosine of the one angle taken from a single sincos call.
 __device__ __forceinline__ void se3_exp_device(const double* xi, Pose& T) {
@@ -174,7 +255,8 @@ __device__ __forceinline__ void se3_exp_device(const double* xi, Pose& T) {
   double s, c;
   sincos(angle, &s, &c);
   double k[3] = {r[0], r[1], r[2]};
-  if (n2 > 0.0) { k[0] = r[0] / angle; k[1] = r[1] / angle; k[2] = r[2] / angle; }
+  const double inv_angle = 1.0 / angle;
+  if (n2 > 0.0) { k[0] = r[0] * inv_angle; k[1] = r[1] * inv_angle; k[2] = r[2] * inv_angle; }
   const double sx = s * k[0], sy = s * k[1], sz = s * k[2];
   const double cx = (1.0 - c) * k[0], cy = (1.0 - c) * k[1], cz = (1.0 - c) * k[2];
   double tmp;
@@ -188,7 +270,7 @@ __device__ __forceinline__ void se3_exp_device(const double* xi, Pose& T) {
     T.t[0] = xi[0]; T.t[1] = xi[1]; T.t[2] = xi[2];
     return;
   }
-  const double f1 = s / angle, f2 = (1.0 - c) / angle;
+  const double f1 = s * inv_angle, f2 = (1.0 - c) * inv_angle;
   double J[9];
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc)
@@ -211,26 +293,28 @@ struct RoundHead {
 template <int BLOCK>
 struct PrologueShared {
   double fin[BLOCK / kSlots][kSlots];
+  double totals[kSlots];
   double pose[12];
   int stop;
 };
 
-// Prologue of a round, run by EVERY workgroup (identical arithmetic on identical inputs, so every
-// workgroup derives the same pose): fold the previous round's partial rows in a fixed order, solve
-// the 6x6 system, advance the pose, test convergence.  All global loads (rows and state) are issued
-// before the first wait; wave 0 alone runs the solve while the other waves park at the barrier, so
-// they do not steal its issue slots.  Workgroup 0 also publishes the new state and the log row for
-// the next launch / the host.  Reference: the merge, solve, compose and convergence test of
-// src/Registration.cpp:71-79, :20-25.
+// The two halves of a round's prologue, run by EVERY workgroup (identical arithmetic on identical
+// inputs, so every workgroup derives the same pose).  Reference: the merge, solve, compose and
+// convergence test of src/Registration.cpp:71-79, :20-25.
+//
+// prologue_fold: issue every global load (previous rows, state) before the first wait, fold the rows
+// in a fixed order into LDS, return the OLD pose.  prologue_solve (wave 0 only): finish the fold,
+// pivoted LDLT, se(3) exponential, compose, convergence test; the new pose goes to LDS, and from
+// workgroup 0 to the state / log the next launch and the host read.
 template <int BLOCK>
-__device__ __forceinline__ RoundHead round_prologue(const IterArgs& a, PrologueShared<BLOCK>& sh) {
+__device__ __forceinline__ RoundHead prologue_fold(const IterArgs& a, PrologueShared<BLOCK>& sh,
+                                                   int& it, int& max_it, double& cos_thr,
+                                                   double& tsq_thr) {
   constexpr int kGroups = BLOCK / kSlots;
   constexpr int kBatch = 16;  // independent loads in flight per thread; the add order stays fixed
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x;
   const AlignState* in = a.state_in;
-  AlignState* out = a.state_out;
 
-  // rows first (the long pole), then the state, all in flight together
   const uint32_t slot = tid & (kSlots - 1), group = tid / kSlots;
   double row[kBatch];
 #pragma unroll
@@ -243,16 +327,16 @@ __device__ __forceinline__ RoundHead round_prologue(const IterArgs& a, PrologueS
   for (int k = 0; k < 9; ++k) head.total.R[k] = in->pose[k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) head.total.t[k] = in->pose[9 + k];
-  const int it = in->iteration;
-  const int max_it = in->max_iteration;
-  const double cos_thr = in->cosine_threshold, tsq_thr = in->translation_sq_threshold;
+  it = in->iteration;
+  max_it = in->max_iteration;
+  cos_thr = in->cosine_threshold;
+  tsq_thr = in->translation_sq_threshold;
   head.stop = in->done != 0;
   if (head.stop || a.prev_rows == 0) {
     // nothing to fold: either the loop ended in an earlier launch, or this is the first round
-    if (blockIdx.x == 0 && tid == 0) *out = *in;
+    if (blockIdx.x == 0 && tid == 0) *a.state_out = *in;
     return head;
   }
-
   double s = 0.0;
 #pragma unroll
   for (int u = 0; u < kBatch; ++u) s += row[u];
@@ -266,60 +350,59 @@ __device__ __forceinline__ RoundHead round_prologue(const IterArgs& a, PrologueS
     for (int u = 0; u < kBatch; ++u) s += row[u];
   }
   sh.fin[group][slot] = s;
-  const uint64_t p1 = a.stamps ? wall_clock64() : 0;
-  __syncthreads();
-  const uint64_t p2 = a.stamps ? wall_clock64() : 0;
-  uint64_t p3 = 0;
-
-  if (wave == 0) {
-    double tot = 0.0;
-    if (lane < kSlots) {
-      tot = sh.fin[0][lane];
-#pragma unroll
-      for (int g = 1; g < kGroups; ++g) tot += sh.fin[g][lane];
-    }
-    double xi[6];
-    ldlt6_solve_wave(tot, lane, xi);
-    Pose step, next;
-    se3_exp_device(xi, step);
-    pose_compose(step, head.total, next);
-    const bool conv = converged(step, cos_thr, tsq_thr);
-    const bool stop = conv || (it + 1 >= max_it);
-    p3 = a.stamps ? wall_clock64() : 0;
-    // static register indices only: a dynamically indexed private array would go to scratch
-#pragma unroll
-    for (int k = 0; k < 9; ++k) if (lane == (uint32_t)k) sh.pose[k] = next.R[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) if (lane == (uint32_t)(9 + k)) sh.pose[9 + k] = next.t[k];
-    if (lane == 0) sh.stop = stop ? 1 : 0;
-    if (blockIdx.x == 0) {
-      if (lane < kSlots) a.log[(size_t)it * kSlots + lane] = tot;
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { out->pose[k] = next.R[k]; out->step[k] = step.R[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { out->pose[9 + k] = next.t[k]; out->step[9 + k] = step.t[k]; }
-        out->cosine_threshold = cos_thr;
-        out->translation_sq_threshold = tsq_thr;
-        out->max_iteration = max_it;
-        out->iteration = it + 1;
-        out->converged = conv ? 1 : 0;
-        out->done = stop ? 1 : 0;
-      }
-    }
-  }
-  __syncthreads();
-  if (a.stamps && blockIdx.x == 0 && tid == 0) {
-    atomicAdd((unsigned long long*)&a.stamps[5], (unsigned long long)(p2 - p1));
-    atomicAdd((unsigned long long*)&a.stamps[6], (unsigned long long)(p3 - p2));
-    atomicAdd((unsigned long long*)&a.stamps[7], (unsigned long long)(wall_clock64() - p3));
-  }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) head.total.R[k] = sh.pose[k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) head.total.t[k] = sh.pose[9 + k];
-  head.stop = sh.stop != 0;
   return head;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void prologue_solve(const IterArgs& a, PrologueShared<BLOCK>& sh,
+                                               const Pose& old_total, uint32_t lane, int it,
+                                               int max_it, double cos_thr, double tsq_thr) {
+  constexpr int kGroups = BLOCK / kSlots;
+  double tot = 0.0;
+  if (lane < kSlots) {
+    tot = sh.fin[0][lane];
+#pragma unroll
+    for (int g = 1; g < kGroups; ++g) tot += sh.fin[g][lane];
+  }
+  // the 27 sums to every lane (same wave wrote them: LDS is in order within a wave)
+  if (lane < kSlots) sh.totals[lane] = tot;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double A[21], g[6], xi[6];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) A[k] = sh.totals[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) g[k] = -sh.totals[21 + k];
+  if (!ldlt6_solve_spd(A, g, xi)) ldlt6_solve_wave(tot, lane, xi);  // uniform branch
+  Pose step, next;
+  se3_exp_device(xi, step);
+  pose_compose(step, old_total, next);
+  const bool conv = converged(step, cos_thr, tsq_thr);
+  const bool stop = conv || (it + 1 >= max_it);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sh.pose[k] = next.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sh.pose[9 + k] = next.t[k];
+    sh.stop = stop ? 1 : 0;
+  }
+  if (blockIdx.x == 0) {
+    AlignState* out = a.state_out;
+    if (lane < kSlots) a.log[(size_t)it * kSlots + lane] = tot;
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { out->pose[k] = next.R[k]; out->step[k] = step.R[k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { out->pose[9 + k] = next.t[k]; out->step[9 + k] = step.t[k]; }
+      out->cosine_threshold = cos_thr;
+      out->translation_sq_threshold = tsq_thr;
+      out->max_iteration = max_it;
+      out->iteration = it + 1;
+      out->converged = conv ? 1 : 0;
+      out->done = stop ? 1 : 0;
+    }
+  }
 }
 
 __device__ __forceinline__ void load_point(const IterArgs& a, uint32_t i, double (&q)[kScanPlanes]) {
@@ -328,29 +411,125 @@ __device__ __forceinline__ void load_point(const IterArgs& a, uint32_t i, double
   for (int k = 0; k < kScanPlanes; ++k) q[k] = s[k * a.stride];
 }
 
+// One correspondence: p (already in the map frame), scan covariance C, voxel mean / covariance.
+// ICP::computeJTJAndJTr in structured form (J = [I | -[p]x]); S holds C_voxel on entry.
+__device__ __forceinline__ void accumulate_match(const double* R, const double (&p)[3],
+                                                 const double (&C)[9], const double (&mu)[3],
+                                                 double (&S)[9], double (&v)[kSlots]) {
+  // S = R C R^T + C_voxel
+  double RC[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      RC[r + 3 * c] = R[r] * C[3 * c] + R[r + 3] * C[1 + 3 * c] + R[r + 6] * C[2 + 3 * c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      S[r + 3 * c] += RC[r] * R[c] + RC[r + 3] * R[c + 3] + RC[r + 6] * R[c + 6];
+
+  double W[9];
+  inv3(S, W);
+  const double e0 = p[0] - mu[0], e1 = p[1] - mu[1], e2 = p[2] - mu[2];
+  // Q = [p]x W  (rows 3..5, columns 0..2 of J^T Sigma^-1 J)
+  double Q[9];  // Q[r + 3c]
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    Q[0 + 3 * c] = p[1] * W[2 + 3 * c] - p[2] * W[1 + 3 * c];
+    Q[1 + 3 * c] = p[2] * W[0 + 3 * c] - p[0] * W[2 + 3 * c];
+    Q[2 + 3 * c] = p[0] * W[1 + 3 * c] - p[1] * W[0 + 3 * c];
+  }
+  // lower triangle of J^T Sigma^-1 J, row by row
+  v[0] += W[0];
+  v[1] += W[1]; v[2] += W[4];
+  v[3] += W[2]; v[4] += W[5]; v[5] += W[8];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int base = (3 + r) * (4 + r) / 2;
+    const double q0 = Q[r], q1 = Q[r + 3], q2 = Q[r + 6];
+    v[base + 0] += q0; v[base + 1] += q1; v[base + 2] += q2;
+    v[base + 3] += q2 * p[1] - q1 * p[2];
+    if (r >= 1) v[base + 4] += q0 * p[2] - q2 * p[0];
+    if (r >= 2) v[base + 5] += q1 * p[0] - q0 * p[1];
+  }
+  // J^T Sigma^-1 r
+  v[21] += W[0] * e0 + W[3] * e1 + W[6] * e2;
+  v[22] += W[1] * e0 + W[4] * e1 + W[7] * e2;
+  v[23] += W[2] * e0 + W[5] * e1 + W[8] * e2;
+  v[24] += Q[0] * e0 + Q[3] * e1 + Q[6] * e2;
+  v[25] += Q[1] * e0 + Q[4] * e1 + Q[7] * e2;
+  v[26] += Q[2] * e0 + Q[5] * e1 + Q[8] * e2;
+  v[kCountSlot] += 1.0;
+}
+
 // One VGICP round.  Launch j reads state j&1 and the rows launch j-1 wrote, writes state (j+1)&1
-// and its own rows; the host alternates the buffers.  Order inside a workgroup: issue the first
-// point's loads (they do not depend on the pose), run the prologue while they fly, then the gather
-// + accumulate loop, then reduce to one 256-byte row with plain stores — the kernel boundary is the
-// only synchronisation between workgroups.
+// and its own rows; the host alternates the buffers; the kernel boundary is the only synchronisation
+// between workgroups.  Inside a workgroup wave 0 is the SOLVER (it owns no points); waves 1.. are
+// workers, BLOCK-64 points per workgroup pass:
+//   all      issue the loads of the previous rows, the state and (workers) the first point; fold rows
+//   solver   LDLT solve, exponential, compose, convergence -> new pose in LDS       } concurrently,
+//   workers  transform the point with the OLD pose, probe the table, start loading  } between two
+//            the voxel record it lands in                                           } barriers
+//   workers  transform with the NEW pose; the key almost never changes between rounds (steps are far
+//            smaller than a voxel), so the prefetched record is already in registers — the table's
+//            latency hides behind the solve; a changed key is simply probed again
+//   workers  accumulate, grid-stride over further points, butterfly, one 256-byte row per workgroup.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
   constexpr int kWaves = BLOCK / 64;
+  constexpr int kWorkers = BLOCK - 64;
   __shared__ PrologueShared<BLOCK> sh;
   __shared__ double red[kWaves][kSlots];
 
   const uint64_t t_begin = a.stamps ? wall_clock64() : 0;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t stride_pts = gridDim.x * BLOCK;
-  uint32_t i = blockIdx.x * BLOCK + tid;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool worker = wave != 0;
+  const uint32_t stride_pts = gridDim.x * kWorkers;
+  uint32_t i = worker ? blockIdx.x * kWorkers + (tid - 64) : a.n;
 
   double q[kScanPlanes];
 #pragma unroll
   for (int k = 0; k < kScanPlanes; ++k) q[k] = 0.0;
   if (i < a.n) load_point(a, i, q);
 
-  const RoundHead head = round_prologue<BLOCK>(a, sh);
-  if (head.stop) return;  // uniform across the grid
+  int it, max_it;
+  double cos_thr, tsq_thr;
+  RoundHead head = prologue_fold<BLOCK>(a, sh, it, max_it, cos_thr, tsq_thr);
+  if (head.stop) return;  // uniform across the grid: the loop ended in an earlier launch
+  const bool solving = a.prev_rows != 0;  // uniform
+  if (solving) __syncthreads();
+  const uint64_t t_fold = a.stamps ? wall_clock64() : 0;
+
+  // speculative lookup with the old pose (workers) || solve (wave 0)
+  int32_t okx = 0, oky = 0, okz = 0;
+  bool hit = false;
+  double mu[3] = {0.0, 0.0, 0.0}, S[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) S[k] = 0.0;
+  if (worker) {
+    if (i < a.n) {
+      double p[3];
+      transform_point(head.total.R, head.total.t, q[0], q[1], q[2], p);
+      okx = voxel_coord(p[0], a.voxel_size);
+      oky = voxel_coord(p[1], a.voxel_size);
+      okz = voxel_coord(p[2], a.voxel_size);
+      hit = find_and_load(a.table, a.mask, okx, oky, okz, mu, S);
+    }
+  } else if (solving) {
+    prologue_solve<BLOCK>(a, sh, head.total, lane, it, max_it, cos_thr, tsq_thr);
+    if (a.stamps && blockIdx.x == 0 && tid == 0)
+      atomicAdd((unsigned long long*)&a.stamps[6], (unsigned long long)(wall_clock64() - t_fold));
+  }
+  if (solving) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) head.total.R[k] = sh.pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) head.total.t[k] = sh.pose[9 + k];
+    head.stop = sh.stop != 0;
+    if (head.stop) return;  // uniform: converged, or max_iteration reached
+  }
   const uint64_t t_head = a.stamps ? wall_clock64() : 0;
   const double* R = head.total.R;
   const double* t = head.total.t;
@@ -359,6 +538,7 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
 #pragma unroll
   for (int k = 0; k < kSlots; ++k) v[k] = 0.0;
 
+  bool first = true;
   while (i < a.n) {
     const double x = q[0], y = q[1], z = q[2];
     double C[9];
@@ -373,83 +553,35 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
     const int32_t kx = voxel_coord(p[0], a.voxel_size);
     const int32_t ky = voxel_coord(p[1], a.voxel_size);
     const int32_t kz = voxel_coord(p[2], a.voxel_size);
-    const VoxelRecord* rec = find_voxel(a.table, a.mask, kx, ky, kz);
-    if (rec == nullptr) continue;
-
-    double mu[3], S[9];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) mu[k] = rec->mean[k];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) S[k] = rec->cov[k];
-
-    // S = R C R^T + C_voxel
-    double RC[9];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-        RC[r + 3 * c] = R[r] * C[3 * c] + R[r + 3] * C[1 + 3 * c] + R[r + 6] * C[2 + 3 * c];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-        S[r + 3 * c] += RC[r] * R[c] + RC[r + 3] * R[c + 3] + RC[r + 6] * R[c + 6];
-
-    double W[9];
-    inv3(S, W);
-    const double e0 = p[0] - mu[0], e1 = p[1] - mu[1], e2 = p[2] - mu[2];
-    // Q = [p]x W  (rows 3..5, columns 0..2 of J^T Sigma^-1 J)
-    double Q[9];  // Q[r + 3c]
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      Q[0 + 3 * c] = p[1] * W[2 + 3 * c] - p[2] * W[1 + 3 * c];
-      Q[1 + 3 * c] = p[2] * W[0 + 3 * c] - p[0] * W[2 + 3 * c];
-      Q[2 + 3 * c] = p[0] * W[1 + 3 * c] - p[1] * W[0 + 3 * c];
-    }
-    // lower triangle of J^T Sigma^-1 J, row by row
-    v[0] += W[0];
-    v[1] += W[1]; v[2] += W[4];
-    v[3] += W[2]; v[4] += W[5]; v[5] += W[8];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int base = (3 + r) * (4 + r) / 2;
-      const double q0 = Q[r], q1 = Q[r + 3], q2 = Q[r + 6];
-      v[base + 0] += q0; v[base + 1] += q1; v[base + 2] += q2;
-      v[base + 3] += q2 * p[1] - q1 * p[2];
-      if (r >= 1) v[base + 4] += q0 * p[2] - q2 * p[0];
-      if (r >= 2) v[base + 5] += q1 * p[0] - q0 * p[1];
-    }
-    // J^T Sigma^-1 r
-    v[21] += W[0] * e0 + W[3] * e1 + W[6] * e2;
-    v[22] += W[1] * e0 + W[4] * e1 + W[7] * e2;
-    v[23] += W[2] * e0 + W[5] * e1 + W[8] * e2;
-    v[24] += Q[0] * e0 + Q[3] * e1 + Q[6] * e2;
-    v[25] += Q[1] * e0 + Q[4] * e1 + Q[7] * e2;
-    v[26] += Q[2] * e0 + Q[5] * e1 + Q[8] * e2;
-    v[kCountSlot] += 1.0;
+    if (!first || kx != okx || ky != oky || kz != okz)
+      hit = find_and_load(a.table, a.mask, kx, ky, kz, mu, S);
+    first = false;
+    if (hit) accumulate_match(R, p, C, mu, S, v);
   }
   const uint64_t t_loop = a.stamps ? wall_clock64() : 0;
 
   // ---- wave: 32-slot halving butterfly; lane l ends with slot (l >> 1) summed over 64 lanes ----
-  const uint32_t lane = tid & 63, wave = tid >> 6;
-  fold<32, 32>(v, (lane & 32) != 0);
-  fold<16, 16>(v, (lane & 16) != 0);
-  fold<8, 8>(v, (lane & 8) != 0);
-  fold<4, 4>(v, (lane & 4) != 0);
-  fold<2, 2>(v, (lane & 2) != 0);
-  const double wsum = v[0] + __shfl_xor(v[0], 1, 64);
-  if ((lane & 1) == 0) red[wave][lane >> 1] = wsum;
+  if (worker) {
+    fold_swap<32, false>(v);
+    fold_swap<16, true>(v);
+    fold<8, 8>(v, (lane & 8) != 0);
+    fold<4, 4>(v, (lane & 4) != 0);
+    fold<2, 2>(v, (lane & 2) != 0);
+    const double wsum = v[0] + __shfl_xor(v[0], 1, 64);
+    if ((lane & 1) == 0) red[wave][lane >> 1] = wsum;
+  }
   __syncthreads();
-  // ---- workgroup: fixed-order sum over waves, one plain 256-byte row per workgroup ----
+  // ---- workgroup: fixed-order sum over the worker waves, one plain 256-byte row per workgroup ----
   if (tid < kSlots) {
-    double tot = red[0][tid];
+    double tot = red[1][tid];
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) tot += red[w][tid];
+    for (int w = 2; w < kWaves; ++w) tot += red[w][tid];
     a.rows[(size_t)blockIdx.x * kSlots + tid] = tot;
   }
-  if (a.stamps && blockIdx.x == 0 && tid == 0) {
+  if (a.stamps && blockIdx.x == 0 && tid == 64) {
     const uint64_t t_end = wall_clock64();
-    atomicAdd((unsigned long long*)&a.stamps[0], (unsigned long long)(t_head - t_begin));
+    atomicAdd((unsigned long long*)&a.stamps[0], (unsigned long long)(t_fold - t_begin));
+    atomicAdd((unsigned long long*)&a.stamps[5], (unsigned long long)(t_head - t_fold));
     atomicAdd((unsigned long long*)&a.stamps[1], (unsigned long long)(t_loop - t_head));
     atomicAdd((unsigned long long*)&a.stamps[2], (unsigned long long)(t_end - t_loop));
     atomicAdd((unsigned long long*)&a.stamps[4], 1ull);
@@ -461,7 +593,12 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void close_kernel(IterArgs a) {
   __shared__ PrologueShared<BLOCK> sh;
-  (void)round_prologue<BLOCK>(a, sh);
+  int it, max_it;
+  double cos_thr, tsq_thr;
+  const RoundHead head = prologue_fold<BLOCK>(a, sh, it, max_it, cos_thr, tsq_thr);
+  if (head.stop || a.prev_rows == 0) return;
+  __syncthreads();
+  if (threadIdx.x < 64) prologue_solve<BLOCK>(a, sh, head.total, threadIdx.x, it, max_it, cos_thr, tsq_thr);
 }
 
 // Multi-GPU only: fold this rank's rows into one row (fixed order) so the all-reduce moves 256 B.
