@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvgicp_hip.so")
 
 OK, ERR_BAD_ARGUMENT, ERR_HIP, ERR_RCCL, ERR_TABLE_FULL, ERR_DEGENERATE, ERR_NO_DEVICE, ERR_NOT_READY = range(8)
 FLAG_PROFILE = 1
-FLAG_NO_GRAPH = 2
+FLAG_NO_PERSISTENT = 2
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/vgicp_hip.h declares

@@ -90,6 +90,10 @@ struct vgicp_ctx {
   AlignState* h_state = nullptr;  // pinned, kMaxChunksInFlight + 1 slots
   double* d_rows[2] = {nullptr, nullptr};  // partial rows, ping-pong like the state
   double* d_sums = nullptr;       // one row: the all-reduce message (multi-GPU)
+  // persistent single-launch align (single GPU)
+  uint32_t* d_sync = nullptr;     // kShards arrival counters (one 128-byte line each) + error word
+  double* d_rows_persist = nullptr;  // [2][CUs][kSlots]
+  bool persistent_enabled = true; // cleared by VGICP_PERSISTENT=0 or after an in-kernel wait timed out
   int iter_block = 512;           // threads per workgroup of the iteration kernel (measured best at C2)
   double* d_log = nullptr;
   double* h_log = nullptr;  // pinned
@@ -294,6 +298,52 @@ void state_to_pose(const double* pose12, double* m16) {
   pose_to_mat4(T, m16);
 }
 
+// The whole align in one launch (single GPU). Returns VGICP_OK and *ran = true when the kernel
+// completed; *ran = false when it could not be used or gave up (the caller then uses launches).
+int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params* params,
+                         AlignState* result, bool* ran, float* device_ms) {
+  *ran = false;
+  const uint32_t workers = 512 - 64;
+  uint32_t grid = (ctx->n + workers - 1) / workers;
+  grid = std::min<uint32_t>(std::max<uint32_t>(grid, 1), (uint32_t)ctx->cu_count);  // all resident
+  AlignState* h0 = &ctx->h_state[0];
+  std::memset(h0, 0, sizeof(AlignState));
+  pose_to_state(guess, h0->pose);
+  h0->cosine_threshold = params->cosine_threshold;
+  h0->translation_sq_threshold = params->translation_sq_threshold;
+  h0->max_iteration = params->max_iteration;
+  VG_HIP(ctx, hipMemcpyAsync(ctx->d_state, h0, sizeof(AlignState), hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_sync, 0, (kShards + 1) * kCounterStride * sizeof(uint32_t), ctx->stream));
+  PersistArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.scan = ctx->d_scan;
+  a.stride = ctx->stride;
+  a.n = ctx->n;
+  a.mask = (uint32_t)(ctx->slots - 1);
+  a.table = ctx->table;
+  a.voxel_size = ctx->voxel_size;
+  a.rows = ctx->d_rows_persist;
+  a.counters = ctx->d_sync;
+  a.error = ctx->d_sync + kShards * kCounterStride;
+  a.state = ctx->d_state;
+  a.log = ctx->d_log;
+  a.spin_limit = 400000;  // ~0.2 s of polling before giving up
+  a.stamps = ctx->d_stamps;
+  VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+  VG_HIP(ctx, launch_persistent(ctx->stream, a, grid));
+  VG_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(result, ctx->d_state, sizeof(AlignState), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, a.error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VG_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_begin, ctx->ev_end));
+  if (ctx->h_counters[0] != 0) {
+    ctx->persistent_enabled = false;  // not every workgroup was resident: stop trying on this context
+    return VGICP_OK;
+  }
+  *ran = true;
+  return VGICP_OK;
+}
+
 int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, double* out_pose,
               vgicp_stats* stats) {
   const double t0 = now_seconds();
@@ -307,6 +357,40 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
   const bool profile = (params->flags & VGICP_FLAG_PROFILE) != 0;
   int chunk = params->chunk_iterations > 0 ? params->chunk_iterations : kDefaultChunk;
   if (profile) chunk = 1;
+
+  if (ctx->persistent_enabled && ctx->comm == nullptr && !profile && max_it > 0 &&
+      (params->flags & VGICP_FLAG_NO_PERSISTENT) == 0) {
+    bool ran = false;
+    float ms = 0.f;
+    AlignState* hf = &ctx->h_state[0];
+    rc = run_align_persistent(ctx, guess, params, &ctx->h_state[1], &ran, &ms);
+    if (rc != VGICP_OK) return rc;
+    if (ran) {
+      *hf = ctx->h_state[1];
+      const bool want_log = stats && (stats->corr_count || stats->normal_eq);
+      if (want_log) {
+        VG_HIP(ctx, hipMemcpyAsync(ctx->h_log, ctx->d_log, (size_t)hf->iteration * kSlots * sizeof(double),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      }
+      state_to_pose(hf->pose, out_pose);
+      if (stats) {
+        stats->iterations = hf->iteration;
+        stats->converged = hf->converged;
+        stats->world_size = 1;
+        stats->launches = 1;
+        stats->device_seconds = ms * 1e-3;
+        for (int it = 0; it < hf->iteration; ++it) {
+          const double* row = ctx->h_log + (size_t)it * kSlots;
+          if (stats->corr_count) stats->corr_count[it] = (uint64_t)row[kCountSlot];
+          if (stats->normal_eq) std::memcpy(stats->normal_eq + (size_t)it * kNormalEq, row, kNormalEq * sizeof(double));
+        }
+        stats->seconds = now_seconds() - t0;
+      }
+      if (!finite16(out_pose)) return fail(ctx, VGICP_ERR_DEGENERATE, "solved pose is not finite (singular normal equations)");
+      return VGICP_OK;
+    }
+  }
 
   AlignState* h0 = &ctx->h_state[0];
   std::memset(h0, 0, sizeof(AlignState));
@@ -442,6 +526,10 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   for (int k = 0; k < 2; ++k)
     VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows[k]),
                         (size_t)kMaxIterBlocks * kSlots * sizeof(double)));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sync), (kShards + 1) * kCounterStride * sizeof(uint32_t)));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows_persist),
+                      2 * (size_t)ctx->cu_count * kSlots * sizeof(double)));
+  if (const char* pe = std::getenv("VGICP_PERSISTENT")) ctx->persistent_enabled = pe[0] != '0';
   if (const char* blk = std::getenv("VGICP_ITER_BLOCK")) {
     const int b = std::atoi(blk);
     if (b == 256 || b == 512 || b == 1024) ctx->iter_block = b;
@@ -449,8 +537,8 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sums), kSlots * sizeof(double)));
   VG_CREATE(hipMemset(ctx->d_state, 0, 2 * sizeof(AlignState)));
   if (const char* dbg = std::getenv("VGICP_DEBUG_STAMPS"); dbg && dbg[0] == '1') {
-    VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_stamps), 8 * sizeof(uint64_t)));
-    VG_CREATE(hipMemset(ctx->d_stamps, 0, 8 * sizeof(uint64_t)));
+    VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_stamps), 32 * sizeof(uint64_t)));
+    VG_CREATE(hipMemset(ctx->d_stamps, 0, 32 * sizeof(uint64_t)));
   }
   VG_CREATE(hipEventCreate(&ctx->ev_begin));
   VG_CREATE(hipEventCreate(&ctx->ev_end));
@@ -467,13 +555,22 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
   if (ctx->d_stamps) {
-    uint64_t h[8] = {0};
+    uint64_t h[32] = {0};
     if (hipMemcpy(h, ctx->d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[4] > 0) {
       const double k = 0.01 / (double)h[4];  // 100 MHz ticks -> us per launch
       std::fprintf(stderr, "[vgicp stamps] body launches %llu | workgroup 0, first worker lane: loads+fold+barrier %.2f us, "
                    "speculative probe || solve, to 2nd barrier %.2f us, verify+accumulate loop %.2f us, "
                    "butterfly+row store %.2f us | solver wave: solve+publish %.2f us\n", (unsigned long long)h[4], h[0] * k,
                    h[5] * k, h[1] * k, h[2] * k, h[6] * k);
+    }
+    if (hipMemcpy(h, ctx->d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[13] > 0) {
+      for (int o = 8; o <= 16; o += 8) {
+        const double k = 0.01 / (double)h[o + 5];  // 100 MHz ticks -> us per round
+        std::fprintf(stderr, "[vgicp stamps] persistent, %s, %llu rounds: accumulate+butterfly %.2f us, publish %.2f us, "
+                     "wait for all rows %.2f us, row loads+fold %.2f us, solve+broadcast %.2f us\n",
+                     o == 8 ? "solver wave" : "first worker lane", (unsigned long long)h[o + 5], h[o] * k, h[o + 1] * k,
+                     h[o + 2] * k, h[o + 3] * k, h[o + 4] * k);
+      }
     }
     (void)hipFree(ctx->d_stamps);
   }
@@ -485,6 +582,8 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipFree(ctx->d_scan_aos);
   (void)hipFree(ctx->d_state);
   (void)hipHostFree(ctx->h_state);
+  (void)hipFree(ctx->d_sync);
+  (void)hipFree(ctx->d_rows_persist);
   (void)hipFree(ctx->d_rows[0]);
   (void)hipFree(ctx->d_rows[1]);
   (void)hipFree(ctx->d_sums);

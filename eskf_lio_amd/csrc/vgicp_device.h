@@ -67,7 +67,31 @@ struct IterArgs {
                       // ticks, summed over launches; nullptr in normal operation
 };
 
+// Arguments of the persistent single-launch align (single GPU): every round of the loop runs inside
+// one kernel, workgroups exchange their 256-byte rows through `rows` (two buffers by round parity)
+// and signal arrival on `counters` (kShards words, each on a 128-byte line of its own).
+constexpr int kShards = 8;          // arrival counters; a workgroup uses shard blockIdx % kShards
+constexpr int kCounterStride = 32;  // uint32 words between two counters (128 bytes)
+struct PersistArgs {
+  const double* scan;  // SoA planes
+  uint64_t stride;
+  uint32_t n;
+  uint32_t mask;
+  const VoxelRecord* table;
+  double voxel_size;
+  double* rows;         // [2][grid][kSlots]
+  uint32_t* counters;   // zeroed by the host before every launch
+  AlignState* state;    // in: guess, thresholds, max_iteration; out: final state
+  double* log;          // [max_iteration][kSlots]
+  uint32_t* error;      // set to 1 when an in-kernel wait exceeds spin_limit (host falls back to launches)
+  uint32_t spin_limit;
+  uint32_t pad;
+  uint64_t* stamps;
+};
+
 // ---- launchers (defined in vgicp_kernels.hip) ----
+// The whole ICP::align loop in one launch (512-thread workgroups, at most one per CU).
+hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid);
 // One VGICP round over the resident scan: prologue folds args.prev and advances the pose, body
 // accumulates this round's rows. block = 256 / 512 / 1024 threads per workgroup.
 hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, int block);

@@ -113,6 +113,13 @@ __device__ __forceinline__ void fold_swap(double (&v)[kSlots]) {
   }
 }
 
+// A value that is the same in every lane, moved to scalar registers (frees its VGPR pair).
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
@@ -405,10 +412,11 @@ __device__ __forceinline__ void prologue_solve(const IterArgs& a, PrologueShared
   }
 }
 
-__device__ __forceinline__ void load_point(const IterArgs& a, uint32_t i, double (&q)[kScanPlanes]) {
-  const double* s = a.scan + i;
+__device__ __forceinline__ void load_point(const double* scan, uint64_t stride, uint32_t i,
+                                           double (&q)[kScanPlanes]) {
+  const double* s = scan + i;
 #pragma unroll
-  for (int k = 0; k < kScanPlanes; ++k) q[k] = s[k * a.stride];
+  for (int k = 0; k < kScanPlanes; ++k) q[k] = s[k * stride];
 }
 
 // One correspondence: p (already in the map frame), scan covariance C, voxel mean / covariance.
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
   double q[kScanPlanes];
 #pragma unroll
   for (int k = 0; k < kScanPlanes; ++k) q[k] = 0.0;
-  if (i < a.n) load_point(a, i, q);
+  if (i < a.n) load_point(a.scan, a.stride, i, q);
 
   int it, max_it;
   double cos_thr, tsq_thr;
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
     const uint32_t inext = i + stride_pts;
-    if (inext < a.n) load_point(a, inext, q);  // prefetch the next point under this one's gather
+    if (inext < a.n) load_point(a.scan, a.stride, inext, q);  // prefetch the next point under this one's gather
     i = inext;
 
     double p[3];
@@ -599,6 +607,253 @@ __global__ __launch_bounds__(BLOCK) void close_kernel(IterArgs a) {
   if (head.stop || a.prev_rows == 0) return;
   __syncthreads();
   if (threadIdx.x < 64) prologue_solve<BLOCK>(a, sh, head.total, threadIdx.x, it, max_it, cos_thr, tsq_thr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent variant: the whole loop of ICP::align (src/Registration.cpp:15-28) in ONE launch.
+//
+// Same arithmetic, same fixed summation orders and the same workgroup geometry as iterate_kernel
+// (so both variants return the same bits); what changes is how a round's partial rows travel:
+//   producer  wave 0 stores the workgroup's row write-through (sc1, 8-byte stores), drains them
+//             (s_waitcnt vmcnt(0)), then ONE lane adds 1 to the arrival counter of its shard
+//   consumer  wave 0 polls the kShards counters (sc1 loads, s_sleep between polls, bounded), the
+//             workgroup barrier releases the other waves, every thread then reads the rows with sc1
+//             loads (L1-bypassing) — the hand-off form measured valid on gfx950 in
+//             MI355X_MICROARCH.md "Valid forms" (one lane signals for all stores of its workgroup;
+//             sc1 stores and sc1 loads; one workgroup per CU; no dispatch-order assumption)
+// Rows are double-buffered by round parity: a workgroup can be at most one round ahead of the
+// slowest one, because it needs everyone's row of round r before it can publish round r+1.
+// Gains over one launch per round: no kernel boundary (~4 us of dispatch, acquire/release and skew
+// per round), the scan point stays in registers, and the voxel record a point used in round r is the
+// speculation for round r+1 — the table is touched again only when a point changes voxel.
+// Needs every workgroup resident (grid <= CUs, one 512-thread workgroup per CU); a wait that exceeds
+// spin_limit sets *error and ends the kernel, and the host re-runs the align with iterate_kernel.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+__device__ __forceinline__ void store_through(double* p, double v) {
+  __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_through(const double* p) {
+  return __longlong_as_double(
+      (long long)__hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
+  constexpr int kWaves = BLOCK / 64;
+  constexpr int kWorkers = BLOCK - 64;
+  constexpr int kGroups = BLOCK / kSlots;
+  constexpr int kBatch = 16;
+  __shared__ PrologueShared<BLOCK> sh;
+  __shared__ double red[kWaves][kSlots];
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool worker = wave != 0;
+  const uint32_t grid = gridDim.x, blk = blockIdx.x;
+  const uint32_t stride_pts = grid * kWorkers;
+  const uint32_t first = worker ? blk * kWorkers + (tid - 64) : a.n;
+  const uint32_t my_shard = blk % kShards;
+  // arrivals per round on the shard this lane polls (lanes 0..kShards-1 of wave 0)
+  const uint32_t shard_blocks = lane < kShards ? (grid + kShards - 1 - lane) / kShards : 0u;
+
+  RoundHead head;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) head.total.R[k] = a.state->pose[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) head.total.t[k] = a.state->pose[9 + k];
+  const double cos_thr = a.state->cosine_threshold, tsq_thr = a.state->translation_sq_threshold;
+  const int max_it = a.state->max_iteration;
+
+  double q0[kScanPlanes];
+#pragma unroll
+  for (int k = 0; k < kScanPlanes; ++k) q0[k] = 0.0;
+  const bool have = first < a.n;
+  if (have) load_point(a.scan, a.stride, first, q0);
+
+  // what the first point used last round: key, hit flag, voxel payload (raw)
+  bool spec = false, hit = false;
+  int32_t okx = 0, oky = 0, okz = 0;
+  double mu[3] = {0.0, 0.0, 0.0}, Sv[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Sv[k] = 0.0;
+
+  uint64_t t_mark = a.stamps ? wall_clock64() : 0;
+  uint64_t acc_body = 0, acc_publish = 0, acc_wait = 0, acc_rows = 0, acc_solve = 0;
+  int it = 0;
+  bool conv = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) head.total.R[k] = uniform_f64(head.total.R[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) head.total.t[k] = uniform_f64(head.total.t[k]);
+  for (;;) {
+    const double* R = head.total.R;
+    const double* t = head.total.t;
+    double v[kSlots];
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) v[k] = 0.0;
+    if (worker) {
+      if (have) {
+        double p[3], C[9], S[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) C[k] = q0[3 + k];
+        transform_point(R, t, q0[0], q0[1], q0[2], p);
+        const int32_t kx = voxel_coord(p[0], a.voxel_size);
+        const int32_t ky = voxel_coord(p[1], a.voxel_size);
+        const int32_t kz = voxel_coord(p[2], a.voxel_size);
+        if (!spec || kx != okx || ky != oky || kz != okz) {
+          hit = find_and_load(a.table, a.mask, kx, ky, kz, mu, Sv);
+          okx = kx; oky = ky; okz = kz;
+          spec = true;
+        }
+        if (hit) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) S[k] = Sv[k];
+          accumulate_match(R, p, C, mu, S, v);
+        }
+      }
+      for (uint32_t i = first + stride_pts; i < a.n; i += stride_pts) {  // scans larger than the grid
+        double q[kScanPlanes], p[3], C[9], m2[3], S[9];
+        load_point(a.scan, a.stride, i, q);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
+        transform_point(R, t, q[0], q[1], q[2], p);
+        if (find_and_load(a.table, a.mask, voxel_coord(p[0], a.voxel_size),
+                          voxel_coord(p[1], a.voxel_size), voxel_coord(p[2], a.voxel_size), m2, S))
+          accumulate_match(R, p, C, m2, S, v);
+      }
+      fold_swap<32, false>(v);
+      fold_swap<16, true>(v);
+      fold<8, 8>(v, (lane & 8) != 0);
+      fold<4, 4>(v, (lane & 4) != 0);
+      fold<2, 2>(v, (lane & 2) != 0);
+      const double wsum = v[0] + __shfl_xor(v[0], 1, 64);
+      if ((lane & 1) == 0) red[wave][lane >> 1] = wsum;
+    }
+    __syncthreads();
+    if (a.stamps) { const uint64_t n = wall_clock64(); acc_body += n - t_mark; t_mark = n; }
+
+    // ---- publish this workgroup's row, then wait until every workgroup has published ----
+    double* rows = a.rows + (size_t)(it & 1) * grid * kSlots;
+    if (wave == 0) {
+      if (lane < kSlots) {
+        double tot = red[1][lane];
+#pragma unroll
+        for (int w = 2; w < kWaves; ++w) tot += red[w][lane];
+        store_through(rows + (size_t)blk * kSlots + lane, tot);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has left this CU before the signal
+      if (lane == 0)
+        __hip_atomic_fetch_add((gu32*)(a.counters + my_shard * kCounterStride), 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      if (a.stamps) { const uint64_t n = wall_clock64(); acc_publish += n - t_mark; t_mark = n; }
+      const uint32_t target = shard_blocks * (uint32_t)(it + 1);
+      bool arrived = false;
+      for (uint32_t spins = 0; spins < a.spin_limit; ++spins) {
+        const uint32_t c = lane < kShards
+                               ? __hip_atomic_load((gu32*)(a.counters + lane * kCounterStride),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : 0xFFFFFFFFu;
+        if (__all(c >= target)) { arrived = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (lane == 0) sh.stop = arrived ? 0 : 2;
+    }
+    __syncthreads();
+    if (sh.stop == 2) {  // uniform: a workgroup never arrived (not all resident?) — give up, host falls back
+      if (tid == 0) __hip_atomic_store((gu32*)a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (a.stamps && wave != 0) { const uint64_t n = wall_clock64(); acc_publish += 0; acc_wait += n - t_mark; t_mark = n; }
+    if (a.stamps && wave == 0) { const uint64_t n = wall_clock64(); acc_wait += n - t_mark; t_mark = n; }
+
+    // ---- every workgroup folds all rows in the same fixed order (as round_prologue does) ----
+    {
+      const uint32_t slot = tid & (kSlots - 1), group = tid / kSlots;
+      double row[kBatch];
+      double s = 0.0;
+      for (uint32_t b0 = group; b0 < grid; b0 += kGroups * kBatch) {
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const uint32_t b = b0 + u * kGroups;
+          row[u] = b < grid ? load_through(rows + (size_t)b * kSlots + slot) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) s += row[u];
+      }
+      sh.fin[group][slot] = s;
+    }
+    __syncthreads();
+    if (a.stamps) { const uint64_t n = wall_clock64(); acc_rows += n - t_mark; t_mark = n; }
+
+    if (wave == 0) {
+      double tot = 0.0;
+      if (lane < kSlots) {
+        tot = sh.fin[0][lane];
+#pragma unroll
+        for (int g = 1; g < kGroups; ++g) tot += sh.fin[g][lane];
+        sh.totals[lane] = tot;
+        if (blk == 0) a.log[(size_t)it * kSlots + lane] = tot;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double A[21], g[6], xi[6];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) A[k] = sh.totals[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) g[k] = -sh.totals[21 + k];
+      if (!ldlt6_solve_spd(A, g, xi)) ldlt6_solve_wave(tot, lane, xi);  // uniform branch
+      Pose next, step;
+      se3_exp_device(xi, step);
+      pose_compose(step, head.total, next);
+      conv = converged(step, cos_thr, tsq_thr);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sh.pose[k] = next.R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sh.pose[9 + k] = next.t[k];
+        sh.stop = (conv || (it + 1 >= max_it)) ? 1 : 0;
+        if (blk == 0) {  // the last increment, for the state the host reads
+#pragma unroll
+          for (int k = 0; k < 9; ++k) a.state->step[k] = step.R[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a.state->step[9 + k] = step.t[k];
+          a.state->converged = conv ? 1 : 0;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) head.total.R[k] = uniform_f64(sh.pose[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) head.total.t[k] = uniform_f64(sh.pose[9 + k]);
+    const bool stop = sh.stop != 0;
+    ++it;
+    if (a.stamps) { const uint64_t n = wall_clock64(); acc_solve += n - t_mark; t_mark = n; }
+    if (stop) break;
+    __syncthreads();  // sh.stop / sh.pose are rewritten next round
+  }
+
+  if (blk == 0 && tid == 0) {
+    AlignState* out = a.state;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out->pose[k] = head.total.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out->pose[9 + k] = head.total.t[k];
+    out->iteration = it;
+    out->done = 1;
+  }
+  if (a.stamps && blk == 0 && (tid == 0 || tid == 64)) {
+    const int o = tid == 0 ? 8 : 16;  // solver wave / first worker lane
+    atomicAdd((unsigned long long*)&a.stamps[o + 0], (unsigned long long)acc_body);
+    atomicAdd((unsigned long long*)&a.stamps[o + 1], (unsigned long long)acc_publish);
+    atomicAdd((unsigned long long*)&a.stamps[o + 2], (unsigned long long)acc_wait);
+    atomicAdd((unsigned long long*)&a.stamps[o + 3], (unsigned long long)acc_rows);
+    atomicAdd((unsigned long long*)&a.stamps[o + 4], (unsigned long long)acc_solve);
+    atomicAdd((unsigned long long*)&a.stamps[o + 5], (unsigned long long)it);
+  }
 }
 
 // Multi-GPU only: fold this rank's rows into one row (fixed order) so the all-reduce moves 256 B.
@@ -816,6 +1071,11 @@ hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, in
     case 1024: hipLaunchKernelGGL(iterate_kernel<1024>, dim3(grid), dim3(1024), 0, s, args); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid) {
+  hipLaunchKernelGGL(persistent_kernel<512>, dim3(grid), dim3(512), 0, s, args);
   return hipGetLastError();
 }
 

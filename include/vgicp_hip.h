@@ -58,7 +58,8 @@ typedef struct vgicp_params {
 } vgicp_params;
 
 #define VGICP_FLAG_PROFILE 1u        /* bracket every iteration launch with HIP events (kernel_ms) */
-#define VGICP_FLAG_NO_GRAPH 2u       /* enqueue plain launches instead of replaying a hipGraph */
+#define VGICP_FLAG_NO_PERSISTENT 2u  /* one launch per iteration instead of the single persistent launch
+                                        (always the case with a communicator or VGICP_FLAG_PROFILE) */
 
 /* What the reference only prints or drops: per-call convergence (its converged_ member is sticky,
  * include/ESKF_LIO/Registration.hpp:50) and the per-iteration correspondence counts. */

@@ -181,22 +181,52 @@ def test_chunking_and_workgroup_schedule_do_not_change_results(c1_gpu, c1_inputs
     from eskf_lio_amd import capi, synth
     vmap, pts, covs = c1_inputs
     guess = synth.default_guess()
-    base = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, chunk_iterations=20)
+    NP = capi.FLAG_NO_PERSISTENT                                   # chunking belongs to the per-launch loop
+    base = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, chunk_iterations=20, flags=NP)
     for chunk in (1, 3, 7, 64):
-        r = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, chunk_iterations=chunk)
+        r = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, chunk_iterations=chunk, flags=NP)
         assert np.array_equal(r.pose, base.pose) and np.array_equal(r.corr_count, base.corr_count)
     r = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, flags=capi.FLAG_PROFILE)
     assert np.array_equal(r.pose, base.pose) and r.kernel_ms is not None and (r.kernel_ms[:20] > 0).all()
     # early exit: converging run, every chunk size reports the same iteration count and pose
     spts, scovs, _ = synth.make_structured_scan(5_000, vmap)
-    ref = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999, chunk_iterations=100)
+    ref = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999, chunk_iterations=100, flags=NP)
     for chunk in (1, 2, 4, 5):
-        r = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999, chunk_iterations=chunk)
+        r = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999, chunk_iterations=chunk, flags=NP)
         assert r.iterations == ref.iterations == 3 and r.converged
         assert np.array_equal(r.pose, ref.pose) and r.launches < 100
     # bit-reproducible run to run (the reference is not: SURVEY.md F10)
-    again = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, chunk_iterations=20)
+    again = c1_gpu.align(pts, covs, guess, 20, 1e-6, 2.0, chunk_iterations=20, flags=NP)
     assert np.array_equal(again.pose, base.pose) and np.array_equal(again.normal_eq, base.normal_eq)
+
+
+def test_persistent_and_per_launch_variants_return_the_same_bits(c1_gpu, c1_inputs):
+    """The single-launch persistent loop and the one-launch-per-round loop share arithmetic, summation
+    order and workgroup geometry; only the way rows travel differs (in-kernel sc1 hand-off vs kernel
+    boundary). A stale or torn row in the in-kernel exchange would show up here as a bit difference."""
+    from eskf_lio_amd import capi, synth
+    vmap, pts, covs = c1_inputs
+    g = synth.default_guess()
+    per_launch = c1_gpu.align(pts, covs, g, 20, 1e-6, 2.0, flags=capi.FLAG_NO_PERSISTENT)
+    assert per_launch.launches == 21
+    for _ in range(40):                                            # many epochs over the same row buffers
+        one = c1_gpu.align(pts, covs, g, 20, 1e-6, 2.0)
+        assert one.launches == 1 and one.iterations == 20
+        assert np.array_equal(one.pose, per_launch.pose)
+        assert np.array_equal(one.normal_eq, per_launch.normal_eq)
+        assert np.array_equal(one.corr_count, per_launch.corr_count)
+    spts, scovs, _ = synth.make_structured_scan(5_000, vmap)
+    a = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999)
+    b = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999, flags=capi.FLAG_NO_PERSISTENT)
+    assert a.converged and b.converged and a.iterations == b.iterations == 3
+    assert np.array_equal(a.pose, b.pose) and np.array_equal(a.normal_eq, b.normal_eq)
+    for n in (1, 449, 4999):                                       # ragged grids
+        a = c1_gpu.align(pts[:n], covs[:n], g, 5, 1e-6, 2.0, allow_degenerate=True)
+        b = c1_gpu.align(pts[:n], covs[:n], g, 5, 1e-6, 2.0, flags=capi.FLAG_NO_PERSISTENT, allow_degenerate=True)
+        assert np.array_equal(a.normal_eq, b.normal_eq)            # every round's sums: bit for bit
+        # the pose after the LAST solve comes from two separately compiled copies of the solve
+        # (persistent_kernel vs close_kernel): identical up to the last bit of tiny entries
+        assert np.abs(a.pose - b.pose).max() < 1e-15
 
 
 def test_resident_scan_is_not_modified_by_align(c1_gpu, c1_inputs):
