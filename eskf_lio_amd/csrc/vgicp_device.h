@@ -23,7 +23,7 @@ constexpr int kSlots = 32;      // doubles per partial row
 constexpr int kNormalEq = 27;   // 21 lower-triangle JTJ entries + 6 JTr entries
 constexpr int kCountSlot = 27;  // match count travels as an exact double
 constexpr int kScanPlanes = 12;
-constexpr int kMaxIterBlocks = 2048;  // grid cap; larger scans grid-stride
+constexpr int kMaxIterBlocks = 512;  // grid cap (every workgroup folds all rows: keep them few); larger scans grid-stride
 
 enum : int32_t { SLOT_EMPTY = 0, SLOT_FULL = 1, SLOT_TOMB = 2, SLOT_LOCKED = 3 };
 

@@ -34,7 +34,7 @@ def one(pattern):
 
 
 def short(name):
-    for key in ("iterate_kernel", "close_kernel", "pack_scan_kernel", "upsert_kernel", "fold_rows_kernel",
+    for key in ("persistent_kernel", "iterate_kernel", "close_kernel", "pack_scan_kernel", "upsert_kernel", "fold_rows_kernel",
                 "table_clear_kernel"):
         if key in name:
             return key
@@ -72,8 +72,13 @@ if fetch:
     factor = 96.0 * n_points / pack if pack == pack and pack > 0 else float("nan")
     it_f = np.array(fetch.get("iterate_kernel", [np.nan])) * kib
     it_w = np.array(write.get("iterate_kernel", [np.nan])) * kib
+    pk_f = np.array(fetch.get("persistent_kernel", [np.nan])) * kib
+    pk_w = np.array(write.get("persistent_kernel", [np.nan])) * kib
     summary["traffic"] = {
         "unit": "bytes per launch",
+        "persistent_kernel_fetch_raw": float(np.mean(pk_f)),
+        "persistent_kernel_write": float(np.mean(pk_w)),
+        "persistent_kernel_total_calibrated": float(np.mean(pk_f) * factor + np.mean(pk_w)),
         "iterate_kernel_fetch_raw": float(np.mean(it_f)),
         "iterate_kernel_write": float(np.mean(it_w)),
         "pack_scan_fetch_raw": float(pack), "pack_scan_known_read_bytes": 96.0 * n_points,
