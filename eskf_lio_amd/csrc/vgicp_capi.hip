@@ -91,7 +91,9 @@ struct vgicp_ctx {
   double* d_rows[2] = {nullptr, nullptr};  // partial rows, ping-pong like the state
   double* d_sums = nullptr;       // one row: the all-reduce message (multi-GPU)
   // persistent single-launch align (single GPU)
-  uint32_t* d_sync = nullptr;     // kShards arrival counters (one 128-byte line each) + error word
+  uint32_t* d_sync = nullptr;     // kShards arrival counters (one 128-byte line each); they only grow
+  uint32_t persist_base[kShards] = {0};  // host copy of the counters' values between launches
+  uint32_t persist_seq = 0;
   double* d_rows_persist = nullptr;  // [2][CUs][kSlots]
   bool persistent_enabled = true; // cleared by VGICP_PERSISTENT=0 or after an in-kernel wait timed out
   int iter_block = 512;           // threads per workgroup of the iteration kernel (measured best at C2)
@@ -187,13 +189,20 @@ int ensure_scan(vgicp_ctx* ctx, size_t n) {
 
 int ensure_log(vgicp_ctx* ctx, int iterations) {
   if (iterations <= ctx->log_capacity) return VGICP_OK;
-  if (ctx->d_log) VG_HIP(ctx, hipFree(ctx->d_log));
-  if (ctx->h_log) VG_HIP(ctx, hipHostFree(ctx->h_log));
+  if (ctx->d_log) VG_HIP(ctx, hipFree(ctx->d_log - kSlots));
+  if (ctx->h_log) VG_HIP(ctx, hipHostFree(ctx->h_log - kSlots));
   ctx->d_log = ctx->h_log = nullptr;
   ctx->log_capacity = 0;
+  // one header row in front of the log: the persistent launch leaves its final AlignState there, so a
+  // single device-to-host copy brings state and log back
   const int cap = std::max(iterations, 128);
-  VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_log), (size_t)cap * kSlots * sizeof(double)));
-  VG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_log), (size_t)cap * kSlots * sizeof(double), 0));
+  double* d = nullptr;
+  double* h = nullptr;
+  VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), (size_t)(cap + 1) * kSlots * sizeof(double)));
+  VG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&h), (size_t)(cap + 1) * kSlots * sizeof(double), 0));
+  VG_HIP(ctx, hipMemset(d, 0, kSlots * sizeof(double)));
+  ctx->d_log = d + kSlots;
+  ctx->h_log = h + kSlots;
   ctx->log_capacity = cap;
   return VGICP_OK;
 }
@@ -303,17 +312,11 @@ void state_to_pose(const double* pose12, double* m16) {
 int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params* params,
                          AlignState* result, bool* ran, float* device_ms) {
   *ran = false;
+  static_assert(sizeof(AlignState) <= kSlots * sizeof(double), "the state must fit the log's header row");
   const uint32_t workers = 512 - 64;
   uint32_t grid = (ctx->n + workers - 1) / workers;
   grid = std::min<uint32_t>(std::max<uint32_t>(grid, 1), (uint32_t)ctx->cu_count);  // all resident
-  AlignState* h0 = &ctx->h_state[0];
-  std::memset(h0, 0, sizeof(AlignState));
-  pose_to_state(guess, h0->pose);
-  h0->cosine_threshold = params->cosine_threshold;
-  h0->translation_sq_threshold = params->translation_sq_threshold;
-  h0->max_iteration = params->max_iteration;
-  VG_HIP(ctx, hipMemcpyAsync(ctx->d_state, h0, sizeof(AlignState), hipMemcpyHostToDevice, ctx->stream));
-  VG_HIP(ctx, hipMemsetAsync(ctx->d_sync, 0, (kShards + 1) * kCounterStride * sizeof(uint32_t), ctx->stream));
+  const int max_it = params->max_iteration;
   PersistArgs a;
   std::memset(&a, 0, sizeof a);
   a.scan = ctx->d_scan;
@@ -324,22 +327,34 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.voxel_size = ctx->voxel_size;
   a.rows = ctx->d_rows_persist;
   a.counters = ctx->d_sync;
-  a.error = ctx->d_sync + kShards * kCounterStride;
-  a.state = ctx->d_state;
+  a.state = reinterpret_cast<AlignState*>(ctx->d_log - kSlots);
   a.log = ctx->d_log;
   a.spin_limit = 400000;  // ~0.2 s of polling before giving up
+  a.seq = ++ctx->persist_seq == 0 ? ++ctx->persist_seq : ctx->persist_seq;  // never 0
+  pose_to_state(guess, a.pose0);
+  a.cosine_threshold = params->cosine_threshold;
+  a.translation_sq_threshold = params->translation_sq_threshold;
+  a.max_iteration = max_it;
+  for (int k = 0; k < kShards; ++k) a.base[k] = ctx->persist_base[k];
   a.stamps = ctx->d_stamps;
+  // one launch, one copy back (state header + the log rows), one synchronisation
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
   VG_HIP(ctx, launch_persistent(ctx->stream, a, grid));
   VG_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(result, ctx->d_state, sizeof(AlignState), hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, a.error, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_log - kSlots, ctx->d_log - kSlots,
+                             (size_t)(max_it + 1) * kSlots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   VG_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_begin, ctx->ev_end));
-  if (ctx->h_counters[0] != 0) {
-    ctx->persistent_enabled = false;  // not every workgroup was resident: stop trying on this context
+  std::memcpy(result, ctx->h_log - kSlots, sizeof(AlignState));
+  if (result->seq != a.seq) {
+    // an in-kernel wait timed out (not every workgroup resident): resynchronise and stop trying here
+    ctx->persistent_enabled = false;
+    VG_HIP(ctx, hipMemsetAsync(ctx->d_sync, 0, (kShards + 1) * kCounterStride * sizeof(uint32_t), ctx->stream));
+    for (int k = 0; k < kShards; ++k) ctx->persist_base[k] = 0;
     return VGICP_OK;
   }
+  for (int k = 0; k < kShards; ++k)
+    ctx->persist_base[k] += ((grid + kShards - 1 - (uint32_t)k) / kShards) * (uint32_t)result->iteration;
   *ran = true;
   return VGICP_OK;
 }
@@ -367,12 +382,6 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
     if (rc != VGICP_OK) return rc;
     if (ran) {
       *hf = ctx->h_state[1];
-      const bool want_log = stats && (stats->corr_count || stats->normal_eq);
-      if (want_log) {
-        VG_HIP(ctx, hipMemcpyAsync(ctx->h_log, ctx->d_log, (size_t)hf->iteration * kSlots * sizeof(double),
-                                   hipMemcpyDeviceToHost, ctx->stream));
-        VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      }
       state_to_pose(hf->pose, out_pose);
       if (stats) {
         stats->iterations = hf->iteration;
@@ -527,6 +536,7 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
     VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows[k]),
                         (size_t)kMaxIterBlocks * kSlots * sizeof(double)));
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sync), (kShards + 1) * kCounterStride * sizeof(uint32_t)));
+  VG_CREATE(hipMemset(ctx->d_sync, 0, (kShards + 1) * kCounterStride * sizeof(uint32_t)));
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows_persist),
                       2 * (size_t)ctx->cu_count * kSlots * sizeof(double)));
   if (const char* pe = std::getenv("VGICP_PERSISTENT")) ctx->persistent_enabled = pe[0] != '0';
@@ -587,8 +597,8 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipFree(ctx->d_rows[0]);
   (void)hipFree(ctx->d_rows[1]);
   (void)hipFree(ctx->d_sums);
-  (void)hipFree(ctx->d_log);
-  (void)hipHostFree(ctx->h_log);
+  if (ctx->d_log) (void)hipFree(ctx->d_log - kSlots);
+  if (ctx->h_log) (void)hipHostFree(ctx->h_log - kSlots);
   if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
   if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
   for (auto& e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);

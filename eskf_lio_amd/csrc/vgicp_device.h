@@ -47,6 +47,8 @@ struct AlignState {
   int32_t iteration;  // rounds executed so far
   int32_t done;       // set on convergence or when iteration == max_iteration
   int32_t converged;
+  uint32_t seq;       // persistent launch: echo of PersistArgs::seq, written last (0 from the per-launch loop)
+  uint32_t pad;
 };
 
 struct IterArgs {
@@ -81,11 +83,17 @@ struct PersistArgs {
   double voxel_size;
   double* rows;         // [2][grid][kSlots]
   uint32_t* counters;   // zeroed by the host before every launch
-  AlignState* state;    // in: guess, thresholds, max_iteration; out: final state
+  AlignState* state;    // out: final state; state->seq == seq tells the host the loop ran to its end
   double* log;          // [max_iteration][kSlots]
-  uint32_t* error;      // set to 1 when an in-kernel wait exceeds spin_limit (host falls back to launches)
-  uint32_t spin_limit;
+  uint32_t spin_limit;  // an in-kernel wait longer than this gives up (host falls back to launches)
+  uint32_t seq;
+  // inputs travel with the dispatch packet: no host-to-device copy and no memset per align
+  double pose0[12];     // guess: R column-major (9) then t (3)
+  double cosine_threshold;
+  double translation_sq_threshold;
+  int32_t max_iteration;
   uint32_t pad;
+  uint32_t base[kShards];  // value of each arrival counter before this launch (they only ever grow)
   uint64_t* stamps;
 };
 

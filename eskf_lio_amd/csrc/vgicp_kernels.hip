@@ -657,14 +657,17 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   const uint32_t my_shard = blk % kShards;
   // arrivals per round on the shard this lane polls (lanes 0..kShards-1 of wave 0)
   const uint32_t shard_blocks = lane < kShards ? (grid + kShards - 1 - lane) / kShards : 0u;
+  uint32_t shard_base = 0;
+#pragma unroll
+  for (int k = 0; k < kShards; ++k) if (lane == (uint32_t)k) shard_base = a.base[k];
 
   RoundHead head;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) head.total.R[k] = a.state->pose[k];
+  for (int k = 0; k < 9; ++k) head.total.R[k] = a.pose0[k];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) head.total.t[k] = a.state->pose[9 + k];
-  const double cos_thr = a.state->cosine_threshold, tsq_thr = a.state->translation_sq_threshold;
-  const int max_it = a.state->max_iteration;
+  for (int k = 0; k < 3; ++k) head.total.t[k] = a.pose0[9 + k];
+  const double cos_thr = a.cosine_threshold, tsq_thr = a.translation_sq_threshold;
+  const int max_it = a.max_iteration;
 
   double q0[kScanPlanes];
 #pragma unroll
@@ -748,23 +751,21 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
         __hip_atomic_fetch_add((gu32*)(a.counters + my_shard * kCounterStride), 1u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
       if (a.stamps) { const uint64_t n = wall_clock64(); acc_publish += n - t_mark; t_mark = n; }
-      const uint32_t target = shard_blocks * (uint32_t)(it + 1);
+      const uint32_t target = shard_base + shard_blocks * (uint32_t)(it + 1);
       bool arrived = false;
       for (uint32_t spins = 0; spins < a.spin_limit; ++spins) {
         const uint32_t c = lane < kShards
                                ? __hip_atomic_load((gu32*)(a.counters + lane * kCounterStride),
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                               : 0xFFFFFFFFu;
-        if (__all(c >= target)) { arrived = true; break; }
+                               : target;
+        if (__all((int32_t)(c - target) >= 0)) { arrived = true; break; }  // wrap-safe
         __builtin_amdgcn_s_sleep(1);
       }
       if (lane == 0) sh.stop = arrived ? 0 : 2;
     }
     __syncthreads();
-    if (sh.stop == 2) {  // uniform: a workgroup never arrived (not all resident?) — give up, host falls back
-      if (tid == 0) __hip_atomic_store((gu32*)a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
+    if (sh.stop == 2) return;  // uniform: a workgroup never arrived (not all resident?) — give up; the
+                               // host sees state->seq != seq and falls back to one launch per round
     if (a.stamps && wave != 0) { const uint64_t n = wall_clock64(); acc_publish += 0; acc_wait += n - t_mark; t_mark = n; }
     if (a.stamps && wave == 0) { const uint64_t n = wall_clock64(); acc_wait += n - t_mark; t_mark = n; }
 
@@ -842,8 +843,13 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
     for (int k = 0; k < 9; ++k) out->pose[k] = head.total.R[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) out->pose[9 + k] = head.total.t[k];
+    out->cosine_threshold = cos_thr;
+    out->translation_sq_threshold = tsq_thr;
+    out->max_iteration = max_it;
     out->iteration = it;
     out->done = 1;
+    out->pad = 0;
+    out->seq = a.seq;
   }
   if (a.stamps && blk == 0 && (tid == 0 || tid == 64)) {
     const int o = tid == 0 ? 8 : 16;  // solver wave / first worker lane
