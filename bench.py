@@ -49,7 +49,7 @@ def algorithmic_bytes(n_points: int, matches: float) -> float:
     return 112.0 * n_points + 96.0 * matches
 
 
-def measured_traffic(config: str, world: int):
+def measured_traffic(config: str, world: int, kernel: str):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (C2, 1 GPU)."""
     import glob
     if config != "C2" or world != 1:
@@ -60,10 +60,9 @@ def measured_traffic(config: str, world: int):
             t = json.load(open(f)).get("traffic")
         except Exception:
             continue
-        for key in ("persistent_kernel_total_calibrated", "iterate_kernel_total_calibrated"):
-            if t and key in t and t[key] == t[key]:
-                best = t[key]
-                break
+        key = f"{kernel}_total_calibrated"
+        if t and key in t and t[key] == t[key]:
+            best = t[key]
     return best
 
 
@@ -116,7 +115,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_COMM=1 runs the multi-GPU code path (process group, unique-id hand-off, RCCL
+    # all-reduce per iteration) with however many ranks there are — on one GPU a way to exercise it
+    force_comm = os.environ.get("BENCH_FORCE_COMM", "0") == "1"
+    use_dist = world > 1 or force_comm
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     n_points, n_voxels = synth.CONFIGS[args.config]
@@ -128,7 +133,7 @@ def main():
     ctx = capi.Context(local_rank)
     ctx.map_reset(vmap.voxel_size, n_voxels)
     ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
-    if world > 1:
+    if use_dist:
         ctx.comm_init(world, rank, share_unique_id(ctx, rank))
     ctx.scan_upload(pts[lo:hi], covs[lo:hi])
 
@@ -137,7 +142,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -151,7 +156,7 @@ def main():
         dev_s += res.device_seconds
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -195,7 +200,7 @@ def main():
                             f"(cosine_threshold 2.0 forces all), scan resident in HBM",
                 "points": n_points, "voxels": n_voxels, "iterations": ITERATIONS,
                 "sharding": f"contiguous point shards over {world} rank(s), replicated map, "
-                            f"RCCL all-reduce of 28 doubles per iteration" if world > 1 else "single GPU",
+                            f"RCCL all-reduce of 28 doubles per iteration" if use_dist else "single GPU",
                 "matches_per_iteration": float(res.corr_count.mean()),
             },
             "roofline": {
@@ -204,7 +209,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.config, world),
+                "traffic": measured_traffic(args.config, world,
+                                            "persistent_kernel" if persistent else "iterate_kernel"),
                 "kernel": "vgicp::persistent_kernel" if persistent else "vgicp::iterate_kernel",
                 "rounds_per_launch": rounds_per_launch,
                 "bytes_per_launch": bytes_per_launch,
@@ -228,7 +234,7 @@ def main():
             out["parity"] = {"identical_counts": same_counts, "pose_delta_m": dt}
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
