@@ -25,6 +25,7 @@ UNIQUE_ID_BYTES = 128
 EXPORTS = (
     "vgicp_abi_version", "vgicp_create", "vgicp_destroy", "vgicp_last_error", "vgicp_device_info",
     "vgicp_map_reset", "vgicp_map_upsert", "vgicp_map_erase", "vgicp_map_size",
+    "vgicp_map_insert_scan", "vgicp_map_evict", "vgicp_map_export",
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
     "vgicp_accumulate", "vgicp_match", "vgicp_voxel_index",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
@@ -76,6 +77,9 @@ def load_library() -> C.CDLL:
     lib.vgicp_map_upsert.argtypes = [vp, sz, ip, dp, dp]
     lib.vgicp_map_erase.argtypes = [vp, sz, ip]
     lib.vgicp_map_size.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    lib.vgicp_map_insert_scan.argtypes = [vp, sz, dp, dp, dp, sz, C.POINTER(sz)]
+    lib.vgicp_map_evict.argtypes = [vp, dp, C.c_double, C.POINTER(sz)]
+    lib.vgicp_map_export.argtypes = [vp, sz, ip, dp, dp, C.POINTER(C.c_uint64), C.POINTER(sz)]
     lib.vgicp_align.argtypes = [vp, sz, dp, dp, dp, C.POINTER(Params), dp, C.POINTER(Stats)]
     lib.vgicp_scan_upload.argtypes = [vp, sz, dp, dp]
     lib.vgicp_align_resident.argtypes = [vp, dp, C.POINTER(Params), dp, C.POINTER(Stats)]
@@ -212,6 +216,36 @@ class Context:
         v, s = C.c_size_t(), C.c_size_t()
         self._check(self._lib.vgicp_map_size(self._h, C.byref(v), C.byref(s)))
         return v.value, s.value
+
+    def map_insert_scan(self, points, covs, transform, max_points_per_voxel: int) -> int:
+        """LocalMap::updateLocalMap's insertion loop on the device; returns the number of new voxels."""
+        points, covs = _f64(points, 3), _f64(covs, 9)
+        if points.shape[0] != covs.shape[0]:
+            raise ValueError("points / covs disagree in length")
+        T = pose_to_abi(transform)
+        new = C.c_size_t()
+        self._check(self._lib.vgicp_map_insert_scan(self._h, points.shape[0], _dp(points), _dp(covs), _dp(T),
+                                                    int(max_points_per_voxel), C.byref(new)))
+        return new.value
+
+    def map_evict(self, position, distance_threshold: float) -> int:
+        pos = np.ascontiguousarray(position, dtype=np.float64).reshape(3)
+        removed = C.c_size_t()
+        self._check(self._lib.vgicp_map_evict(self._h, _dp(pos), float(distance_threshold), C.byref(removed)))
+        return removed.value
+
+    def map_export(self):
+        """(keys, means, covs, counts) of every voxel in the mirror, sorted by key."""
+        n = self.map_size()[0]
+        keys = np.zeros((n, 3), dtype=np.int32)
+        means, covs = np.zeros((n, 3)), np.zeros((n, 9))
+        counts = np.zeros(n, dtype=np.uint64)
+        w = C.c_size_t()
+        self._check(self._lib.vgicp_map_export(self._h, n, keys.ctypes.data_as(C.POINTER(C.c_int32)), _dp(means),
+                                               _dp(covs), counts.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(w)))
+        assert w.value == n
+        order = np.lexsort(keys.T)
+        return keys[order], means[order], covs[order], counts[order]
 
     # -- registration --
     def scan_upload(self, points, covs):

@@ -702,6 +702,89 @@ int vgicp_map_size(const vgicp_ctx* ctx, size_t* voxels, size_t* table_slots) {
   return VGICP_OK;
 }
 
+int vgicp_map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
+                          const double transform[16], size_t max_points_per_voxel, size_t* new_voxels) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (new_voxels) *new_voxels = 0;
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (n == 0) return VGICP_OK;
+  if (!points || !covs || !transform) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
+  if (max_points_per_voxel == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "max_points_per_voxel must be >= 1");
+  if (n > 0x7FFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_table(ctx, n);  // every point may open a voxel
+  if (rc != VGICP_OK) return rc;
+  const size_t pb = ((n * 3 * sizeof(double)) + 255) & ~size_t(255);
+  const size_t cb = ((n * 9 * sizeof(double)) + 255) & ~size_t(255);
+  const size_t sb = map_insert_scratch_bytes((uint32_t)n);
+  rc = ensure_stage(ctx, pb + cb + sb);
+  if (rc != VGICP_OK) return rc;
+  char* base = static_cast<char*>(ctx->d_stage);
+  double pose12[12];
+  pose_to_state(transform, pose12);
+  VG_HIP(ctx, hipMemcpyAsync(base, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(base + pb, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size,
+                                reinterpret_cast<const double*>(base), reinterpret_cast<const double*>(base + pb),
+                                (uint32_t)n, pose12, (uint64_t)max_points_per_voxel, base + pb + cb, sb,
+                                ctx->d_counters));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->voxels += ctx->h_counters[0];
+  if (new_voxels) *new_voxels = ctx->h_counters[0];
+  if (ctx->h_counters[1] != 0) return fail(ctx, VGICP_ERR_TABLE_FULL, "voxel table probe sequence exhausted");
+  return VGICP_OK;
+}
+
+int vgicp_map_evict(vgicp_ctx* ctx, const double position[3], double distance_threshold, size_t* removed) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (removed) *removed = 0;
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (!position) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, launch_map_evict(ctx->stream, ctx->table, ctx->slots, ctx->voxel_size, position,
+                               distance_threshold, ctx->d_counters));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->voxels -= ctx->h_counters[0];
+  ctx->tombstones += ctx->h_counters[0];
+  if (removed) *removed = ctx->h_counters[0];
+  return VGICP_OK;
+}
+
+int vgicp_map_export(vgicp_ctx* ctx, size_t capacity, int32_t* keys, double* means, double* covs,
+                     uint64_t* counts, size_t* written) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!written) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "written is NULL");
+  *written = 0;
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (capacity == 0 || ctx->voxels == 0) return VGICP_OK;
+  if (!keys || !means || !covs || !counts) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL array pointer");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t cap = std::min<size_t>(capacity, ctx->voxels);
+  const size_t kb = (cap * 3 * sizeof(int32_t) + 255) & ~size_t(255);
+  const size_t mb = (cap * 3 * sizeof(double) + 255) & ~size_t(255);
+  const size_t cb = (cap * 9 * sizeof(double) + 255) & ~size_t(255);
+  const size_t nb = cap * sizeof(uint64_t);
+  int rc = ensure_stage(ctx, kb + mb + cb + nb);
+  if (rc != VGICP_OK) return rc;
+  char* b = static_cast<char*>(ctx->d_stage);
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, launch_map_export(ctx->stream, ctx->table, ctx->slots, (uint32_t)cap,
+                                reinterpret_cast<int32_t*>(b), reinterpret_cast<double*>(b + kb),
+                                reinterpret_cast<double*>(b + kb + mb), reinterpret_cast<uint64_t*>(b + kb + mb + cb),
+                                ctx->d_counters));
+  VG_HIP(ctx, hipMemcpyAsync(keys, b, cap * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(means, b + kb, cap * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(covs, b + kb + mb, cap * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(counts, b + kb + mb + cb, cap * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *written = cap;
+  return VGICP_OK;
+}
+
 int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const double* covs) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (n > 0 && (!points || !covs)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");

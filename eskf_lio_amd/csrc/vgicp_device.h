@@ -34,7 +34,8 @@ struct alignas(128) VoxelRecord {
   int32_t state;
   double mean[3];
   double cov[9];  // column-major
-  double pad[2];
+  uint64_t count;     // numPoints of the reference's Voxel (device-side insertion freezes it at the cap)
+  uint64_t reserved;
 };
 static_assert(sizeof(VoxelRecord) == 128, "one voxel = one 128-byte line");
 
@@ -126,5 +127,22 @@ hipError_t launch_match(hipStream_t s, const double* points_aos, const double* c
                         uint32_t* block_counts, uint32_t* total, double* src_points,
                         double* src_covs, double* map_points, double* map_covs, uint64_t* src_index);
 uint32_t match_blocks(uint32_t n);
+
+// ---- vgicp_mapupdate.hip: LocalMap::updateLocalMap's insert / evict loops on the device ----
+// Scratch the insertion needs for n points (bytes), and the insertion itself: transform, find-or-claim
+// the voxel of every point, order the points of a voxel by scan index, apply the reference's
+// constructor / addPoint rule sequentially per voxel. counters[0] receives the number of new voxels.
+size_t map_insert_scratch_bytes(uint32_t n);
+hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, double voxel_size,
+                             const double* points_aos, const double* covs_aos, uint32_t n,
+                             const double pose12[12], uint64_t max_points, void* scratch,
+                             size_t scratch_bytes, uint32_t* counters);
+// Erase every voxel whose centre is farther than `distance` from `position`; counters[0] += erased.
+hipError_t launch_map_evict(hipStream_t s, VoxelRecord* table, uint64_t slots, double voxel_size,
+                            const double position[3], double distance, uint32_t* counters);
+// Append every FULL record to the output arrays (unordered); counters[0] = records written.
+hipError_t launch_map_export(hipStream_t s, const VoxelRecord* table, uint64_t slots, uint32_t capacity,
+                             int32_t* keys, double* means, double* covs, uint64_t* counts,
+                             uint32_t* counters);
 
 }  // namespace vgicp

@@ -23,48 +23,10 @@
 //     the kernel boundary is the only grid-wide synchronisation and no workgroup runs a serial tail
 //     alone (the first version's ticket + write-through + last-workgroup tail cost 13 us per round).
 #include "vgicp_device.h"
+#include "vgicp_device_fn.h"
 
 namespace vgicp {
 namespace {
-
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  return h;
-}
-__device__ __forceinline__ uint32_t voxel_hash(int32_t x, int32_t y, int32_t z) {
-  uint32_t h = fmix32((uint32_t)x * 0x9E3779B1u + 0x7F4A7C15u);
-  h = fmix32(h ^ ((uint32_t)y * 0x85EBCA77u));
-  h = fmix32(h ^ ((uint32_t)z * 0xC2B2AE3Du));
-  return h;
-}
-
-// LocalMap::getVoxelIndex: IEEE division, floor, double -> int32.
-__device__ __forceinline__ int32_t voxel_coord(double x, double voxel_size) {
-  return (int32_t)floor(x / voxel_size);
-}
-
-// q = R p + t evaluated as Open3D's homogeneous product does (left to right, no FMA contraction),
-// so the first round reproduces the CPU path's voxel keys bit for bit.
-__device__ __forceinline__ void transform_point(const double* R, const double* t, double x, double y,
-                                                double z, double* q) {
-#pragma clang fp contract(off)
-  q[0] = ((R[0] * x + R[3] * y) + R[6] * z) + t[0];
-  q[1] = ((R[1] * x + R[4] * y) + R[7] * z) + t[1];
-  q[2] = ((R[2] * x + R[5] * y) + R[8] * z) + t[2];
-}
-
-// Probe for the voxel that contains the key. Returns the record or nullptr.
-__device__ __forceinline__ const VoxelRecord* find_voxel(const VoxelRecord* table, uint32_t mask,
-                                                         int32_t kx, int32_t ky, int32_t kz) {
-  uint32_t slot = voxel_hash(kx, ky, kz) & mask;
-  for (;;) {
-    const VoxelRecord* rec = table + slot;
-    const int4 ks = *reinterpret_cast<const int4*>(rec);
-    if (ks.w == SLOT_EMPTY) return nullptr;
-    if (ks.w == SLOT_FULL && ks.x == kx && ks.y == ky && ks.z == kz) return rec;
-    slot = (slot + 1) & mask;
-  }
-}
 
 // Lookup + payload: probe the key word(s), then fetch the 96-byte payload of the matching record as
 // six 16-byte loads (same 128-byte line as the key, so they are L1/L2 hits).  Requesting key and
@@ -904,7 +866,7 @@ __global__ void table_clear_kernel(VoxelRecord* table, uint64_t slots) {
 // different key and is skipped; tombstones are never reused (rehash reclaims them).
 __device__ __forceinline__ bool insert_voxel(VoxelRecord* table, uint32_t mask, int32_t kx,
                                              int32_t ky, int32_t kz, const double* mean,
-                                             const double* cov, uint32_t* counters) {
+                                             const double* cov, uint64_t count, uint32_t* counters) {
   uint32_t slot = voxel_hash(kx, ky, kz) & mask;
   for (uint32_t probes = 0; probes <= mask; ++probes) {
     VoxelRecord* rec = table + slot;
@@ -916,6 +878,8 @@ __device__ __forceinline__ bool insert_voxel(VoxelRecord* table, uint32_t mask, 
         rec->key[0] = kx; rec->key[1] = ky; rec->key[2] = kz;
         for (int k = 0; k < 3; ++k) rec->mean[k] = mean[k];
         for (int k = 0; k < 9; ++k) rec->cov[k] = cov[k];
+        rec->count = count;
+        rec->reserved = 0;
         __hip_atomic_store(&rec->state, SLOT_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         atomicAdd(&counters[0], 1u);
         return true;
@@ -941,8 +905,9 @@ __global__ void upsert_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
   double mean[3], cov[9];
   for (int k = 0; k < 3; ++k) mean[k] = means[3 * (size_t)i + k];
   for (int k = 0; k < 9; ++k) cov[k] = covs[9 * (size_t)i + k];
+  // numPoints of a voxel mirrored from the host is not part of the batch: a new record starts at 1
   insert_voxel(table, mask, keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2],
-               mean, cov, counters);
+               mean, cov, 1, counters);
 }
 
 __global__ void rehash_kernel(const VoxelRecord* __restrict__ old_table, uint64_t old_slots,
@@ -954,7 +919,7 @@ __global__ void rehash_kernel(const VoxelRecord* __restrict__ old_table, uint64_
   double mean[3], cov[9];
   for (int k = 0; k < 3; ++k) mean[k] = rec->mean[k];
   for (int k = 0; k < 9; ++k) cov[k] = rec->cov[k];
-  insert_voxel(table, mask, rec->key[0], rec->key[1], rec->key[2], mean, cov, counters);
+  insert_voxel(table, mask, rec->key[0], rec->key[1], rec->key[2], mean, cov, rec->count, counters);
 }
 
 __global__ void erase_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,

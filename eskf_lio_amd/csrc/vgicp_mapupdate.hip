@@ -1,0 +1,273 @@
+// vgicp_mapupdate.hip — LocalMap::updateLocalMap's insert and evict loops on the device
+// (reference src/LocalMap.cpp:44-72, include/ESKF_LIO/LocalMap.hpp:63-89).
+//
+// The reference inserts serially: for every point in scan order, find its voxel; a missing voxel is
+// constructed from the point (mean = p, covariance = C, numPoints = 1), an existing one takes
+// Voxel::addPoint — mean <- (n*mean + p)/(n+1), covariance likewise, while numPoints < maxNumPoints.
+// The result depends on the ORDER of the points inside a voxel, so the device version keeps it:
+//   1. prepare   one thread per point: transform point and covariance exactly as Open3D does (no FMA
+//                contraction, same evaluation order), voxel key, find-or-CLAIM the voxel's slot
+//                (claims race through a CAS; same-key racers spin on the LOCKED word until the winner,
+//                which finishes its critical section inside the same loop iteration, publishes FULL)
+//   2. sort      stable radix sort of (slot, point index) by slot (hipCUB): the points of one voxel
+//                become one segment, still in scan order
+//   3. apply     the thread at the head of a segment walks it and applies the constructor / addPoint
+//                arithmetic of the reference sequentially, in registers, one record write at the end
+// Arithmetic is bit-exact with the CPU path (tests compare means, covariances and counts with `==`).
+#include <hipcub/hipcub.hpp>
+
+#include "vgicp_device.h"
+#include "vgicp_device_fn.h"
+
+namespace vgicp {
+namespace {
+
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+
+// C <- R C R^T evaluated as Eigen evaluates (R * C) * R^T: left to right, every product and sum
+// rounded once.
+__device__ __forceinline__ void rotate_cov_exact(const double* R, const double* C, double* out) {
+#pragma clang fp contract(off)
+  double RC[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      RC[r + 3 * c] = (R[r] * C[3 * c] + R[r + 3] * C[1 + 3 * c]) + R[r + 6] * C[2 + 3 * c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      out[r + 3 * c] = (RC[r] * R[c] + RC[r + 3] * R[c + 3]) + RC[r + 6] * R[c + 6];
+}
+
+struct InsertScratch {
+  double* wpts;        // n x 3 world points
+  double* wcovs;       // n x 9 world covariances
+  uint32_t* slot_in;   // n
+  uint32_t* slot_out;  // n (sorted)
+  uint32_t* idx_in;    // n
+  uint32_t* idx_out;   // n (sorted)
+  void* cub;           // radix sort temp storage
+  size_t cub_bytes;
+};
+
+__host__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+__host__ inline size_t sort_temp_bytes(uint32_t n) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const uint32_t*>(nullptr),
+                                           static_cast<uint32_t*>(nullptr),
+                                           static_cast<const uint32_t*>(nullptr),
+                                           static_cast<uint32_t*>(nullptr), (int)n);
+  return bytes;
+}
+
+__host__ inline InsertScratch carve(void* base, uint32_t n, size_t cub_bytes) {
+  char* p = static_cast<char*>(base);
+  InsertScratch s;
+  s.wpts = reinterpret_cast<double*>(p); p += align256((size_t)n * 3 * sizeof(double));
+  s.wcovs = reinterpret_cast<double*>(p); p += align256((size_t)n * 9 * sizeof(double));
+  s.slot_in = reinterpret_cast<uint32_t*>(p); p += align256((size_t)n * sizeof(uint32_t));
+  s.slot_out = reinterpret_cast<uint32_t*>(p); p += align256((size_t)n * sizeof(uint32_t));
+  s.idx_in = reinterpret_cast<uint32_t*>(p); p += align256((size_t)n * sizeof(uint32_t));
+  s.idx_out = reinterpret_cast<uint32_t*>(p); p += align256((size_t)n * sizeof(uint32_t));
+  s.cub = p;
+  s.cub_bytes = cub_bytes;
+  return s;
+}
+
+struct Pose12 {
+  double v[12];
+};
+
+__global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double voxel_size,
+                                      const double* __restrict__ pts, const double* __restrict__ covs,
+                                      uint32_t n, Pose12 pose, double* __restrict__ wpts,
+                                      double* __restrict__ wcovs, uint32_t* __restrict__ slot_of,
+                                      uint32_t* __restrict__ idx_of, uint32_t* counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double p[3], C[9], W[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) C[k] = covs[9 * (size_t)i + k];
+  transform_point(pose.v, pose.v + 9, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], p);
+  rotate_cov_exact(pose.v, C, W);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wpts[3 * (size_t)i + k] = p[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wcovs[9 * (size_t)i + k] = W[k];
+  const int32_t kx = voxel_coord(p[0], voxel_size);
+  const int32_t ky = voxel_coord(p[1], voxel_size);
+  const int32_t kz = voxel_coord(p[2], voxel_size);
+
+  uint32_t slot = voxel_hash(kx, ky, kz) & mask;
+  uint32_t found = kNoSlot;
+  // `spins` bounds the waits on LOCKED words so that a bug can only fail the call, never hang the GPU
+  for (uint32_t probes = 0, spins = 0; probes <= mask && spins < (1u << 22); ++spins) {
+    VoxelRecord* rec = table + slot;
+    int32_t state = __hip_atomic_load(&rec->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (state == SLOT_EMPTY) {
+      int32_t expected = SLOT_EMPTY;
+      if (__hip_atomic_compare_exchange_strong(&rec->state, &expected, SLOT_LOCKED, __ATOMIC_RELAXED,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        // new voxel: key now, statistics in the apply pass (count 0 marks "not constructed yet")
+        rec->key[0] = kx; rec->key[1] = ky; rec->key[2] = kz;
+        rec->count = 0;
+        rec->reserved = 0;
+        __hip_atomic_store(&rec->state, SLOT_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&counters[0], 1u);
+        found = slot;
+        break;
+      }
+      continue;  // lost the race: look at the same slot again
+    }
+    if (state == SLOT_LOCKED) continue;  // a claim in flight (perhaps of this very key): wait for it
+    if (state == SLOT_FULL) {
+      // keys are written before FULL is released; read them through the L2 (another CU may own them)
+      const int32_t a = __hip_atomic_load(&rec->key[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int32_t b = __hip_atomic_load(&rec->key[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int32_t c = __hip_atomic_load(&rec->key[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a == kx && b == ky && c == kz) { found = slot; break; }
+    }
+    slot = (slot + 1) & mask;  // other key or tombstone
+    ++probes;
+  }
+  if (found == kNoSlot) atomicAdd(&counters[1], 1u);
+  slot_of[i] = found;
+  idx_of[i] = i;
+}
+
+// Voxel(max, p, C) / Voxel::addPoint applied to the segment that starts at sorted position j.
+__global__ void insert_apply_kernel(VoxelRecord* table, const uint32_t* __restrict__ slot_sorted,
+                                    const uint32_t* __restrict__ idx_sorted, uint32_t n,
+                                    const double* __restrict__ wpts, const double* __restrict__ wcovs,
+                                    uint64_t max_points) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t slot = slot_sorted[j];
+  if (slot == kNoSlot) return;
+  if (j > 0 && slot_sorted[j - 1] == slot) return;  // not the head of its segment
+  VoxelRecord* rec = table + slot;
+  uint64_t count = rec->count;
+  double mean[3], cov[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) mean[k] = rec->mean[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) cov[k] = rec->cov[k];
+  for (uint32_t q = j; q < n && slot_sorted[q] == slot; ++q) {
+    const uint32_t i = idx_sorted[q];
+    if (count == 0) {  // constructor
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mean[k] = wpts[3 * (size_t)i + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cov[k] = wcovs[9 * (size_t)i + k];
+      count = 1;
+    } else if (count < max_points) {  // addPoint
+#pragma clang fp contract(off)
+      const double nn = (double)count, n1 = (double)(count + 1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mean[k] = (nn * mean[k] + wpts[3 * (size_t)i + k]) / n1;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cov[k] = (nn * cov[k] + wcovs[9 * (size_t)i + k]) / n1;
+      ++count;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) rec->mean[k] = mean[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) rec->cov[k] = cov[k];
+  rec->count = count;
+}
+
+// LocalMap::needsPointRemoval (src/LocalMap.cpp:149-154): |(index + 0.5) * voxelSize - position| > d
+__global__ void evict_kernel(VoxelRecord* table, uint64_t slots, double voxel_size, double px,
+                             double py, double pz, double distance, uint32_t* counters) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slots) return;
+  VoxelRecord* rec = table + i;
+  if (rec->state != SLOT_FULL) return;
+  bool far;
+  {
+#pragma clang fp contract(off)
+    const double dx = ((double)rec->key[0] + 0.5) * voxel_size - px;
+    const double dy = ((double)rec->key[1] + 0.5) * voxel_size - py;
+    const double dz = ((double)rec->key[2] + 0.5) * voxel_size - pz;
+    far = sqrt((dx * dx + dy * dy) + dz * dz) > distance;
+  }
+  if (far) {
+    rec->state = SLOT_TOMB;
+    atomicAdd(&counters[0], 1u);
+  }
+}
+
+__global__ void export_kernel(const VoxelRecord* __restrict__ table, uint64_t slots, uint32_t capacity,
+                              int32_t* __restrict__ keys, double* __restrict__ means,
+                              double* __restrict__ covs, uint64_t* __restrict__ counts,
+                              uint32_t* counters) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slots) return;
+  const VoxelRecord* rec = table + i;
+  if (rec->state != SLOT_FULL) return;
+  const uint32_t pos = atomicAdd(&counters[0], 1u);
+  if (pos >= capacity) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    keys[3 * (size_t)pos + k] = rec->key[k];
+    means[3 * (size_t)pos + k] = rec->mean[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) covs[9 * (size_t)pos + k] = rec->cov[k];
+  counts[pos] = rec->count;
+}
+
+inline uint32_t blocks_for(uint64_t work, uint32_t block) { return (uint32_t)((work + block - 1) / block); }
+
+}  // namespace
+
+size_t map_insert_scratch_bytes(uint32_t n) {
+  const uint32_t m = n ? n : 1;
+  return align256((size_t)m * 3 * sizeof(double)) + align256((size_t)m * 9 * sizeof(double)) +
+         4 * align256((size_t)m * sizeof(uint32_t)) + align256(sort_temp_bytes(m)) + 256;
+}
+
+hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, double voxel_size,
+                             const double* points_aos, const double* covs_aos, uint32_t n,
+                             const double pose12[12], uint64_t max_points, void* scratch,
+                             size_t scratch_bytes, uint32_t* counters) {
+  if (n == 0) return hipSuccess;
+  if (scratch_bytes < map_insert_scratch_bytes(n)) return hipErrorInvalidValue;
+  size_t cub_bytes = sort_temp_bytes(n);
+  InsertScratch w = carve(scratch, n, cub_bytes);
+  Pose12 pose;
+  for (int k = 0; k < 12; ++k) pose.v[k] = pose12[k];
+  hipLaunchKernelGGL(insert_prepare_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask,
+                     voxel_size, points_aos, covs_aos, n, pose, w.wpts, w.wcovs, w.slot_in, w.idx_in,
+                     counters);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // stable: equal slots keep ascending point index = scan order
+  e = hipcub::DeviceRadixSort::SortPairs(w.cub, cub_bytes, w.slot_in, w.slot_out, w.idx_in, w.idx_out,
+                                         (int)n, 0, 32, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(insert_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, w.slot_out,
+                     w.idx_out, n, w.wpts, w.wcovs, max_points);
+  return hipGetLastError();
+}
+
+hipError_t launch_map_evict(hipStream_t s, VoxelRecord* table, uint64_t slots, double voxel_size,
+                            const double position[3], double distance, uint32_t* counters) {
+  hipLaunchKernelGGL(evict_kernel, dim3(blocks_for(slots, 256)), dim3(256), 0, s, table, slots,
+                     voxel_size, position[0], position[1], position[2], distance, counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_map_export(hipStream_t s, const VoxelRecord* table, uint64_t slots, uint32_t capacity,
+                             int32_t* keys, double* means, double* covs, uint64_t* counts,
+                             uint32_t* counters) {
+  hipLaunchKernelGGL(export_kernel, dim3(blocks_for(slots, 256)), dim3(256), 0, s, table, slots,
+                     capacity, keys, means, covs, counts, counters);
+  return hipGetLastError();
+}
+
+}  // namespace vgicp

@@ -102,6 +102,25 @@ int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double
 int vgicp_map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys);
 int vgicp_map_size(const vgicp_ctx* ctx, size_t* voxels, size_t* table_slots);
 
+/* ---- device-side map maintenance -------------------------------------------
+ * The insertion loop of LocalMap::updateLocalMap on the device (src/LocalMap.cpp:15,44-58 with
+ * Voxel's constructor and Voxel::addPoint, include/ESKF_LIO/LocalMap.hpp:72-87): the n points (scan
+ * frame) are moved by `transform` exactly as cloud->Transform() does, then inserted IN SCAN ORDER —
+ * a missing voxel is constructed from the point, an existing one takes the running-mean update while
+ * it holds fewer than max_points_per_voxel points.  Means, covariances and counts come out bit for
+ * bit as the reference's serial loop leaves them.  Do not mix with vgicp_map_upsert on one voxel
+ * (an upserted voxel starts at count 1).  new_voxels (optional) receives the number of voxels created. */
+int vgicp_map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
+                          const double transform[16], size_t max_points_per_voxel, size_t* new_voxels);
+/* The eviction loop (src/LocalMap.cpp:60-72, needsPointRemoval :149-154): erase every voxel whose
+ * centre (index + 0.5) * voxel_size is farther than distance_threshold from position. */
+int vgicp_map_evict(vgicp_ctx* ctx, const double position[3], double distance_threshold,
+                    size_t* removed);
+/* Read the mirror back (order unspecified): keys n x 3, means n x 3, covs n x 9, counts n.
+ * `written` receives min(voxels, capacity). For tests and for LocalMap::save(). */
+int vgicp_map_export(vgicp_ctx* ctx, size_t capacity, int32_t* keys, double* means, double* covs,
+                     uint64_t* counts, size_t* written);
+
 /* ---- registration ---------------------------------------------------------------------------
  * vgicp_align replaces ICP::align(cloud, localMap, guess) (src/Registration.cpp:7-35; declared
  * include/ESKF_LIO/Registration.hpp:30-32) including the hot loop it drives:

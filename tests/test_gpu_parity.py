@@ -365,6 +365,93 @@ def test_host_mirror_motion_gate_and_eviction(oracle, tmp_path):
     assert "POINTS" in open(tmp_path / "map.pcd").read() and "extrinsic" in open(tmp_path / "traj.json").read()
 
 
+# ---- LocalMap::updateLocalMap's insert / evict loops on the device ---------------
+def _sorted_oracle_export(om):
+    k, m, c, n = om.export()
+    order = np.lexsort(k.T)
+    return k[order], m[order], c[order], n[order]
+
+
+@pytest.mark.parametrize("cap", [1, 3, 1000])
+def test_device_map_insertion_is_bit_exact(gpu_ctx, c1_inputs, oracle, cap):
+    """Several scans, several points per voxel, moved by different poses: the device insertion leaves
+    the same voxels, means, covariances and counts as the reference's serial loop — compared with ==."""
+    from eskf_lio_amd import synth
+    vmap, pts, covs = c1_inputs
+    rng = np.random.default_rng(100 + cap)
+    poses = [np.eye(4), synth.se3_to_SE3([0.2, 0.1, 0.0, 0.0, 0.0, 0.02]), synth.se3_to_SE3([0.4, -0.2, 0.1, 0.01, 0.0, 0.04]),
+             synth.se3_to_SE3([-0.3, 0.2, 0.0, 0.0, -0.02, 0.1])]
+    gpu_ctx.map_reset(0.3, 0)                                      # growth + rehash on the way (keeps counts)
+    om = oracle.OracleMap(0.3, cap)
+    total_new = 0
+    for T in poses:
+        sel = rng.choice(50_000, 12_000, replace=True)             # repeats: many points per voxel
+        p = vmap.means[sel] + rng.normal(scale=0.05, size=(12_000, 3))
+        c = covs[rng.choice(5_000, 12_000)]
+        before = gpu_ctx.map_size()[0]
+        new = gpu_ctx.map_insert_scan(p, c, T, cap)
+        total_new += new
+        assert gpu_ctx.map_size()[0] == before + new
+        wp, wc = oracle.transform(p, c, T)                         # cloud->Transform(T), then the loop
+        om.insert(wp, wc)
+        assert gpu_ctx.map_size()[0] == len(om)
+    gk, gm, gc, gn = gpu_ctx.map_export()
+    ok, om_, oc, on = _sorted_oracle_export(om)
+    assert total_new == len(om) and np.array_equal(gk, ok)
+    assert np.array_equal(gn, on) and on.max() == min(cap, on.max()) and (cap == 1 or on.max() > 1)
+    assert np.array_equal(gm, om_) and np.array_equal(gc, oc)      # bit for bit
+    # the registration reads the device-built map like a host-built one
+    g = synth.default_guess()
+    got = gpu_ctx.align(pts, covs, g, 10, 1e-6, 2.0)
+    ref = om.align(pts, covs, g, 10, 1e-6, 2.0)
+    assert_align_parity(got, ref)
+
+
+def test_device_map_insert_edge_cases(gpu_ctx, oracle):
+    gpu_ctx.map_reset(0.3, 0)
+    assert gpu_ctx.map_insert_scan(np.zeros((0, 3)), np.zeros((0, 9)), np.eye(4), 5) == 0
+    # every point in ONE voxel (longest possible segment, all claims race for one slot)
+    rng = np.random.default_rng(4)
+    p = 0.15 + 0.1 * rng.random((5_000, 3))
+    c = np.tile(np.eye(3).reshape(1, 9), (5_000, 1)) * rng.random((5_000, 1))
+    om = oracle.OracleMap(0.3, 1000)
+    om.insert(p, c)
+    assert gpu_ctx.map_insert_scan(p, c, np.eye(4), 1000) == 1
+    gk, gm, gc, gn = gpu_ctx.map_export()
+    ok, om_, oc, on = _sorted_oracle_export(om)
+    assert gn[0] == on[0] == 1000 and np.array_equal(gk, ok)
+    assert np.array_equal(gm, om_) and np.array_equal(gc, oc)
+    # all points in distinct voxels, negative coordinates and exact cell faces included
+    grid = np.stack(np.meshgrid(np.arange(-20, 20), np.arange(-20, 20), np.arange(-2, 2), indexing="ij"), -1).reshape(-1, 3)
+    p = grid * 0.3                                                  # on the faces
+    c = np.tile(np.eye(3).reshape(1, 9), (len(p), 1))
+    gpu_ctx.map_reset(0.3, 0)
+    om = oracle.OracleMap(0.3, 20)
+    om.insert(p, c)
+    assert gpu_ctx.map_insert_scan(p, c, np.eye(4), 20) == len(om)
+    assert np.array_equal(gpu_ctx.map_export()[0], _sorted_oracle_export(om)[0])
+
+
+def test_device_map_eviction_matches_the_reference_rule(gpu_ctx, c1_inputs):
+    vmap, _, _ = c1_inputs
+    gpu_ctx.map_reset(vmap.voxel_size, 0)
+    gpu_ctx.map_insert_scan(vmap.means, vmap.covs, np.eye(4), 10)
+    pos = np.array([1.3, -0.7, 0.4])
+    centre = (vmap.keys.astype(np.float64) + 0.5) * vmap.voxel_size
+    d = np.sqrt(((centre - pos) ** 2).sum(axis=1))
+    for thr in (6.0, 3.0):
+        far = d > thr
+        expect_removed = int(far.sum()) - (50_000 - gpu_ctx.map_size()[0])
+        assert gpu_ctx.map_evict(pos, thr) == expect_removed
+        keys = gpu_ctx.map_export()[0]
+        want = vmap.keys[~far]
+        assert np.array_equal(keys, want[np.lexsort(want.T)])
+    # evicted voxels can come back (tombstones are skipped, not reused, until the next rehash)
+    back = gpu_ctx.map_insert_scan(vmap.means, vmap.covs, np.eye(4), 10)
+    assert back == int((d > 3.0).sum()) and gpu_ctx.map_size()[0] == 50_000
+    assert np.array_equal(gpu_ctx.map_export()[0], vmap.keys[np.lexsort(vmap.keys.T)])
+
+
 # ---- multi-GPU code path on one device: RCCL communicator of size 1 ---------------------------
 def test_rccl_path_world_size_one(c1_gpu, c1_inputs):
     from eskf_lio_amd import synth
