@@ -34,7 +34,7 @@ def load_library() -> C.CDLL:
     lib.host_last_error.restype = C.c_char_p
     lib.host_localmap_create_config.restype = vp
     lib.host_localmap_create_config.argtypes = [C.c_double, sz, C.c_double, C.c_double, C.c_int, C.c_double,
-                                                C.c_double]
+                                                C.c_double, C.c_int]
     lib.host_localmap_create.restype = vp
     lib.host_localmap_create.argtypes = [C.c_double, sz]
     lib.host_localmap_destroy.argtypes = [vp]
@@ -74,7 +74,8 @@ class LocalMap:
             self._h = self._lib.host_localmap_create_config(
                 float(voxelSize), int(maxNumPointsPerVoxel), float(config["translation_sq_threshold"]),
                 float(config["cosine_threshold"]), int(bool(config["remove_distant_points"])),
-                float(config["distance_threshold"]), float(config["removing_period"]))
+                float(config["distance_threshold"]), float(config["removing_period"]),
+                int(bool(config.get("device_resident", False))))
         if not self._h:
             raise RuntimeError(self._lib.host_last_error().decode())
 

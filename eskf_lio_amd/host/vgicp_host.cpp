@@ -53,7 +53,7 @@ const char * host_last_error(void) {return g_error.c_str();}
 LocalMap * host_localmap_create_config(
   double voxel_size, size_t max_points_per_voxel, double translation_sq_threshold,
   double cosine_threshold, int remove_distant_points, double distance_threshold,
-  double remove_period)
+  double remove_period, int device_resident)
 {
   LocalMap * out = nullptr;
   guarded(
@@ -66,6 +66,7 @@ LocalMap * host_localmap_create_config(
       c.removeDistantPoints = remove_distant_points != 0;
       c.distanceThreshold = distance_threshold;
       c.removePeriod = remove_period;
+      c.deviceResident = device_resident != 0;
       out = new LocalMap(c);
     });
   return out;
@@ -124,6 +125,10 @@ size_t host_localmap_export(
   uint64_t * counts)
 {
   size_t w = 0;
+  if (map->deviceResident()) {
+    if (vgicp_map_export(map->context(), capacity, keys, means, covs, counts, &w) != VGICP_OK) {return 0;}
+    return w;
+  }
   for (const auto & kv : map->grid()) {
     if (w == capacity) {break;}
     keys[3 * w] = kv.first.i;

@@ -54,6 +54,12 @@ struct LocalMapConfig
   bool removeDistantPoints = true;
   double distanceThreshold = 100.0;
   double removePeriod = 10.0;
+  // false: the host std::unordered_map is authoritative and the device mirror is fed batches (keeps
+  //        every raw point for save(), as the reference does).
+  // true:  the voxel grid lives on the device only — insertion and eviction run there
+  //        (vgicp_map_insert_scan / vgicp_map_evict, same arithmetic, same results); save() then writes
+  //        one point per voxel (its mean) because the raw points are not kept.
+  bool deviceResident = false;
 };
 
 namespace shim
@@ -155,6 +161,7 @@ public:
     , removeDistantPoints_(config.removeDistantPoints)
     , distanceThreshold_(config.distanceThreshold)
     , removePeriod_(config.removePeriod)
+    , deviceResident_(config.deviceResident)
     , visualize_(visualize)
     , ctx_(ctx ? ctx : shim::defaultContext())
   {
@@ -214,6 +221,27 @@ public:
 
     const auto & points = cloud->points_;
     const auto & covariances = cloud->covariances_;
+    if (deviceResident_) {
+      // the cloud is already in the world frame (transformed in place above, as the reference does)
+      const Isometry3d identity = Isometry3d::Identity();
+      if (!points.empty()) {
+        shim::check(
+          ctx_, vgicp_map_insert_scan(
+            ctx_, points.size(), points.data()->data(), covariances.data()->data(),
+            shim::poseData(identity), maxNumPointsPerVoxel_, nullptr), "vgicp_map_insert_scan");
+      }
+      if (removeDistantPoints_ && now() - currentRemoveTime_ > removePeriod_) {
+        const Vector3d position = transform.translation();
+        const double pos[3] = {position(0), position(1), position(2)};
+        size_t numRemovedVoxels = 0;
+        shim::check(ctx_, vgicp_map_evict(ctx_, pos, distanceThreshold_, &numRemovedVoxels), "vgicp_map_evict");
+        currentRemoveTime_ = now();
+        std::cout << "removed " << numRemovedVoxels << " voxels\n";
+      }
+      prevTransform_ = transform;
+      hasPrevTransform_ = true;
+      return;
+    }
     std::vector<Voxel *> touched;
     std::vector<Key> touchedKeys;
     for (size_t i = 0; i < points.size(); ++i) {
@@ -294,7 +322,23 @@ public:
   // JSON array of column-major "extrinsic" arrays (the field Open3D's trajectory reader uses).
   void save(const std::string & cloud_path, const std::string & trajectory_path) const
   {
-    size_t total = 0;
+    std::vector<double> deviceMeans;
+    if (deviceResident_) {
+      const size_t n = size();
+      std::vector<int32_t> keys(3 * n);
+      std::vector<double> covs(9 * n);
+      std::vector<uint64_t> counts(n);
+      deviceMeans.resize(3 * n);
+      size_t written = 0;
+      if (n) {
+        shim::check(
+          ctx_, vgicp_map_export(
+            ctx_, n, keys.data(), deviceMeans.data(), covs.data(), counts.data(),
+            &written), "vgicp_map_export");
+      }
+      deviceMeans.resize(3 * written);
+    }
+    size_t total = deviceMeans.size() / 3;
     for (const auto & kv : voxelGrid_) {total += kv.second.points.size();}
     std::ofstream pcd(cloud_path);
     pcd << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 8 8 8\n"
@@ -303,6 +347,9 @@ public:
     pcd.precision(17);
     for (const auto & kv : voxelGrid_) {
       for (const auto & p : kv.second.points) {pcd << p(0) << ' ' << p(1) << ' ' << p(2) << '\n';}
+    }
+    for (size_t v = 0; v + 2 < deviceMeans.size(); v += 3) {
+      pcd << deviceMeans[v] << ' ' << deviceMeans[v + 1] << ' ' << deviceMeans[v + 2] << '\n';
     }
     std::ofstream traj(trajectory_path);
     traj.precision(17);
@@ -317,7 +364,14 @@ public:
   }
 
   // ---- additions (not in the reference) ----
-  size_t size() const {return voxelGrid_.size();}
+  size_t size() const
+  {
+    if (!deviceResident_) {return voxelGrid_.size();}
+    size_t voxels = 0;
+    shim::check(ctx_, vgicp_map_size(ctx_, &voxels, nullptr), "vgicp_map_size");
+    return voxels;
+  }
+  bool deviceResident() const {return deviceResident_;}
   double voxelSize() const {return voxelSize_;}
   vgicp_ctx * context() const {return ctx_;}
   const VoxelGrid & grid() const {return voxelGrid_;}
@@ -397,6 +451,7 @@ private:
   bool removeDistantPoints_;
   double distanceThreshold_;
   double removePeriod_;
+  bool deviceResident_ = false;
   double currentRemoveTime_ = std::numeric_limits<double>::lowest();
   Isometry3d prevTransform_ = Isometry3d::Identity();
   bool hasPrevTransform_ = false;

@@ -338,6 +338,39 @@ def test_host_mirror_localmap_and_icp(c1_inputs, oracle):
     assert dt <= TIGHT_POSE_TOL and dr <= TIGHT_POSE_TOL
 
 
+def test_host_mirror_device_resident_map(c1_inputs, oracle, tmp_path):
+    """LocalMapConfig::deviceResident: updateLocalMap inserts and evicts on the device; the voxels it
+    leaves are the reference's, bit for bit, and ICP::align reads them as usual."""
+    from eskf_lio_amd import host, synth
+    vmap, pts, covs = c1_inputs
+    rng = np.random.default_rng(33)
+    cfg = dict(translation_sq_threshold=-1.0, cosine_threshold=2.0, remove_distant_points=False,
+               distance_threshold=1e9, removing_period=1e9, device_resident=True)
+    lmap = host.LocalMap(0.3, 20, cfg)
+    omap = oracle.OracleMap(0.3, 20)
+    for T in (np.eye(4), synth.se3_to_SE3([0.2, 0.1, 0.0, 0.0, 0.0, 0.02]), synth.se3_to_SE3([0.4, 0.2, 0.0, 0.0, 0.0, 0.04])):
+        p = vmap.means[rng.choice(50_000, 8_000)] + rng.normal(scale=0.02, size=(8_000, 3))
+        c = covs[rng.choice(5_000, 8_000)]
+        wp, wc = lmap.updateLocalMap(p, c, T)
+        op, oc = oracle.transform(p, c, T)
+        assert np.array_equal(wp, op) and np.array_equal(wc, oc)
+        omap.insert(op, oc)
+        assert len(lmap) == len(omap)
+    hk, hm, hc, hn = lmap.export()
+    ok, om_, oc_, on = omap.export()
+    oh, oo = np.lexsort(hk.T), np.lexsort(ok.T)
+    assert np.array_equal(hk[oh], ok[oo]) and np.array_equal(hn[oh], on[oo])
+    assert np.array_equal(hm[oh], om_[oo]) and np.array_equal(hc[oh], oc_[oo])
+    icp = host.ICP(20, 1e-6, 2.0)
+    T = icp.align(pts, covs, lmap, synth.default_guess())
+    ref = omap.align(pts, covs, synth.default_guess(), 20, 1e-6, 2.0)
+    assert np.array_equal(icp.correspondence_counts, ref.corr_count)
+    dt, dr = pose_error(T, ref.pose)
+    assert dt <= TIGHT_POSE_TOL and dr <= TIGHT_POSE_TOL
+    lmap.save(str(tmp_path / "m.pcd"), str(tmp_path / "t.json"))
+    assert f"POINTS {len(omap)}" in open(tmp_path / "m.pcd").read()
+
+
 def test_host_mirror_motion_gate_and_eviction(oracle, tmp_path):
     from eskf_lio_amd import host, synth
     cfg = dict(translation_sq_threshold=1e-2, cosine_threshold=0.985, remove_distant_points=True,
