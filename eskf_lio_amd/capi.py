@@ -25,7 +25,7 @@ UNIQUE_ID_BYTES = 128
 EXPORTS = (
     "vgicp_abi_version", "vgicp_create", "vgicp_destroy", "vgicp_last_error", "vgicp_device_info",
     "vgicp_map_reset", "vgicp_map_upsert", "vgicp_map_erase", "vgicp_map_size",
-    "vgicp_map_insert_scan", "vgicp_map_evict", "vgicp_map_export",
+    "vgicp_map_insert_scan", "vgicp_map_insert_resident", "vgicp_map_evict", "vgicp_map_export",
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
     "vgicp_accumulate", "vgicp_match", "vgicp_voxel_index",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     lib.vgicp_map_erase.argtypes = [vp, sz, ip]
     lib.vgicp_map_size.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
     lib.vgicp_map_insert_scan.argtypes = [vp, sz, dp, dp, dp, sz, C.POINTER(sz)]
+    lib.vgicp_map_insert_resident.argtypes = [vp, dp, sz, C.POINTER(sz)]
     lib.vgicp_map_evict.argtypes = [vp, dp, C.c_double, C.POINTER(sz)]
     lib.vgicp_map_export.argtypes = [vp, sz, ip, dp, dp, C.POINTER(C.c_uint64), C.POINTER(sz)]
     lib.vgicp_align.argtypes = [vp, sz, dp, dp, dp, C.POINTER(Params), dp, C.POINTER(Stats)]
@@ -226,6 +227,13 @@ class Context:
         new = C.c_size_t()
         self._check(self._lib.vgicp_map_insert_scan(self._h, points.shape[0], _dp(points), _dp(covs), _dp(T),
                                                     int(max_points_per_voxel), C.byref(new)))
+        return new.value
+
+    def map_insert_resident(self, transform, max_points_per_voxel: int) -> int:
+        """Insert the scan that is already resident (the one the last align registered)."""
+        T = pose_to_abi(transform)
+        new = C.c_size_t()
+        self._check(self._lib.vgicp_map_insert_resident(self._h, _dp(T), int(max_points_per_voxel), C.byref(new)))
         return new.value
 
     def map_evict(self, position, distance_threshold: float) -> int:

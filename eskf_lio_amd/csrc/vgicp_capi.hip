@@ -737,6 +737,37 @@ int vgicp_map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const 
   return VGICP_OK;
 }
 
+int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel,
+                              size_t* new_voxels) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (new_voxels) *new_voxels = 0;
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload first");
+  if (!transform) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
+  if (max_points_per_voxel == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "max_points_per_voxel must be >= 1");
+  if (ctx->comm) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "resident scan is a shard: use vgicp_map_insert_scan with the whole scan");
+  const size_t n = ctx->n;
+  if (n == 0) return VGICP_OK;
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_table(ctx, n);
+  if (rc != VGICP_OK) return rc;
+  const size_t sb = map_insert_scratch_bytes((uint32_t)n);
+  rc = ensure_stage(ctx, sb);
+  if (rc != VGICP_OK) return rc;
+  double pose12[12];
+  pose_to_state(transform, pose12);
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size,
+                                ctx->d_scan_aos, ctx->d_scan_aos + 3 * ctx->scan_capacity, (uint32_t)n, pose12,
+                                (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_counters));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->voxels += ctx->h_counters[0];
+  if (new_voxels) *new_voxels = ctx->h_counters[0];
+  if (ctx->h_counters[1] != 0) return fail(ctx, VGICP_ERR_TABLE_FULL, "voxel table probe sequence exhausted");
+  return VGICP_OK;
+}
+
 int vgicp_map_evict(vgicp_ctx* ctx, const double position[3], double distance_threshold, size_t* removed) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (removed) *removed = 0;

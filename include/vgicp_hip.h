@@ -112,6 +112,12 @@ int vgicp_map_size(const vgicp_ctx* ctx, size_t* voxels, size_t* table_slots);
  * (an upserted voxel starts at count 1).  new_voxels (optional) receives the number of voxels created. */
 int vgicp_map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
                           const double transform[16], size_t max_points_per_voxel, size_t* new_voxels);
+/* The same for the scan that is already resident (vgicp_scan_upload / the last vgicp_align): the
+ * per-frame sequence of src/Odometry.cpp:79,86 — register, then insert with the pose found — without a
+ * second upload.  With a communicator every rank holds only its shard, so use vgicp_map_insert_scan
+ * with the whole scan there (the map is replicated). */
+int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel,
+                              size_t* new_voxels);
 /* The eviction loop (src/LocalMap.cpp:60-72, needsPointRemoval :149-154): erase every voxel whose
  * centre (index + 0.5) * voxel_size is farther than distance_threshold from position. */
 int vgicp_map_evict(vgicp_ctx* ctx, const double position[3], double distance_threshold,

@@ -485,6 +485,48 @@ def test_device_map_eviction_matches_the_reference_rule(gpu_ctx, c1_inputs):
     assert np.array_equal(gpu_ctx.map_export()[0], vmap.keys[np.lexsort(vmap.keys.T)])
 
 
+# ---- BASELINE config C4's stand-in: a synthetic frame stream through register -> insert ----------
+def test_frame_stream_trajectory_matches_the_cpu_loop(gpu_ctx, oracle):
+    """The per-frame sequence of src/Odometry.cpp:79,86 without the filter: align the scan against the
+    map with the previous pose as the guess, then insert it with the pose found.  The HILTI bag is not
+    available, so a sensor is moved through a synthetic world; the GPU loop and the
+    CPU loop must produce the same trajectory, the same counts and — frame after frame — the same map."""
+    from eskf_lio_amd import synth
+    world = synth.make_map(60_000, seed=77)                        # the world the scans see
+    rng = np.random.default_rng(9)
+    cap, frames, n = 20, 8, 6_000
+    truth = [synth.se3_to_SE3([0.12 * f, 0.05 * f, 0.01 * f, 0.0, 0.002 * f, 0.01 * f]) for f in range(frames)]
+    gpu_ctx.map_reset(0.3, 0)
+    om = oracle.OracleMap(0.3, cap)
+    pose_g = pose_c = truth[0]
+    for f in range(frames):
+        pick = rng.choice(60_000, n, replace=False)
+        Tinv = synth.invert_pose(truth[f])
+        scan = (world.means[pick] + rng.normal(scale=0.01, size=(n, 3))) @ Tinv[:3, :3].T + Tinv[:3, 3]
+        cov = synth._conjugate(Tinv[:3, :3], world.covs[pick])
+        if f > 0:
+            got = gpu_ctx.align(scan, cov, pose_g, 30, 1e-6, 0.9999)
+            ref = om.align(scan, cov, pose_c, 30, 1e-6, 0.9999)
+            assert got.iterations == ref.iterations and got.converged == ref.converged
+            assert np.array_equal(got.corr_count, ref.corr_count)
+            dt, dr = pose_error(got.pose, ref.pose)
+            assert dt <= 1e-9 and dr <= 1e-9
+            et, er = pose_error(got.pose, truth[f])
+            assert et < 5e-3 and er < 2e-3                         # it is actually tracking
+            pose_g, pose_c = got.pose, ref.pose
+            gpu_ctx.map_insert_resident(pose_g, cap)               # the scan align just registered
+        else:
+            gpu_ctx.map_insert_scan(scan, cov, pose_g, cap)
+        wp, wc = oracle.transform(scan, cov, pose_c)
+        om.insert(wp, wc)
+        assert gpu_ctx.map_size()[0] == len(om)
+    gk, gm, gc, gn = gpu_ctx.map_export()
+    k, m, c, cnt = om.export()
+    o = np.lexsort(k.T)
+    assert np.array_equal(gk, k[o]) and np.array_equal(gn, cnt[o])
+    assert np.abs(gm - m[o]).max() < 1e-9 and np.abs(gc - c[o]).max() < 1e-9   # poses agree to 1e-9, so do the maps
+
+
 # ---- multi-GPU code path on one device: RCCL communicator of size 1 ---------------------------
 def test_rccl_path_world_size_one(c1_gpu, c1_inputs):
     from eskf_lio_amd import synth
