@@ -232,6 +232,18 @@ def main():
             same_counts = bool((ref.corr_count == res.corr_count).all())
             dt = float(np.linalg.norm(ref.pose[:3, 3] - res.pose[:3, 3]))
             out["parity"] = {"identical_counts": same_counts, "pose_delta_m": dt}
+        if use_dist:
+            # evidence that the sharded, all-reduced loop computes what one GPU computes: the whole scan
+            # through a second, communicator-free context on this rank
+            with capi.Context(local_rank) as solo:
+                solo.map_reset(vmap.voxel_size, n_voxels)
+                solo.map_upsert(vmap.keys, vmap.means, vmap.covs)
+                one = solo.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0)
+            out["multi_gpu_parity"] = {
+                "identical_counts": bool((one.corr_count == res.corr_count).all()),
+                "pose_delta": float(np.abs(one.pose - res.pose).max()),
+                "against": "the whole scan on one GPU (persistent launch), same process",
+            }
         print(json.dumps(out), flush=True)
     ctx.close()
     if use_dist:
