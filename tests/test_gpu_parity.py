@@ -527,6 +527,18 @@ def test_frame_stream_trajectory_matches_the_cpu_loop(gpu_ctx, oracle):
     assert np.abs(gm - m[o]).max() < 1e-9 and np.abs(gc - c[o]).max() < 1e-9   # poses agree to 1e-9, so do the maps
 
 
+def test_cpp_example_tracks_a_moving_sensor():
+    """examples/register_frames.cpp: the reference's frame loop written in C++ against the shim."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "register_frames")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("frame")]
+    assert len(lines) == 6 and all("converged 1" in ln for ln in lines[1:])
+
+
 # ---- multi-GPU code path on one device: RCCL communicator of size 1 ---------------------------
 def test_rccl_path_world_size_one(c1_gpu, c1_inputs):
     from eskf_lio_amd import synth
