@@ -6,7 +6,12 @@ forces all of them) of config C2 — a 100k-point synthetic un
 1M-voxel synthetic map.  With --gpus N (launched by torch.distributed.run, one rank per GPU) the
 scan is sharded in contiguous blocks over the ranks, the map is replicated, and every iteration ends
 in one RCCL all-reduce of the 28-double normal-equation row ("scaling": "strong": the total work is
-the fixed 100k-point scan BASELINE.json names for 1/2/4/8 GPUs).
+the fixed 100k-point scan BASELINE.json names for 1/2/4/8 GPUs).  Sharding a scan only pays once a
+shard is large enough to amortise the all-reduce, so with N > 1 the warm-up measures both ways of
+registering the scan — sharded, or the whole scan on every rank without communication — and the
+timed region runs the faster one (`config.sharding`, `config.sharding_autotune` report the choice and
+both timings; BENCH_SHARDING=shard|replicate forces one; `multi_gpu_parity` always exercises and checks
+the sharded path).
 
 Timed region: inputs already resident in HBM (scan uploaded, map built) — barrier +
 torch.cuda.synchronize() on both sides, K steps, max over ranks.  `roofline` is measured live over
@@ -137,14 +142,44 @@ def main():
         ctx.comm_init(world, rank, share_unique_id(ctx, rank))
     ctx.scan_upload(pts[lo:hi], covs[lo:hi])
 
-    def step(flags=0):
-        return ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
-
     def fence():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
+
+    # With several ranks there are two ways to register one scan: SHARD it (each rank a contiguous
+    # block of points, one RCCL all-reduce of the 28-double row per iteration) or REPLICATE it (every
+    # rank registers the whole scan with the single-launch loop, no communication).  Sharding only pays
+    # once a shard is large enough to amortise the all-reduce, so the host side measures both during
+    # the warm-up and times the faster one (BENCH_SHARDING=shard|replicate forces a choice).
+    run_ctx, n_local, mode, tuning = ctx, hi - lo, "single", None
+    if use_dist:
+        solo = capi.Context(local_rank)
+        solo.map_reset(vmap.voxel_size, n_voxels)
+        solo.map_upsert(vmap.keys, vmap.means, vmap.covs)
+        solo.scan_upload(pts, covs)
+        timing = {}
+        for name, c in (("shard", ctx), ("replicate", solo)):
+            for _ in range(2):
+                c.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(max(args.warmup, 3)):
+                c.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
+            fence()
+            t = torch.tensor([(time.perf_counter() - t0) / max(args.warmup, 3)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)     # every rank sees the same numbers -> same choice
+            timing[name] = float(t.item())
+        want = os.environ.get("BENCH_SHARDING", "auto")
+        mode = want if want in ("shard", "replicate") else min(timing, key=timing.get)
+        tuning = {"policy": want, "ms_per_step_shard": timing["shard"] * 1e3,
+                  "ms_per_step_replicate": timing["replicate"] * 1e3}
+        if mode == "replicate":
+            run_ctx, n_local = solo, n_points
+
+    def step(flags=0):
+        return run_ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
 
     for _ in range(args.warmup):
         res = step()
@@ -169,14 +204,19 @@ def main():
         kernel_ms.append(r.kernel_ms[:ITERATIONS])
     kernel_ms = np.array(kernel_ms)
     bracketed_s = float(kernel_ms.mean()) * 1e-3
-    matches = float(res.corr_count.mean()) / world  # per-rank share of the matched points
-    bytes_per_round = algorithmic_bytes(hi - lo, matches)
+    # matched points handled by this rank per round (corr_count is summed over the communicator)
+    matches = float(res.corr_count.mean()) / (world if mode == "shard" else 1)
+    bytes_per_round = algorithmic_bytes(n_local, matches)
     persistent = res.launches == 1                   # single GPU: the whole align is ONE launch
     rounds_per_launch = ITERATIONS if persistent else 1
     launches = args.steps * (1 if persistent else ITERATIONS)
     span_s = dev_s / launches                        # timed region: HIP-event span per launch
     bytes_per_launch = bytes_per_round * rounds_per_launch
     achieved = bytes_per_launch / span_s / 1e9
+
+    sharded = None
+    if use_dist:  # a collective: every rank takes part (the comparison happens on rank 0 below)
+        sharded = ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
 
     out = None
     if rank == 0:
@@ -199,8 +239,12 @@ def main():
                             f"(voxel 0.3 m, occupancy 0.5), {ITERATIONS} VGICP iterations per align "
                             f"(cosine_threshold 2.0 forces all), scan resident in HBM",
                 "points": n_points, "voxels": n_voxels, "iterations": ITERATIONS,
-                "sharding": f"contiguous point shards over {world} rank(s), replicated map, "
-                            f"RCCL all-reduce of 28 doubles per iteration" if use_dist else "single GPU",
+                "sharding": {"single": "single GPU",
+                             "shard": f"contiguous point shards over {world} rank(s), replicated map, RCCL "
+                                      f"all-reduce of 28 doubles per iteration",
+                             "replicate": f"whole scan registered on each of the {world} rank(s) (no "
+                                          f"communication): faster than sharding at this size"}[mode],
+                "sharding_autotune": tuning,
                 "matches_per_iteration": float(res.corr_count.mean()),
             },
             "roofline": {
@@ -233,22 +277,26 @@ def main():
             dt = float(np.linalg.norm(ref.pose[:3, 3] - res.pose[:3, 3]))
             out["parity"] = {"identical_counts": same_counts, "pose_delta_m": dt}
         if use_dist:
-            # evidence that the sharded, all-reduced loop computes what one GPU computes: the whole scan
-            # through a second, communicator-free context on this rank
-            with capi.Context(local_rank) as solo:
-                solo.map_reset(vmap.voxel_size, n_voxels)
-                solo.map_upsert(vmap.keys, vmap.means, vmap.covs)
-                one = solo.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0)
+            # evidence that the sharded, all-reduced loop computes what one GPU computes
+            one = solo.align_resident(guess, ITERATIONS, 1e-6, 2.0)
             out["multi_gpu_parity"] = {
-                "identical_counts": bool((one.corr_count == res.corr_count).all()),
-                "pose_delta": float(np.abs(one.pose - res.pose).max()),
-                "against": "the whole scan on one GPU (persistent launch), same process",
+                "identical_counts": bool((one.corr_count == sharded.corr_count).all()),
+                "pose_delta": float(np.abs(one.pose - sharded.pose).max()),
+                "against": "sharded + all-reduced loop vs the whole scan on one GPU (persistent launch)",
             }
-        print(json.dumps(out), flush=True)
+    if use_dist:
+        solo.close()
     ctx.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes last: flush whatever native libraries (RCCL's banner) still hold in
+        # C stdio buffers first, so nothing can follow it on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
