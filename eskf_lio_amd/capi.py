@@ -27,7 +27,7 @@ EXPORTS = (
     "vgicp_map_reset", "vgicp_map_upsert", "vgicp_map_erase", "vgicp_map_size",
     "vgicp_map_insert_scan", "vgicp_map_insert_resident", "vgicp_map_evict", "vgicp_map_export",
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
-    "vgicp_accumulate", "vgicp_match", "vgicp_voxel_index",
+    "vgicp_accumulate", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
 )
 
@@ -87,6 +87,8 @@ def load_library() -> C.CDLL:
     lib.vgicp_accumulate.argtypes = [vp, sz, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64)]
     lib.vgicp_match.argtypes = [vp, sz, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64), C.POINTER(sz)]
     lib.vgicp_voxel_index.argtypes = [vp, sz, dp, ip]
+    lib.vgicp_preprocess.argtypes = [vp, sz, dp, C.c_double, C.c_int, sz, dp, dp, C.POINTER(C.c_uint64),
+                                     C.POINTER(sz)]
     lib.vgicp_comm_unique_id.argtypes = [vp, vp]
     lib.vgicp_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.vgicp_comm_destroy.argtypes = [vp]
@@ -333,6 +335,19 @@ class Context:
         self._check(self._lib.vgicp_voxel_index(self._h, points.shape[0], _dp(points),
                                                 keys.ctypes.data_as(C.POINTER(C.c_int32))))
         return keys
+
+    def preprocess(self, points, voxel_size: float, knn: int = 30):
+        """CloudPreprocessor::voxelDownsampleAndEstimateCovariances (CloudPreprocessor.cpp:76-127) on the
+        device -> (kept points m x 3, covariances m x 9 column-major, indices of the kept points)."""
+        points = _f64(points, 3)
+        n = points.shape[0]
+        op, oc = np.zeros((n, 3)), np.zeros((n, 9))
+        ix = np.zeros(n, dtype=np.uint64)
+        m = C.c_size_t(0)
+        self._check(self._lib.vgicp_preprocess(self._h, n, _dp(points), float(voxel_size), int(knn), n, _dp(op),
+                                               _dp(oc), ix.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(m)))
+        k = m.value
+        return op[:k].copy(), oc[:k].copy(), ix[:k].copy()
 
     # -- multi-GPU --
     def comm_unique_id(self) -> bytes:

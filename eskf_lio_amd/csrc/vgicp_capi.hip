@@ -76,6 +76,8 @@ struct vgicp_ctx {
   // batch staging (upsert / erase / hooks)
   void* d_stage = nullptr;
   size_t stage_bytes = 0;
+  void* d_cells = nullptr;  // cell table of the scan preparation (vgicp_preprocess)
+  size_t cells_bytes = 0;
 
   // resident scan
   double* d_scan_aos = nullptr;  // points (3n) then covs (9n)
@@ -588,6 +590,7 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipFree(ctx->d_counters);
   (void)hipHostFree(ctx->h_counters);
   (void)hipFree(ctx->d_stage);
+  (void)hipFree(ctx->d_cells);
   (void)hipFree(ctx->d_scan);
   (void)hipFree(ctx->d_scan_aos);
   (void)hipFree(ctx->d_state);
@@ -959,6 +962,60 @@ int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* k
   VG_HIP(ctx, launch_voxel_index(ctx->stream, reinterpret_cast<const double*>(b), (uint32_t)n,
                                  ctx->voxel_size, reinterpret_cast<int32_t*>(b + pb)));
   VG_HIP(ctx, hipMemcpyAsync(keys, b + pb, kb, hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VGICP_OK;
+}
+
+int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxel_size, int knn,
+                     size_t capacity, double* out_points, double* out_covs, uint64_t* out_index,
+                     size_t* kept) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
+  *kept = 0;
+  if (!(voxel_size > 0.0)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "voxel_size must be positive");
+  if (knn < 1 || knn > preprocess_max_knn())
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "knn must be in [1, " + std::to_string(preprocess_max_knn()) + "]");
+  if (n == 0) return VGICP_OK;
+  if (!points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
+  if (n > 0x7FFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  // stage: [points 3n][out points 3n][out covs 9n][out index n][scratch]
+  const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
+  const size_t cb = (n * 9 * sizeof(double) + 255) & ~size_t(255);
+  const size_t ib = (n * sizeof(uint64_t) + 255) & ~size_t(255);
+  const size_t sb = preprocess_scratch_bytes((uint32_t)n);
+  int rc = ensure_stage(ctx, pb + pb + cb + ib + sb);
+  if (rc != VGICP_OK) return rc;
+  char* base = static_cast<char*>(ctx->d_stage);
+  const double* d_pts = reinterpret_cast<const double*>(base);
+  double* d_out_pts = reinterpret_cast<double*>(base + pb);
+  double* d_out_covs = reinterpret_cast<double*>(base + 2 * pb);
+  unsigned long long* d_out_idx = reinterpret_cast<unsigned long long*>(base + 2 * pb + cb);
+  void* scratch = base + 2 * pb + cb + ib;
+  VG_HIP(ctx, hipMemcpyAsync(base, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, launch_preprocess_sort(ctx->stream, d_pts, (uint32_t)n, voxel_size, scratch, ctx->d_counters));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t m = ctx->h_counters[0], cells = ctx->h_counters[1];
+  *kept = m;
+  if (m > capacity) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "output capacity smaller than the number of occupied voxels");
+  if (!out_points || !out_covs) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL output pointer");
+  const uint64_t entries = preprocess_cell_entries(cells);
+  const size_t need = preprocess_cell_bytes(entries);
+  if (need > ctx->cells_bytes) {
+    if (ctx->d_cells) VG_HIP(ctx, hipFree(ctx->d_cells));
+    ctx->d_cells = nullptr;
+    ctx->cells_bytes = 0;
+    VG_HIP(ctx, hipMalloc(&ctx->d_cells, need));
+    ctx->cells_bytes = need;
+  }
+  VG_HIP(ctx, launch_preprocess_finish(ctx->stream, d_pts, (uint32_t)n, voxel_size, knn, m, scratch, ctx->d_cells,
+                                       entries, d_out_pts, d_out_covs, d_out_idx, ctx->d_counters));
+  VG_HIP(ctx, hipMemcpyAsync(out_points, d_out_pts, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(out_covs, d_out_covs, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_index)
+    VG_HIP(ctx, hipMemcpyAsync(out_index, d_out_idx, (size_t)m * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VGICP_OK;
 }

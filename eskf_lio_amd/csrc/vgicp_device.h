@@ -133,6 +133,17 @@ uint32_t match_blocks(uint32_t n);
 // the voxel of every point, order the points of a voxel by scan index, apply the reference's
 // constructor / addPoint rule sequentially per voxel. counters[0] receives the number of new voxels.
 size_t map_insert_scratch_bytes(uint32_t n);
+
+// vgicp_preprocess.hip — voxel down-sampling + k-NN covariances (CloudPreprocessor.cpp:76-127)
+size_t preprocess_scratch_bytes(uint32_t n);
+int preprocess_max_knn();
+uint64_t preprocess_cell_entries(uint32_t cells);
+size_t preprocess_cell_bytes(uint64_t entries);
+hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, double h, void* scratch,
+                                  uint32_t* counters);
+hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n, double h, int knn, uint32_t m,
+                                    void* scratch, void* cell_table, uint64_t table_entries, double* out_pts,
+                                    double* out_covs, unsigned long long* out_idx, uint32_t* counters);
 hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, double voxel_size,
                              const double* points_aos, const double* covs_aos, uint32_t n,
                              const double pose12[12], uint64_t max_points, void* scratch,

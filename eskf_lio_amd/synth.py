@@ -218,6 +218,37 @@ def make_structured_scan(num_points: int, vmap: VoxelMap, seed: int = SCAN_SEED,
     return np.ascontiguousarray(pts), covs, T_true
 
 
+def make_lidar_scan(num_points: int, seed: int = SCAN_SEED, extent: float = 40.0, noise: float = 0.02):
+    """Raw-scan stand-in for the scan preparation (CloudPreprocessor.cpp:76-127): a ground plane, two
+    walls and a sparse cloud of clutter, denser near the sensor like a spinning LiDAR's returns, with
+    Irwin-Hall(4) range noise. Deterministic in (num_points, seed)."""
+    idx = np.arange(num_points, dtype=np.uint64)
+    u = [rand_unit(seed, 200 + k, idx) for k in range(8)]
+    kind = u[0]
+    r = extent * u[1] ** 2 + 0.5                    # quadratic: density falls with range
+    phi = 2.0 * np.pi * u[2]
+    x, y = r * np.cos(phi), r * np.sin(phi)
+    z = np.zeros(num_points)
+    wall_a = (kind >= 0.55) & (kind < 0.75)
+    wall_b = (kind >= 0.75) & (kind < 0.92)
+    clutter = kind >= 0.92
+    z = np.where(wall_a | wall_b, 6.0 * u[3], z)
+    y = np.where(wall_a, 7.5 + 0.0 * y, y)
+    x = np.where(wall_a, extent * (2.0 * u[4] - 1.0), x)
+    x = np.where(wall_b, -11.0 + 0.0 * x, x)
+    y = np.where(wall_b, extent * (2.0 * u[4] - 1.0), y)
+    x = np.where(clutter, extent * (2.0 * u[4] - 1.0), x)
+    y = np.where(clutter, extent * (2.0 * u[5] - 1.0), y)
+    z = np.where(clutter, 8.0 * u[3], z)
+    eps = np.zeros((num_points, 3))
+    for a in range(3):
+        acc = np.zeros(num_points)
+        for k in range(4):
+            acc = acc + rand_unit(seed, 220 + 4 * a + k, idx)
+        eps[:, a] = (acc - 2.0) * noise
+    return np.ascontiguousarray(np.stack([x, y, z], axis=1) + eps)
+
+
 # The configurations BASELINE.json names (C1, C2, C5): points, voxels.
 CONFIGS = {
     "C1": (5_000, 50_000),

@@ -161,6 +161,23 @@ int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* co
 /* LocalMap::getVoxelIndex (src/LocalMap.cpp:114-118) evaluated on the device. */
 int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* keys);
 
+/* ---- scan preparation -----------------------------------------------------
+ * CloudPreprocessor::voxelDownsampleAndEstimateCovariances (src/CloudPreprocessor.cpp:76-127): keep the
+ * first point of every voxel of size voxel_size, and give each kept point the covariance of its knn
+ * nearest neighbours in the WHOLE scan (the point itself included; Open3D's cumulant estimate),
+ * regularised to U diag(1, 1, 1e-2) V^T.  knn is KDTreeSearchParamKNN's (30 in the reference), at most
+ * 32 here.  The neighbour search is exact (a Morton-ordered multi-level cell grid searched until the
+ * k-th distance is certified), ties broken by the lower point index.
+ * out_points (capacity x 3), out_covs (capacity x 9, column-major) and out_index (capacity, optional:
+ * the kept points' indices in the input) are written in ascending input order — the reference emits
+ * them in unordered_map iteration order, which callers must not rely on.  *kept receives the number
+ * of voxels occupied; if it exceeds capacity nothing is written and VGICP_ERR_BAD_ARGUMENT is
+ * returned with *kept set, so the caller can retry (capacity = n always suffices).
+ * Voxel indices outside +-2^20 are clamped for the SEARCH grid only (|coordinate| > 2^20 voxel_size). */
+int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxel_size, int knn,
+                     size_t capacity, double* out_points, double* out_covs, uint64_t* out_index,
+                     size_t* kept);
+
 /* ---- multi-GPU: one process per GPU, RCCL all-reduce of the normal equations ----------------
  * Replaces the thread merge of ICP::computeTransform (src/Registration.cpp:71-75) across devices:
  * per iteration one all-reduce (sum) of 28 doubles (21 + 6 + match count) over xGMI.  Rank 0 calls

@@ -64,6 +64,8 @@ def load() -> C.CDLL:
     lib.oracle_align.restype = C.c_int
     lib.oracle_align.argtypes = [vp, sz, dp, dp, dp, C.c_int, C.c_double, C.c_double, C.c_int, dp,
                                  C.POINTER(_Stats)]
+    lib.oracle_preprocess.restype = sz
+    lib.oracle_preprocess.argtypes = [sz, dp, C.c_double, C.c_int, dp, dp, up]
     lib.oracle_max_threads.restype = C.c_int
     _lib = lib
     return lib
@@ -209,3 +211,14 @@ def transform(points, covs, T):
 
 def max_threads() -> int:
     return load().oracle_max_threads()
+
+
+def preprocess(points, voxel_size: float, knn: int = 30):
+    """voxelDownsampleAndEstimateCovariances: (kept points m x 3, covariances m x 9, original indices)."""
+    points = _f64(points, 3)
+    n = points.shape[0]
+    op, oc = np.zeros((n, 3)), np.zeros((n, 9))
+    ix = np.zeros(n, dtype=np.uint64)
+    m = load().oracle_preprocess(n, _dp(points), float(voxel_size), int(knn), _dp(op), _dp(oc),
+                                 ix.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return op[:m].copy(), oc[:m].copy(), ix[:m].copy()

@@ -169,3 +169,27 @@ def align(vmap: NumpyMap, points, covs9, guess, max_iteration, translation_sq_th
             break
         move(step)
     return total, np.array(counts, dtype=np.uint64), np.array(JTJs), np.array(JTrs), converged
+
+
+def preprocess(points, voxel_size, knn=30):
+    """voxelDownsampleAndEstimateCovariances restated with numpy (src/CloudPreprocessor.cpp:76-127):
+    first point per voxel, brute-force k nearest neighbours, population covariance, numpy's SVD for
+    U diag(1, 1, 1e-2) V^T. Output in ascending original index."""
+    pts = np.asarray(points, dtype=np.float64)
+    keys = voxel_index(pts, voxel_size)
+    _, first = np.unique(keys, axis=0, return_index=True)
+    kept = np.sort(first)
+    k = min(knn, pts.shape[0])
+    out = np.zeros((len(kept), 3, 3))
+    F = np.diag([1.0, 1.0, 1e-2])
+    for o, i in enumerate(kept):
+        d = ((pts - pts[i]) ** 2).sum(axis=1)
+        nn = np.argsort(d, kind="stable")[:k]
+        if k >= 3:
+            x = pts[nn]
+            cov = (x[:, :, None] * x[:, None, :]).mean(axis=0) - np.outer(x.mean(axis=0), x.mean(axis=0))
+        else:
+            cov = np.eye(3)
+        U, _, Vt = np.linalg.svd(cov)
+        out[o] = U @ F @ Vt
+    return pts[kept], out, kept

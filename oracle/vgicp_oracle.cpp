@@ -24,6 +24,7 @@
 
 #include <omp.h>
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstring>
@@ -610,6 +611,114 @@ int oracle_align(const oracle_map* map, size_t n, const double* points, const do
     stats->seconds = omp_get_wtime() - t0;
   }
   return 0;
+}
+
+// ---- N2: CloudPreprocessor::voxelDownsampleAndEstimateCovariances (src/CloudPreprocessor.cpp:76-127) ----
+namespace {
+
+// Eigen decomposition of a symmetric 3x3 by cyclic Jacobi rotations; eigenvalues descending, the
+// columns of U the matching unit eigenvectors.  For a symmetric positive semi-definite input this is
+// the U (= V) and the singular values Eigen::JacobiSVD returns, up to the sign of each column.
+void symmetric_eigen3(const M3& Ain, double w[3], M3& U) {
+  double A[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) A[r][c] = Ain(r, c);
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
+    const double diag = std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]);
+    if (off <= 1e-300 || off <= 1e-22 * diag) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {  // A <- A J
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {  // A <- J^T A
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int order[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (A[order[j]][order[j]] > A[order[i]][order[i]]) std::swap(order[i], order[j]);
+  for (int k = 0; k < 3; ++k) {
+    w[k] = A[order[k]][order[k]];
+    for (int r = 0; r < 3; ++r) U(r, k) = V[r][order[k]];
+  }
+}
+
+}  // namespace
+
+extern "C" size_t oracle_preprocess(size_t n, const double* points, double voxel_size, int knn,
+                                    double* out_points, double* out_covs, uint64_t* out_index) {
+  const V3* P = reinterpret_cast<const V3*>(points);
+  // first point per voxel (src/CloudPreprocessor.cpp:87-92)
+  std::unordered_map<Key, size_t, KeyHash> first;
+  for (size_t i = 0; i < n; ++i) first.emplace(voxel_key(P[i], voxel_size), i);
+  std::vector<size_t> kept;
+  kept.reserve(first.size());
+  for (const auto& kv : first) kept.push_back(kv.second);
+  std::sort(kept.begin(), kept.end());
+  const size_t m = kept.size();
+  const size_t K = std::min<size_t>(static_cast<size_t>(knn > 0 ? knn : 0), n);
+#pragma omp parallel
+  {
+    std::vector<std::pair<double, size_t>> dist(n);
+#pragma omp for schedule(dynamic, 16)
+    for (size_t o = 0; o < m; ++o) {
+      const V3 q = P[kept[o]];
+      for (size_t j = 0; j < n; ++j) {
+        const double dx = P[j].x - q.x, dy = P[j].y - q.y, dz = P[j].z - q.z;
+        dist[j] = {dx * dx + dy * dy + dz * dz, j};
+      }
+      std::partial_sort(dist.begin(), dist.begin() + K, dist.end());  // ascending distance, then index
+      M3 cov = identity3();
+      if (K >= 3) {
+        // open3d::utility::ComputeCovariance: cumulants over the neighbours in search order
+        double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t k = 0; k < K; ++k) {
+          const V3& p = P[dist[k].second];
+          c[0] += p.x; c[1] += p.y; c[2] += p.z;
+          c[3] += p.x * p.x; c[4] += p.x * p.y; c[5] += p.x * p.z;
+          c[6] += p.y * p.y; c[7] += p.y * p.z; c[8] += p.z * p.z;
+        }
+        for (double& v : c) v /= static_cast<double>(K);
+        cov(0, 0) = c[3] - c[0] * c[0];
+        cov(1, 1) = c[6] - c[1] * c[1];
+        cov(2, 2) = c[8] - c[2] * c[2];
+        cov(0, 1) = cov(1, 0) = c[4] - c[0] * c[1];
+        cov(0, 2) = cov(2, 0) = c[5] - c[0] * c[2];
+        cov(1, 2) = cov(2, 1) = c[7] - c[1] * c[2];
+      }
+      // U diag(1, 1, 1e-2) V^T (src/CloudPreprocessor.cpp:119-123, CloudPreprocessor.hpp:30-31)
+      double w[3];
+      M3 U;
+      symmetric_eigen3(cov, w, U);
+      const double f[3] = {1.0, 1.0, 1e-2};
+      M3 R;
+      for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc)
+          R(r, cc) = U(r, 0) * f[0] * U(cc, 0) + U(r, 1) * f[1] * U(cc, 1) + U(r, 2) * f[2] * U(cc, 2);
+      std::memcpy(out_points + 3 * o, &q, 24);
+      std::memcpy(out_covs + 9 * o, R.a, 72);
+      out_index[o] = kept[o];
+    }
+  }
+  return m;
 }
 
 int oracle_max_threads(void) { return omp_get_max_threads(); }

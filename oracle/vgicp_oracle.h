@@ -87,6 +87,17 @@ int oracle_align(const oracle_map* map, size_t n, const double* points, const do
                  double cosine_threshold, int mode, double out_pose16[16],
                  oracle_align_stats* stats);
 
+/* CloudPreprocessor::voxelDownsampleAndEstimateCovariances (src/CloudPreprocessor.cpp:76-127):
+ * keep the first point (lowest index) of every voxel of size voxel_size; for every kept point the knn
+ * nearest points of the FULL cloud (the point itself included, Open3D KDTreeSearchParamKNN, default 30),
+ * Open3D's ComputeCovariance over them (cumulants: E[x x^T] - E[x] E[x]^T), then the regularisation
+ * U diag(1, 1, 1e-2) V^T of Eigen's JacobiSVD (for a symmetric positive semi-definite matrix U = V =
+ * eigenvectors, singular values descending); fewer than 3 neighbours -> identity before regularising.
+ * Output order: ascending original index (the reference emits unordered_map iteration order).
+ * out_points m x 3, out_covs m x 9 column-major, out_index m; returns m. Brute-force neighbour search. */
+size_t oracle_preprocess(size_t n, const double* points, double voxel_size, int knn,
+                         double* out_points, double* out_covs, uint64_t* out_index);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -588,3 +588,86 @@ def test_c2_full_size_properties(gpu_ctx, oracle):
     om.insert(vmap.means, vmap.covs)
     ref = om.align(pts, covs, g, 20, 1e-6, 2.0)
     assert_align_parity(a, ref)
+
+
+# ---- N2: scan preparation on the device (CloudPreprocessor.cpp:76-127) ----------------------------
+def _cov_mats(c9):
+    return np.asarray(c9).reshape(-1, 3, 3).transpose(0, 2, 1)
+
+
+def _assert_preprocess_parity(got, ref, pts, tol=1e-9):
+    gp, gc, gi = got
+    rp, rc, ri = ref
+    assert np.array_equal(gi, ri)                                  # kept points: integer work, exact
+    assert np.array_equal(gp, rp) and np.array_equal(gp, pts[gi.astype(np.int64)])
+    G, R = _cov_mats(gc), _cov_mats(rc)
+    # each result is I - 0.99 n n^T with n the neighbourhood's normal: how well n is determined depends
+    # on the gap between the two smallest eigenvalues, so the tolerance applies where the gap is sane
+    err = np.abs(G - R).reshape(len(gi), -1).max(axis=1)
+    assert np.all(err < 1e-5), err.max()
+    assert np.mean(err < tol) > 0.999, (np.mean(err < tol), err.max())
+    ev = np.linalg.eigvalsh(G)
+    assert np.allclose(ev, [1e-2, 1.0, 1.0], atol=1e-11)
+
+
+@pytest.mark.parametrize("n,knn", [(3_000, 30), (20_000, 30), (20_000, 7)])
+def test_preprocess_matches_oracle(gpu_ctx, oracle, n, knn):
+    from eskf_lio_amd import synth
+    pts = synth.make_lidar_scan(n, seed=n + knn)
+    _assert_preprocess_parity(gpu_ctx.preprocess(pts, 0.3, knn), oracle.preprocess(pts, 0.3, knn), pts)
+
+
+def test_preprocess_other_voxel_sizes_and_dense_cells(gpu_ctx, oracle):
+    from eskf_lio_amd import synth
+    pts = synth.make_lidar_scan(15_000, seed=5, extent=10.0)       # many points per voxel
+    for h in (0.1, 0.5, 2.0):
+        _assert_preprocess_parity(gpu_ctx.preprocess(pts, h, 30), oracle.preprocess(pts, h, 30), pts)
+
+
+def test_preprocess_edge_cases(gpu_ctx, oracle):
+    from eskf_lio_amd.capi import VgicpError
+    assert len(gpu_ctx.preprocess(np.zeros((0, 3)), 0.3)[2]) == 0
+    # fewer points than neighbours asked for; fewer than three -> identity before the regularisation
+    two = np.array([[0.0, 0.0, 0.0], [5.0, 0.0, 0.0]])
+    gp, gc, gi = gpu_ctx.preprocess(two, 0.3, 30)
+    assert list(gi) == [0, 1] and np.allclose(_cov_mats(gc), np.diag([1.0, 1.0, 1e-2]), atol=1e-15)
+    rng = np.random.default_rng(3)
+    few = rng.normal(size=(17, 3)) * 3.0
+    _assert_preprocess_parity(gpu_ctx.preprocess(few, 0.3, 30), oracle.preprocess(few, 0.3, 30), few)
+    # far-apart clusters: the search has to climb to the coarsest level or look at everything
+    far = np.concatenate([rng.normal(size=(20, 3)) * 0.05, rng.normal(size=(20, 3)) * 0.05 + 900.0,
+                          rng.normal(size=(5, 3)) * 0.05 - 400.0])
+    _assert_preprocess_parity(gpu_ctx.preprocess(far, 0.3, 30), oracle.preprocess(far, 0.3, 30), far)
+    # negative coordinates and points exactly on voxel faces keep the map's floor() convention
+    grid = np.stack(np.meshgrid(np.arange(-6, 6) * 0.15, np.arange(-6, 6) * 0.15, [0.0, -0.3], indexing="ij"),
+                    axis=-1).reshape(-1, 3)
+    grid = grid + rng.normal(size=grid.shape) * 1e-3 * np.array([0.0, 0.0, 1.0])
+    _assert_preprocess_parity(gpu_ctx.preprocess(grid, 0.3, 12), oracle.preprocess(grid, 0.3, 12), grid)
+    with pytest.raises(VgicpError):
+        gpu_ctx.preprocess(two, 0.3, 33)                            # more neighbours than the kernel holds
+    with pytest.raises(VgicpError):
+        gpu_ctx.preprocess(two, 0.0, 30)
+
+
+def test_preprocess_feeds_the_registration(gpu_ctx, oracle):
+    """Frame pipeline of LIOdometry (src/Odometry.cpp:153-175): prepare the scan, align it, insert it."""
+    from eskf_lio_amd import synth
+    world = synth.make_lidar_scan(60_000, seed=77)
+    gpu_ctx.map_reset(0.3, 0)
+    p0, c0, _ = gpu_ctx.preprocess(world[:30_000], 0.3, 30)
+    gpu_ctx.map_insert_scan(p0, c0, np.eye(4), 100)
+    T = synth.se3_to_SE3(np.array([0.05, -0.03, 0.01, 0.002, -0.003, 0.01]))
+    Tinv = synth.invert_pose(T)
+    moved = world[30_000:] @ Tinv[:3, :3].T + Tinv[:3, 3]
+    p1, c1, i1 = gpu_ctx.preprocess(moved, 0.3, 30)
+    r1 = oracle.preprocess(moved, 0.3, 30)
+    assert np.array_equal(i1, r1[2])
+    got = gpu_ctx.align(p1, c1, np.eye(4), 30, 1e-6, 0.9999)
+    om = oracle.OracleMap(0.3, 100)
+    om.insert(*oracle.transform(*oracle.preprocess(world[:30_000], 0.3, 30)[:2], np.eye(4)))
+    ref = om.align(r1[0], r1[1], np.eye(4), 30, 1e-6, 0.9999)
+    assert got.iterations == ref.iterations and np.array_equal(got.corr_count, ref.corr_count)
+    dt, dr = pose_error(got.pose, ref.pose)
+    assert dt < 1e-6 and dr < 1e-6
+    et, er = pose_error(got.pose, T)
+    assert et < 0.05 and er < 0.01                                 # and it recovers the motion

@@ -266,3 +266,41 @@ def test_synthetic_inputs_are_reproducible(c1_inputs):
     assert np.array_equal(C, C.transpose(0, 2, 1))
     ev = np.linalg.eigvalsh(C[:100])
     assert np.allclose(ev, [0.01, 1.0, 1.0], atol=1e-12)   # R diag(1,1,1e-2) R^T
+
+
+# ---- scan preparation: oracle vs the numpy restatement -------------------------
+def _cov_mats(c9):
+    return np.asarray(c9).reshape(-1, 3, 3).transpose(0, 2, 1)
+
+
+def test_preprocess_oracle_matches_numpy(oracle):
+    """First point per voxel, 30 nearest neighbours, cumulant covariance, U diag(1,1,1e-2) V^T
+    (CloudPreprocessor.cpp:76-127): Jacobi eigenvectors in the oracle, LAPACK's SVD in numpy."""
+    pts = synth.make_lidar_scan(3_000)
+    op, oc, ix = oracle.preprocess(pts, 0.3, 30)
+    npts, ncov, nix = npo.preprocess(pts, 0.3, 30)
+    assert np.array_equal(ix, nix.astype(np.uint64)) and np.array_equal(op, npts)
+    assert 0 < len(ix) < 3_000 and np.all(np.diff(ix.astype(np.int64)) > 0)
+    assert np.abs(_cov_mats(oc) - ncov).max() < 1e-10
+    # every covariance is I - 0.99 u3 u3^T for a unit u3: eigenvalues (1e-2, 1, 1)
+    ev = np.linalg.eigvalsh(_cov_mats(oc))
+    assert np.allclose(ev, [1e-2, 1.0, 1.0], atol=1e-12)
+
+
+def test_preprocess_known_answers(oracle):
+    # K7: points on the plane z = 0 -> normal is z: covariance diag(1, 1, 1e-2)
+    g = np.arange(8, dtype=np.float64)
+    plane = np.stack([*np.meshgrid(g * 0.11, g * 0.13, indexing="ij"), np.zeros((8, 8))], axis=-1).reshape(-1, 3)
+    _, oc, ix = oracle.preprocess(plane, 0.3, 30)
+    assert np.allclose(_cov_mats(oc), np.diag([1.0, 1.0, 1e-2]), atol=1e-12)
+    # the kept point of a voxel is its first point in scan order
+    keys = np.floor(plane / 0.3).astype(np.int32)
+    first = {}
+    for i, k in enumerate(map(tuple, keys)):
+        first.setdefault(k, i)
+    assert sorted(first.values()) == list(ix.astype(np.int64))
+    # K8: fewer than three neighbours available -> identity before the regularisation
+    _, oc, ix = oracle.preprocess(np.array([[0.0, 0.0, 0.0], [5.0, 0.0, 0.0]]), 0.3, 30)
+    assert len(ix) == 2 and np.allclose(_cov_mats(oc), np.diag([1.0, 1.0, 1e-2]), atol=1e-15)
+    # empty scan
+    assert len(oracle.preprocess(np.zeros((0, 3)), 0.3, 30)[2]) == 0
