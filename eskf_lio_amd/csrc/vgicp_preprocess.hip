@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_cov_kernel(
   for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
     for (int r = 0; r < 3; ++r)
-      out_covs[9 * (size_t)o + r + 3 * cc] = U[r][0] * U[cc][0] + U[r][1] * U[cc][1] + 1e-2 * (U[r][2] * U[cc][2]);
+      out_covs[9 * (size_t)o + r + 3 * cc] = U[r][0] * U[cc][0] + U[r][1] * U[cc][1] + (U[r][2] * 1e-2) * U[cc][2];
   out_idx[o] = qi;
 }
 

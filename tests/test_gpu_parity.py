@@ -595,17 +595,20 @@ def _cov_mats(c9):
     return np.asarray(c9).reshape(-1, 3, 3).transpose(0, 2, 1)
 
 
-def _assert_preprocess_parity(got, ref, pts, tol=1e-9):
+def _assert_preprocess_parity(got, ref, pts, exact=True):
     gp, gc, gi = got
     rp, rc, ri = ref
     assert np.array_equal(gi, ri)                                  # kept points: integer work, exact
     assert np.array_equal(gp, rp) and np.array_equal(gp, pts[gi.astype(np.int64)])
     G, R = _cov_mats(gc), _cov_mats(rc)
-    # each result is I - 0.99 n n^T with n the neighbourhood's normal: how well n is determined depends
-    # on the gap between the two smallest eigenvalues, so the tolerance applies where the gap is sane
-    err = np.abs(G - R).reshape(len(gi), -1).max(axis=1)
-    assert np.all(err < 1e-5), err.max()
-    assert np.mean(err < tol) > 0.999, (np.mean(err < tol), err.max())
+    # The device code keeps the oracle's operation order without FMA contraction, and division and
+    # square root are correctly rounded on both sides: the same neighbours give the same bits. (A bound
+    # in terms of a tolerance would have to follow the conditioning of the normal direction, which the
+    # reference's E[xx^T] - E[x]E[x]^T makes arbitrarily bad far from the origin.)
+    if exact:
+        assert np.array_equal(G, R), np.abs(G - R).max()
+    else:
+        assert np.abs(G - R).max() < 1e-9
     ev = np.linalg.eigvalsh(G)
     assert np.allclose(ev, [1e-2, 1.0, 1.0], atol=1e-11)
 
