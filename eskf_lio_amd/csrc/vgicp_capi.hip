@@ -70,7 +70,7 @@ struct vgicp_ctx {
   uint64_t slots = 0;
   uint64_t voxels = 0;      // FULL records
   uint64_t tombstones = 0;
-  uint32_t* d_counters = nullptr;  // 4 words
+  uint32_t* d_counters = nullptr;  // 8 words
   uint32_t* h_counters = nullptr;  // pinned
 
   // batch staging (upsert / erase / hooks)
@@ -529,8 +529,8 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   } while (0)
   VG_CREATE(hipSetDevice(device_id));
   VG_CREATE(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), 4 * sizeof(uint32_t)));
-  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), 4 * sizeof(uint32_t), 0));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), 8 * sizeof(uint32_t)));
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), 8 * sizeof(uint32_t), 0));
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_state), 2 * sizeof(AlignState)));
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state),
                           (1 + kMaxChunksInFlight) * sizeof(AlignState), 0));
@@ -993,7 +993,7 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
   unsigned long long* d_out_idx = reinterpret_cast<unsigned long long*>(base + 2 * pb + cb);
   void* scratch = base + 2 * pb + cb + ib;
   VG_HIP(ctx, hipMemcpyAsync(base, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), ctx->stream));
   VG_HIP(ctx, launch_preprocess_sort(ctx->stream, d_pts, (uint32_t)n, voxel_size, scratch, ctx->d_counters));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1011,12 +1011,18 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
     ctx->cells_bytes = need;
   }
   VG_HIP(ctx, launch_preprocess_finish(ctx->stream, d_pts, (uint32_t)n, voxel_size, knn, m, scratch, ctx->d_cells,
-                                       entries, d_out_pts, d_out_covs, d_out_idx, ctx->d_counters));
+                                       entries, d_out_pts, d_out_covs, d_out_idx, ctx->d_counters,
+                                       std::getenv("VGICP_DEBUG_PREP") ? std::atoi(std::getenv("VGICP_DEBUG_PREP")) : 0));
   VG_HIP(ctx, hipMemcpyAsync(out_points, d_out_pts, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipMemcpyAsync(out_covs, d_out_covs, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (out_index)
     VG_HIP(ctx, hipMemcpyAsync(out_index, d_out_idx, (size_t)m * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (std::getenv("VGICP_DEBUG_PREP"))
+    std::fprintf(stderr, "[vgicp prep] kept %u cells %u fallback %u | point batches total %u (%.1f/query) max %u | cells taken total %u (%.1f/query) max %u | queries starting above the voxel level: %u\n",
+                 m, cells, ctx->h_counters[2], ctx->h_counters[3], ctx->h_counters[3] / (double)m, ctx->h_counters[4],
+                 ctx->h_counters[5], ctx->h_counters[5] / (double)m, ctx->h_counters[6], ctx->h_counters[7]);
   return VGICP_OK;
 }
 

@@ -143,7 +143,7 @@ hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, 
                                   uint32_t* counters);
 hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n, double h, int knn, uint32_t m,
                                     void* scratch, void* cell_table, uint64_t table_entries, double* out_pts,
-                                    double* out_covs, unsigned long long* out_idx, uint32_t* counters);
+                                    double* out_covs, unsigned long long* out_idx, uint32_t* counters, int debug);
 hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, double voxel_size,
                              const double* points_aos, const double* covs_aos, uint32_t n,
                              const double pose12[12], uint64_t max_points, void* scratch,

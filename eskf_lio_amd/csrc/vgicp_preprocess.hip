@@ -5,20 +5,29 @@
 // for each kept point takes its 30 nearest neighbours in the whole scan (the point itself included),
 // Open3D's cumulant covariance over them and the regularisation U diag(1, 1, 1e-2) V^T of a JacobiSVD.
 // Here:
-//   1. every point gets the 63-bit Morton code of its voxel (cell = voxel_size, the same floor(p / h)
-//      as the map keys); ONE stable radix sort (hipCUB) of (code, index) orders the scan so that the
-//      cells of every octree level — h, 2h, 4h, ... — are contiguous runs
-//   2. the first entry of every level-0 run is the first point of its voxel (stable sort keeps scan
-//      order inside a run): that is the down-sampling; the kept indices are then sorted ascending
-//   3. a hash table of (level, cell) -> [start, end) over the sorted order is built for all levels
-//   4. one thread per kept point searches the 27 cells around it at the finest level whose block can
-//      hold k points, keeps the k best (distance, index) pairs sorted in LDS, and accepts the result
-//      only if the k-th distance is within the distance to the block's boundary — otherwise the next
-//      coarser level (twice the cell) is searched; the result is therefore the EXACT k nearest
-//      neighbours, ties broken by index
-//   5. cumulants in ascending-distance order, covariance, cyclic-Jacobi eigen-decomposition (for a
-//      symmetric positive semi-definite matrix U = V = eigenvectors), U diag(1,1,1e-2) U^T.
+//   1. every point gets the 60-bit Morton code of its cell on a grid of voxel_size / 4 (so that
+//      code >> 6 is the Morton code of the voxel, the same floor(p / h) as the map keys); ONE stable
+//      radix sort (hipCUB) of (code, index) orders the scan so that the cells of every octree level —
+//      h/4, h/2, h, 2h, ... — are contiguous runs
+//   2. the lowest index of every voxel-level run is the first point of its voxel: that is the
+//      down-sampling; a prefix sum over scan order gives every kept point its output slot (ascending
+//      index), one over the runs the query list in Morton order
+//   3. a hash table of (level, cell) -> [start, end) over the sorted order is built for all levels:
+//      an octree whose nodes are contiguous runs of the sorted points
+//   4. ONE WAVE per kept point (control flow is uniform, lanes share the work): the farthest of k
+//      consecutive sorted points around the query bounds the k-th distance; the 27 cells around the
+//      query on the level whose block covers that ball seed a pool of cells; the wave repeatedly takes
+//      the nearest cell of the pool (best-first), and either lets its lanes look up the 64 cells two
+//      levels below (one each) or, for a short run, lets them measure its points (one each); passing
+//      points are inserted into the sorted k-list the lanes hold in registers. It stops when the
+//      nearest cell left is farther than the k-th distance: the result is the EXACT k nearest
+//      neighbours, ties broken by index, for work proportional to what lies inside that ball
+//   5. one THREAD per kept point: cumulants in ascending-distance order, covariance, cyclic-Jacobi
+//      eigen-decomposition (for a symmetric positive semi-definite matrix U = V = eigenvectors),
+//      U diag(1,1,1e-2) U^T.
 // Output order is ascending original index (the reference's is unordered_map iteration order).
+// This file is compiled without FMA contraction and keeps the oracle's operation order: the
+// distances, sums and rotations round as they do on the CPU.
 #include <hipcub/hipcub.hpp>
 
 #include "vgicp_device.h"
@@ -28,10 +37,16 @@ namespace vgicp {
 namespace {
 
 constexpr int kMaxKnn = 32;
-constexpr int kLevels = 10;          // cells of h, 2h, ... 512h
-constexpr int kCoordOffset = 1 << 20;  // voxel indices are offset to be non-negative (21 bits per axis)
-constexpr int kKnnBlock = 128;
+constexpr int kFineShift = 2;          // the finest cells are voxel_size / 4
+constexpr int kLevels = 12;            // cells of h/4, h/2, h, ... 512 h
+constexpr int kCoordBits = 20;         // per axis: 60-bit Morton codes, the top 4 bits of a key hold the level
+constexpr int kCoordOffset = 1 << (kCoordBits - 1);  // cell indices are offset to be non-negative
+constexpr int kCoordMax = (1 << kCoordBits) - 1;
+constexpr int kSearchBlock = 256;      // 4 waves = 4 queries per workgroup
+constexpr int kPool = 256;             // cells waiting per query
+constexpr int kCovBlock = 128;
 constexpr unsigned long long kEmptyCell = ~0ull;
+constexpr unsigned long long kKeyMask = (1ull << 60) - 1;
 
 struct CellEntry {
   unsigned long long key;  // (level << 60) | (morton >> 3 level)
@@ -47,12 +62,22 @@ __device__ __forceinline__ unsigned long long spread21(unsigned long long v) {
   v = (v | (v << 2)) & 0x1249249249249249ull;
   return v;
 }
+__device__ __forceinline__ uint32_t compact21(unsigned long long v) {
+  v &= 0x1249249249249249ull;
+  v = (v ^ (v >> 2)) & 0x10C30C30C30C30C3ull;
+  v = (v ^ (v >> 4)) & 0x100F00F00F00F00Full;
+  v = (v ^ (v >> 8)) & 0x1F0000FF0000FFull;
+  v = (v ^ (v >> 16)) & 0x1F00000000FFFFull;
+  v = (v ^ (v >> 32)) & 0x1FFFFFull;
+  return (uint32_t)v;
+}
 __device__ __forceinline__ unsigned long long morton3(uint32_t x, uint32_t y, uint32_t z) {
   return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2);
 }
-__device__ __forceinline__ uint32_t cell_coord(double v, double h) {
-  long long c = (long long)floor(v / h) + kCoordOffset;
-  c = c < 0 ? 0 : (c > 0x1FFFFF ? 0x1FFFFF : c);
+// cell index on the finest grid (cell = fine), offset to be non-negative
+__device__ __forceinline__ uint32_t cell_coord(double v, double fine) {
+  long long c = (long long)floor(v / fine) + kCoordOffset;
+  c = c < 0 ? 0 : (c > kCoordMax ? kCoordMax : c);
   return (uint32_t)c;
 }
 __device__ __forceinline__ unsigned long long cell_key(unsigned long long morton_at_level, int level) {
@@ -63,31 +88,64 @@ __device__ __forceinline__ uint32_t cell_hash(unsigned long long key) {
   return (uint32_t)key;
 }
 
-__global__ void morton_kernel(const double* __restrict__ pts, uint32_t n, double h,
+__global__ void morton_kernel(const double* __restrict__ pts, uint32_t n, double fine,
                               unsigned long long* __restrict__ codes, uint32_t* __restrict__ idx) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  codes[i] = morton3(cell_coord(pts[3 * (size_t)i], h), cell_coord(pts[3 * (size_t)i + 1], h),
-                     cell_coord(pts[3 * (size_t)i + 2], h));
+  codes[i] = morton3(cell_coord(pts[3 * (size_t)i], fine), cell_coord(pts[3 * (size_t)i + 1], fine),
+                     cell_coord(pts[3 * (size_t)i + 2], fine));
   idx[i] = i;
 }
 
-// one pass over the sorted codes: the first entry of a level-0 run is the first point of its voxel
-// (appended to the kept list), and the number of runs over all levels sizes the cell table
-__global__ void run_count_kernel(const unsigned long long* __restrict__ codes, const uint32_t* __restrict__ idx,
-                                 uint32_t n, uint32_t* kept, uint32_t* counters) {
+// One pass over the sorted codes: voxel-level run starts are flagged, the points are copied into sorted
+// order, every point learns its sorted position, and the number of runs over all levels sizes the cell table.
+__global__ void run_count_kernel(const double* __restrict__ pts, const unsigned long long* __restrict__ codes,
+                                 const uint32_t* __restrict__ idx, uint32_t n, double* __restrict__ sorted_pts,
+                                 uint32_t* __restrict__ keep_by_index, uint32_t* __restrict__ voxel_start,
+                                 uint32_t* __restrict__ pos_of_index, uint32_t* __restrict__ voxel_min,
+                                 uint32_t* counters) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned long long c = codes[j];
   const unsigned long long prev = j ? codes[j - 1] : 0ull;
+  const uint32_t i = idx[j];
+  sorted_pts[3 * (size_t)j] = pts[3 * (size_t)i];
+  sorted_pts[3 * (size_t)j + 1] = pts[3 * (size_t)i + 1];
+  sorted_pts[3 * (size_t)j + 2] = pts[3 * (size_t)i + 2];
   uint32_t runs = 0;
 #pragma unroll 1
   for (int l = 0; l < kLevels; ++l) {
     if (j != 0 && (c >> (3 * l)) == (prev >> (3 * l))) break;
-    if (l == 0) kept[atomicAdd(&counters[0], 1u)] = idx[j];
     ++runs;
   }
+  const uint32_t first = (j == 0 || (c >> (3 * kFineShift)) != (prev >> (3 * kFineShift))) ? 1u : 0u;
+  keep_by_index[i] = 0u;
+  voxel_min[j] = 0xFFFFFFFFu;
+  pos_of_index[i] = j;
+  voxel_start[j] = first;
+  if (first) atomicAdd(&counters[0], 1u);
   if (runs) atomicAdd(&counters[1], runs);
+}
+
+// the kept point of a voxel is its FIRST point in scan order: the lowest index of the voxel's run
+// (inside a run the sort orders by the finer cells, not by index)
+__global__ void voxel_min_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ voxel_start,
+                                 const uint32_t* __restrict__ voxel_rank, uint32_t n, uint32_t* voxel_min) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  atomicMin(&voxel_min[voxel_rank[j] + voxel_start[j] - 1u], idx[j]);
+}
+
+// query list in Morton order of the voxels (sorted positions of the kept points) and the kept flags
+__global__ void query_list_kernel(const uint32_t* __restrict__ voxel_start, const uint32_t* __restrict__ voxel_rank,
+                                  const uint32_t* __restrict__ voxel_min, const uint32_t* __restrict__ pos_of_index,
+                                  uint32_t n, uint32_t* __restrict__ queries, uint32_t* __restrict__ keep_by_index) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || !voxel_start[j]) return;
+  const uint32_t r = voxel_rank[j];
+  const uint32_t i = voxel_min[r];
+  queries[r] = pos_of_index[i];
+  keep_by_index[i] = 1u;
 }
 
 // starts of the runs of every level: claim the cell's entry and store the start
@@ -135,6 +193,268 @@ __global__ void cell_end_kernel(const unsigned long long* __restrict__ codes, ui
     if (j + 1 < n && m == (next >> (3 * l))) break;  // not the last of its run (nor of any coarser one)
     CellEntry* e = const_cast<CellEntry*>(find_cell(table, mask, cell_key(m, l)));
     if (e) e->end = j + 1;
+  }
+}
+
+// ---- wave-level helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// value of the lane below (lane 0 keeps its own)
+__device__ __forceinline__ int lane_below_i32(int v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ double lane_below_f64(double v) {
+  return __hiloint2double(lane_below_i32(__double2hiint(v)), lane_below_i32(__double2loint(v)));
+}
+
+// Exact k nearest neighbours of one kept point per wave; writes the neighbours' positions in the sorted
+// order (ascending distance, ties by index) to nbr[slot * kMaxKnn + k] and the point itself to the output.
+__global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
+    const double* __restrict__ spts, const uint32_t* __restrict__ sorted_idx, uint32_t n, double h, int knn,
+    const CellEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ queries,
+    const uint32_t* __restrict__ slot_of_index, uint32_t m, uint32_t* __restrict__ nbr,
+    double* __restrict__ out_pts, unsigned long long* __restrict__ out_idx, uint32_t* counters, int debug) {
+  __shared__ double pool_d[kSearchBlock / 64][kPool];
+  __shared__ unsigned long long pool_key[kSearchBlock / 64][kPool];
+  __shared__ uint32_t pool_start[kSearchBlock / 64][kPool];
+  __shared__ uint32_t pool_end[kSearchBlock / 64][kPool];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const uint32_t qrank = blockIdx.x * (kSearchBlock / 64) + wave;
+  if (qrank >= m) return;  // whole waves leave; nothing below synchronises across waves
+  volatile double* pd = pool_d[wave];
+  volatile unsigned long long* pk = pool_key[wave];
+  volatile uint32_t* ps = pool_start[wave];
+  volatile uint32_t* pe = pool_end[wave];
+  const double fine = h / (double)(1 << kFineShift);
+  const uint32_t qj = uniform_u32(queries[qrank]);
+  const double qx = uniform_f64(spts[3 * (size_t)qj]), qy = uniform_f64(spts[3 * (size_t)qj + 1]),
+               qz = uniform_f64(spts[3 * (size_t)qj + 2]);
+  const int K = knn < (int)n ? knn : (int)n;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+  // the k-list: lane l < found holds the l-th nearest so far
+  double ld = INFINITY;
+  uint32_t li = 0xFFFFFFFFu, lj = 0;
+  int found = 0;
+  double kth = INFINITY;
+  uint32_t kth_id = 0xFFFFFFFFu;
+  uint32_t batches = 0, pops = 0;
+
+  auto dist2 = [&](uint32_t j) {
+    const double dx = spts[3 * (size_t)j] - qx, dy = spts[3 * (size_t)j + 1] - qy, dz = spts[3 * (size_t)j + 2] - qz;
+    return dx * dx + dy * dy + dz * dz;
+  };
+  // Seed: K consecutive points of the sorted order around the query are real points, so the farthest of
+  // them bounds the k-th distance from above.
+  double bound;
+  {
+    const uint32_t half = (uint32_t)K / 2;
+    uint32_t w0 = qj > half ? qj - half : 0;
+    if (w0 + (uint32_t)K > n) w0 = n - (uint32_t)K;
+    double d = lane < K ? dist2(w0 + (uint32_t)lane) : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) d = fmax(d, __shfl_xor(d, o, 64));
+    bound = uniform_f64(d);
+  }
+
+  // every lane brings one candidate (valid, d, id, j); the passing ones are inserted one after the other
+  auto offer = [&](bool valid, double d, uint32_t id, uint32_t j) {
+    ++batches;
+    bool pass = valid && d <= bound && (found < K || d < kth || (d == kth && id < kth_id));
+    unsigned long long todo = __ballot(pass);
+    while (todo) {
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const double cd = readlane_f64(d, src);
+      const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
+      const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)j, src);
+      if (found == K && !(cd < kth || (cd == kth && ci < kth_id))) continue;  // the list moved on
+      const bool less = lane < found && (ld < cd || (ld == cd && li < ci));
+      const int p = __builtin_popcountll(__ballot(less));
+      const double ud = lane_below_f64(ld);
+      const uint32_t ui = (uint32_t)lane_below_i32((int)li), uj = (uint32_t)lane_below_i32((int)lj);
+      if (lane == p) { ld = cd; li = ci; lj = cj; }
+      else if (lane > p) { ld = ud; li = ui; lj = uj; }
+      if (found < K) ++found;
+      if (found == K) {
+        kth = readlane_f64(ld, K - 1);
+        kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
+      }
+    }
+  };
+  // squared distance from the query to the cell (level l, Morton key mk), deflated so that the rounding
+  // between floor(p / fine) and k * fine can never hide a cell
+  auto cell_d2 = [&](int l, unsigned long long mk) {
+    const double size = fine * (double)(1u << l);
+    const double lx = (double)((long long)((unsigned long long)compact21(mk) << l) - kCoordOffset) * fine;
+    const double ly = (double)((long long)((unsigned long long)compact21(mk >> 1) << l) - kCoordOffset) * fine;
+    const double lz = (double)((long long)((unsigned long long)compact21(mk >> 2) << l) - kCoordOffset) * fine;
+    const double ex = fmax(fmax(lx - qx, qx - (lx + size)), 0.0);
+    const double ey = fmax(fmax(ly - qy, qy - (ly + size)), 0.0);
+    const double ez = fmax(fmax(lz - qz, qz - (lz + size)), 0.0);
+    return (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-9);
+  };
+  int waiting = 0;
+  bool overflow = false;
+  // drop the waiting cells that the k-th distance has overtaken since they were pushed
+  auto compact = [&]() {
+    const double limit = found == K ? fmin(bound, kth) : bound;
+    int kept = 0;
+    for (int base = 0; base < waiting; base += 64) {
+      const int i = base + lane;
+      const bool valid = i < waiting;
+      const double d = valid ? pd[i] : 0.0;
+      const unsigned long long key = valid ? pk[i] : 0ull;
+      const uint32_t st = valid ? ps[i] : 0u, en = valid ? pe[i] : 0u;
+      const bool stay = valid && d <= limit;
+      const unsigned long long who = __ballot(stay);
+      const int at = kept + __builtin_popcountll(who & lanes_below);
+      if (stay) { pd[at] = d; pk[at] = key; ps[at] = st; pe[at] = en; }  // at <= i: never ahead of the reads
+      kept += __builtin_popcountll(who);
+    }
+    waiting = kept;
+  };
+  auto push = [&](bool want, double d2, unsigned long long key, uint32_t start, uint32_t end) {
+    const unsigned long long who = __ballot(want);
+    if (waiting + __builtin_popcountll(who) > kPool) compact();
+    const int at = waiting + __builtin_popcountll(who & lanes_below);
+    if (want && at < kPool) {
+      pd[at] = d2;
+      pk[at] = key;
+      ps[at] = start;
+      pe[at] = end;
+    }
+    waiting += __builtin_popcountll(who);
+    if (waiting > kPool) { waiting = kPool; overflow = true; }
+  };
+
+  const uint32_t cx = cell_coord(qx, fine), cy = cell_coord(qy, fine), cz = cell_coord(qz, fine);
+  const double fx = qx / fine - floor(qx / fine), fy = qy / fine - floor(qy / fine), fz = qz / fine - floor(qz / fine);
+  // distance from the query to the faces of the 27-cell block of level l around it
+  auto safe_radius = [&](int l) {
+    const double sub = (double)(1u << l);
+    const double px = (double)(cx & ((1u << l) - 1u)) + fx, py = (double)(cy & ((1u << l) - 1u)) + fy,
+                 pz = (double)(cz & ((1u << l) - 1u)) + fz;
+    const double margin = fmin(fmin(fmin(px, sub - px), fmin(py, sub - py)), fmin(pz, sub - pz));
+    return (sub + margin) * fine * (1.0 - 1e-12);
+  };
+  // the level whose 27-cell block covers the ball of the seed radius: everything that can be among the K
+  // nearest lies inside it
+  int level = 0;
+  for (; level < kLevels; ++level) {
+    const double r = safe_radius(level);
+    if (bound <= r * r) break;
+  }
+  if (level < kLevels) {
+    {
+      const int top = kCoordMax >> level;
+      const int x = (int)(cx >> level) + lane % 3 - 1, y = (int)(cy >> level) + (lane / 3) % 3 - 1,
+                z = (int)(cz >> level) + lane / 9 - 1;
+      bool want = lane < 27 && x >= 0 && y >= 0 && z >= 0 && x <= top && y <= top && z <= top;
+      unsigned long long mk = 0;
+      double d2 = 0.0;
+      uint32_t start = 0, end = 0;
+      if (want) {
+        mk = morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
+        const CellEntry* e = find_cell(table, mask, cell_key(mk, level));
+        want = e != nullptr;
+        if (e) { start = e->start; end = e->end; d2 = cell_d2(level, mk); want = d2 <= bound; }
+      }
+      push(want, d2, cell_key(mk, level), start, end);
+    }
+    while (waiting > 0 && !overflow) {
+      // the nearest waiting cell
+      double best = INFINITY;
+      int at = 0;
+      for (int i = lane; i < waiting; i += 64) {
+        const double d = pd[i];
+        if (d < best) { best = d; at = i; }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const double od = __shfl_xor(best, o, 64);
+        const int oa = __shfl_xor(at, o, 64);
+        if (od < best || (od == best && oa < at)) { best = od; at = oa; }
+      }
+      best = uniform_f64(best);
+      at = (int)uniform_u32((uint32_t)at);
+      const double limit = found == K ? fmin(bound, kth) : bound;
+      if (best > limit) break;  // nothing left can hold one of the K nearest
+      ++pops;
+      const unsigned long long key = pk[at];
+      const uint32_t start = ps[at], end = pe[at];
+      --waiting;
+      if (at != waiting) {  // every lane moves the same entry: a benign same-value write
+        pd[at] = pd[waiting];
+        pk[at] = pk[waiting];
+        ps[at] = ps[waiting];
+        pe[at] = pe[waiting];
+      }
+      const int l = (int)(key >> 60);
+      const unsigned long long mk = key & kKeyMask;
+      if (l == 0 || end - start <= 64u) {
+        for (uint32_t base = start; base < end; base += 64u) {
+          const uint32_t j = base + (uint32_t)lane;
+          const bool valid = j < end;
+          const double d = valid ? dist2(j) : INFINITY;
+          const uint32_t id = valid ? sorted_idx[j] : 0xFFFFFFFFu;
+          offer(valid, d, id, j);
+        }
+      } else {
+        const int step = l >= 2 ? 2 : 1;
+        const int fan = 1 << (3 * step);
+        const unsigned long long cm = (mk << (3 * step)) | (unsigned long long)lane;
+        bool want = lane < fan;
+        double d2 = 0.0;
+        uint32_t cs = 0, ce = 0;
+        if (want) {
+          const CellEntry* e = find_cell(table, mask, cell_key(cm, l - step));
+          want = e != nullptr;
+          if (e) {
+            cs = e->start;
+            ce = e->end;
+            d2 = cell_d2(l - step, cm);
+            want = d2 <= (found == K ? fmin(bound, kth) : bound);
+          }
+        }
+        push(want, d2, cell_key(cm, l - step), cs, ce);
+      }
+    }
+  }
+  if (debug == 1000) overflow = true;
+  if (level >= kLevels || overflow) {  // sparser than the coarsest level resolves (or the pool ran over): everything
+    ld = INFINITY; li = 0xFFFFFFFFu; lj = 0;
+    found = 0; kth = INFINITY; kth_id = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < n; base += 64u) {
+      const uint32_t j = base + (uint32_t)lane;
+      const bool valid = j < n;
+      const double d = valid ? dist2(j) : INFINITY;
+      const uint32_t id = valid ? sorted_idx[j] : 0xFFFFFFFFu;
+      offer(valid, d, id, j);
+    }
+    if (lane == 0) atomicAdd(&counters[2], 1u);
+  }
+  const uint32_t qi = uniform_u32(sorted_idx[qj]);
+  const uint32_t o = uniform_u32(slot_of_index[qi]);
+  if (lane < kMaxKnn) nbr[(size_t)o * kMaxKnn + lane] = lj;
+  if (lane == 0) {
+    out_pts[3 * (size_t)o] = qx; out_pts[3 * (size_t)o + 1] = qy; out_pts[3 * (size_t)o + 2] = qz;
+    out_idx[o] = qi;
+    if (debug) {
+      atomicAdd(&counters[3], batches);
+      atomicMax(&counters[4], batches);
+      atomicAdd(&counters[5], pops);
+      atomicMax(&counters[6], pops);
+      if (level > kFineShift) atomicAdd(&counters[7], 1u);
+    }
   }
 }
 
@@ -190,85 +510,22 @@ __device__ __forceinline__ void symmetric_eigen3(double (&A)[3][3], double (&U)[
     for (int c = 0; c < 3; ++c) U[r][c] = V[r][c];
 }
 
-// Exact k nearest neighbours + covariance + regularisation for the kept points (one thread each).
-__global__ __launch_bounds__(kKnnBlock) void knn_cov_kernel(
-    const double* __restrict__ pts, uint32_t n, double h, int knn, const uint32_t* __restrict__ sorted_idx,
-    const CellEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ kept, uint32_t m,
-    double* __restrict__ out_pts, double* __restrict__ out_covs, unsigned long long* __restrict__ out_idx,
-    uint32_t* counters) {
-  __shared__ double best_d[kMaxKnn][kKnnBlock];
-  __shared__ uint32_t best_i[kMaxKnn][kKnnBlock];
-  const uint32_t t = threadIdx.x;
-  const uint32_t o = blockIdx.x * kKnnBlock + t;
+// Covariance of the neighbours + regularisation, one thread per kept point.
+__global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict__ spts,
+                                                        const uint32_t* __restrict__ nbr, uint32_t m, int found,
+                                                        double* __restrict__ out_covs, const uint32_t* sorted_idx, int debug) {
+  const uint32_t o = blockIdx.x * kCovBlock + threadIdx.x;
   if (o >= m) return;
-  const uint32_t qi = kept[o];
-  const double qx = pts[3 * (size_t)qi], qy = pts[3 * (size_t)qi + 1], qz = pts[3 * (size_t)qi + 2];
-  const int K = knn < (int)n ? knn : (int)n;
-  int found = 0;
-
-  auto offer = [&](uint32_t id) {
-    const double dx = pts[3 * (size_t)id] - qx, dy = pts[3 * (size_t)id + 1] - qy, dz = pts[3 * (size_t)id + 2] - qz;
-    const double d = dx * dx + dy * dy + dz * dz;
-    if (found == K && !(d < best_d[K - 1][t] || (d == best_d[K - 1][t] && id < best_i[K - 1][t]))) return;
-    int j = found < K ? found : K - 1;
-    while (j > 0 && (best_d[j - 1][t] > d || (best_d[j - 1][t] == d && best_i[j - 1][t] > id))) {
-      best_d[j][t] = best_d[j - 1][t];
-      best_i[j][t] = best_i[j - 1][t];
-      --j;
-    }
-    best_d[j][t] = d;
-    best_i[j][t] = id;
-    if (found < K) ++found;
-  };
-
-  const uint32_t cx = cell_coord(qx, h), cy = cell_coord(qy, h), cz = cell_coord(qz, h);
-  bool done = false;
-  for (int l = 0; l < kLevels && !done; ++l) {
-    const int lx = (int)(cx >> l), ly = (int)(cy >> l), lz = (int)(cz >> l);
-    const int top = 0x1FFFFF >> l;
-    // can the 27-cell block hold K points at all?
-    uint32_t population = 0;
-    for (int dz = -1; dz <= 1; ++dz)
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int x = lx + dx, y = ly + dy, z = lz + dz;
-          if (x < 0 || y < 0 || z < 0 || x > top || y > top || z > top) continue;
-          const CellEntry* e = find_cell(table, mask, cell_key(morton3((uint32_t)x, (uint32_t)y, (uint32_t)z), l));
-          if (e) population += e->end - e->start;
-        }
-    if (population < (uint32_t)K && l + 1 < kLevels) continue;
-    found = 0;
-    for (int dz = -1; dz <= 1; ++dz)
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int x = lx + dx, y = ly + dy, z = lz + dz;
-          if (x < 0 || y < 0 || z < 0 || x > top || y > top || z > top) continue;
-          const CellEntry* e = find_cell(table, mask, cell_key(morton3((uint32_t)x, (uint32_t)y, (uint32_t)z), l));
-          if (!e) continue;
-          for (uint32_t j = e->start; j < e->end; ++j) offer(sorted_idx[j]);
-        }
-    // every point outside the block is farther than the distance to the block's nearest face
-    const double fx = qx / h - floor(qx / h), fy = qy / h - floor(qy / h), fz = qz / h - floor(qz / h);
-    // position of the query inside its level-l cell, in units of h
-    const double sub = (double)(1 << l);
-    const double px = (double)(cx & ((1u << l) - 1u)) + fx, py = (double)(cy & ((1u << l) - 1u)) + fy,
-                 pz = (double)(cz & ((1u << l) - 1u)) + fz;
-    const double margin = fmin(fmin(fmin(px, sub - px), fmin(py, sub - py)), fmin(pz, sub - pz));
-    const double safe = (sub + margin) * h * (1.0 - 1e-12);
-    if (found == K && best_d[K - 1][t] <= safe * safe) done = true;
+  if (debug >= 2 && debug < 100) {
+    for (int k = 0; k < 9; ++k) out_covs[9 * (size_t)o + k] = (double)sorted_idx[nbr[(size_t)o * kMaxKnn + (debug - 2) + k]];
+    return;
   }
-  if (!done) {  // sparser than the coarsest level resolves (or fewer than K points near): look at everything
-    found = 0;
-    for (uint32_t id = 0; id < n; ++id) offer(id);
-    atomicAdd(&counters[2], 1u);
-  }
-
   double cov[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   if (found >= 3) {
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < found; ++k) {
-      const uint32_t id = best_i[k][t];
-      const double x = pts[3 * (size_t)id], y = pts[3 * (size_t)id + 1], z = pts[3 * (size_t)id + 2];
+      const uint32_t j = nbr[(size_t)o * kMaxKnn + k];
+      const double x = spts[3 * (size_t)j], y = spts[3 * (size_t)j + 1], z = spts[3 * (size_t)j + 2];
       c[0] += x; c[1] += y; c[2] += z;
       c[3] += x * x; c[4] += x * y; c[5] += x * z;
       c[6] += y * y; c[7] += y * z; c[8] += z * z;
@@ -285,13 +542,11 @@ __global__ __launch_bounds__(kKnnBlock) void knn_cov_kernel(
   }
   double U[3][3];
   symmetric_eigen3(cov, U);
-  out_pts[3 * (size_t)o] = qx; out_pts[3 * (size_t)o + 1] = qy; out_pts[3 * (size_t)o + 2] = qz;
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
     for (int r = 0; r < 3; ++r)
       out_covs[9 * (size_t)o + r + 3 * cc] = U[r][0] * U[cc][0] + U[r][1] * U[cc][1] + (U[r][2] * 1e-2) * U[cc][2];
-  out_idx[o] = qi;
 }
 
 __global__ void cell_clear_kernel(CellEntry* table, uint64_t entries) {
@@ -307,25 +562,32 @@ __host__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 __host__ inline uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
 struct Layout {
-  size_t codes_in, codes_out, idx_in, idx_out, kept_a, kept_b, cub, total;
+  size_t codes_in, codes_out, idx_in, idx_out, spts, keep_i, keep_p, rank_i, rank_p, queries, pos_i, vmin, nbr, cub, total;
   size_t cub_bytes;
 };
 
 __host__ inline Layout layout_for(uint32_t n) {
   Layout L;
-  size_t sort_pairs = 0, sort_keys = 0;
+  size_t sort_pairs = 0, scan = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_pairs, (const unsigned long long*)nullptr,
                                            (unsigned long long*)nullptr, (const uint32_t*)nullptr,
                                            (uint32_t*)nullptr, (int)n);
-  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_keys, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-  L.cub_bytes = sort_pairs > sort_keys ? sort_pairs : sort_keys;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+  L.cub_bytes = sort_pairs > scan ? sort_pairs : scan;
   size_t off = 0;
   L.codes_in = off; off += align256((size_t)n * 8);
   L.codes_out = off; off += align256((size_t)n * 8);
   L.idx_in = off; off += align256((size_t)n * 4);
   L.idx_out = off; off += align256((size_t)n * 4);
-  L.kept_a = off; off += align256((size_t)n * 4);
-  L.kept_b = off; off += align256((size_t)n * 4);
+  L.spts = off; off += align256((size_t)n * 24);
+  L.keep_i = off; off += align256((size_t)n * 4);
+  L.keep_p = off; off += align256((size_t)n * 4);
+  L.rank_i = off; off += align256((size_t)n * 4);
+  L.rank_p = off; off += align256((size_t)n * 4);
+  L.queries = off; off += align256((size_t)n * 4);
+  L.pos_i = off; off += align256((size_t)n * 4);
+  L.vmin = off; off += align256((size_t)n * 4);
+  L.nbr = off; off += align256((size_t)n * kMaxKnn * 4);
   L.cub = off; off += align256(L.cub_bytes);
   L.total = off + 256;
   return L;
@@ -338,8 +600,8 @@ int preprocess_max_knn() { return kMaxKnn; }
 uint64_t preprocess_cell_entries(uint32_t cells) { return pow2_at_least((uint64_t)cells * 2 + 64); }
 size_t preprocess_cell_bytes(uint64_t entries) { return entries * sizeof(CellEntry); }
 
-// Stage A: Morton codes, the sort, the kept list (counters[0] = kept points) and the number of cells
-// over all levels (counters[1]).
+// Stage A: Morton codes, the sort, the points in sorted order, the kept flags with their two prefix sums,
+// the query list; counters[0] = kept points, counters[1] = cells over all levels.
 hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, double h, void* scratch,
                                   uint32_t* counters) {
   const Layout L = layout_for(n);
@@ -348,40 +610,58 @@ hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, 
   auto* codes_out = reinterpret_cast<unsigned long long*>(b + L.codes_out);
   auto* idx_in = reinterpret_cast<uint32_t*>(b + L.idx_in);
   auto* idx_out = reinterpret_cast<uint32_t*>(b + L.idx_out);
-  auto* kept_a = reinterpret_cast<uint32_t*>(b + L.kept_a);
-  hipLaunchKernelGGL(morton_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, h, codes_in, idx_in);
+  auto* spts = reinterpret_cast<double*>(b + L.spts);
+  auto* keep_i = reinterpret_cast<uint32_t*>(b + L.keep_i);
+  auto* keep_p = reinterpret_cast<uint32_t*>(b + L.keep_p);
+  auto* rank_i = reinterpret_cast<uint32_t*>(b + L.rank_i);
+  auto* rank_p = reinterpret_cast<uint32_t*>(b + L.rank_p);
+  auto* queries = reinterpret_cast<uint32_t*>(b + L.queries);
+  const double fine = h / (double)(1 << kFineShift);
+  hipLaunchKernelGGL(morton_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, fine, codes_in, idx_in);
   size_t cub_bytes = L.cub_bytes;
   hipError_t e = hipcub::DeviceRadixSort::SortPairs(b + L.cub, cub_bytes, codes_in, codes_out, idx_in, idx_out,
-                                                    (int)n, 0, 63, s);
+                                                    (int)n, 0, 3 * kCoordBits, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(run_count_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, idx_out, n, kept_a,
-                     counters);
+  auto* pos_i = reinterpret_cast<uint32_t*>(b + L.pos_i);
+  auto* vmin = reinterpret_cast<uint32_t*>(b + L.vmin);
+  hipLaunchKernelGGL(run_count_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, codes_out, idx_out, n, spts,
+                     keep_i, keep_p, pos_i, vmin, counters);
+  cub_bytes = L.cub_bytes;
+  e = hipcub::DeviceScan::ExclusiveSum(b + L.cub, cub_bytes, keep_p, rank_p, (int)n, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(voxel_min_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, idx_out, keep_p, rank_p, n, vmin);
+  hipLaunchKernelGGL(query_list_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, keep_p, rank_p, vmin, pos_i, n,
+                     queries, keep_i);
+  cub_bytes = L.cub_bytes;
+  e = hipcub::DeviceScan::ExclusiveSum(b + L.cub, cub_bytes, keep_i, rank_i, (int)n, s);
+  if (e != hipSuccess) return e;
   return hipGetLastError();
 }
 
-// Stage B: the cell table (entries = preprocess_cell_entries(counters[1])), the kept indices in
-// ascending order, then the neighbour search + covariance for each of the m kept points.
+// Stage B: the cell table (entries = preprocess_cell_entries(counters[1])), the neighbour search (one wave
+// per kept point), the covariances (one thread per kept point).
 hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n, double h, int knn, uint32_t m,
                                     void* scratch, void* cell_table, uint64_t table_entries, double* out_pts,
-                                    double* out_covs, unsigned long long* out_idx, uint32_t* counters) {
+                                    double* out_covs, unsigned long long* out_idx, uint32_t* counters, int debug) {
   if (m == 0) return hipSuccess;
   const Layout L = layout_for(n);
   char* b = static_cast<char*>(scratch);
   auto* codes_out = reinterpret_cast<unsigned long long*>(b + L.codes_out);
   auto* idx_out = reinterpret_cast<uint32_t*>(b + L.idx_out);
-  auto* kept_a = reinterpret_cast<uint32_t*>(b + L.kept_a);
-  auto* kept_b = reinterpret_cast<uint32_t*>(b + L.kept_b);
+  auto* spts = reinterpret_cast<double*>(b + L.spts);
+  auto* rank_i = reinterpret_cast<uint32_t*>(b + L.rank_i);
+  auto* queries = reinterpret_cast<uint32_t*>(b + L.queries);
+  auto* nbr = reinterpret_cast<uint32_t*>(b + L.nbr);
   auto* table = static_cast<CellEntry*>(cell_table);
   const uint32_t mask = (uint32_t)(table_entries - 1);
   hipLaunchKernelGGL(cell_clear_kernel, dim3(blocks_for(table_entries, 256)), dim3(256), 0, s, table,
                      table_entries);
   hipLaunchKernelGGL(cell_start_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
   hipLaunchKernelGGL(cell_end_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
-  size_t cub_bytes = L.cub_bytes;
-  hipError_t e = hipcub::DeviceRadixSort::SortKeys(b + L.cub, cub_bytes, kept_a, kept_b, (int)m, 0, 32, s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(knn_cov_kernel, dim3(blocks_for(m, kKnnBlock)), dim3(kKnnBlock), 0, s, pts, n, h, knn,
-                     idx_out, table, mask, kept_b, m, out_pts, out_covs, out_idx, counters);
+  hipLaunchKernelGGL(knn_search_kernel, dim3(blocks_for(m, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
+                     n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
+  const int found = knn < (int)n ? knn : (int)n;
+  hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, spts, nbr, m, found, out_covs, idx_out, debug);
   return hipGetLastError();
 }
 
