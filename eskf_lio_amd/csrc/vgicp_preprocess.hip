@@ -42,7 +42,7 @@ constexpr int kLevels = 12;            // cells of h/4, h/2, h, ... 512 h
 constexpr int kCoordBits = 20;         // per axis: 60-bit Morton codes, the top 4 bits of a key hold the level
 constexpr int kCoordOffset = 1 << (kCoordBits - 1);  // cell indices are offset to be non-negative
 constexpr int kCoordMax = (1 << kCoordBits) - 1;
-constexpr int kSearchBlock = 256;      // 4 waves = 4 queries per workgroup
+constexpr int kSearchBlock = 64;       // one wave = one query per workgroup
 constexpr int kPool = 256;             // cells waiting per query
 constexpr int kCovBlock = 128;
 constexpr unsigned long long kEmptyCell = ~0ull;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   int found = 0;
   double kth = INFINITY;
   uint32_t kth_id = 0xFFFFFFFFu;
-  uint32_t batches = 0, pops = 0;
+  uint32_t batches = 0, pops = 0, spills = 0;
 
   auto dist2 = [&](uint32_t j) {
     const double dx = spts[3 * (size_t)j] - qx, dy = spts[3 * (size_t)j + 1] - qy, dz = spts[3 * (size_t)j + 2] - qz;
@@ -303,7 +303,6 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     return (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-9);
   };
   int waiting = 0;
-  bool overflow = false;
   // drop the waiting cells that the k-th distance has overtaken since they were pushed
   auto compact = [&]() {
     const double limit = found == K ? fmin(bound, kth) : bound;
@@ -322,21 +321,35 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     }
     waiting = kept;
   };
+  // the caller has made sure that the pool has room
   auto push = [&](bool want, double d2, unsigned long long key, uint32_t start, uint32_t end) {
     const unsigned long long who = __ballot(want);
-    if (waiting + __builtin_popcountll(who) > kPool) compact();
     const int at = waiting + __builtin_popcountll(who & lanes_below);
-    if (want && at < kPool) {
+    if (want) {
       pd[at] = d2;
       pk[at] = key;
       ps[at] = start;
       pe[at] = end;
     }
     waiting += __builtin_popcountll(who);
-    if (waiting > kPool) { waiting = kPool; overflow = true; }
   };
 
   const uint32_t cx = cell_coord(qx, fine), cy = cell_coord(qy, fine), cz = cell_coord(qz, fine);
+  {
+    // A second bound: the finest cell around the query that holds K points has them all within its
+    // diagonal (lane l asks for level l). Sorted-order neighbours can be far apart where the Morton
+    // curve jumps; this bound cannot.
+    uint32_t population = 0;
+    if (lane < kLevels) {
+      const CellEntry* e = find_cell(table, mask, cell_key(morton3(cx >> lane, cy >> lane, cz >> lane), lane));
+      if (e) population = e->end - e->start;
+    }
+    const unsigned long long enough = __ballot(population >= (uint32_t)K);
+    if (enough) {
+      const double size = fine * (double)(1u << __builtin_ctzll(enough));
+      bound = fmin(bound, 3.0 * size * size * (1.0 + 1e-9));
+    }
+  }
   const double fx = qx / fine - floor(qx / fine), fy = qy / fine - floor(qy / fine), fz = qz / fine - floor(qz / fine);
   // distance from the query to the faces of the 27-cell block of level l around it
   auto safe_radius = [&](int l) {
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       }
       push(want, d2, cell_key(mk, level), start, end);
     }
-    while (waiting > 0 && !overflow) {
+    while (waiting > 0) {
       // the nearest waiting cell
       double best = INFINITY;
       int at = 0;
@@ -400,15 +413,8 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       }
       const int l = (int)(key >> 60);
       const unsigned long long mk = key & kKeyMask;
-      if (l == 0 || end - start <= 64u) {
-        for (uint32_t base = start; base < end; base += 64u) {
-          const uint32_t j = base + (uint32_t)lane;
-          const bool valid = j < end;
-          const double d = valid ? dist2(j) : INFINITY;
-          const uint32_t id = valid ? sorted_idx[j] : 0xFFFFFFFFu;
-          offer(valid, d, id, j);
-        }
-      } else {
+      bool measure = l == 0 || end - start <= 64u;
+      if (!measure) {  // one lane per cell two levels down (one level above the finest)
         const int step = l >= 2 ? 2 : 1;
         const int fan = 1 << (3 * step);
         const unsigned long long cm = (mk << (3 * step)) | (unsigned long long)lane;
@@ -422,17 +428,29 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
             cs = e->start;
             ce = e->end;
             d2 = cell_d2(l - step, cm);
-            want = d2 <= (found == K ? fmin(bound, kth) : bound);
+            want = d2 <= limit;
           }
         }
-        push(want, d2, cell_key(cm, l - step), cs, ce);
+        const int incoming = __builtin_popcountll(__ballot(want));
+        if (waiting + incoming > kPool) compact();
+        if (waiting + incoming > kPool) {  // no room even so: measure this cell's points instead (still exact)
+          measure = true;
+          ++spills;
+        } else {
+          push(want, d2, cell_key(cm, l - step), cs, ce);
+        }
+      }
+      if (measure) {
+        for (uint32_t base = start; base < end; base += 64u) {
+          const uint32_t j = base + (uint32_t)lane;
+          const bool valid = j < end;
+          const double d = valid ? dist2(j) : INFINITY;
+          const uint32_t id = valid ? sorted_idx[j] : 0xFFFFFFFFu;
+          offer(valid, d, id, j);
+        }
       }
     }
-  }
-  if (debug == 1000) overflow = true;
-  if (level >= kLevels || overflow) {  // sparser than the coarsest level resolves (or the pool ran over): everything
-    ld = INFINITY; li = 0xFFFFFFFFu; lj = 0;
-    found = 0; kth = INFINITY; kth_id = 0xFFFFFFFFu;
+  } else {  // sparser than the coarsest level resolves: every point of the scan
     for (uint32_t base = 0; base < n; base += 64u) {
       const uint32_t j = base + (uint32_t)lane;
       const bool valid = j < n;
@@ -440,8 +458,9 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       const uint32_t id = valid ? sorted_idx[j] : 0xFFFFFFFFu;
       offer(valid, d, id, j);
     }
-    if (lane == 0) atomicAdd(&counters[2], 1u);
+    spills += 1000000u;
   }
+  if (lane == 0 && spills) atomicAdd(&counters[2], 1u);
   const uint32_t qi = uniform_u32(sorted_idx[qj]);
   const uint32_t o = uniform_u32(slot_of_index[qi]);
   if (lane < kMaxKnn) nbr[(size_t)o * kMaxKnn + lane] = lj;
@@ -513,13 +532,9 @@ __device__ __forceinline__ void symmetric_eigen3(double (&A)[3][3], double (&U)[
 // Covariance of the neighbours + regularisation, one thread per kept point.
 __global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict__ spts,
                                                         const uint32_t* __restrict__ nbr, uint32_t m, int found,
-                                                        double* __restrict__ out_covs, const uint32_t* sorted_idx, int debug) {
+                                                        double* __restrict__ out_covs) {
   const uint32_t o = blockIdx.x * kCovBlock + threadIdx.x;
   if (o >= m) return;
-  if (debug >= 2 && debug < 100) {
-    for (int k = 0; k < 9; ++k) out_covs[9 * (size_t)o + k] = (double)sorted_idx[nbr[(size_t)o * kMaxKnn + (debug - 2) + k]];
-    return;
-  }
   double cov[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   if (found >= 3) {
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -661,7 +676,7 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
   hipLaunchKernelGGL(knn_search_kernel, dim3(blocks_for(m, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
                      n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
   const int found = knn < (int)n ? knn : (int)n;
-  hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, spts, nbr, m, found, out_covs, idx_out, debug);
+  hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, spts, nbr, m, found, out_covs);
   return hipGetLastError();
 }
 
