@@ -50,6 +50,10 @@ def load_library() -> C.CDLL:
     lib.host_icp_destroy.argtypes = [vp]
     lib.host_icp_align.argtypes = [vp, sz, dp, dp, vp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_uint64), sz]
+    lib.host_preprocessor_create.restype = vp
+    lib.host_preprocessor_create.argtypes = [C.c_double]
+    lib.host_preprocessor_destroy.argtypes = [vp]
+    lib.host_preprocessor_downsample.argtypes = [vp, sz, dp, dp, dp, C.POINTER(sz)]
     _lib = lib
     return lib
 
@@ -153,3 +157,29 @@ class ICP:
         self.iterations, self.converged = it.value, bool(conv.value)
         self.correspondence_counts = counts[:it.value].copy()
         return capi.pose_from_abi(out)
+
+
+class CloudPreprocessor:
+    """ESKF_LIO::CloudPreprocessor's scan-preparation half (include/eskf_lio_shim/CloudPreprocessor.hpp;
+    reference include/ESKF_LIO/CloudPreprocessor.hpp:35-36, src/CloudPreprocessor.cpp:76-127)."""
+
+    def __init__(self, voxel_size: float):
+        self._lib = load_library()
+        self._h = self._lib.host_preprocessor_create(float(voxel_size))
+        if not self._h:
+            raise RuntimeError(self._lib.host_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.host_preprocessor_destroy(self._h)
+            self._h = None
+
+    def voxelDownsampleAndEstimateCovariances(self, points):
+        """cloud.points_ in -> (cloud.points_, cloud.covariances_) out."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        n = pts.shape[0]
+        op, oc = np.zeros((n, 3)), np.zeros((n, 9))
+        kept = C.c_size_t(0)
+        _check(self._lib, self._lib.host_preprocessor_downsample(self._h, n, _dp(pts), _dp(op), _dp(oc),
+                                                                 C.byref(kept)))
+        return op[:kept.value].copy(), oc[:kept.value].copy()

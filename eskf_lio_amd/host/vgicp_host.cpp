@@ -1,5 +1,5 @@
-// vgicp_host.cpp — builds the C++ host mirror (include/eskf_lio_shim/: ESKF_LIO::LocalMap and
-// ESKF_LIO::ICP with the reference's method signatures) into libvgicp_host.so and gives it a small
+// vgicp_host.cpp — builds the C++ host mirror (include/eskf_lio_shim/: ESKF_LIO::LocalMap,
+// ESKF_LIO::ICP and ESKF_LIO::CloudPreprocessor with the reference's method signatures) into libvgicp_host.so and gives it a small
 // C surface so the Python parity tests can drive the SAME C++ objects a patched Odometry.cpp would
 // (reference call sites: src/Odometry.cpp:61,86, src/ErrorStateKF.cpp:130).
 // Compiled with plain g++ against the dependency-free stand-in types (no Eigen / Open3D here); all
@@ -9,8 +9,10 @@
 #include <memory>
 #include <string>
 
+#include "../../include/eskf_lio_shim/CloudPreprocessor.hpp"
 #include "../../include/eskf_lio_shim/Registration.hpp"
 
+using ESKF_LIO::CloudPreprocessor;
 using ESKF_LIO::ICP;
 using ESKF_LIO::Isometry3d;
 using ESKF_LIO::LocalMap;
@@ -176,6 +178,40 @@ int host_icp_align(
       if (converged) {*converged = st.converged ? 1 : 0;}
       for (size_t k = 0; k < st.correspondenceCounts.size() && k < corr_capacity; ++k) {
         corr_count[k] = st.correspondenceCounts[k];
+      }
+    });
+}
+
+// CloudPreprocessor(config) — cloud_preprocessor.voxel_size
+CloudPreprocessor * host_preprocessor_create(double voxel_size)
+{
+  CloudPreprocessor * out = nullptr;
+  guarded(
+    [&] {
+      ESKF_LIO::CloudPreprocessorConfig c;
+      c.voxelSize = voxel_size;
+      out = new CloudPreprocessor(c);
+    });
+  return out;
+}
+void host_preprocessor_destroy(CloudPreprocessor * p) {delete p;}
+
+// preprocessor->voxelDownsampleAndEstimateCovariances(cloud): the cloud is n points (covariances are
+// produced); out arrays hold n entries, *kept receives the new size of the cloud.
+int host_preprocessor_downsample(
+  const CloudPreprocessor * p, size_t n, const double * points, double * out_points, double * out_covs,
+  size_t * kept)
+{
+  return guarded(
+    [&] {
+      PointCloud cloud;
+      cloud.points_.resize(n);
+      if (n) {std::memcpy(cloud.points_.data(), points, n * 24);}
+      p->voxelDownsampleAndEstimateCovariances(cloud);
+      *kept = cloud.points_.size();
+      if (*kept) {
+        std::memcpy(out_points, cloud.points_.data(), *kept * 24);
+        std::memcpy(out_covs, cloud.covariances_.data(), *kept * 72);
       }
     });
 }

@@ -674,3 +674,16 @@ def test_preprocess_feeds_the_registration(gpu_ctx, oracle):
     assert dt < 1e-6 and dr < 1e-6
     et, er = pose_error(got.pose, T)
     assert et < 0.05 and er < 0.01                                 # and it recovers the motion
+
+
+def test_host_mirror_cloud_preprocessor(oracle):
+    """ESKF_LIO::CloudPreprocessor::voxelDownsampleAndEstimateCovariances through the C++ mirror
+    (include/eskf_lio_shim/CloudPreprocessor.hpp): the cloud comes back as the oracle leaves it."""
+    from eskf_lio_amd import host, synth
+    pts = synth.make_lidar_scan(8_000, seed=21)
+    pre = host.CloudPreprocessor(0.3)
+    gp, gc = pre.voxelDownsampleAndEstimateCovariances(pts)
+    rp, rc, _ = oracle.preprocess(pts, 0.3, 30)
+    assert np.array_equal(gp, rp) and np.array_equal(gc, rc)
+    gp, gc = pre.voxelDownsampleAndEstimateCovariances(np.zeros((0, 3)))
+    assert gp.shape == (0, 3) and gc.shape == (0, 9)
