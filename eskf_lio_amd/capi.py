@@ -27,7 +27,7 @@ EXPORTS = (
     "vgicp_map_reset", "vgicp_map_upsert", "vgicp_map_erase", "vgicp_map_size",
     "vgicp_map_insert_scan", "vgicp_map_insert_resident", "vgicp_map_evict", "vgicp_map_export",
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
-    "vgicp_accumulate", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess",
+    "vgicp_accumulate", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
 )
 
@@ -87,6 +87,7 @@ def load_library() -> C.CDLL:
     lib.vgicp_accumulate.argtypes = [vp, sz, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64)]
     lib.vgicp_match.argtypes = [vp, sz, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64), C.POINTER(sz)]
     lib.vgicp_voxel_index.argtypes = [vp, sz, dp, ip]
+    lib.vgicp_deskew.argtypes = [vp, sz, dp, dp, sz, dp, C.POINTER(C.c_int64)]
     lib.vgicp_preprocess.argtypes = [vp, sz, dp, C.c_double, C.c_int, sz, dp, dp, C.POINTER(C.c_uint64),
                                      C.POINTER(sz)]
     lib.vgicp_comm_unique_id.argtypes = [vp, vp]
@@ -348,6 +349,20 @@ class Context:
                                                _dp(oc), ix.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(m)))
         k = m.value
         return op[:k].copy(), oc[:k].copy(), ix[:k].copy()
+
+    def deskew(self, points, point_time, states):
+        """CloudPreprocessor::deskew (CloudPreprocessor.cpp:25-74) on the device. states: S x 8 (timestamp,
+        position, quaternion x y z w). -> (points, count); count is -1 with the points unchanged where the
+        reference would run off its state queue."""
+        pts = _f64(points, 3).copy()
+        t = np.ascontiguousarray(point_time, dtype=np.float64).reshape(-1)
+        st = _f64(states, 8)
+        if t.shape[0] != pts.shape[0]:
+            raise ValueError("one capture time per point")
+        done = C.c_int64(0)
+        self._check(self._lib.vgicp_deskew(self._h, pts.shape[0], _dp(pts), _dp(t), st.shape[0], _dp(st),
+                                           C.byref(done)))
+        return pts, int(done.value)
 
     # -- multi-GPU --
     def comm_unique_id(self) -> bytes:

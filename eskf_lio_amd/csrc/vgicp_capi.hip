@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <limits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1023,6 +1024,123 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
     std::fprintf(stderr, "[vgicp prep] kept %u cells %u fallback %u | point batches total %u (%.1f/query) max %u | cells taken total %u (%.1f/query) max %u | queries starting above the voxel level: %u\n",
                  m, cells, ctx->h_counters[2], ctx->h_counters[3], ctx->h_counters[3] / (double)m, ctx->h_counters[4],
                  ctx->h_counters[5], ctx->h_counters[5] / (double)m, ctx->h_counters[6], ctx->h_counters[7]);
+  return VGICP_OK;
+}
+
+namespace {
+// Host side of the deskew: one pose per IMU state, (pose at the end of the sweep)^-1 * state pose. Same
+// formulas and evaluation order as Eigen's Quaterniond::toRotationMatrix / slerp and Isometry3d products.
+struct Pose12 { double R[9]; double t[3]; };  // R column-major
+void quat_matrix(const double q[4], double R[9]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz); R[3] = txy - twz; R[6] = txz + twy;
+  R[1] = txy + twz; R[4] = 1.0 - (txx + tzz); R[7] = tyz - twx;
+  R[2] = txz - twy; R[5] = tyz + twx; R[8] = 1.0 - (txx + tyy);
+}
+void rotate(const double R[9], const double v[3], double out[3]) {
+  for (int r = 0; r < 3; ++r) out[r] = R[r] * v[0] + R[r + 3] * v[1] + R[r + 6] * v[2];
+}
+Pose12 pose_product(const Pose12& A, const Pose12& B) {
+  Pose12 C;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) {
+      double s = A.R[r] * B.R[3 * c];
+      s += A.R[r + 3] * B.R[3 * c + 1];
+      s += A.R[r + 6] * B.R[3 * c + 2];
+      C.R[r + 3 * c] = s;
+    }
+  double rt[3];
+  rotate(A.R, B.t, rt);
+  for (int k = 0; k < 3; ++k) C.t[k] = rt[k] + A.t[k];
+  return C;
+}
+Pose12 pose_inverted(const Pose12& A) {
+  Pose12 C;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) C.R[r + 3 * c] = A.R[c + 3 * r];
+  double rt[3];
+  rotate(C.R, A.t, rt);
+  for (int k = 0; k < 3; ++k) C.t[k] = -rt[k];
+  return C;
+}
+void quat_slerp(const double a[4], const double b[4], double t, double out[4]) {
+  const double one = 1.0 - std::numeric_limits<double>::epsilon();
+  const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  const double absD = std::fabs(d);
+  double scale0, scale1;
+  if (absD >= one) {
+    scale0 = 1.0 - t;
+    scale1 = t;
+  } else {
+    const double theta = std::acos(absD);
+    const double sinTheta = std::sin(theta);
+    scale0 = std::sin((1.0 - t) * theta) / sinTheta;
+    scale1 = std::sin(t * theta) / sinTheta;
+  }
+  if (d < 0.0) scale1 = -scale1;
+  for (int k = 0; k < 4; ++k) out[k] = scale0 * a[k] + scale1 * b[k];
+}
+}  // namespace
+
+int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_time, size_t num_states,
+                 const double* states, int64_t* transformed) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!transformed) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "transformed is NULL");
+  *transformed = 0;
+  if (n == 0 || num_states == 0) return VGICP_OK;
+  if (!points || !point_time || !states) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
+  if (n > 0x7FFFFFFFull || num_states > 0x7FFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan or state queue too large");
+  const double t_end = point_time[n - 1];
+  long before = (long)num_states - 1;
+  while (before >= 0 && states[8 * before] > t_end) --before;
+  if (before < 0 || (size_t)before + 1 >= num_states) {  // the reference would step off its deque here
+    *transformed = -1;
+    return VGICP_OK;
+  }
+  const size_t used = (size_t)before + 2;  // states 0 .. the first one after the end of the sweep
+  const double* s1 = states + 8 * before;
+  const double* s2 = s1 + 8;
+  const double factor = (t_end - s1[0]) / (s2[0] - s1[0] + 1e-6);
+  double q[4];
+  quat_slerp(s1 + 4, s2 + 4, factor, q);
+  Pose12 end_pose;
+  quat_matrix(q, end_pose.R);
+  for (int k = 0; k < 3; ++k) end_pose.t[k] = s1[1 + k] + factor * (s2[1 + k] - s1[1 + k]);
+  const Pose12 end_inv = pose_inverted(end_pose);
+  std::vector<double> host(used * 13);  // [state times | 12 doubles per state]
+  for (size_t s = 0; s < used; ++s) {
+    Pose12 T;
+    quat_matrix(states + 8 * s + 4, T.R);
+    for (int k = 0; k < 3; ++k) T.t[k] = states[8 * s + 1 + k];
+    T = pose_product(end_inv, T);
+    host[s] = states[8 * s];
+    std::memcpy(&host[used + 12 * s], T.R, 9 * sizeof(double));
+    std::memcpy(&host[used + 12 * s + 9], T.t, 3 * sizeof(double));
+  }
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
+  const size_t tb = (n * sizeof(double) + 255) & ~size_t(255);
+  const size_t sb = (used * 13 * sizeof(double) + 255) & ~size_t(255);
+  const size_t eb = (used * sizeof(uint32_t) + 255) & ~size_t(255);
+  int rc = ensure_stage(ctx, pb + tb + sb + eb);
+  if (rc != VGICP_OK) return rc;
+  char* base = static_cast<char*>(ctx->d_stage);
+  double* d_pts = reinterpret_cast<double*>(base);
+  double* d_time = reinterpret_cast<double*>(base + pb);
+  double* d_states = reinterpret_cast<double*>(base + pb + tb);
+  uint32_t* d_ends = reinterpret_cast<uint32_t*>(base + pb + tb + sb);
+  VG_HIP(ctx, hipMemcpyAsync(d_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(d_states, host.data(), used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, launch_deskew(ctx->stream, d_pts, (uint32_t)n, d_time, d_states, (uint32_t)used, d_states + used, d_ends));
+  VG_HIP(ctx, hipMemcpyAsync(points, d_pts, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, d_ends + (used - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *transformed = (int64_t)ctx->h_counters[0];
   return VGICP_OK;
 }
 

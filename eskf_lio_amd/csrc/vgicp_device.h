@@ -144,6 +144,9 @@ hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, 
 hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n, double h, int knn, uint32_t m,
                                     void* scratch, void* cell_table, uint64_t table_entries, double* out_pts,
                                     double* out_covs, unsigned long long* out_idx, uint32_t* counters, int debug);
+// CloudPreprocessor::deskew: ends = scratch of `states` words; poses = 12 doubles per state (R column-major, t)
+hipError_t launch_deskew(hipStream_t s, double* pts, uint32_t n, const double* point_time, const double* state_time,
+                         uint32_t states, const double* poses, uint32_t* ends);
 hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, double voxel_size,
                              const double* points_aos, const double* covs_aos, uint32_t n,
                              const double pose12[12], uint64_t max_points, void* scratch,

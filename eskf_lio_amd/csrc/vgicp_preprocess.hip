@@ -572,6 +572,59 @@ __global__ void cell_clear_kernel(CellEntry* table, uint64_t entries) {
   table[i].end = 0;
 }
 
+// ---- CloudPreprocessor::deskew (src/CloudPreprocessor.cpp:25-74) -----------------------------------
+// The reference walks the IMU states in order and, for each, advances over the points taken before the
+// state's timestamp, starting where the previous state stopped; a state whose search reaches the end of
+// the scan moves nothing. ends[s] is where state s stopped (one workgroup, states in sequence, the search
+// itself parallel), so the segments are the reference's even when the point times are not monotonic.
+constexpr int kBoundsBlock = 1024;
+__global__ __launch_bounds__(kBoundsBlock) void deskew_bounds_kernel(const double* __restrict__ point_time,
+                                                                     uint32_t n,
+                                                                     const double* __restrict__ state_time,
+                                                                     uint32_t states, uint32_t* __restrict__ ends) {
+  __shared__ uint32_t first_hit;
+  uint32_t start = 0;
+  for (uint32_t s = 0; s < states; ++s) {
+    if (threadIdx.x == 0) first_hit = 0xFFFFFFFFu;
+    __syncthreads();
+    const double ts = state_time[s];
+    for (uint32_t i = start + threadIdx.x; i < n; i += kBoundsBlock) {
+      if (!(point_time[i] < ts)) {  // this thread's first point at or after the state's time
+        atomicMin(&first_hit, i);
+        break;
+      }
+      if (i > *(volatile uint32_t*)&first_hit) break;  // someone found an earlier one already
+    }
+    __syncthreads();
+    const uint32_t hit = first_hit;
+    if (hit != 0xFFFFFFFFu) start = hit;  // else: the search ran to the end and the reference keeps its old bound
+    if (threadIdx.x == 0) ends[s] = start;
+    __syncthreads();
+  }
+}
+
+// p <- T_s p for the state s whose segment holds the point; poses: 12 doubles per state, R column-major
+// then t. Evaluated in the order of Eigen's Isometry3d * Vector3d (this file has no FMA contraction).
+__global__ void deskew_apply_kernel(double* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ ends,
+                                    uint32_t states, const double* __restrict__ poses) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = states;  // first s with i < ends[s]
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (i < ends[mid]) hi = mid; else lo = mid + 1;
+  }
+  if (lo >= states) return;  // after the last segment: left as it is
+  const double* T = poses + 12 * (size_t)lo;
+  const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+  const double rx = T[0] * x + T[3] * y + T[6] * z;
+  const double ry = T[1] * x + T[4] * y + T[7] * z;
+  const double rz = T[2] * x + T[5] * y + T[8] * z;
+  pts[3 * (size_t)i] = rx + T[9];
+  pts[3 * (size_t)i + 1] = ry + T[10];
+  pts[3 * (size_t)i + 2] = rz + T[11];
+}
+
 inline uint32_t blocks_for(uint64_t work, uint32_t block) { return (uint32_t)((work + block - 1) / block); }
 __host__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 __host__ inline uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
@@ -677,6 +730,14 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
                      n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
   const int found = knn < (int)n ? knn : (int)n;
   hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, spts, nbr, m, found, out_covs);
+  return hipGetLastError();
+}
+
+hipError_t launch_deskew(hipStream_t s, double* pts, uint32_t n, const double* point_time, const double* state_time,
+                         uint32_t states, const double* poses, uint32_t* ends) {
+  if (n == 0 || states == 0) return hipSuccess;
+  hipLaunchKernelGGL(deskew_bounds_kernel, dim3(1), dim3(kBoundsBlock), 0, s, point_time, n, state_time, states, ends);
+  hipLaunchKernelGGL(deskew_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, ends, states, poses);
   return hipGetLastError();
 }
 

@@ -51,7 +51,8 @@ def load_library() -> C.CDLL:
     lib.host_icp_align.argtypes = [vp, sz, dp, dp, vp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_uint64), sz]
     lib.host_preprocessor_create.restype = vp
-    lib.host_preprocessor_create.argtypes = [C.c_double]
+    lib.host_preprocessor_create.argtypes = [C.c_double, dp]
+    lib.host_preprocessor_process.argtypes = [vp, sz, dp, dp, sz, dp, dp, dp, C.POINTER(sz)]
     lib.host_preprocessor_destroy.argtypes = [vp]
     lib.host_preprocessor_downsample.argtypes = [vp, sz, dp, dp, dp, C.POINTER(sz)]
     _lib = lib
@@ -163,9 +164,10 @@ class CloudPreprocessor:
     """ESKF_LIO::CloudPreprocessor's scan-preparation half (include/eskf_lio_shim/CloudPreprocessor.hpp;
     reference include/ESKF_LIO/CloudPreprocessor.hpp:35-36, src/CloudPreprocessor.cpp:76-127)."""
 
-    def __init__(self, voxel_size: float):
+    def __init__(self, voxel_size: float, T_il=None):
         self._lib = load_library()
-        self._h = self._lib.host_preprocessor_create(float(voxel_size))
+        t = capi.pose_to_abi(np.eye(4) if T_il is None else T_il)
+        self._h = self._lib.host_preprocessor_create(float(voxel_size), _dp(t))
         if not self._h:
             raise RuntimeError(self._lib.host_last_error().decode())
 
@@ -182,4 +184,17 @@ class CloudPreprocessor:
         kept = C.c_size_t(0)
         _check(self._lib, self._lib.host_preprocessor_downsample(self._h, n, _dp(pts), _dp(op), _dp(oc),
                                                                  C.byref(kept)))
+        return op[:kept.value].copy(), oc[:kept.value].copy()
+
+    def process(self, states, points, pointTime):
+        """process(states, lidarMeas): extrinsic -> deskew -> down-sampling + covariances
+        (reference src/CloudPreprocessor.cpp:8-23). states: S x 8 (timestamp, position, quaternion xyzw)."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(pointTime, dtype=np.float64).reshape(-1)
+        st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 8)
+        n = pts.shape[0]
+        op, oc = np.zeros((n, 3)), np.zeros((n, 9))
+        kept = C.c_size_t(0)
+        _check(self._lib, self._lib.host_preprocessor_process(self._h, n, _dp(pts), _dp(t), st.shape[0], _dp(st),
+                                                              _dp(op), _dp(oc), C.byref(kept)))
         return op[:kept.value].copy(), oc[:kept.value].copy()

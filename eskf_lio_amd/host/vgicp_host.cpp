@@ -6,7 +6,9 @@
 // compute goes through libvgicp_hip.so.
 #define ESKF_LIO_SHIM_FORCE_POD 1
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <stdexcept>
 #include <string>
 
 #include "../../include/eskf_lio_shim/CloudPreprocessor.hpp"
@@ -182,14 +184,15 @@ int host_icp_align(
     });
 }
 
-// CloudPreprocessor(config) — cloud_preprocessor.voxel_size
-CloudPreprocessor * host_preprocessor_create(double voxel_size)
+// CloudPreprocessor(config) — cloud_preprocessor.voxel_size, sensors.lidar.extrinsics as a 4x4
+CloudPreprocessor * host_preprocessor_create(double voxel_size, const double T_il[16])
 {
   CloudPreprocessor * out = nullptr;
   guarded(
     [&] {
       ESKF_LIO::CloudPreprocessorConfig c;
       c.voxelSize = voxel_size;
+      if (T_il) {std::memcpy(c.T_il, T_il, sizeof c.T_il);}
       out = new CloudPreprocessor(c);
     });
   return out;
@@ -213,6 +216,35 @@ int host_preprocessor_downsample(
         std::memcpy(out_points, cloud.points_.data(), *kept * 24);
         std::memcpy(out_covs, cloud.covariances_.data(), *kept * 72);
       }
+    });
+}
+
+// preprocessor->process(states, lidarMeas): extrinsic, deskew, down-sampling + covariances.
+// states: num_states x 8 (timestamp, position, quaternion x y z w).
+int host_preprocessor_process(
+  const CloudPreprocessor * p, size_t n, const double * points, const double * point_time,
+  size_t num_states, const double * states, double * out_points, double * out_covs, size_t * kept)
+{
+  return guarded(
+    [&] {
+      auto meas = std::make_shared<ESKF_LIO::LidarMeasurement>();
+      meas->cloud = std::make_shared<PointCloud>();
+      meas->cloud->points_.resize(n);
+      if (n) {std::memcpy(meas->cloud->points_.data(), points, n * 24);}
+      meas->pointTime.assign(point_time, point_time + n);
+      std::deque<ESKF_LIO::State> queue(num_states);
+      for (size_t s = 0; s < num_states; ++s) {
+        queue[s].timestamp = states[8 * s];
+        for (int a = 0; a < 3; ++a) {queue[s].position(a) = states[8 * s + 1 + a];}
+        for (int a = 0; a < 4; ++a) {queue[s].attitude.c[a] = states[8 * s + 4 + a];}
+      }
+      p->process(queue, meas);
+      *kept = meas->cloud->points_.size();
+      if (*kept) {
+        std::memcpy(out_points, meas->cloud->points_.data(), *kept * 24);
+        std::memcpy(out_covs, meas->cloud->covariances_.data(), *kept * 72);
+      }
+      if (!meas->pointTime.empty()) {throw std::runtime_error("process() must clear pointTime");}
     });
 }
 

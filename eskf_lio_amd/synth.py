@@ -249,6 +249,34 @@ def make_lidar_scan(num_points: int, seed: int = SCAN_SEED, extent: float = 40.0
     return np.ascontiguousarray(np.stack([x, y, z], axis=1) + eps)
 
 
+def make_imu_states(num_states: int, t0: float = 100.0, rate_hz: float = 400.0, seed: int = SCAN_SEED):
+    """IMU-rate state queue for the deskew (ErrorStateKF::getStates, reference Types.hpp:31-40): a smooth
+    motion sampled at rate_hz. -> num_states x 8: timestamp, position xyz, attitude quaternion x y z w."""
+    k = np.arange(num_states, dtype=np.float64)
+    t = t0 + k / rate_hz
+    tau = t - t0
+    idx = np.arange(6, dtype=np.uint64)
+    a = rand_unit(seed, 300, idx) - 0.5
+    pos = np.stack([2.0 * tau + 0.3 * a[0] * np.sin(7.0 * tau), 0.5 * a[1] * tau + 0.1 * np.sin(5.0 * tau),
+                    0.05 * np.sin(11.0 * tau + a[2])], axis=1)
+    rv = np.stack([0.2 * a[3] * tau, 0.1 * np.sin(3.0 * tau) * (0.5 + a[4]), 0.6 * tau * (0.5 + a[5])], axis=1)
+    ang = np.linalg.norm(rv, axis=1)
+    axis = np.where(ang[:, None] > 0, rv / np.maximum(ang, 1e-300)[:, None], np.array([[0.0, 0.0, 1.0]]))
+    quat = np.concatenate([axis * np.sin(0.5 * ang)[:, None], np.cos(0.5 * ang)[:, None]], axis=1)
+    return np.ascontiguousarray(np.concatenate([t[:, None], pos, quat], axis=1))
+
+
+def make_point_times(num_points: int, t_first: float, t_last: float, seed: int = SCAN_SEED, jitter: float = 0.0):
+    """Per-point capture times of one sweep: ascending from t_first to t_last; jitter > 0 perturbs them
+    (firing-order noise), which makes the sequence locally non-monotonic like a real multi-beam sensor."""
+    idx = np.arange(num_points, dtype=np.uint64)
+    t = t_first + (t_last - t_first) * (np.arange(num_points) / max(num_points - 1, 1))
+    if jitter > 0.0:
+        t = t + jitter * (rand_unit(seed, 310, idx) - 0.5)
+        t[-1] = t_last
+    return np.ascontiguousarray(t)
+
+
 # The configurations BASELINE.json names (C1, C2, C5): points, voxels.
 CONFIGS = {
     "C1": (5_000, 50_000),

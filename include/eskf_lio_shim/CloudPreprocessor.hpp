@@ -10,15 +10,23 @@
 // KDTreeSearchParamKNN's default (30); fewer than 3 neighbours give the regularised identity.
 // Behaviour changed on purpose: the output is in ascending scan order — the reference's order is
 // the iteration order of an unordered_map (src/CloudPreprocessor.cpp:96-101), which no caller may
-// rely on.  deskew() (src/CloudPreprocessor.cpp:25-74, row N4 of SURVEY.md 8(f)) stays on the host
-// and is not part of this header.
+// rely on.
+// process() and deskew() (include/ESKF_LIO/CloudPreprocessor.hpp:34,41-43, src/CloudPreprocessor.cpp:8-74)
+// are here too: process() applies the LiDAR->IMU extrinsic, deskews with the IMU states through
+// vgicp_deskew() and prepares the scan, in the reference's order.  Where the reference's deskew would step
+// off its state queue (no state at or before the end of the sweep, or none after it: undefined behaviour
+// there) this one throws std::runtime_error.
 #ifndef ESKF_LIO_SHIM_CLOUD_PREPROCESSOR_HPP_
 #define ESKF_LIO_SHIM_CLOUD_PREPROCESSOR_HPP_
 
 #include <cstdint>
+#include <deque>
 #include <vector>
 
 #include "LocalMap.hpp"
+#if defined(ESKF_LIO_SHIM_NATIVE_TYPES)
+#include "ESKF_LIO/Types.hpp"  // the reference's State / LidarMeasurement
+#endif
 
 namespace ESKF_LIO
 {
@@ -29,13 +37,17 @@ struct CloudPreprocessorConfig
 {
   double voxelSize = 0.3;
   int knn = 30;  // open3d::geometry::KDTreeSearchParamKNN's default
+  // sensors.lidar.extrinsics (quaternion + translation) as the 4x4 the reference builds from them
+  // (include/ESKF_LIO/CloudPreprocessor.hpp:20-28), column-major; identity by default
+  double T_il[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 };
 
 class CloudPreprocessor
 {
 public:
   explicit CloudPreprocessor(const CloudPreprocessorConfig & config, vgicp_ctx * ctx = nullptr)
-  : voxelSize_(config.voxelSize), knn_(config.knn), ctx_(ctx ? ctx : shim::defaultContext())
+  : voxelSize_(config.voxelSize), knn_(config.knn), T_il_(shim::poseFromData(config.T_il)),
+    ctx_(ctx ? ctx : shim::defaultContext())
   {
   }
 
@@ -44,8 +56,27 @@ public:
   : voxelSize_(config["cloud_preprocessor"]["voxel_size"].as<double>()), knn_(30),
     ctx_(shim::defaultContext())
   {
+    auto lidar = config["sensors"]["lidar"];
+    auto lidar_quat = lidar["extrinsics"]["quaternion"].as<std::vector<double>>();
+    auto lidar_trans = lidar["extrinsics"]["translation"].as<std::vector<double>>();
+    Eigen::Quaterniond quat = Eigen::Map<Eigen::Quaterniond>(lidar_quat.data());
+    T_il_.linear() = quat.toRotationMatrix();
+    T_il_.translation() = Eigen::Map<Eigen::Vector3d>(lidar_trans.data());
   }
 #endif
+
+  // reference src/CloudPreprocessor.cpp:8-23
+  void process(const std::deque<State> & states, LidarMeasurementPtr lidarMeas) const
+  {
+    auto & cloudPoints = lidarMeas->cloud->points_;
+    lidarMeas->cloud->Transform(T_il_.matrix());
+    if (!states.empty()) {
+      deskew(states, lidarMeas->pointTime, cloudPoints);
+    }
+    lidarMeas->pointTime.clear();
+    lidarMeas->pointTime.shrink_to_fit();
+    voxelDownsampleAndEstimateCovariances(*lidarMeas->cloud);
+  }
 
   void voxelDownsampleAndEstimateCovariances(PointCloud & cloud) const
   {
@@ -72,11 +103,37 @@ public:
 
   double voxelSize() const {return voxelSize_;}
 
+  // reference src/CloudPreprocessor.cpp:25-74 (private there; public here so that tests can reach it)
+  void deskew(
+    const std::deque<State> & states, const std::vector<double> & pointTime,
+    std::vector<Vector3d> & points) const
+  {
+    std::vector<double> packed(states.size() * 8);
+    size_t k = 0;
+    for (const auto & state : states) {
+      packed[k++] = state.timestamp;
+      for (int a = 0; a < 3; ++a) {packed[k++] = state.position(a);}
+      const double * q = shim::quatData(state.attitude);
+      for (int a = 0; a < 4; ++a) {packed[k++] = q[a];}
+    }
+    int64_t moved = 0;
+    shim::check(
+      ctx_,
+      vgicp_deskew(
+        ctx_, points.size(), points.empty() ? nullptr : reinterpret_cast<double *>(points.data()),
+        pointTime.data(), states.size(), packed.data(), &moved),
+      "vgicp_deskew");
+    if (moved < 0) {
+      throw std::runtime_error("deskew: the IMU states do not bracket the end of the sweep");
+    }
+  }
+
 private:
   CloudPreprocessor() = delete;
 
   double voxelSize_;
   int knn_;
+  Isometry3d T_il_;
   vgicp_ctx * ctx_;
 };
 }  // namespace ESKF_LIO

@@ -33,9 +33,11 @@ using Vector3d = Eigen::Vector3d;
 using Vector3i = Eigen::Vector3i;
 using Matrix3d = Eigen::Matrix3d;
 using Isometry3d = Eigen::Isometry3d;
+using Quaterniond = Eigen::Quaterniond;
 
 namespace shim
 {
+inline const double * quatData(const Quaterniond & q) {return q.coeffs().data();}  // x y z w
 inline const double * poseData(const Isometry3d & T) {return T.matrix().data();}
 inline Isometry3d poseFromData(const double * m16)
 {
@@ -177,9 +179,42 @@ inline Isometry3d poseFromData(const double * m16)
 }
 }  // namespace shim
 
+// Eigen::Quaterniond's storage: coefficients x, y, z, w
+struct Quaterniond
+{
+  double c[4] = {0.0, 0.0, 0.0, 1.0};
+};
+
+namespace shim
+{
+inline const double * quatData(const Quaterniond & q) {return q.c;}
+}  // namespace shim
+
 #endif
 
 using PointCloudPtr = std::shared_ptr<PointCloud>;
+
+#if !defined(ESKF_LIO_SHIM_NATIVE_TYPES)
+// Stand-ins for the parts of the reference's include/ESKF_LIO/Types.hpp the scan preparation reads
+// (State: Types.hpp:31-40, LidarMeasurement: Types.hpp:22-29). With the native types the reference's own
+// Types.hpp provides them.
+struct State
+{
+  double timestamp = 0.0;
+  Vector3d position{};
+  Vector3d velocity{};
+  Quaterniond attitude{};
+};
+
+struct LidarMeasurement
+{
+  PointCloudPtr cloud;
+  std::vector<double> pointTime;
+  double startTime = 0.0;
+  double endTime = 0.0;
+};
+using LidarMeasurementPtr = std::shared_ptr<LidarMeasurement>;
+#endif
 
 }  // namespace ESKF_LIO
 

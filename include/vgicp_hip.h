@@ -179,6 +179,18 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
                      size_t capacity, double* out_points, double* out_covs, uint64_t* out_index,
                      size_t* kept);
 
+/* CloudPreprocessor::deskew (src/CloudPreprocessor.cpp:25-74, Utils::interpolateSE3 / transformPoints
+ * src/Utils.cpp:13-20,65-75), SURVEY.md 8(f) N4: every point taken before an IMU state's timestamp is moved
+ * by (pose at the last point's time)^-1 * (that state's pose), in place.  point_time: n capture times
+ * (the reference's LidarMeasurement::pointTime); states: num_states x 8 doubles = timestamp, position xyz,
+ * attitude quaternion in Eigen's coefficient order x y z w, ascending in time (what ErrorStateKF::getStates
+ * returns, reference Types.hpp:31-36).  The walk over point_time is the reference's sequential one, so the
+ * points after the last state at or before the end of the sweep stay as they are.  *transformed receives
+ * the number of leading points moved, or -1 with the points untouched where the reference would leave its
+ * state queue (no state at or before the last point's time, or none after it). */
+int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_time, size_t num_states,
+                 const double* states, int64_t* transformed);
+
 /* ---- multi-GPU: one process per GPU, RCCL all-reduce of the normal equations ----------------
  * Replaces the thread merge of ICP::computeTransform (src/Registration.cpp:71-75) across devices:
  * per iteration one all-reduce (sum) of 28 doubles (21 + 6 + match count) over xGMI.  Rank 0 calls

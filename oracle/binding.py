@@ -66,6 +66,8 @@ def load() -> C.CDLL:
                                  C.POINTER(_Stats)]
     lib.oracle_preprocess.restype = sz
     lib.oracle_preprocess.argtypes = [sz, dp, C.c_double, C.c_int, dp, dp, up]
+    lib.oracle_deskew.restype = C.c_int64
+    lib.oracle_deskew.argtypes = [sz, dp, dp, sz, dp]
     lib.oracle_max_threads.restype = C.c_int
     _lib = lib
     return lib
@@ -222,3 +224,14 @@ def preprocess(points, voxel_size: float, knn: int = 30):
     m = load().oracle_preprocess(n, _dp(points), float(voxel_size), int(knn), _dp(op), _dp(oc),
                                  ix.ctypes.data_as(C.POINTER(C.c_uint64)))
     return op[:m].copy(), oc[:m].copy(), ix[:m].copy()
+
+
+def deskew(points, point_time, states):
+    """CloudPreprocessor::deskew: states S x 8 (timestamp, position, quaternion xyzw) -> (points, count);
+    count is -1 (points unchanged) where the reference would run off its state queue."""
+    points = _f64(points, 3).copy()
+    t = np.ascontiguousarray(point_time, dtype=np.float64).reshape(-1)
+    st = _f64(states, 8)
+    assert t.shape[0] == points.shape[0]
+    done = load().oracle_deskew(points.shape[0], _dp(points), _dp(t), st.shape[0], _dp(st))
+    return points, int(done)

@@ -193,3 +193,59 @@ def preprocess(points, voxel_size, knn=30):
         U, _, Vt = np.linalg.svd(cov)
         out[o] = U @ F @ Vt
     return pts[kept], out, kept
+
+
+def _quat_matrix(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _slerp(a, b, t):
+    d = float(a @ b)
+    if abs(d) >= 1.0 - np.finfo(np.float64).eps:
+        s0, s1 = 1.0 - t, t
+    else:
+        th = np.arccos(abs(d))
+        s0, s1 = np.sin((1.0 - t) * th) / np.sin(th), np.sin(t * th) / np.sin(th)
+    if d < 0:
+        s1 = -s1
+    return s0 * a + s1 * b
+
+
+def deskew(points, point_time, states):
+    """CloudPreprocessor::deskew restated with 4x4 matrices (src/CloudPreprocessor.cpp:25-74,
+    src/Utils.cpp:65-75). -> (points, number of leading points moved) or (points, -1)."""
+    pts = np.asarray(points, dtype=np.float64).copy()
+    t = np.asarray(point_time, dtype=np.float64)
+    st = np.asarray(states, dtype=np.float64).reshape(-1, 8)
+    n, S = len(pts), len(st)
+    if n == 0 or S == 0:
+        return pts, 0
+    t_end = t[-1]
+    before = np.flatnonzero(st[:, 0] <= t_end)
+    if len(before) == 0 or before[-1] + 1 >= S:
+        return pts, -1
+    b = int(before[-1])
+    a = b + 1
+    f = (t_end - st[b, 0]) / (st[a, 0] - st[b, 0] + 1e-6)
+    T_end = np.eye(4)
+    T_end[:3, :3] = _quat_matrix(_slerp(st[b, 4:], st[a, 4:], f))
+    T_end[:3, 3] = st[b, 1:4] + f * (st[a, 1:4] - st[b, 1:4])
+    T_end_inv = np.linalg.inv(T_end)
+    start = end = 0
+    for s in range(a + 1):
+        start = end
+        later = np.flatnonzero(t[start:] >= st[s, 0])       # first point at or after this state's time
+        if len(later) == 0:
+            continue                                          # search ran to the end: nothing moves
+        end = start + int(later[0])
+        if end == start:
+            continue
+        T = np.eye(4)
+        T[:3, :3] = _quat_matrix(st[s, 4:])
+        T[:3, 3] = st[s, 1:4]
+        T = T_end_inv @ T
+        pts[start:end] = pts[start:end] @ T[:3, :3].T + T[:3, 3]
+    return pts, end

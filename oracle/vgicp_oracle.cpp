@@ -721,6 +721,107 @@ extern "C" size_t oracle_preprocess(size_t n, const double* points, double voxel
   return m;
 }
 
+// ---- CloudPreprocessor::deskew (src/CloudPreprocessor.cpp:25-74) ----------------------------------
+namespace {
+struct Pose34 {  // Eigen::Isometry3d as far as it is used here: linear part + translation
+  M3 R;
+  V3 t;
+};
+// Eigen::Quaterniond::toRotationMatrix, coefficients in Eigen's storage order (x, y, z, w)
+inline M3 quat_to_matrix(const double q[4]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  M3 R;
+  R(0, 0) = 1.0 - (tyy + tzz); R(0, 1) = txy - twz; R(0, 2) = txz + twy;
+  R(1, 0) = txy + twz; R(1, 1) = 1.0 - (txx + tzz); R(1, 2) = tyz - twx;
+  R(2, 0) = txz - twy; R(2, 1) = tyz + twx; R(2, 2) = 1.0 - (txx + tyy);
+  return R;
+}
+// Eigen::QuaternionBase::slerp
+inline void quat_slerp(const double a[4], const double b[4], double t, double out[4]) {
+  const double one = 1.0 - std::numeric_limits<double>::epsilon();
+  const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  const double absD = std::fabs(d);
+  double scale0, scale1;
+  if (absD >= one) {
+    scale0 = 1.0 - t;
+    scale1 = t;
+  } else {
+    const double theta = std::acos(absD);
+    const double sinTheta = std::sin(theta);
+    scale0 = std::sin((1.0 - t) * theta) / sinTheta;
+    scale1 = std::sin(t * theta) / sinTheta;
+  }
+  if (d < 0.0) scale1 = -scale1;
+  for (int k = 0; k < 4; ++k) out[k] = scale0 * a[k] + scale1 * b[k];
+}
+inline Pose34 pose_compose(const Pose34& A, const Pose34& B) {  // Isometry3d * Isometry3d
+  Pose34 C;
+  C.R = mul(A.R, B.R);
+  const V3 rt = mul(A.R, B.t);
+  C.t = {rt.x + A.t.x, rt.y + A.t.y, rt.z + A.t.z};
+  return C;
+}
+inline Pose34 pose_inverse(const Pose34& A) {  // Isometry3d::inverse(): R^T, -(R^T t)
+  Pose34 C;
+  C.R = transpose(A.R);
+  const V3 rt = mul(C.R, A.t);
+  C.t = {-rt.x, -rt.y, -rt.z};
+  return C;
+}
+}  // namespace
+
+// states: num_states x 8 doubles (timestamp, position xyz, attitude quaternion x y z w), ascending time.
+// Returns the number of leading points that were transformed (the rest are left as they are, exactly like
+// the reference's loop), or -1 when the reference would run off its state queue (no state at or before
+// the last point's time, or none after it): nothing is touched then.
+int64_t oracle_deskew(size_t n, double* points, const double* point_time, size_t num_states,
+                      const double* states) {
+  if (n == 0 || num_states == 0) return 0;
+  V3* P = reinterpret_cast<V3*>(points);
+  const double t_end = point_time[n - 1];
+  long b = static_cast<long>(num_states) - 1;
+  while (b >= 0 && states[8 * b] > t_end) --b;  // src/CloudPreprocessor.cpp:35-42
+  if (b < 0 || static_cast<size_t>(b) + 1 >= num_states) return -1;
+  const size_t a = static_cast<size_t>(b) + 1;    // stateAfterLidarEnd (:44)
+  // Utils::interpolateSE3 (src/Utils.cpp:65-75)
+  const double* s1 = states + 8 * b;
+  const double* s2 = states + 8 * a;
+  const double factor = (t_end - s1[0]) / (s2[0] - s1[0] + 1e-6);
+  double q[4];
+  quat_slerp(s1 + 4, s2 + 4, factor, q);
+  Pose34 end_pose;
+  end_pose.R = quat_to_matrix(q);
+  end_pose.t = {s1[1] + factor * (s2[1] - s1[1]), s1[2] + factor * (s2[2] - s1[2]), s1[3] + factor * (s2[3] - s1[3])};
+  const Pose34 end_inv = pose_inverse(end_pose);
+  size_t start = 0, end = 0;
+  for (size_t s = 0; s <= a; ++s) {  // states.cbegin() .. stateAfterLidarEnd.base() (:51)
+    start = end;
+    size_t i = start;
+    while (i < n) {
+      if (point_time[i] < states[8 * s]) {
+        ++i;
+      } else {
+        end = i;
+        break;
+      }
+    }
+    if (start == end) continue;
+    Pose34 T;
+    T.R = quat_to_matrix(states + 8 * s + 4);
+    T.t = {states[8 * s + 1], states[8 * s + 2], states[8 * s + 3]};
+    T = pose_compose(end_inv, T);
+    for (size_t k = start; k < end; ++k) {  // Utils::transformPoints (src/Utils.cpp:13-20)
+      const V3 r = mul(T.R, P[k]);
+      P[k] = {r.x + T.t.x, r.y + T.t.y, r.z + T.t.z};
+    }
+  }
+  return static_cast<int64_t>(end);
+}
+
 int oracle_max_threads(void) { return omp_get_max_threads(); }
 
 }  // extern "C"

@@ -98,6 +98,17 @@ int oracle_align(const oracle_map* map, size_t n, const double* points, const do
 size_t oracle_preprocess(size_t n, const double* points, double voxel_size, int knn,
                          double* out_points, double* out_covs, uint64_t* out_index);
 
+/* CloudPreprocessor::deskew (src/CloudPreprocessor.cpp:25-74) with Utils::interpolateSE3 and
+ * Utils::transformPoints (src/Utils.cpp:13-20,65-75): every point taken before an IMU state's timestamp is
+ * moved by (pose at the last point's time)^-1 * (that state's pose); the scan over point_time is the
+ * reference's sequential one (a state whose search reaches the end of the scan moves nothing, so the points
+ * after the last state at or before the end time stay as they are). states: num_states x 8 doubles =
+ * timestamp, position xyz, attitude quaternion in Eigen's coefficient order x y z w.  points are changed in
+ * place.  Returns the number of leading points transformed, or -1 (nothing touched) where the reference
+ * would leave its state queue: no state at or before the last point's time, or none after it. */
+int64_t oracle_deskew(size_t n, double* points, const double* point_time, size_t num_states,
+                      const double* states);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

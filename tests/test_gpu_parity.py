@@ -687,3 +687,60 @@ def test_host_mirror_cloud_preprocessor(oracle):
     assert np.array_equal(gp, rp) and np.array_equal(gc, rc)
     gp, gc = pre.voxelDownsampleAndEstimateCovariances(np.zeros((0, 3)))
     assert gp.shape == (0, 3) and gc.shape == (0, 9)
+
+
+# ---- N4: deskew on the device (CloudPreprocessor.cpp:25-74) -----------------------------------------
+@pytest.mark.parametrize("n,states,jitter", [(5_000, 48, 0.0), (120_000, 45, 0.0), (30_000, 48, 2e-3)])
+def test_deskew_matches_oracle(gpu_ctx, oracle, n, states, jitter):
+    from eskf_lio_amd import synth
+    st = synth.make_imu_states(states, seed=n)
+    t = synth.make_point_times(n, st[1, 0] + 1e-4, st[-3, 0] + 0.4 / 400.0, seed=n, jitter=jitter)
+    pts = synth.make_lidar_scan(n, seed=n)
+    gp, gdone = gpu_ctx.deskew(pts, t, st)
+    rp, rdone = oracle.deskew(pts, t, st)
+    assert gdone == rdone and 0 < gdone < n                        # segment bounds: integer work, exact
+    assert np.array_equal(gp, rp)                                  # same formulas, same order, no contraction
+    assert np.array_equal(gp[gdone:], pts[gdone:])
+
+
+def test_deskew_edge_cases(gpu_ctx, oracle):
+    from eskf_lio_amd import synth
+    st = synth.make_imu_states(12, seed=4)
+    t = synth.make_point_times(300, st[1, 0] + 1e-4, st[-3, 0] + 1e-3, seed=4)
+    pts = synth.make_lidar_scan(300, seed=4)
+    for states, times in ((st[:3], t), (st, t - 1.0)):            # queue does not bracket the sweep's end
+        gp, done = gpu_ctx.deskew(pts, times, states)
+        assert done == -1 == oracle.deskew(pts, times, states)[1] and np.array_equal(gp, pts)
+    assert gpu_ctx.deskew(np.zeros((0, 3)), np.zeros(0), st)[1] == 0
+    # all points before the first state: one segment, moved with the first state's pose
+    early = np.full(300, st[0, 0] - 1e-3)
+    early[-1] = st[5, 0] + 1e-4
+    gp, done = gpu_ctx.deskew(pts, early, st)
+    rp, rdone = oracle.deskew(pts, early, st)
+    assert done == rdone == 299 and np.array_equal(gp, rp)
+    # times equal to a state's timestamp belong to the NEXT state (strict <), and a sweep whose times
+    # go backwards is cut where the reference's sequential walk cuts it
+    back = t.copy()
+    back[100:200] = back[100:200][::-1]
+    back[50] = st[4, 0]
+    gp, done = gpu_ctx.deskew(pts, back, st)
+    rp, rdone = oracle.deskew(pts, back, st)
+    assert done == rdone and np.array_equal(gp, rp)
+
+
+def test_host_mirror_cloud_preprocessor_process(oracle):
+    """CloudPreprocessor::process through the C++ mirror: LiDAR->IMU extrinsic, deskew, scan preparation
+    (reference src/CloudPreprocessor.cpp:8-23) against the same chain of oracle calls."""
+    from eskf_lio_amd import host, synth
+    n = 20_000
+    st = synth.make_imu_states(48, seed=31)
+    t = synth.make_point_times(n, st[1, 0] + 1e-4, st[-3, 0] + 1e-3, seed=31)
+    pts = synth.make_lidar_scan(n, seed=31)
+    T_il = synth.se3_to_SE3(np.array([0.05, -0.02, 0.1, 0.01, -0.02, 0.03]))
+    gp, gc = host.CloudPreprocessor(0.3, T_il).process(st, pts, t)
+    moved, _ = oracle.transform(pts, np.tile(np.eye(3).reshape(9), (n, 1)), T_il)   # Open3D Transform
+    desk, done = oracle.deskew(moved, t, st)
+    rp, rc, _ = oracle.preprocess(desk, 0.3, 30)
+    assert done > 0 and np.array_equal(gp, rp) and np.array_equal(gc, rc)
+    with pytest.raises(RuntimeError):
+        host.CloudPreprocessor(0.3).process(st[:3], pts, t)         # states end before the sweep does

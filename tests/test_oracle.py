@@ -304,3 +304,48 @@ def test_preprocess_known_answers(oracle):
     assert len(ix) == 2 and np.allclose(_cov_mats(oc), np.diag([1.0, 1.0, 1e-2]), atol=1e-15)
     # empty scan
     assert len(oracle.preprocess(np.zeros((0, 3)), 0.3, 30)[2]) == 0
+
+
+# ---- deskew: oracle vs the numpy restatement ------------------------------------
+def _deskew_case(n=5_000, states=48, jitter=0.0, seed=9):
+    st = synth.make_imu_states(states, seed=seed)
+    # the sweep starts a little after the first state and ends between the last two states but one
+    t = synth.make_point_times(n, st[1, 0] + 1e-4, st[-3, 0] + 0.4 / 400.0, seed=seed, jitter=jitter)
+    pts = synth.make_lidar_scan(n, seed=seed)
+    return pts, t, st
+
+
+def test_deskew_oracle_matches_numpy(oracle):
+    for jitter in (0.0, 2e-3):
+        pts, t, st = _deskew_case(jitter=jitter)
+        op, done = oracle.deskew(pts, t, st)
+        npts, ndone = npo.deskew(pts, t, st)
+        assert done == ndone and 0 < done < len(pts)
+        assert np.abs(op - npts).max() < 1e-11
+        assert np.array_equal(op[done:], pts[done:])               # the tail of the sweep is left as it is
+        assert np.abs(op[:done] - pts[:done]).max() > 1e-3          # and the rest really moved
+
+
+def test_deskew_known_answers(oracle):
+    pts, t, st = _deskew_case(n=400, states=12)
+    # K9: a sensor at rest: every pose equals the end pose, nothing moves (up to rounding of R^T R)
+    rest = st.copy()
+    rest[:, 1:4] = [1.0, -2.0, 0.5]
+    rest[:, 4:] = [0.0, 0.0, np.sin(0.2), np.cos(0.2)]
+    op, done = oracle.deskew(pts, t, rest)
+    assert done > 0 and np.abs(op - pts).max() < 1e-13
+    # K10: pure translation along x at 2 m/s: a point taken dt before the end moves by about -2 dt in x...
+    lin = st.copy()
+    lin[:, 1:4] = np.stack([2.0 * (st[:, 0] - st[0, 0]), 0 * st[:, 0], 0 * st[:, 0]], axis=1)
+    lin[:, 4:] = [0.0, 0.0, 0.0, 1.0]
+    op, done = oracle.deskew(pts, t, lin)
+    shift = op[:done] - pts[:done]
+    assert np.abs(shift[:, 1:]).max() == 0.0
+    # ...where the pose used is the one of the first state at or after the point's time (IMU period 2.5 ms)
+    state_of = np.searchsorted(lin[:, 0], t[:done], side="right")
+    expect = lin[state_of, 1] - 2.0 * (t[-1] - st[0, 0])
+    assert np.abs(shift[:, 0] - expect).max() < 1e-4
+    # the state queue does not bracket the end of the sweep: the reference would run off it
+    assert oracle.deskew(pts, t, st[:3])[1] == -1                   # no state after the last point
+    assert oracle.deskew(pts, t - 1.0, st)[1] == -1                 # no state at or before it
+    assert oracle.deskew(np.zeros((0, 3)), np.zeros(0), st)[1] == 0
