@@ -1101,7 +1101,6 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
     *transformed = -1;
     return VGICP_OK;
   }
-  const size_t used = (size_t)before + 2;  // states 0 .. the first one after the end of the sweep
   const double* s1 = states + 8 * before;
   const double* s2 = s1 + 8;
   const double factor = (t_end - s1[0]) / (s2[0] - s1[0] + 1e-6);
@@ -1111,6 +1110,15 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
   quat_matrix(q, end_pose.R);
   for (int k = 0; k < 3; ++k) end_pose.t[k] = s1[1 + k] + factor * (s2[1 + k] - s1[1 + k]);
   const Pose12 end_inv = pose_inverted(end_pose);
+  // The reference walks ALL states (its deque is never trimmed, so it grows by 400 entries per second). A
+  // state whose timestamp is not above the smallest capture time can never take a point (the walk's
+  // test "pointTime < timestamp" fails for whichever point it looks at), so leading ones are skipped here.
+  double earliest = point_time[0];
+  for (size_t i = 1; i < n; ++i) earliest = point_time[i] < earliest ? point_time[i] : earliest;
+  size_t first = 0;
+  while (first + 1 < (size_t)before + 2 && states[8 * first] <= earliest) ++first;
+  states += 8 * first;
+  const size_t used = (size_t)before + 2 - first;  // up to the first state after the end of the sweep
   std::vector<double> host(used * 13);  // [state times | 12 doubles per state]
   for (size_t s = 0; s < used; ++s) {
     Pose12 T;

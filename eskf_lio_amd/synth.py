@@ -277,6 +277,67 @@ def make_point_times(num_points: int, t_first: float, t_last: float, seed: int =
     return np.ascontiguousarray(t)
 
 
+# ---- a moving sensor: IMU + LiDAR stream for the replay harness (eskf_lio_amd/replay.py) -------------
+STREAM_T0 = 1000.0          # absolute time of the end of the first sweep
+STREAM_GRAVITY = np.array([0.0, 0.0, 9.805])   # the reference's convention: v' = R a + g (ErrorStateKF.cpp:96-98)
+
+
+def stream_pose(tau):
+    """Pose of the IMU in the world, tau seconds after the end of the first sweep (at rest before it).
+    -> (R [..., 3, 3], p [..., 3], world acceleration [..., 3]); vectorised over tau."""
+    tau = np.asarray(tau, dtype=np.float64)
+    s = np.maximum(tau, 0.0)
+    moving = (tau > 0.0).astype(np.float64)
+    amp = np.array([1.5, 0.5, 0.05])
+    om = np.array([2.0, 1.4, 2.6])
+    p = amp * (1.0 - np.cos(om * s[..., None]))
+    acc = amp * om * om * np.cos(om * s[..., None]) * moving[..., None]
+    yaw, pitch, roll = 0.25 * (1 - np.cos(1.6 * s)), 0.03 * (1 - np.cos(2.2 * s)), 0.02 * (1 - np.cos(1.4 * s))
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    R = np.empty(tau.shape + (3, 3))
+    R[..., 0, 0], R[..., 0, 1], R[..., 0, 2] = cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr
+    R[..., 1, 0], R[..., 1, 1], R[..., 1, 2] = sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr
+    R[..., 2, 0], R[..., 2, 1], R[..., 2, 2] = -sp, cp * sr, cp * cr
+    return R, p, acc
+
+
+def make_sensor_stream(frames: int = 5, points_per_frame: int = 8_000, seed: int = SCAN_SEED,
+                       world_points: int = 60_000, imu_rate: float = 400.0, sweep: float = 0.1):
+    """-> (events, truth): events = [(arrival time, ("imu", t, gyro, accel) | ("lidar", points float32-exact,
+    pointTime))] sorted by arrival; truth = [(end time, 4x4 pose)] per LiDAR frame. The sensor sits still
+    until the first sweep ends, then moves along stream_pose(); every LiDAR point is seen from the pose at
+    its own capture time, so later sweeps are motion-distorted like a real spinning sensor's."""
+    world = make_lidar_scan(world_points, seed=seed, extent=25.0)
+    world[:, 2] -= 1.2                                            # the IMU rides 1.2 m above the ground
+    events, truth = [], []
+    n_imu = int(round((0.02 + sweep * (frames - 1) + 0.0125) * imu_rate)) + 1
+    tau_imu = -0.0213 + np.arange(n_imu) / imu_rate               # never exactly on a sweep boundary
+    R, _, acc = stream_pose(tau_imu)
+    d = 1e-5
+    Rm, _, _ = stream_pose(tau_imu - d)
+    Rp, _, _ = stream_pose(tau_imu + d)
+    dR = np.einsum("nji,njk->nik", Rm, Rp)                        # R(t-d)^T R(t+d) ~ I + 2 d [w]x
+    gyro = np.stack([dR[:, 2, 1] - dR[:, 1, 2], dR[:, 0, 2] - dR[:, 2, 0], dR[:, 1, 0] - dR[:, 0, 1]], axis=1) / (4 * d)
+    accel = np.einsum("nji,nj->ni", R, acc - STREAM_GRAVITY)      # R^T (a - g)
+    for t, w, a in zip(tau_imu, gyro, accel):
+        events.append((STREAM_T0 + t, ("imu", STREAM_T0 + t, w.copy(), a.copy())))
+    idx_all = np.arange(world_points, dtype=np.uint64)
+    for k in range(frames):
+        end = sweep * k
+        pick = np.sort(np.argsort(rand_u64(seed + 17 * (k + 1), 400, idx_all), kind="stable")[:points_per_frame])
+        tau = np.linspace(end - sweep + 1e-4, end, points_per_frame)
+        Rk, pk, _ = stream_pose(tau)
+        local = np.einsum("nji,nj->ni", Rk, world[pick] - pk)     # R(t_i)^T (W_i - p(t_i))
+        local = local.astype(np.float32).astype(np.float64)       # what a PointCloud2 carries
+        events.append((STREAM_T0 + end + 5e-4, ("lidar", np.ascontiguousarray(local), STREAM_T0 + tau)))
+        Re, pe, _ = stream_pose(np.array(end))
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = Re, pe
+        truth.append((STREAM_T0 + end, T))
+    events.sort(key=lambda e: e[0])
+    return events, truth
+
+
 # The configurations BASELINE.json names (C1, C2, C5): points, voxels.
 CONFIGS = {
     "C1": (5_000, 50_000),

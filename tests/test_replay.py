@@ -1,0 +1,156 @@
+"""the ROS-free replay harness (eskf_lio_amd/replay.py).
+
+CPU part: the wire formats (CDR encodings of sensor_msgs/Imu and sensor_msgs/PointCloud2 inside a rosbag2
+sqlite3 file), the estimator restatement and the frame loop, driven by the oracle. GPU part: the same
+loop driven by the MI355X path, compared with the oracle-driven run frame by frame."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import pose_error
+from eskf_lio_amd import replay, synth
+from replay_backends import OracleBackend, stream_events
+
+
+@pytest.fixture(scope="module")
+def stream():
+    events, truth = synth.make_sensor_stream(frames=5, points_per_frame=6_000)
+    return stream_events(replay, events), truth
+
+
+@pytest.fixture(scope="module")
+def oracle_run(stream, oracle):
+    events, _ = stream
+    backend = OracleBackend(replay.DEFAULT_CONFIG, oracle)
+    odo = replay.Odometry(replay.DEFAULT_CONFIG, backend)
+    return odo.run([(a, _clone(m)) for a, m in events]), backend
+
+
+def _clone(m):
+    if isinstance(m, replay.ImuMeasurement):
+        return replay.ImuMeasurement(m.timestamp, m.angularVelocity.copy(), m.acceleration.copy())
+    return replay.LidarMeasurement(m.points.copy(), m.pointTime.copy())
+
+
+def test_cdr_messages_round_trip():
+    imu = replay.ImuMeasurement(1234.567891234, np.array([0.1, -0.2, 0.3]), np.array([9.0, -0.5, 0.25]))
+    back = replay.decode_imu(replay.encode_imu(imu))
+    assert abs(back.timestamp - imu.timestamp) < 2e-9            # stamp travels as sec + nanosec
+    assert np.array_equal(back.angularVelocity, imu.angularVelocity)
+    assert np.array_equal(back.acceleration, imu.acceleration)
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(257, 3)).astype(np.float32).astype(np.float64)
+    t = 1000.0 + np.sort(rng.uniform(0, 0.1, size=257))
+    cloud = replay.decode_pointcloud2(replay.encode_pointcloud2(pts, t))
+    assert np.array_equal(cloud.points, pts) and np.array_equal(cloud.pointTime, t)
+    assert cloud.startTime == t[0] and cloud.endTime == t[-1]    # Subscriber.hpp:97-98
+    with pytest.raises(ValueError):
+        replay.decode_imu(b"\x07\x07")
+
+
+def test_rosbag2_round_trip_and_player_order(stream, tmp_path):
+    events, _ = stream
+    path = str(tmp_path / "synthetic_0.db3")
+    replay.write_rosbag2(path, reversed(events))                  # written out of order on purpose
+    back = replay.read_rosbag2(path)
+    assert len(back) == len(events)
+    assert all(b[0] <= c[0] for b, c in zip(back, back[1:]))      # played in bag-time order
+    for (a0, m0), (a1, m1) in zip(events, back):
+        assert type(m0) is type(m1) and abs(a0 - a1) < 1e-9
+        if isinstance(m0, replay.LidarMeasurement):
+            assert np.array_equal(m0.points, m1.points) and np.array_equal(m0.pointTime, m1.pointTime)
+        else:
+            assert abs(m0.timestamp - m1.timestamp) < 2e-9 and np.array_equal(m0.acceleration, m1.acceleration)
+    with pytest.raises(FileNotFoundError):
+        replay.read_rosbag2(str(tmp_path / "missing.db3"))
+
+
+def test_rotation_helpers_are_consistent():
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        r = rng.normal(size=3)
+        r = r / np.linalg.norm(r) * rng.uniform(0.0, 3.0)        # below pi: the vector is recovered as it is
+        q = replay.rotation_vector_to_quat(r)
+        R = replay.quat_to_matrix(q)
+        assert np.allclose(R, synth.se3_to_SE3(np.concatenate([np.zeros(3), r]))[:3, :3], atol=1e-13)
+        assert np.allclose(replay.rotation_matrix_to_vector(R), r, atol=1e-12)
+        q2 = replay.matrix_to_quat(R)
+        assert np.allclose(q2 * np.sign(q2[3]), q * np.sign(q[3]), atol=1e-13)
+    a, b = replay.rotation_vector_to_quat(np.array([0.3, 0.1, -0.2])), replay.rotation_vector_to_quat(np.array([-0.1, 0.4, 0.2]))
+    assert np.allclose(replay.quat_to_matrix(replay.quat_multiply(a, b)), replay.quat_to_matrix(a) @ replay.quat_to_matrix(b))
+    assert np.array_equal(replay.rotation_matrix_to_vector(np.eye(3)), np.zeros(3))
+
+
+def test_filter_prediction_follows_the_imu():
+    """ErrorStateKF::process alone (no update): integrating the stream's IMU reproduces the motion."""
+    events, truth = synth.make_sensor_stream(frames=3, points_per_frame=10)
+    kf = replay.ErrorStateKF(replay.DEFAULT_CONFIG, align=None)
+    kf.initialize(synth.STREAM_T0)
+    for _, e in events:
+        if e[0] == "imu" and e[1] >= synth.STREAM_T0:
+            kf.process(replay.ImuMeasurement(e[1], e[2], e[3]))
+    last = kf.getStates()[-1]
+    R, p, _ = synth.stream_pose(np.array(last.timestamp - synth.STREAM_T0))
+    assert np.linalg.norm(last.position - p) < 5e-3               # 0.2 s of dead reckoning at 400 Hz
+    assert np.abs(replay.quat_to_matrix(last.attitude) - R).max() < 1e-3
+    assert np.all(np.linalg.eigvalsh(last.P) > 0) and last.P[0, 0] > 1e-3   # covariance grows, stays PD
+    before = len(kf.getStates())
+    kf.process(replay.ImuMeasurement(last.timestamp - 1.0, np.zeros(3), np.zeros(3)))   # dt < 0: dropped
+    assert len(kf.getStates()) == before
+
+
+def test_oracle_driven_replay_tracks_the_motion(stream, oracle_run, tmp_path):
+    _, truth = stream
+    traj, backend = oracle_run
+    assert len(traj) == len(truth) and all(2 <= it <= 10 for it in backend.iterations)
+    for (stamp, T), (tstamp, G) in zip(traj, truth):
+        dt, dr = pose_error(T, G)
+        assert stamp == tstamp and dt < 0.02 and dr < 2e-3         # centimetre-level odometry
+    path = str(tmp_path / "traj.tum")
+    replay.write_tum(path, traj)
+    rows = np.loadtxt(path)
+    assert rows.shape == (len(traj), 8) and np.allclose(np.linalg.norm(rows[:, 4:], axis=1), 1.0, atol=1e-8)
+    assert np.allclose(rows[:, 1:4], [T[:3, 3] for _, T in traj], atol=1e-8)
+
+
+def test_replay_from_a_bag_equals_replay_from_memory(stream, oracle, oracle_run, tmp_path):
+    events, _ = stream
+    path = str(tmp_path / "run.db3")
+    replay.write_rosbag2(path, events)
+    backend = OracleBackend(replay.DEFAULT_CONFIG, oracle)
+    traj = replay.Odometry(replay.DEFAULT_CONFIG, backend).run(replay.read_rosbag2(path))
+    for (s0, T0), (s1, T1) in zip(oracle_run[0], traj):
+        assert abs(s0 - s1) < 1e-9 and np.abs(T0 - T1).max() < 1e-7   # stamps are quantised to nanoseconds
+
+
+def test_frames_wait_for_the_imu(stream, oracle):
+    """Odometry.cpp:66-70: a sweep is not processed until an IMU sample at or after its end has arrived."""
+    events, _ = stream
+    backend = OracleBackend(replay.DEFAULT_CONFIG, oracle)
+    odo = replay.Odometry(replay.DEFAULT_CONFIG, backend)
+    lidar_seen = 0
+    for arrival, m in events:
+        odo.run([(arrival, _clone(m))])
+        if isinstance(m, replay.LidarMeasurement):
+            lidar_seen += 1
+            if lidar_seen == 2:
+                # second sweep arrived, the IMU sample covering its end has not: still only the first pose
+                assert len(odo.trajectory) == 1 and odo.lidar is not None
+    assert len(odo.trajectory) == lidar_seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_map", [False, True])
+def test_gpu_driven_replay_matches_the_oracle_driven_one(stream, oracle_run, device_map):
+    """The whole per-frame chain on the MI355X (extrinsic -> vgicp_deskew -> vgicp_preprocess -> vgicp_align ->
+    map update) against the same chain on the CPU, frame by frame."""
+    events, truth = stream
+    backend = replay.GpuBackend(replay.DEFAULT_CONFIG, device_resident_map=device_map)
+    traj = replay.Odometry(replay.DEFAULT_CONFIG, backend).run([(a, _clone(m)) for a, m in events])
+    ref_traj, ref_backend = oracle_run
+    assert len(traj) == len(ref_traj) == len(truth)
+    assert backend.iterations == ref_backend.iterations               # same Gauss-Newton rounds per frame
+    for (s0, T0), (s1, T1) in zip(ref_traj, traj):
+        dt, dr = pose_error(T1, T0)
+        assert s0 == s1 and dt < 1e-8 and dr < 1e-8
