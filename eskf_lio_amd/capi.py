@@ -28,6 +28,7 @@ EXPORTS = (
     "vgicp_map_insert_scan", "vgicp_map_insert_resident", "vgicp_map_evict", "vgicp_map_export",
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
     "vgicp_accumulate", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
+    "vgicp_scan_prepare", "vgicp_scan_download",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
 )
 
@@ -87,6 +88,9 @@ def load_library() -> C.CDLL:
     lib.vgicp_accumulate.argtypes = [vp, sz, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64)]
     lib.vgicp_match.argtypes = [vp, sz, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64), C.POINTER(sz)]
     lib.vgicp_voxel_index.argtypes = [vp, sz, dp, ip]
+    lib.vgicp_scan_prepare.argtypes = [vp, sz, dp, dp, sz, dp, dp, C.c_double, C.c_int, C.POINTER(sz),
+                                       C.POINTER(C.c_int64)]
+    lib.vgicp_scan_download.argtypes = [vp, sz, dp, dp, C.POINTER(sz)]
     lib.vgicp_deskew.argtypes = [vp, sz, dp, dp, sz, dp, C.POINTER(C.c_int64)]
     lib.vgicp_preprocess.argtypes = [vp, sz, dp, C.c_double, C.c_int, sz, dp, dp, C.POINTER(C.c_uint64),
                                      C.POINTER(sz)]
@@ -363,6 +367,31 @@ class Context:
         self._check(self._lib.vgicp_deskew(self._h, pts.shape[0], _dp(pts), _dp(t), st.shape[0], _dp(st),
                                            C.byref(done)))
         return pts, int(done.value)
+
+    def scan_prepare(self, points, point_time=None, states=None, extrinsic=None, voxel_size: float = 0.3,
+                     knn: int = 30):
+        """CloudPreprocessor::process on the device, the prepared scan stays resident -> (kept, deskewed)."""
+        pts = _f64(points, 3)
+        n = pts.shape[0]
+        st = _f64(states, 8) if states is not None and len(states) else np.zeros((0, 8))
+        t = np.ascontiguousarray(point_time, dtype=np.float64).reshape(-1) if point_time is not None else np.zeros(0)
+        if st.shape[0] and t.shape[0] != n:
+            raise ValueError("one capture time per point")
+        ext = pose_to_abi(extrinsic) if extrinsic is not None else None
+        kept, moved = C.c_size_t(0), C.c_int64(0)
+        self._check(self._lib.vgicp_scan_prepare(self._h, n, _dp(pts), _dp(t) if t.size else None, st.shape[0],
+                                                 _dp(st) if st.size else None, _dp(ext) if ext is not None else None,
+                                                 float(voxel_size), int(knn), C.byref(kept), C.byref(moved)))
+        return kept.value, int(moved.value)
+
+    def scan_download(self):
+        """The resident scan -> (points n x 3, covs n x 9)."""
+        n = C.c_size_t(0)
+        self._check(self._lib.vgicp_scan_download(self._h, 0, None, None, C.byref(n)))   # size query
+        cap = n.value
+        pts, covs = np.zeros((cap, 3)), np.zeros((cap, 9))
+        self._check(self._lib.vgicp_scan_download(self._h, cap, _dp(pts), _dp(covs), C.byref(n)))
+        return pts[:n.value], covs[:n.value]
 
     # -- multi-GPU --
     def comm_unique_id(self) -> bytes:

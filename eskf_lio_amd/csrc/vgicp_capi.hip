@@ -967,33 +967,22 @@ int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* k
   return VGICP_OK;
 }
 
-int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxel_size, int knn,
-                     size_t capacity, double* out_points, double* out_covs, uint64_t* out_index,
-                     size_t* kept) {
-  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
-  if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
-  *kept = 0;
-  if (!(voxel_size > 0.0)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "voxel_size must be positive");
-  if (knn < 1 || knn > preprocess_max_knn())
-    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "knn must be in [1, " + std::to_string(preprocess_max_knn()) + "]");
-  if (n == 0) return VGICP_OK;
-  if (!points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
-  if (n > 0x7FFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
-  VG_HIP(ctx, hipSetDevice(ctx->device));
-  // stage: [points 3n][out points 3n][out covs 9n][out index n][scratch]
-  const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
-  const size_t cb = (n * 9 * sizeof(double) + 255) & ~size_t(255);
-  const size_t ib = (n * sizeof(uint64_t) + 255) & ~size_t(255);
-  const size_t sb = preprocess_scratch_bytes((uint32_t)n);
-  int rc = ensure_stage(ctx, pb + pb + cb + ib + sb);
-  if (rc != VGICP_OK) return rc;
-  char* base = static_cast<char*>(ctx->d_stage);
-  const double* d_pts = reinterpret_cast<const double*>(base);
-  double* d_out_pts = reinterpret_cast<double*>(base + pb);
-  double* d_out_covs = reinterpret_cast<double*>(base + 2 * pb);
-  unsigned long long* d_out_idx = reinterpret_cast<unsigned long long*>(base + 2 * pb + cb);
-  void* scratch = base + 2 * pb + cb + ib;
-  VG_HIP(ctx, hipMemcpyAsync(base, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+namespace {
+int ensure_cells(vgicp_ctx* ctx, size_t need) {
+  if (need <= ctx->cells_bytes) return VGICP_OK;
+  if (ctx->d_cells) VG_HIP(ctx, hipFree(ctx->d_cells));
+  ctx->d_cells = nullptr;
+  ctx->cells_bytes = 0;
+  VG_HIP(ctx, hipMalloc(&ctx->d_cells, need));
+  ctx->cells_bytes = need;
+  return VGICP_OK;
+}
+
+// The scan preparation on points that are already on the device; outputs stay on the device. One host
+// synchronisation in the middle (number of kept points and of octree cells). capacity bounds *kept.
+int preprocess_on_device(vgicp_ctx* ctx, const double* d_pts, size_t n, double voxel_size, int knn, void* scratch,
+                         size_t capacity, double* d_out_pts, double* d_out_covs, unsigned long long* d_out_idx,
+                         uint32_t* kept) {
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), ctx->stream));
   VG_HIP(ctx, launch_preprocess_sort(ctx->stream, d_pts, (uint32_t)n, voxel_size, scratch, ctx->d_counters));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1001,29 +990,64 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
   const uint32_t m = ctx->h_counters[0], cells = ctx->h_counters[1];
   *kept = m;
   if (m > capacity) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "output capacity smaller than the number of occupied voxels");
-  if (!out_points || !out_covs) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL output pointer");
   const uint64_t entries = preprocess_cell_entries(cells);
-  const size_t need = preprocess_cell_bytes(entries);
-  if (need > ctx->cells_bytes) {
-    if (ctx->d_cells) VG_HIP(ctx, hipFree(ctx->d_cells));
-    ctx->d_cells = nullptr;
-    ctx->cells_bytes = 0;
-    VG_HIP(ctx, hipMalloc(&ctx->d_cells, need));
-    ctx->cells_bytes = need;
-  }
+  int rc = ensure_cells(ctx, preprocess_cell_bytes(entries));
+  if (rc != VGICP_OK) return rc;
+  const int debug = std::getenv("VGICP_DEBUG_PREP") ? std::atoi(std::getenv("VGICP_DEBUG_PREP")) : 0;
   VG_HIP(ctx, launch_preprocess_finish(ctx->stream, d_pts, (uint32_t)n, voxel_size, knn, m, scratch, ctx->d_cells,
-                                       entries, d_out_pts, d_out_covs, d_out_idx, ctx->d_counters,
-                                       std::getenv("VGICP_DEBUG_PREP") ? std::atoi(std::getenv("VGICP_DEBUG_PREP")) : 0));
+                                       entries, d_out_pts, d_out_covs, d_out_idx, ctx->d_counters, debug));
+  if (debug) {
+    VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::fprintf(stderr, "[vgicp prep] kept %u cells %u queries that spilled %u | point batches total %u (%.1f/query) max %u | cells taken total %u (%.1f/query) max %u | queries starting above the voxel level: %u\n",
+                 m, cells, ctx->h_counters[2], ctx->h_counters[3], ctx->h_counters[3] / (double)(m ? m : 1), ctx->h_counters[4],
+                 ctx->h_counters[5], ctx->h_counters[5] / (double)(m ? m : 1), ctx->h_counters[6], ctx->h_counters[7]);
+  }
+  return VGICP_OK;
+}
+
+int check_preprocess_args(vgicp_ctx* ctx, size_t n, double voxel_size, int knn) {
+  if (!(voxel_size > 0.0)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "voxel_size must be positive");
+  if (knn < 1 || knn > preprocess_max_knn())
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "knn must be in [1, " + std::to_string(preprocess_max_knn()) + "]");
+  if (n > 0x7FFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
+  return VGICP_OK;
+}
+}  // namespace
+
+int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxel_size, int knn,
+                     size_t capacity, double* out_points, double* out_covs, uint64_t* out_index,
+                     size_t* kept) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
+  *kept = 0;
+  int rc = check_preprocess_args(ctx, n, voxel_size, knn);
+  if (rc != VGICP_OK) return rc;
+  if (n == 0) return VGICP_OK;
+  if (!points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  // stage: [points 3n][out points 3n][out covs 9n][out index n][scratch]
+  const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
+  const size_t cb = (n * 9 * sizeof(double) + 255) & ~size_t(255);
+  const size_t ib = (n * sizeof(uint64_t) + 255) & ~size_t(255);
+  const size_t sb = preprocess_scratch_bytes((uint32_t)n);
+  rc = ensure_stage(ctx, pb + pb + cb + ib + sb);
+  if (rc != VGICP_OK) return rc;
+  char* base = static_cast<char*>(ctx->d_stage);
+  double* d_out_pts = reinterpret_cast<double*>(base + pb);
+  double* d_out_covs = reinterpret_cast<double*>(base + 2 * pb);
+  unsigned long long* d_out_idx = reinterpret_cast<unsigned long long*>(base + 2 * pb + cb);
+  VG_HIP(ctx, hipMemcpyAsync(base, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  uint32_t m = 0;
+  rc = preprocess_on_device(ctx, reinterpret_cast<const double*>(base), n, voxel_size, knn, base + 2 * pb + cb + ib,
+                            out_points && out_covs ? capacity : 0, d_out_pts, d_out_covs, d_out_idx, &m);
+  *kept = m;
+  if (rc != VGICP_OK) return rc;
   VG_HIP(ctx, hipMemcpyAsync(out_points, d_out_pts, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipMemcpyAsync(out_covs, d_out_covs, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (out_index)
     VG_HIP(ctx, hipMemcpyAsync(out_index, d_out_idx, (size_t)m * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (std::getenv("VGICP_DEBUG_PREP"))
-    std::fprintf(stderr, "[vgicp prep] kept %u cells %u fallback %u | point batches total %u (%.1f/query) max %u | cells taken total %u (%.1f/query) max %u | queries starting above the voxel level: %u\n",
-                 m, cells, ctx->h_counters[2], ctx->h_counters[3], ctx->h_counters[3] / (double)m, ctx->h_counters[4],
-                 ctx->h_counters[5], ctx->h_counters[5] / (double)m, ctx->h_counters[6], ctx->h_counters[7]);
   return VGICP_OK;
 }
 
@@ -1086,21 +1110,15 @@ void quat_slerp(const double a[4], const double b[4], double t, double out[4]) {
 }
 }  // namespace
 
-int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_time, size_t num_states,
-                 const double* states, int64_t* transformed) {
-  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
-  if (!transformed) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "transformed is NULL");
-  *transformed = 0;
-  if (n == 0 || num_states == 0) return VGICP_OK;
-  if (!points || !point_time || !states) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
-  if (n > 0x7FFFFFFFull || num_states > 0x7FFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan or state queue too large");
+namespace {
+// [state times | 12 doubles per state] for the states that can own points; false where the reference would
+// step off its deque (no state at or before the last point's time, or none after it).
+bool deskew_table(size_t n, const double* point_time, size_t num_states, const double* states,
+                  std::vector<double>& host, size_t& used) {
   const double t_end = point_time[n - 1];
   long before = (long)num_states - 1;
   while (before >= 0 && states[8 * before] > t_end) --before;
-  if (before < 0 || (size_t)before + 1 >= num_states) {  // the reference would step off its deque here
-    *transformed = -1;
-    return VGICP_OK;
-  }
+  if (before < 0 || (size_t)before + 1 >= num_states) return false;
   const double* s1 = states + 8 * before;
   const double* s2 = s1 + 8;
   const double factor = (t_end - s1[0]) / (s2[0] - s1[0] + 1e-6);
@@ -1118,8 +1136,8 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
   size_t first = 0;
   while (first + 1 < (size_t)before + 2 && states[8 * first] <= earliest) ++first;
   states += 8 * first;
-  const size_t used = (size_t)before + 2 - first;  // up to the first state after the end of the sweep
-  std::vector<double> host(used * 13);  // [state times | 12 doubles per state]
+  used = (size_t)before + 2 - first;  // up to the first state after the end of the sweep
+  host.assign(used * 13, 0.0);
   for (size_t s = 0; s < used; ++s) {
     Pose12 T;
     quat_matrix(states + 8 * s + 4, T.R);
@@ -1128,6 +1146,24 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
     host[s] = states[8 * s];
     std::memcpy(&host[used + 12 * s], T.R, 9 * sizeof(double));
     std::memcpy(&host[used + 12 * s + 9], T.t, 3 * sizeof(double));
+  }
+  return true;
+}
+}  // namespace
+
+int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_time, size_t num_states,
+                 const double* states, int64_t* transformed) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!transformed) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "transformed is NULL");
+  *transformed = 0;
+  if (n == 0 || num_states == 0) return VGICP_OK;
+  if (!points || !point_time || !states) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
+  if (n > 0x7FFFFFFFull || num_states > 0x7FFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan or state queue too large");
+  std::vector<double> host;
+  size_t used = 0;
+  if (!deskew_table(n, point_time, num_states, states, host, used)) {
+    *transformed = -1;
+    return VGICP_OK;
   }
   VG_HIP(ctx, hipSetDevice(ctx->device));
   const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
@@ -1149,6 +1185,90 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, d_ends + (used - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *transformed = (int64_t)ctx->h_counters[0];
+  return VGICP_OK;
+}
+
+int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
+                       size_t num_states, const double* states, const double extrinsic[16],
+                       double voxel_size, int knn, size_t* kept, int64_t* deskewed) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
+  *kept = 0;
+  if (deskewed) *deskewed = 0;
+  int rc = check_preprocess_args(ctx, n, voxel_size, knn);
+  if (rc != VGICP_OK) return rc;
+  if (ctx->comm) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the prepared scan is whole: not available on a communicator (shards)");
+  if (n > 0 && !points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
+  const bool with_deskew = n > 0 && num_states > 0;
+  if (with_deskew && (!point_time || !states)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
+  if (num_states > 0x7FFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "state queue too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  rc = ensure_scan(ctx, n);
+  if (rc != VGICP_OK) return rc;
+  ctx->scan_ready = false;
+  ctx->n = 0;
+  ctx->stride = ctx->scan_capacity;
+  if (n == 0) {
+    ctx->scan_ready = true;
+    return VGICP_OK;
+  }
+  std::vector<double> host;
+  size_t used = 0;
+  if (with_deskew && !deskew_table(n, point_time, num_states, states, host, used)) {
+    if (deskewed) *deskewed = -1;
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the IMU states do not bracket the end of the sweep");
+  }
+  // stage: [points 3n][times n][state table][segment ends][kept index n][scratch]
+  const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
+  const size_t tb = (n * sizeof(double) + 255) & ~size_t(255);
+  const size_t sb = (used * 13 * sizeof(double) + 255) & ~size_t(255);
+  const size_t eb = (used * sizeof(uint32_t) + 255) & ~size_t(255);
+  const size_t ib = (n * sizeof(uint64_t) + 255) & ~size_t(255);
+  rc = ensure_stage(ctx, pb + tb + sb + eb + ib + preprocess_scratch_bytes((uint32_t)n));
+  if (rc != VGICP_OK) return rc;
+  char* base = static_cast<char*>(ctx->d_stage);
+  double* d_pts = reinterpret_cast<double*>(base);
+  double* d_time = reinterpret_cast<double*>(base + pb);
+  double* d_states = reinterpret_cast<double*>(base + pb + tb);
+  uint32_t* d_ends = reinterpret_cast<uint32_t*>(base + pb + tb + sb);
+  unsigned long long* d_idx = reinterpret_cast<unsigned long long*>(base + pb + tb + sb + eb);
+  void* scratch = base + pb + tb + sb + eb + ib;
+  VG_HIP(ctx, hipMemcpyAsync(d_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (extrinsic) VG_HIP(ctx, launch_transform_points(ctx->stream, d_pts, (uint32_t)n, extrinsic));
+  if (with_deskew) {
+    VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VG_HIP(ctx, hipMemcpyAsync(d_states, host.data(), used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VG_HIP(ctx, launch_deskew(ctx->stream, d_pts, (uint32_t)n, d_time, d_states, (uint32_t)used, d_states + used, d_ends));
+    VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters + 4, d_ends + (used - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  double* aos_pts = ctx->d_scan_aos;
+  double* aos_cov = ctx->d_scan_aos + 3 * ctx->scan_capacity;
+  uint32_t m = 0;
+  rc = preprocess_on_device(ctx, d_pts, n, voxel_size, knn, scratch, n, aos_pts, aos_cov, d_idx, &m);  // syncs
+  if (rc != VGICP_OK) return rc;
+  if (with_deskew && deskewed) *deskewed = (int64_t)ctx->h_counters[4];
+  if (m > 0) VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, m, ctx->d_scan, ctx->stride));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->n = m;
+  ctx->scan_ready = true;
+  *kept = m;
+  return VGICP_OK;
+}
+
+int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double* covs, size_t* n) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!n) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "n is NULL");
+  *n = 0;
+  if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload or vgicp_scan_prepare first");
+  *n = ctx->n;
+  if (ctx->n == 0 || (!points && !covs)) return VGICP_OK;  // both NULL: size query
+  if (capacity < ctx->n) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "capacity smaller than the resident scan");
+  if (!points || !covs) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL output pointer");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  VG_HIP(ctx, hipMemcpyAsync(points, ctx->d_scan_aos, (size_t)ctx->n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(covs, ctx->d_scan_aos + 3 * ctx->scan_capacity, (size_t)ctx->n * 9 * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VGICP_OK;
 }
 

@@ -144,6 +144,7 @@ hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, 
 hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n, double h, int knn, uint32_t m,
                                     void* scratch, void* cell_table, uint64_t table_entries, double* out_pts,
                                     double* out_covs, unsigned long long* out_idx, uint32_t* counters, int debug);
+hipError_t launch_transform_points(hipStream_t s, double* pts, uint32_t n, const double T16[16]);
 // CloudPreprocessor::deskew: ends = scratch of `states` words; poses = 12 doubles per state (R column-major, t)
 hipError_t launch_deskew(hipStream_t s, double* pts, uint32_t n, const double* point_time, const double* state_time,
                          uint32_t states, const double* poses, uint32_t* ends);

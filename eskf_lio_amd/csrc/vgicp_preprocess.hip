@@ -625,6 +625,21 @@ __global__ void deskew_apply_kernel(double* __restrict__ pts, uint32_t n, const 
   pts[3 * (size_t)i + 2] = rz + T[11];
 }
 
+// Open3D PointCloud::Transform on points only: p <- (T [p;1]).xyz / w (what cloud->Transform(T_il) does
+// at src/CloudPreprocessor.cpp:14 before any covariance exists). T: column-major 4x4 in the dispatch packet.
+struct Mat16 { double m[16]; };
+__global__ void transform_points_kernel(double* __restrict__ pts, uint32_t n, Mat16 T) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+  double q[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = T.m[r] * x + T.m[r + 4] * y + T.m[r + 8] * z + T.m[r + 12];
+  pts[3 * (size_t)i] = q[0] / q[3];
+  pts[3 * (size_t)i + 1] = q[1] / q[3];
+  pts[3 * (size_t)i + 2] = q[2] / q[3];
+}
+
 inline uint32_t blocks_for(uint64_t work, uint32_t block) { return (uint32_t)((work + block - 1) / block); }
 __host__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 __host__ inline uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
@@ -730,6 +745,14 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
                      n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
   const int found = knn < (int)n ? knn : (int)n;
   hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, spts, nbr, m, found, out_covs);
+  return hipGetLastError();
+}
+
+hipError_t launch_transform_points(hipStream_t s, double* pts, uint32_t n, const double T16[16]) {
+  if (n == 0) return hipSuccess;
+  Mat16 T;
+  for (int k = 0; k < 16; ++k) T.m[k] = T16[k];
+  hipLaunchKernelGGL(transform_points_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, T);
   return hipGetLastError();
 }
 

@@ -603,3 +603,51 @@ class GpuBackend:
 
     def update_map(self, points, covs, transform, initialize):
         self.map.updateLocalMap(points, covs, transform, initialize)
+
+
+class DeviceBackend:
+    """The frame chain with the scan never leaving the GPU: vgicp_scan_prepare (extrinsic, deskew, preparation)
+    -> vgicp_align_resident -> vgicp_map_insert_resident, straight on the C ABI (eskf_lio_amd/capi.py). Per
+    frame the host sends 32 bytes per raw point and the IMU states, and receives the pose. The map is the
+    device-resident voxel grid; the motion gate of LocalMap::needsMapUpdate (src/LocalMap.cpp:132-147) is a
+    few flops and stays on the host."""
+
+    def __init__(self, config: dict, device: int = 0):
+        from . import capi
+        self.ctx = capi.Context(device)
+        lm = config["local_map"]
+        self.ctx.map_reset(lm["voxel_size"], 0)
+        self.cap = int(lm["max_num_points_per_voxel"])
+        self.gate = (lm["translation_sq_threshold"], lm["cosine_threshold"])
+        self.evict = (bool(lm["remove_distant_points"]), float(lm["distance_threshold"]), float(lm["removing_period"]))
+        self.last_evict = time.perf_counter()
+        self.prev: Optional[np.ndarray] = None
+        self.reg = config["registration"]
+        self.voxel = config["cloud_preprocessor"]["voxel_size"]
+        self.T_il = np.asarray(config["lidar_extrinsic"], dtype=np.float64)
+        self.iterations: List[int] = []
+        self.kept: List[int] = []
+
+    def preprocess(self, states, points, pointTime):
+        kept, _ = self.ctx.scan_prepare(points, pointTime, states, self.T_il, self.voxel, 30)
+        self.kept.append(kept)
+        return None, None                                   # the prepared scan is on the device
+
+    def align(self, points, covs, guess):
+        r = self.ctx.align_resident(guess, self.reg["max_iteration"], self.reg["translation_sq_threshold"],
+                                    self.reg["cosine_threshold"])
+        self.iterations.append(r.iterations)
+        return r.pose
+
+    def update_map(self, points, covs, transform, initialize):
+        if not initialize and self.prev is not None:
+            moved = np.linalg.inv(self.prev) @ transform
+            cosine = 0.5 * (np.trace(moved[:3, :3]) - 1.0)
+            if not (cosine < self.gate[1] or float(moved[:3, 3] @ moved[:3, 3]) > self.gate[0]):
+                self.prev = transform.copy()
+                return
+        self.ctx.map_insert_resident(transform, self.cap)
+        if self.evict[0] and time.perf_counter() - self.last_evict > self.evict[2]:
+            self.ctx.map_evict(transform[:3, 3], self.evict[1])
+            self.last_evict = time.perf_counter()
+        self.prev = transform.copy()

@@ -191,6 +191,23 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
 int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_time, size_t num_states,
                  const double* states, int64_t* transformed);
 
+/* CloudPreprocessor::process (src/CloudPreprocessor.cpp:8-23) in one call with the result LEFT ON THE
+ * DEVICE as the resident scan: extrinsic (Open3D Transform of the points by the column-major 4x4, NULL =
+ * none), deskew (skipped when num_states is 0, like process() with an empty state queue), down-sampling
+ * and covariances.  vgicp_align_resident / vgicp_map_insert_resident then work on it without the scan
+ * ever returning to the host: per frame one upload of 32 bytes per raw point and the pose back — the
+ * frame sequence of src/Odometry.cpp:73-87.  *kept receives the size of the prepared scan, *deskewed
+ * (optional) what vgicp_deskew reports.  Unlike vgicp_deskew, states that do not bracket the end of the
+ * sweep are an error here (VGICP_ERR_BAD_ARGUMENT, *deskewed = -1, no scan resident).  Not available on
+ * a communicator (the resident scan of a rank is a shard there). */
+int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
+                       size_t num_states, const double* states, const double extrinsic[16],
+                       double voxel_size, int knn, size_t* kept, int64_t* deskewed);
+/* Copies the resident scan (vgicp_scan_upload / vgicp_scan_prepare) to the host: points n x 3, covs n x 9
+ * column-major, e.g. for a host-side map or for saving. capacity in points; with both pointers NULL only
+ * *n is written (size query). */
+int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double* covs, size_t* n);
+
 /* ---- multi-GPU: one process per GPU, RCCL all-reduce of the normal equations ----------------
  * Replaces the thread merge of ICP::computeTransform (src/Registration.cpp:71-75) across devices:
  * per iteration one all-reduce (sum) of 28 doubles (21 + 6 + match count) over xGMI.  Rank 0 calls

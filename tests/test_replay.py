@@ -154,3 +154,47 @@ def test_gpu_driven_replay_matches_the_oracle_driven_one(stream, oracle_run, dev
     for (s0, T0), (s1, T1) in zip(ref_traj, traj):
         dt, dr = pose_error(T1, T0)
         assert s0 == s1 and dt < 1e-8 and dr < 1e-8
+
+
+@pytest.mark.gpu
+def test_resident_frame_chain_matches_the_oracle_driven_replay(stream, oracle_run):
+    """vgicp_scan_prepare -> vgicp_align_resident -> vgicp_map_insert_resident: the scan never returns to the
+    host between the raw sweep and the pose; trajectory and round counts equal the CPU chain's."""
+    events, _ = stream
+    backend = replay.DeviceBackend(replay.DEFAULT_CONFIG)
+    traj = replay.Odometry(replay.DEFAULT_CONFIG, backend).run([(a, _clone(m)) for a, m in events])
+    ref_traj, ref_backend = oracle_run
+    assert backend.iterations == ref_backend.iterations and len(traj) == len(ref_traj)
+    for (s0, T0), (s1, T1) in zip(ref_traj, traj):
+        dt, dr = pose_error(T1, T0)
+        assert s0 == s1 and dt < 1e-8 and dr < 1e-8
+    backend.ctx.close()
+
+
+@pytest.mark.gpu
+def test_scan_prepare_equals_the_separate_calls(gpu_ctx, oracle):
+    n = 20_000
+    st = synth.make_imu_states(48, seed=41)
+    t = synth.make_point_times(n, st[1, 0] + 1e-4, st[-3, 0] + 1e-3, seed=41)
+    pts = synth.make_lidar_scan(n, seed=41)
+    T_il = synth.se3_to_SE3(np.array([0.05, -0.02, 0.1, 0.01, -0.02, 0.03]))
+    kept, moved = gpu_ctx.scan_prepare(pts, t, st, T_il, 0.3, 30)
+    gp, gc = gpu_ctx.scan_download()
+    ext, _ = oracle.transform(pts, np.tile(np.eye(3).reshape(9), (n, 1)), T_il)
+    desk, done = oracle.deskew(ext, t, st)
+    rp, rc, _ = oracle.preprocess(desk, 0.3, 30)
+    assert kept == len(rp) and moved == done
+    assert np.array_equal(gp, rp) and np.array_equal(gc, rc)       # the whole chain, bit for bit
+    # no IMU states: process() with an empty queue skips the deskew; no extrinsic either
+    kept, moved = gpu_ctx.scan_prepare(pts, None, None, None, 0.3, 30)
+    gp, gc = gpu_ctx.scan_download()
+    rp, rc, _ = oracle.preprocess(pts, 0.3, 30)
+    assert moved == 0 and np.array_equal(gp, rp) and np.array_equal(gc, rc)
+    # states that do not bracket the sweep are an error and leave no scan behind
+    from eskf_lio_amd.capi import VgicpError
+    with pytest.raises(VgicpError):
+        gpu_ctx.scan_prepare(pts, t, st[:3], None, 0.3, 30)
+    with pytest.raises(VgicpError):
+        gpu_ctx.scan_download()
+    assert gpu_ctx.scan_prepare(np.zeros((0, 3)), None, None, None, 0.3, 30) == (0, 0)
+    assert gpu_ctx.scan_download()[0].shape == (0, 3)

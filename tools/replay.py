@@ -5,6 +5,7 @@ path doing the per-frame work, writes the trajectory in TUM format and prints th
 usage: python tools/replay.py --bag run_0.db3 [--imu-topic /alphasense/imu] [--lidar-topic /hesai/pandar]
        python tools/replay.py --synthetic 20 --points 60000          (GPU box; no recording needed)
 options: --out traj.tum   --device-map (keep the voxel grid on the GPU only)   --write-bag file.db3
+         --resident (the scan never leaves the GPU between the raw sweep and the pose)
 The configuration is the reference's config/hilti_config.yaml as a dict (eskf_lio_amd/replay.py:DEFAULT_CONFIG);
 --config file.yaml overrides it with a file of the reference's own layout."""
 import argparse
@@ -55,6 +56,8 @@ def main():
     ap.add_argument("--out", default="trajectory.tum")
     ap.add_argument("--write-bag", default=None, help="also store the synthetic stream as a rosbag2 file")
     ap.add_argument("--device-map", action="store_true")
+    ap.add_argument("--resident", action="store_true",
+                    help="scan stays on the GPU from the raw sweep to the pose (vgicp_scan_prepare chain)")
     args = ap.parse_args()
     cfg, imu_topic, lidar_topic = replay.DEFAULT_CONFIG, replay.IMU_TOPIC, replay.LIDAR_TOPIC
     if args.config:
@@ -72,7 +75,8 @@ def main():
             replay.write_rosbag2(args.write_bag, events, imu_topic, lidar_topic)
     else:
         ap.error("one of --bag / --synthetic is required")
-    odo = replay.Odometry(cfg, replay.GpuBackend(cfg, device_resident_map=args.device_map))
+    backend = replay.DeviceBackend(cfg) if args.resident else replay.GpuBackend(cfg, device_resident_map=args.device_map)
+    odo = replay.Odometry(cfg, backend)
     traj = odo.run(events)
     replay.write_tum(args.out, traj)
     print(f"{len(traj)} poses -> {args.out}; Gauss-Newton rounds per frame: {odo.backend.iterations}")
