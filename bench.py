@@ -141,9 +141,21 @@ def main():
     ctx = capi.Context(local_rank)
     ctx.map_reset(vmap.voxel_size, n_voxels)
     ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+    shard_error = None
     if use_dist:
-        ctx.comm_init(world, rank, share_unique_id(ctx, rank))
-    ctx.scan_upload(pts[lo:hi], covs[lo:hi])
+        # The module's own RCCL communicator (the sharded loop's all-reduce). If it cannot be set up on this
+        # box the independent-scans mode still runs; every rank has to see the same verdict.
+        try:
+            ctx.comm_init(world, rank, share_unique_id(ctx, rank))
+        except Exception as e:  # noqa: BLE001 - reported in the JSON line
+            shard_error = f"{type(e).__name__}: {e}"
+        bad = torch.tensor([1 if shard_error else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) and shard_error is None:
+            shard_error = "communicator set-up failed on another rank"
+            ctx.comm_destroy()
+    if shard_error is None:
+        ctx.scan_upload(pts[lo:hi], covs[lo:hi])
 
     def fence():
         torch.cuda.synchronize()
@@ -164,7 +176,8 @@ def main():
         own_pts, own_covs = synth.make_uniform_scan(n_points, vmap, seed=synth.SCAN_SEED + rank)
         solo.scan_upload(own_pts, own_covs)              # rank 0 keeps the common scan (seed + 0)
         timing = {}
-        for name, c in (("shard", ctx), ("replicate", solo)):
+        modes = (("replicate", solo),) if shard_error else (("shard", ctx), ("replicate", solo))
+        for name, c in modes:
             for _ in range(2):
                 c.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
             fence()
@@ -176,12 +189,14 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)     # every rank sees the same numbers -> same choice
             timing[name] = float(t.item())
         want = os.environ.get("BENCH_SHARDING", "auto")
-        rate = {"shard": n_points * ITERATIONS / timing["shard"],                 # one scan per step
-                "replicate": world * n_points * ITERATIONS / timing["replicate"]}  # one scan per rank per step
-        mode = want if want in ("shard", "replicate") else max(rate, key=rate.get)
-        tuning = {"policy": want, "ms_per_step_shard": timing["shard"] * 1e3,
-                  "ms_per_step_replicate": timing["replicate"] * 1e3,
-                  "points_per_s_shard": rate["shard"], "points_per_s_replicate": rate["replicate"]}
+        rate = {"replicate": world * n_points * ITERATIONS / timing["replicate"]}   # one scan per rank per step
+        if "shard" in timing:
+            rate["shard"] = n_points * ITERATIONS / timing["shard"]                  # one scan per step
+        mode = want if want in rate else max(rate, key=rate.get)
+        tuning = {"policy": want, "ms_per_step_replicate": timing["replicate"] * 1e3,
+                  "points_per_s_replicate": rate["replicate"],
+                  "ms_per_step_shard": timing["shard"] * 1e3 if "shard" in timing else None,
+                  "points_per_s_shard": rate.get("shard"), "shard_error": shard_error}
         if mode == "replicate":
             run_ctx, n_local = solo, n_points
 
@@ -222,7 +237,7 @@ def main():
     achieved = bytes_per_launch / span_s / 1e9
 
     sharded = None
-    if use_dist:  # a collective: every rank takes part (the comparison happens on rank 0 below)
+    if use_dist and shard_error is None:  # a collective: every rank takes part (compared on rank 0 below)
         sharded = ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
 
     out = None
@@ -288,7 +303,7 @@ def main():
             same_counts = bool((ref.corr_count == res.corr_count).all())
             dt = float(np.linalg.norm(ref.pose[:3, 3] - res.pose[:3, 3]))
             out["parity"] = {"identical_counts": same_counts, "pose_delta_m": dt}
-        if use_dist:
+        if use_dist and sharded is not None:
             # evidence that the sharded, all-reduced loop computes what one GPU computes
             one = solo.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0)
             out["multi_gpu_parity"] = {
