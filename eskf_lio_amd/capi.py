@@ -139,8 +139,22 @@ class AlignResult:
     kernel_ms: Optional[np.ndarray] = None
     status: int = OK
     message: str = ""
-    JTJ: np.ndarray = field(default=None, repr=False)  # iterations x 6 x 6 (mirrored)
-    JTr: np.ndarray = field(default=None, repr=False)  # iterations x 6
+    _expanded: Optional[tuple] = field(default=None, repr=False)
+
+    def _expand(self):
+        if self._expanded is None:   # unpacked on first use: diagnostics, not part of an align
+            self._expanded = expand_normal_eq(self.normal_eq)
+        return self._expanded
+
+    @property
+    def JTJ(self) -> np.ndarray:
+        """iterations x 6 x 6 (mirrored from the packed lower triangle)."""
+        return self._expand()[0]
+
+    @property
+    def JTr(self) -> np.ndarray:
+        """iterations x 6."""
+        return self._expand()[1]
 
 
 def expand_normal_eq(rows: np.ndarray):
@@ -286,13 +300,12 @@ class Context:
         allow = (ERR_DEGENERATE,) if allow_degenerate else ()
         self._check(rc, allow)
         it = st.iterations
-        JTJ, JTr = expand_normal_eq(neq[:it])
         return AlignResult(pose=pose_from_abi(out), iterations=it, converged=bool(st.converged),
                            world_size=st.world_size, launches=st.launches, seconds=st.seconds,
-                           device_seconds=st.device_seconds, corr_count=counts[:it].copy(),
-                           normal_eq=neq[:it].copy(),
-                           kernel_ms=kms[:st.launches].copy() if flags & FLAG_PROFILE else None,
-                           status=rc, message=self.last_error() if rc else "", JTJ=JTJ, JTr=JTr)
+                           device_seconds=st.device_seconds, corr_count=counts[:it],
+                           normal_eq=neq[:it],
+                           kernel_ms=kms[:st.launches] if flags & FLAG_PROFILE else None,
+                           status=rc, message=self.last_error() if rc else "")
 
     def align(self, points, covs, guess, max_iteration, translation_sq_threshold, cosine_threshold,
               chunk_iterations: int = 0, flags: int = 0, allow_degenerate: bool = False) -> AlignResult:
