@@ -59,7 +59,16 @@ def main():
     out.update(keys=tmap.keys, means=tmap.means, covs=tmap.covs, points=tpts, point_covs=tcovs,
                voxel_size=np.float64(tmap.voxel_size))
     np.savez(os.path.join(HERE, "tiny.npz"), **out)
-    for f in ("c1_uniform.npz", "c1_structured.npz", "tiny.npz"):
+    # the steps either side of the path: hermetic, inputs stored
+    raw = synth.make_lidar_scan(700, seed=0x5052)
+    st = synth.make_imu_states(20, seed=0x5052)
+    t = synth.make_point_times(700, st[1, 0] + 1e-4, st[-3, 0] + 1e-3, seed=0x5052)
+    desk, moved = oracle.deskew(raw, t, st)
+    kp, kc, ki = oracle.preprocess(desk, 0.3, 30)
+    np.savez(os.path.join(HERE, "frame_small.npz"), points=raw, point_time=t, states=st, deskewed=desk,
+             moved=np.int64(moved), kept_points=kp, kept_covs=kc, kept_index=ki, voxel_size=np.float64(0.3),
+             knn=np.int32(30))
+    for f in ("c1_uniform.npz", "c1_structured.npz", "tiny.npz", "frame_small.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

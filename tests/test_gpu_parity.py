@@ -744,3 +744,18 @@ def test_host_mirror_cloud_preprocessor_process(oracle):
     assert done > 0 and np.array_equal(gp, rp) and np.array_equal(gc, rc)
     with pytest.raises(RuntimeError):
         host.CloudPreprocessor(0.3).process(st[:3], pts, t)         # states end before the sweep does
+
+
+def test_frame_chain_against_golden_fixture(gpu_ctx):
+    """The committed frame fixture (tests/golden/frame_small.npz): deskew, scan preparation and the fused
+    resident chain reproduce the stored outputs exactly."""
+    g = np.load(os.path.join(GOLDEN, "frame_small.npz"))
+    desk, moved = gpu_ctx.deskew(g["points"], g["point_time"], g["states"])
+    assert moved == int(g["moved"]) and np.array_equal(desk, g["deskewed"])
+    kp, kc, ki = gpu_ctx.preprocess(desk, float(g["voxel_size"]), int(g["knn"]))
+    assert np.array_equal(ki, g["kept_index"]) and np.array_equal(kp, g["kept_points"])
+    assert np.array_equal(kc, g["kept_covs"])
+    kept, moved2 = gpu_ctx.scan_prepare(g["points"], g["point_time"], g["states"], None, float(g["voxel_size"]),
+                                        int(g["knn"]))
+    rp, rc = gpu_ctx.scan_download()
+    assert kept == len(ki) and moved2 == moved and np.array_equal(rp, kp) and np.array_equal(rc, kc)

@@ -349,3 +349,17 @@ def test_deskew_known_answers(oracle):
     assert oracle.deskew(pts, t, st[:3])[1] == -1                   # no state after the last point
     assert oracle.deskew(pts, t - 1.0, st)[1] == -1                 # no state at or before it
     assert oracle.deskew(np.zeros((0, 3)), np.zeros(0), st)[1] == 0
+
+
+def test_golden_frame_fixture_is_hermetic(oracle):
+    """tests/golden/frame_small.npz: a stored 700-point sweep, its IMU states, and what deskew and scan
+    preparation make of it (regression for the oracle; the GPU suite checks the device against it)."""
+    g = np.load(os.path.join(GOLDEN, "frame_small.npz"))
+    desk, moved = oracle.deskew(g["points"], g["point_time"], g["states"])
+    assert moved == int(g["moved"]) and np.array_equal(desk, g["deskewed"])
+    kp, kc, ki = oracle.preprocess(desk, float(g["voxel_size"]), int(g["knn"]))
+    assert np.array_equal(ki, g["kept_index"]) and np.array_equal(kp, g["kept_points"])
+    assert np.abs(kc - g["kept_covs"]).max() < 1e-12
+    npts, ncov, nidx = npo.preprocess(g["deskewed"], float(g["voxel_size"]), int(g["knn"]))
+    assert np.array_equal(nidx, g["kept_index"].astype(np.int64))
+    assert np.abs(ncov - g["kept_covs"].reshape(-1, 3, 3).transpose(0, 2, 1)).max() < 1e-10
