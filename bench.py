@@ -57,19 +57,22 @@ def algorithmic_bytes(n_points: int, matches: float) -> float:
     return 112.0 * n_points + 96.0 * matches
 
 
-def measured_traffic(config: str, world: int, kernel: str):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (C2, 1 GPU)."""
+def measured_traffic(n_points: int, world: int, kernel: str):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary taken at this scan
+    size on one GPU (profiles/*_summary.json, tools/profile_gpu.sh + tools/summarize_profile.py)."""
     import glob
-    if config != "C2" or world != 1:
+    if world != 1:
         return None
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
-            t = json.load(open(f)).get("traffic")
+            d = json.load(open(f))
+            t = d.get("traffic")
+            points = d.get("bench", {}).get("config", {}).get("points", 100_000)
         except Exception:
             continue
         key = f"{kernel}_total_calibrated"
-        if t and key in t and t[key] == t[key]:
+        if t and points == n_points and key in t and t[key] == t[key]:
             best = t[key]
     return best
 
@@ -280,7 +283,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.config, world,
+                "traffic": measured_traffic(n_points, world,
                                             "persistent_kernel" if persistent else "iterate_kernel"),
                 "kernel": "vgicp::persistent_kernel" if persistent else "vgicp::iterate_kernel",
                 "rounds_per_launch": rounds_per_launch,
