@@ -338,6 +338,7 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.cosine_threshold = params->cosine_threshold;
   a.translation_sq_threshold = params->translation_sq_threshold;
   a.max_iteration = max_it;
+  a.stash_points = std::getenv("VGICP_NO_STASH") ? 0u : persistent_stash_points(ctx->n, grid);
   for (int k = 0; k < kShards; ++k) a.base[k] = ctx->persist_base[k];
   a.stamps = ctx->d_stamps;
   // one launch, one copy back (state header + the log rows), one synchronisation

@@ -93,7 +93,7 @@ struct PersistArgs {
   double cosine_threshold;
   double translation_sq_threshold;
   int32_t max_iteration;
-  uint32_t pad;
+  uint32_t stash_points;   // extra points per thread kept in LDS across rounds (scans larger than the grid)
   uint32_t base[kShards];  // value of each arrival counter before this launch (they only ever grow)
   uint64_t* stamps;
 };
@@ -101,6 +101,7 @@ struct PersistArgs {
 // ---- launchers (defined in vgicp_kernels.hip) ----
 // The whole ICP::align loop in one launch (512-thread workgroups, at most one per CU).
 hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid);
+uint32_t persistent_stash_points(uint32_t n, uint32_t grid);  // what launch_persistent can keep in LDS
 // One VGICP round over the resident scan: prologue folds args.prev and advances the pose, body
 // accumulates this round's rows. block = 256 / 512 / 1024 threads per workgroup.
 hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, int block);

@@ -610,6 +610,10 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   constexpr int kBatch = 16;
   __shared__ PrologueShared<BLOCK> sh;
   __shared__ double red[kWaves][kSlots];
+  // Scans larger than the grid: a thread owns several points. The first stays in registers; the next
+  // a.stash_points are parked here after round 0 (plane-major per point: conflict-free), so only the rest
+  // is re-read from HBM every round.
+  extern __shared__ double stash[];
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool worker = wave != 0;
@@ -678,9 +682,22 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
           accumulate_match(R, p, C, mu, S, v);
         }
       }
-      for (uint32_t i = first + stride_pts; i < a.n; i += stride_pts) {  // scans larger than the grid
+      uint32_t parked = 0;
+      for (uint32_t i = first + stride_pts; i < a.n; i += stride_pts, ++parked) {  // scans larger than the grid
         double q[kScanPlanes], p[3], C[9], m2[3], S[9];
-        load_point(a.scan, a.stride, i, q);
+        if (parked < a.stash_points) {
+          double* slot = stash + (size_t)parked * kScanPlanes * kWorkers + (tid - 64);
+          if (it == 0) {
+            load_point(a.scan, a.stride, i, q);
+#pragma unroll
+            for (int k = 0; k < kScanPlanes; ++k) slot[k * kWorkers] = q[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < kScanPlanes; ++k) q[k] = slot[k * kWorkers];
+          }
+        } else {
+          load_point(a.scan, a.stride, i, q);
+        }
 #pragma unroll
         for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
         transform_point(R, t, q[0], q[1], q[2], p);
@@ -1045,8 +1062,30 @@ hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, in
   return hipGetLastError();
 }
 
+namespace {
+constexpr uint32_t kPersistWorkers = 512 - 64;
+constexpr uint32_t kStashBytesPerPoint = kScanPlanes * kPersistWorkers * sizeof(double);  // 43 008
+constexpr uint32_t kMaxStashPoints = 3;  // 129 KB of the CU's 160 KB LDS, beside ~12 KB of static use
+}  // namespace
+
+uint32_t persistent_stash_points(uint32_t n, uint32_t grid) {
+  const uint64_t per_round = (uint64_t)grid * kPersistWorkers;
+  if (n <= per_round) return 0;
+  const uint64_t extra = (n - 1) / per_round;  // points per thread beyond the first (upper bound)
+  return (uint32_t)(extra < kMaxStashPoints ? extra : kMaxStashPoints);
+}
+
 hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid) {
-  hipLaunchKernelGGL(persistent_kernel<512>, dim3(grid), dim3(512), 0, s, args);
+  static bool raised = false;
+  if (!raised) {  // LDS beyond the default 64 KB per workgroup has to be asked for once
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<512>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(kMaxStashPoints * kStashBytesPerPoint));
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(persistent_kernel<512>, dim3(grid), dim3(512), args.stash_points * kStashBytesPerPoint, s,
+                     args);
   return hipGetLastError();
 }
 

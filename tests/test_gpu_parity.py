@@ -759,3 +759,27 @@ def test_frame_chain_against_golden_fixture(gpu_ctx):
                                         int(g["knn"]))
     rp, rc = gpu_ctx.scan_download()
     assert kept == len(ki) and moved2 == moved and np.array_equal(rp, kp) and np.array_equal(rc, kc)
+
+
+def test_scans_larger_than_the_grid_park_points_in_lds(gpu_ctx, c1_inputs, monkeypatch):
+    """A scan with more points than the persistent launch has worker threads: every thread owns several
+    points, the first stays in registers and up to three more are parked in LDS after round 0. Results do
+    not depend on the parking and agree with the per-launch loop."""
+    from eskf_lio_amd import synth
+    vmap = c1_inputs[0]
+    pts, covs = synth.make_uniform_scan(400_000, vmap, seed=77)   # ~3.5 points per worker thread
+    gpu_ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+    gpu_ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+    gpu_ctx.scan_upload(pts, covs)
+    g = synth.default_guess()
+    parked = gpu_ctx.align_resident(g, 12, 1e-6, 2.0, chunk_iterations=12)
+    assert parked.launches == 1 and parked.iterations == 12
+    monkeypatch.setenv("VGICP_NO_STASH", "1")
+    plain = gpu_ctx.align_resident(g, 12, 1e-6, 2.0, chunk_iterations=12)
+    monkeypatch.delenv("VGICP_NO_STASH")
+    assert np.array_equal(parked.pose, plain.pose) and np.array_equal(parked.normal_eq, plain.normal_eq)
+    loop = gpu_ctx.align_resident(g, 12, 1e-6, 2.0, chunk_iterations=4, flags=2)   # VGICP_FLAG_NO_PERSISTENT
+    assert loop.launches > 1 and np.array_equal(loop.corr_count, parked.corr_count)
+    # a different partition of the points into workgroups: same sums up to the order of addition
+    assert np.allclose(loop.normal_eq, parked.normal_eq, rtol=1e-11, atol=1e-9)
+    assert np.abs(loop.pose - parked.pose).max() < 1e-12
