@@ -620,6 +620,14 @@ def test_preprocess_matches_oracle(gpu_ctx, oracle, n, knn):
     _assert_preprocess_parity(gpu_ctx.preprocess(pts, 0.3, knn), oracle.preprocess(pts, 0.3, knn), pts)
 
 
+def test_preprocess_full_size_sweep(gpu_ctx, oracle):
+    """A 100 000-point sweep (the size of one spinning-LiDAR revolution): dense ground near the sensor, walls,
+    8 % clutter — queries whose cell pool overflows and spills are part of it. Bit-exact like the small ones."""
+    from eskf_lio_amd import synth
+    pts = synth.make_lidar_scan(100_000, seed=11)
+    _assert_preprocess_parity(gpu_ctx.preprocess(pts, 0.3, 30), oracle.preprocess(pts, 0.3, 30), pts)
+
+
 def test_preprocess_other_voxel_sizes_and_dense_cells(gpu_ctx, oracle):
     from eskf_lio_amd import synth
     pts = synth.make_lidar_scan(15_000, seed=5, extent=10.0)       # many points per voxel
