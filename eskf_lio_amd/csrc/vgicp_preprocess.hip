@@ -227,8 +227,13 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   __shared__ uint32_t pool_end[kSearchBlock / 64][kPool];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  const uint32_t qrank = blockIdx.x * (kSearchBlock / 64) + wave;
-  if (qrank >= m) return;  // whole waves leave; nothing below synchronises across waves
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous
+  // eighth of the Morton-ordered queries, so that neighbouring queries (same cells, same points) share an L2.
+  constexpr uint32_t kXcds = 8;
+  const uint32_t per_xcd = (m + kXcds - 1) / kXcds;
+  const uint32_t slot_in_xcd = (blockIdx.x / kXcds) * (kSearchBlock / 64) + wave;
+  const uint32_t qrank = (blockIdx.x % kXcds) * per_xcd + slot_in_xcd;
+  if (slot_in_xcd >= per_xcd || qrank >= m) return;  // whole waves leave; nothing below synchronises across waves
   volatile double* pd = pool_d[wave];
   volatile unsigned long long* pk = pool_key[wave];
   volatile uint32_t* ps = pool_start[wave];
@@ -741,7 +746,8 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
                      table_entries);
   hipLaunchKernelGGL(cell_start_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
   hipLaunchKernelGGL(cell_end_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
-  hipLaunchKernelGGL(knn_search_kernel, dim3(blocks_for(m, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
+  // 8 XCDs x ceil(m / 8) queries each (see the kernel's query mapping)
+  hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((m + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
                      n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
   const int found = knn < (int)n ? knn : (int)n;
   hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, spts, nbr, m, found, out_covs);
