@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     const CellEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ queries,
     const uint32_t* __restrict__ slot_of_index, uint32_t m, uint32_t* __restrict__ nbr,
     double* __restrict__ out_pts, unsigned long long* __restrict__ out_idx, uint32_t* counters, int debug) {
-  __shared__ double pool_d[kSearchBlock / 64][kPool];
+  __shared__ float pool_d[kSearchBlock / 64][kPool];   // cell distances rounded DOWN: ordering and pruning stay safe
   __shared__ unsigned long long pool_key[kSearchBlock / 64][kPool];
   __shared__ uint32_t pool_start[kSearchBlock / 64][kPool];
   __shared__ uint32_t pool_end[kSearchBlock / 64][kPool];
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   const uint32_t slot_in_xcd = (blockIdx.x / kXcds) * (kSearchBlock / 64) + wave;
   const uint32_t qrank = (blockIdx.x % kXcds) * per_xcd + slot_in_xcd;
   if (slot_in_xcd >= per_xcd || qrank >= m) return;  // whole waves leave; nothing below synchronises across waves
-  volatile double* pd = pool_d[wave];
+  volatile float* pd = pool_d[wave];
   volatile unsigned long long* pk = pool_key[wave];
   volatile uint32_t* ps = pool_start[wave];
   volatile uint32_t* pe = pool_end[wave];
@@ -315,10 +315,10 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     for (int base = 0; base < waiting; base += 64) {
       const int i = base + lane;
       const bool valid = i < waiting;
-      const double d = valid ? pd[i] : 0.0;
+      const float d = valid ? pd[i] : 0.0f;
       const unsigned long long key = valid ? pk[i] : 0ull;
       const uint32_t st = valid ? ps[i] : 0u, en = valid ? pe[i] : 0u;
-      const bool stay = valid && d <= limit;
+      const bool stay = valid && (double)d <= limit;
       const unsigned long long who = __ballot(stay);
       const int at = kept + __builtin_popcountll(who & lanes_below);
       if (stay) { pd[at] = d; pk[at] = key; ps[at] = st; pe[at] = en; }  // at <= i: never ahead of the reads
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     const unsigned long long who = __ballot(want);
     const int at = waiting + __builtin_popcountll(who & lanes_below);
     if (want) {
-      pd[at] = d2;
+      pd[at] = __double2float_rd(d2);
       pk[at] = key;
       ps[at] = start;
       pe[at] = end;
@@ -390,20 +390,18 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     }
     while (waiting > 0) {
       // the nearest waiting cell
-      double best = INFINITY;
+      float mine = INFINITY;
       int at = 0;
       for (int i = lane; i < waiting; i += 64) {
-        const double d = pd[i];
-        if (d < best) { best = d; at = i; }
+        const float d = pd[i];
+        if (d < mine) { mine = d; at = i; }
       }
+      float least = mine;
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        const double od = __shfl_xor(best, o, 64);
-        const int oa = __shfl_xor(at, o, 64);
-        if (od < best || (od == best && oa < at)) { best = od; at = oa; }
-      }
-      best = uniform_f64(best);
-      at = (int)uniform_u32((uint32_t)at);
+      for (int o = 32; o >= 1; o >>= 1) least = fminf(least, __shfl_xor(least, o, 64));
+      const int owner = __builtin_ctzll(__ballot(mine == least));   // the lowest lane holding the minimum
+      at = __builtin_amdgcn_readlane(at, owner);
+      const double best = (double)__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, least)));
       const double limit = found == K ? fmin(bound, kth) : bound;
       if (best > limit) break;  // nothing left can hold one of the K nearest
       ++pops;
