@@ -209,7 +209,8 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 }
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // value of the lane below (lane 0 keeps its own)
-__device__ __forceinline__ int lane_below_i32(int v) { return __shfl_up(v, 1, 64); }
+// DPP wave_shr:1 (GFX9): one VALU move, no trip through the LDS crossbar
+__device__ __forceinline__ int lane_below_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
 __device__ __forceinline__ double lane_below_f64(double v) {
   return __hiloint2double(lane_below_i32(__double2hiint(v)), lane_below_i32(__double2loint(v)));
 }
