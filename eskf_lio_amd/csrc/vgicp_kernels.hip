@@ -45,15 +45,34 @@ __device__ __forceinline__ bool find_and_load(const VoxelRecord* table, uint32_t
   return true;
 }
 
-// One halving step of the wave butterfly through the LDS crossbar (ds_bpermute): N live values ->
-// N/2, exchanging with lane ^ MASK.
+// Value of lane ^ MASK for MASK in {8, 4, 2, 1}, by DPP inside the 16-lane row (VALU moves; ds_bpermute
+// would send each value through the LDS crossbar and put its latency on the reduction's dependent path):
+// 8 = rotate the row by 8; 4 = shift by 4 towards the lower lanes for banks 0 and 2, towards the upper ones
+// for banks 1 and 3; 2 and 1 = quad permutes.
+template <int MASK>
+__device__ __forceinline__ int xor_lane_i32(int x) {
+  static_assert(MASK == 8 || MASK == 4 || MASK == 2 || MASK == 1, "row-local masks only");
+  if constexpr (MASK == 8) return __builtin_amdgcn_update_dpp(x, x, 0x128 /* row_ror:8 */, 0xF, 0xF, false);
+  if constexpr (MASK == 4) {
+    const int lower = __builtin_amdgcn_update_dpp(x, x, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+    return __builtin_amdgcn_update_dpp(lower, x, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+  }
+  if constexpr (MASK == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false);
+  return __builtin_amdgcn_update_dpp(x, x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+}
+template <int MASK>
+__device__ __forceinline__ double xor_lane_f64(double v) {
+  return __hiloint2double(xor_lane_i32<MASK>(__double2hiint(v)), xor_lane_i32<MASK>(__double2loint(v)));
+}
+
+// One halving step of the wave butterfly: N live values -> N/2, exchanging with lane ^ MASK.
 template <int N, int MASK>
 __device__ __forceinline__ void fold(double (&v)[kSlots], bool upper) {
 #pragma unroll
   for (int j = 0; j < N / 2; ++j) {
     const double keep = upper ? v[j + N / 2] : v[j];
     const double send = upper ? v[j] : v[j + N / 2];
-    v[j] = keep + __shfl_xor(send, MASK, 64);
+    v[j] = keep + xor_lane_f64<MASK>(send);
   }
 }
 
@@ -537,7 +556,7 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
     fold<8, 8>(v, (lane & 8) != 0);
     fold<4, 4>(v, (lane & 4) != 0);
     fold<2, 2>(v, (lane & 2) != 0);
-    const double wsum = v[0] + __shfl_xor(v[0], 1, 64);
+    const double wsum = v[0] + xor_lane_f64<1>(v[0]);
     if ((lane & 1) == 0) red[wave][lane >> 1] = wsum;
   }
   __syncthreads();
@@ -710,7 +729,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       fold<8, 8>(v, (lane & 8) != 0);
       fold<4, 4>(v, (lane & 4) != 0);
       fold<2, 2>(v, (lane & 2) != 0);
-      const double wsum = v[0] + __shfl_xor(v[0], 1, 64);
+      const double wsum = v[0] + xor_lane_f64<1>(v[0]);
       if ((lane & 1) == 0) red[wave][lane >> 1] = wsum;
     }
     __syncthreads();
