@@ -109,3 +109,22 @@ def test_pose_abi_roundtrip():
     rows = np.arange(27.0)[None]
     JTJ, JTr = capi.expand_normal_eq(rows)
     assert JTJ[0, 3, 1] == 7 and JTJ[0, 1, 3] == 7 and JTJ[0, 5, 5] == 20 and JTr[0, 0] == 21
+
+
+def test_bench_refuses_to_run_without_a_gpu_and_prices_bytes_as_designed():
+    """bench.py has no CPU fallback; its byte model is SURVEY.md 8(d)'s 112 N + 96 M per round, and its
+    traffic figure comes from the PMC summary taken at the same scan size."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                          capture_output=True, text=True, cwd=root)
+    assert proc.returncode != 0 and "no HIP device" in (proc.stderr + proc.stdout)
+    assert proc.stdout.strip() == ""                                 # no JSON line without a measurement
+    sys.path.insert(0, root)
+    import bench
+    assert bench.algorithmic_bytes(100_000, 49_912.8) == 112 * 100_000 + 96 * 49_912.8
+    c2 = bench.measured_traffic(100_000, 1, "persistent_kernel")
+    c5 = bench.measured_traffic(1_000_000, 1, "persistent_kernel")
+    assert c2 is not None and c5 is not None and c5 > 50 * c2        # per launch of 20 rounds
+    assert bench.measured_traffic(100_000, 8, "persistent_kernel") is None
