@@ -791,3 +791,34 @@ def test_scans_larger_than_the_grid_park_points_in_lds(gpu_ctx, c1_inputs, monke
     # a different partition of the points into workgroups: same sums up to the order of addition
     assert np.allclose(loop.normal_eq, parked.normal_eq, rtol=1e-11, atol=1e-9)
     assert np.abs(loop.pose - parked.pose).max() < 1e-12
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_align_randomised_configurations(gpu_ctx, oracle, seed):
+    """Random small problems: voxel sizes 0.1-1.0, maps shifted up to tens of kilometres from the origin (keys
+    of both signs, large magnitudes), full and sparse occupancy, ragged sizes, the reference's own thresholds.
+    Identical counts and the contractual pose tolerance (and 1e-7 of slack-free agreement) against the oracle."""
+    from eskf_lio_amd import synth
+    rng = np.random.default_rng(1000 + seed)
+    voxel = float(rng.choice([0.1, 0.3, 0.5, 1.0]))
+    n_vox = int(rng.integers(500, 20_000))
+    n_pts = int(rng.integers(1, 7_000))
+    vmap = synth.make_map(n_vox, seed=0x4D00 + seed, voxel_size=voxel)
+    shift_cells = rng.integers(-200_000, 200_000, size=3).astype(np.int64) * int(seed % 3 != 0)
+    keys = (vmap.keys.astype(np.int64) + shift_cells).astype(np.int32)
+    means = vmap.means + shift_cells * voxel
+    pts, covs, _ = synth.make_structured_scan(min(n_pts, n_vox), vmap, seed=0x5300 + seed, noise=0.01 * voxel)
+    T_shift = np.eye(4)
+    T_shift[:3, 3] = shift_cells * voxel
+    # the scan lives in the sensor frame; the guess carries the big translation
+    guess = T_shift @ synth.se3_to_SE3(rng.normal(size=6) * np.array([0.02, 0.02, 0.02, 0.004, 0.004, 0.004]) * voxel / 0.3)
+    om = oracle.OracleMap(voxel, 1)
+    om.insert(means, vmap.covs)
+    ref = om.align(pts, covs, guess, 100, 1e-6, 0.9999)
+    gpu_ctx.map_reset(voxel, 0)
+    gpu_ctx.map_upsert(keys, means, vmap.covs)
+    got = gpu_ctx.align(pts, covs, guess, 100, 1e-6, 0.9999)
+    assert got.iterations == ref.iterations and got.converged == ref.converged
+    assert np.array_equal(got.corr_count, ref.corr_count)
+    dt, dr = pose_error(got.pose, ref.pose)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and dt < 1e-7 and dr < 1e-9
