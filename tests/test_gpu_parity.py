@@ -822,3 +822,26 @@ def test_align_randomised_configurations(gpu_ctx, oracle, seed):
     assert np.array_equal(got.corr_count, ref.corr_count)
     dt, dr = pose_error(got.pose, ref.pose)
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and dt < 1e-7 and dr < 1e-9
+
+
+def test_preprocess_survives_non_finite_points(gpu_ctx, oracle):
+    """NaN / infinite coordinates are garbage in, garbage out — but never a hang or a crash, and the finite part
+    of the scan is prepared as if the bad points were not neighbours of anything."""
+    from eskf_lio_amd import synth
+    pts = synth.make_lidar_scan(4_000, seed=13)
+    bad = pts.copy()
+    bad[100] = [np.nan, 0.0, 0.0]
+    bad[200] = [np.inf, 1.0, 2.0]
+    bad[300] = [1.0, -np.inf, np.nan]
+    gp, gc, gi = gpu_ctx.preprocess(bad, 0.3, 30)
+    assert len(gi) > 0 and np.all(np.diff(gi.astype(np.int64)) > 0)
+    finite = np.isfinite(gp).all(axis=1)
+    ev = np.linalg.eigvalsh(gc[finite].reshape(-1, 3, 3))
+    assert np.allclose(ev, [1e-2, 1.0, 1.0], atol=1e-9)
+    # the clean scan without those three points gives the same covariances for the points both runs keep
+    keep = np.ones(len(pts), dtype=bool)
+    keep[[100, 200, 300]] = False
+    rp, rc, ri = oracle.preprocess(pts[keep], 0.3, 30)
+    orig = np.flatnonzero(keep)[ri.astype(np.int64)]
+    common, ia, ib = np.intersect1d(gi.astype(np.int64), orig, return_indices=True)
+    assert len(common) > 0.99 * len(ri) and np.array_equal(gc[ia], rc[ib])
