@@ -486,8 +486,18 @@ class ErrorStateKF:
         return new.pose()
 
 
-def pack_states(states: List[State]) -> np.ndarray:
-    """std::deque<State> -> S x 8 (timestamp, position, quaternion x y z w): what vgicp_deskew takes."""
+def pack_states(states: List[State], earliest_point_time: Optional[float] = None) -> np.ndarray:
+    """std::deque<State> -> S x 8 (timestamp, position, quaternion x y z w): what vgicp_deskew takes.
+    The reference never trims its deque (400 states per second pile up); a state whose timestamp is not above
+    the earliest capture time of the sweep cannot take a point in the deskew's walk, so with
+    earliest_point_time given all but the last of those leading states are left out (same result)."""
+    if earliest_point_time is not None:
+        first = 0
+        for k in range(len(states) - 1, -1, -1):             # states are in time order: scan from the back
+            if states[k].timestamp <= earliest_point_time:
+                first = k
+                break
+        states = states[first:]
     out = np.zeros((len(states), 8))
     for k, s in enumerate(states):
         out[k, 0] = s.timestamp
@@ -546,7 +556,7 @@ class Odometry:
         if self.filter.getLastStateTime() < meas.endTime:   # :66-70: wait for the next IMU sample
             return False
         started = time.perf_counter()
-        states = pack_states(self.filter.getStates())
+        states = pack_states(self.filter.getStates(), float(np.min(meas.pointTime)))
         meas.points, meas.covariances = self.backend.preprocess(states, meas.points, meas.pointTime)
         self._clock("cloud preprocessor", started)
         started = time.perf_counter()
