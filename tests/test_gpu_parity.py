@@ -539,6 +539,19 @@ def test_cpp_example_tracks_a_moving_sensor():
     assert len(lines) == 6 and all("converged 1" in ln for ln in lines[1:])
 
 
+def test_cpp_frame_chain_classes_and_resident_abi_agree():
+    """examples/frame_chain.cpp: CloudPreprocessor::process -> ICP::align -> LocalMap::updateLocalMap in C++ on
+    the shim, and the same frames through vgicp_scan_prepare / align_resident / map_insert_resident."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "frame_chain")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("frame")]
+    assert len(lines) == 6 and "deskewed" in lines[1]
+
+
 # ---- multi-GPU code path on one device: RCCL communicator of size 1 ---------------------------
 def test_rccl_path_world_size_one(c1_gpu, c1_inputs):
     from eskf_lio_amd import synth
