@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvgicp_hip.so")
 OK, ERR_BAD_ARGUMENT, ERR_HIP, ERR_RCCL, ERR_TABLE_FULL, ERR_DEGENERATE, ERR_NO_DEVICE, ERR_NOT_READY = range(8)
 FLAG_PROFILE = 1
 FLAG_NO_PERSISTENT = 2
+SOLVE_FORCE_PIVOTED = 1
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/vgicp_hip.h declares
@@ -27,7 +28,7 @@ EXPORTS = (
     "vgicp_map_reset", "vgicp_map_upsert", "vgicp_map_erase", "vgicp_map_size",
     "vgicp_map_insert_scan", "vgicp_map_insert_resident", "vgicp_map_evict", "vgicp_map_export",
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
-    "vgicp_accumulate", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
+    "vgicp_accumulate", "vgicp_solve_step", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_scan_prepare", "vgicp_scan_download",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
 )
@@ -86,6 +87,7 @@ def load_library() -> C.CDLL:
     lib.vgicp_scan_upload.argtypes = [vp, sz, dp, dp]
     lib.vgicp_align_resident.argtypes = [vp, dp, C.POINTER(Params), dp, C.POINTER(Stats)]
     lib.vgicp_accumulate.argtypes = [vp, sz, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64)]
+    lib.vgicp_solve_step.argtypes = [vp, dp, dp, C.c_double, C.c_double, C.c_uint32, dp, dp, ip, ip]
     lib.vgicp_match.argtypes = [vp, sz, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64), C.POINTER(sz)]
     lib.vgicp_voxel_index.argtypes = [vp, sz, dp, ip]
     lib.vgicp_scan_prepare.argtypes = [vp, sz, dp, dp, sz, dp, dp, C.c_double, C.c_int, C.POINTER(sz),
@@ -335,6 +337,20 @@ class Context:
         self._check(self._lib.vgicp_accumulate(self._h, points.shape[0], _dp(points), _dp(covs), _dp(g),
                                                _dp(JTJ), _dp(JTr), C.byref(cnt)))
         return JTJ.reshape(6, 6).T.copy(), JTr, cnt.value
+
+    def solve_step(self, JTJ, JTr, cosine_threshold: float = 0.9999, translation_sq_threshold: float = 1e-6,
+                   force_pivoted: bool = False):
+        """ldlt().solve(-JTr) + se3ToSE3 + convergenceCheck on the device -> (se3, step 4x4, used_pivoted,
+        converged). JTJ: 6x6 (row, col) numpy; only its lower triangle is read."""
+        A = np.ascontiguousarray(np.asarray(JTJ, dtype=np.float64).reshape(6, 6).T).reshape(36)
+        b = np.ascontiguousarray(JTr, dtype=np.float64).reshape(6)
+        se3, step = np.zeros(6), np.zeros(16)
+        piv, conv = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.vgicp_solve_step(self._h, _dp(A), _dp(b), float(cosine_threshold),
+                                               float(translation_sq_threshold),
+                                               SOLVE_FORCE_PIVOTED if force_pivoted else 0, _dp(se3), _dp(step),
+                                               C.byref(piv), C.byref(conv)))
+        return se3, pose_from_abi(step), bool(piv.value), bool(conv.value)
 
     def match(self, points, covs):
         points, covs = _f64(points, 3), _f64(covs, 9)

@@ -899,6 +899,36 @@ int vgicp_accumulate(vgicp_ctx* ctx, size_t n, const double* points, const doubl
   return VGICP_OK;
 }
 
+int vgicp_solve_step(vgicp_ctx* ctx, const double JTJ[36], const double JTr[6], double cosine_threshold,
+                     double translation_sq_threshold, uint32_t flags, double se3[6], double step[16],
+                     int32_t* used_pivoted, int32_t* converged) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!JTJ || !JTr || !se3 || !step) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage(ctx, 64 * sizeof(double));
+  if (rc != VGICP_OK) return rc;
+  double packed[32] = {0.0};
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c <= r; ++c) packed[tri6(r, c)] = JTJ[r + 6 * c];  // the lower triangle, as Eigen's LDLT reads it
+  for (int k = 0; k < 6; ++k) packed[21 + k] = JTr[k];
+  double* d_in = static_cast<double*>(ctx->d_stage);
+  double* d_out = d_in + 32;
+  double out[20];
+  VG_HIP(ctx, hipMemcpyAsync(d_in, packed, sizeof packed, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, launch_solve_step(ctx->stream, d_in, cosine_threshold, translation_sq_threshold,
+                                (flags & VGICP_SOLVE_FORCE_PIVOTED) ? 1 : 0, d_out));
+  VG_HIP(ctx, hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 6; ++k) se3[k] = out[k];
+  Pose T;
+  for (int k = 0; k < 9; ++k) T.R[k] = out[6 + k];
+  for (int k = 0; k < 3; ++k) T.t[k] = out[15 + k];
+  pose_to_mat4(T, step);
+  if (used_pivoted) *used_pivoted = out[18] != 0.0;
+  if (converged) *converged = out[19] != 0.0;
+  return VGICP_OK;
+}
+
 int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
                 double* src_points, double* src_covs, double* map_points, double* map_covs,
                 uint64_t* src_index, size_t* matched) {

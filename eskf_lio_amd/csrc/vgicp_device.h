@@ -110,6 +110,9 @@ hipError_t launch_close(hipStream_t s, const IterArgs& args);
 // Multi-GPU: fold nrows rows into sums[kSlots] (the 256-byte message of the all-reduce).
 hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, const AlignState* state,
                             double* sums);
+// Test hook: solve + exponential + convergence test of one round on given normal equations (one wave).
+hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosine_threshold,
+                             double translation_sq_threshold, int force_pivoted, double* out20);
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
                             uint32_t n, double* soa, uint64_t stride);
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots);

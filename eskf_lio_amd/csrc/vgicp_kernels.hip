@@ -101,92 +101,27 @@ __device__ __forceinline__ double uniform_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
-
-// Pivoted LDL^T solve of the 6x6 normal equations by ONE wave (all 64 lanes must call it).
-// Same algorithm as vgicp_math.h's ldlt6_solve — Eigen's LDLT: largest remaining |diagonal| first,
-// symmetric swap, invalid (zero) pivots leave their column untouched, D pseudo-inverted — but laid
-// out across lanes: lane 6r + c holds A(r, c) of the full symmetric matrix, the pivot search reads
-// the diagonal through v_readlane (uniform), the swap and the rank-1 update are lane shuffles. The
-// serial form costs ~10 us of dependent LDS traffic on one lane; this one is a few hundred cycles.
-// tot: lane l < 27 holds entry l of the packed row (21 lower-triangle entries of J^T S^-1 J, then
-// the 6 entries of J^T S^-1 r). Every lane returns x = A^-1 (-J^T r).
-__device__ __forceinline__ void ldlt6_solve_wave(double tot, uint32_t lane, double (&x)[6]) {
-  const int cell = lane < 36 ? (int)lane : 0;
-  const int r = cell / 6, c = cell % 6;
-  double a = __shfl(tot, r >= c ? tri6(r, c) : tri6(c, r), 64);
-  int perm[6] = {0, 1, 2, 3, 4, 5};
-  bool zero_diag = false;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    if (zero_diag) break;
-    int p = k;
-    double best = fabs(readlane_f64(a, 7 * k));
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      const double d = fabs(readlane_f64(a, 7 * i));
-      if (d > best) { best = d; p = i; }
-    }
-    perm[k] = p;
-    if (p != k) {  // uniform: symmetric row/column swap k <-> p
-      const int sr = (r == k) ? p : (r == p) ? k : r;
-      const int sc = (c == k) ? p : (c == p) ? k : c;
-      a = __shfl(a, 6 * sr + sc, 64);
-    }
-    const double akk = readlane_f64(a, 7 * k);
-    const bool valid = fabs(akk) > 0.0;
-    if (k == 0 && !valid) {  // the whole diagonal is zero: identity transpositions, nothing to do
-      perm[0] = 0;
-      zero_diag = true;
-    } else if (valid) {
-      const double a_rk = __shfl(a, 6 * r + k, 64);
-      const double a_kc = __shfl(a, 6 * k + c, 64);
-      const double l_rk = a_rk / akk;
-      if (r > k && c > k) a -= l_rk * a_kc;
-      else if (r > k && c == k) a = l_rk;
-    }
+// Fallback of the 6x6 solve: vgicp_math.h's ldlt6_solve — Eigen's pivoted LDLT with pseudo-inverted D, the
+// operation order of the published algorithm, no contraction — run by lane 0 on an LDS work array (the
+// pivoting makes every index dynamic), the solution then read by every lane.  It is taken only when the
+// natural-order factorisation below meets a pivot that is not safely positive (singular or indefinite
+// normal equations, "no correspondences" included), so its ~10 us of dependent LDS traffic are off the
+// hot path.  packed: LDS, 21 lower-triangle entries then the 6 of J^T r; work: LDS, kSolveWork doubles.
+// All 64 lanes of the wave must call it.
+constexpr int kSolveWork = kLdltWork + 16;
+__device__ __forceinline__ void ldlt6_solve_pivoted(const double* packed, double* work, uint32_t lane,
+                                                    double (&x)[6]) {
+  double* rhs = work + kLdltWork;
+  double* sol = work + kLdltWork + 8;
+  if (lane == 0) {
+    for (int k = 0; k < 6; ++k) rhs[k] = -packed[21 + k];
+    ldlt6_solve(packed, rhs, sol, work);
   }
-  double L[6][6], D[6];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    D[i] = readlane_f64(a, 7 * i);
-#pragma unroll
-    for (int j = 0; j < i; ++j) L[i][j] = readlane_f64(a, 6 * i + j);
-  }
-  double y[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] = -readlane_f64(tot, 21 + i);
-  if (!zero_diag) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-#pragma unroll
-      for (int q = k + 1; q < 6; ++q)
-        if (perm[k] == q) { const double t = y[k]; y[k] = y[q]; y[q] = t; }
-  }
-#pragma unroll
-  for (int i = 1; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j < i; ++j) y[i] -= L[i][j] * y[j];
-  const double tol = 2.2250738585072014e-308;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] = (fabs(D[i]) > tol) ? y[i] / D[i] : 0.0;
-#pragma unroll
-  for (int i = 4; i >= 0; --i)
-#pragma unroll
-    for (int j = i + 1; j < 6; ++j) y[i] -= L[j][i] * y[j];
-  if (!zero_diag) {
-#pragma unroll
-    for (int k = 5; k >= 0; --k)
-#pragma unroll
-      for (int q = k + 1; q < 6; ++q)
-        if (perm[k] == q) { const double t = y[k]; y[k] = y[q]; y[q] = t; }
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] = y[i];
+  for (int k = 0; k < 6; ++k) x[k] = sol[k];
 }
 
 // Fast path of the 6x6 solve: LDL^T in natural order, fully unrolled, everything in registers with
@@ -282,6 +217,7 @@ template <int BLOCK>
 struct PrologueShared {
   double fin[BLOCK / kSlots][kSlots];
   double totals[kSlots];
+  double work[kSolveWork];
   double pose[12];
   int stop;
 };
@@ -362,7 +298,7 @@ __device__ __forceinline__ void prologue_solve(const IterArgs& a, PrologueShared
   for (int k = 0; k < 21; ++k) A[k] = sh.totals[k];
 #pragma unroll
   for (int k = 0; k < 6; ++k) g[k] = -sh.totals[21 + k];
-  if (!ldlt6_solve_spd(A, g, xi)) ldlt6_solve_wave(tot, lane, xi);  // uniform branch
+  if (!ldlt6_solve_spd(A, g, xi)) ldlt6_solve_pivoted(sh.totals, sh.work, lane, xi);  // uniform branch
   Pose step, next;
   se3_exp_device(xi, step);
   pose_compose(step, old_total, next);
@@ -590,6 +526,45 @@ __global__ __launch_bounds__(BLOCK) void close_kernel(IterArgs a) {
   if (threadIdx.x < 64) prologue_solve<BLOCK>(a, sh, head.total, threadIdx.x, it, max_it, cos_thr, tsq_thr);
 }
 
+// Test hook (vgicp_solve_step): the tail of one round on given normal equations, run by ONE wave with
+// the very device functions the loop kernels inline — JTJ.ldlt().solve(-JTr), Utils::se3ToSE3 and
+// ICP::convergenceCheck (src/Registration.cpp:78-79,37-50, src/Utils.cpp:40-63).
+// packed: 21 lower-triangle entries row by row, then the 6 entries of JTr.
+// out: [0..5] se3, [6..14] step R (column-major), [15..17] step t, [18] 1.0 when the pivoted
+// (Eigen-faithful) solve produced the result, [19] 1.0 when the step passes the convergence test.
+__global__ __launch_bounds__(64) void solve_step_kernel(const double* __restrict__ packed, double cos_thr,
+                                                        double tsq_thr, int force_pivoted,
+                                                        double* __restrict__ out) {
+  __shared__ double totals[kSlots];
+  __shared__ double work[kSolveWork];
+  const uint32_t lane = threadIdx.x;
+  if (lane < kSlots) totals[lane] = lane < kNormalEq ? packed[lane] : 0.0;
+  __syncthreads();
+  double A[21], g[6], xi[6];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) A[k] = packed[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) g[k] = -packed[21 + k];
+  bool pivoted = force_pivoted != 0;
+  if (pivoted || !ldlt6_solve_spd(A, g, xi)) {  // uniform branch
+    ldlt6_solve_pivoted(totals, work, lane, xi);
+    pivoted = true;
+  }
+  Pose step;
+  se3_exp_device(xi, step);
+  const bool conv = converged(step, cos_thr, tsq_thr);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[k] = xi[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[6 + k] = step.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[15 + k] = step.t[k];
+    out[18] = pivoted ? 1.0 : 0.0;
+    out[19] = conv ? 1.0 : 0.0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Persistent variant: the whole loop of ICP::align (src/Registration.cpp:15-28) in ONE launch.
 //
@@ -803,7 +778,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       for (int k = 0; k < 21; ++k) A[k] = sh.totals[k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) g[k] = -sh.totals[21 + k];
-      if (!ldlt6_solve_spd(A, g, xi)) ldlt6_solve_wave(tot, lane, xi);  // uniform branch
+      if (!ldlt6_solve_spd(A, g, xi)) ldlt6_solve_pivoted(sh.totals, sh.work, lane, xi);  // uniform branch
       Pose next, step;
       se3_exp_device(xi, step);
       pose_compose(step, head.total, next);
@@ -1110,6 +1085,13 @@ hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t gr
 
 hipError_t launch_close(hipStream_t s, const IterArgs& args) {
   hipLaunchKernelGGL(close_kernel<1024>, dim3(1), dim3(1024), 0, s, args);
+  return hipGetLastError();
+}
+
+hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosine_threshold,
+                             double translation_sq_threshold, int force_pivoted, double* out20) {
+  hipLaunchKernelGGL(solve_step_kernel, dim3(1), dim3(64), 0, s, packed27, cosine_threshold,
+                     translation_sq_threshold, force_pivoted, out20);
   return hipGetLastError();
 }
 

@@ -111,11 +111,18 @@ VG_HD void inv3(const double* m, double* inv) {
 VG_HD constexpr int tri6(int r, int c) { return r * (r + 1) / 2 + c; }
 
 // Solve A x = b for symmetric 6x6 A given by its packed lower triangle (21 values), with the
-// pivoted LDL^T of Eigen's LDLT (largest remaining |diagonal| first, D pseudo-inverted with
-// tolerance = smallest normal double).  A all-zero with b all-zero returns x = 0, as Eigen does.
-// `work` holds >= 48 doubles of scratch the caller provides (LDS on the device: the pivoting makes
-// the indices dynamic, and private arrays with dynamic indices would spill to scratch memory).
+// pivoted LDL^T of Eigen's LDLT as published (unblocked in-place form): largest remaining |diagonal|
+// first, symmetric swap inside the lower triangle, temp = D(0..k-1) .* row k, the diagonal and the
+// column below it each reduced by ONE dot product with temp (dot first, then the subtraction), a zero
+// pivot leaves its column undivided, D pseudo-inverted with tolerance = smallest normal double.
+// A all-zero with b all-zero returns x = 0, as Eigen does.  No FMA contraction anywhere, so with the
+// same operation order the CPU oracle returns the same bits on any system, rank-deficient ones with
+// noise pivots included.  `work` holds >= kLdltWork doubles the caller provides (LDS on the device:
+// pivoting makes the indices dynamic, and private arrays with dynamic indices would go to scratch).
 VG_HD void ldlt6_solve(const double* lower21, const double* b, double* x, double* work) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   double* A = work;        // 6x6, row-major A[6 * r + c], lower triangle live
   double* y = work + 36;   // 6
   double* tmp = work + 42; // 6
@@ -124,7 +131,6 @@ VG_HD void ldlt6_solve(const double* lower21, const double* b, double* x, double
   int perm_packed = 0;     // 3 bits per pivot index
   bool zero_diag = false;
   for (int k = 0; k < 6; ++k) {
-    // pivot search on the remaining diagonal
     int p = k;
     double best = fabs(A[7 * k]);
     for (int i = k + 1; i < 6; ++i) {
@@ -133,7 +139,6 @@ VG_HD void ldlt6_solve(const double* lower21, const double* b, double* x, double
     }
     perm_packed |= p << (3 * k);
     if (p != k) {
-      // symmetric row/column swap touching the lower triangle only
       for (int j = 0; j < k; ++j) { const double s = A[6 * k + j]; A[6 * k + j] = A[6 * p + j]; A[6 * p + j] = s; }
       for (int i = p + 1; i < 6; ++i) { const double s = A[6 * i + k]; A[6 * i + k] = A[6 * i + p]; A[6 * i + p] = s; }
       for (int i = k + 1; i < p; ++i) { const double s = A[6 * i + k]; A[6 * i + k] = A[6 * p + i]; A[6 * p + i] = s; }
@@ -141,20 +146,19 @@ VG_HD void ldlt6_solve(const double* lower21, const double* b, double* x, double
     }
     if (k > 0) {
       for (int j = 0; j < k; ++j) tmp[j] = A[7 * j] * A[6 * k + j];
-      double akk = A[7 * k];
-      for (int j = 0; j < k; ++j) akk -= A[6 * k + j] * tmp[j];
-      A[7 * k] = akk;
+      double dot = 0.0;
+      for (int j = 0; j < k; ++j) dot += A[6 * k + j] * tmp[j];
+      A[7 * k] -= dot;
       for (int i = k + 1; i < 6; ++i) {
-        double v = A[6 * i + k];
-        for (int j = 0; j < k; ++j) v -= A[6 * i + j] * tmp[j];
-        A[6 * i + k] = v;
+        double d = 0.0;
+        for (int j = 0; j < k; ++j) d += A[6 * i + j] * tmp[j];
+        A[6 * i + k] -= d;
       }
     }
     const double akk = A[7 * k];
     const bool valid = fabs(akk) > 0.0;
     if (k == 0 && !valid) {
-      // the whole diagonal is zero: Eigen stops here with identity transpositions
-      zero_diag = true;
+      zero_diag = true;    // the whole diagonal is zero: Eigen stops here with identity transpositions
       break;
     }
     if (valid)
@@ -166,21 +170,12 @@ VG_HD void ldlt6_solve(const double* lower21, const double* b, double* x, double
       const int p = (perm_packed >> (3 * k)) & 7;
       if (p != k) { const double s = y[k]; y[k] = y[p]; y[p] = s; }
     }
-  // L y = Pb (unit lower)
-  for (int i = 1; i < 6; ++i) {
-    double v = y[i];
-    for (int j = 0; j < i; ++j) v -= A[6 * i + j] * y[j];
-    y[i] = v;
-  }
-  // pseudo-inverse of D
+  for (int i = 1; i < 6; ++i)            // L y = P b (unit lower), one term at a time
+    for (int j = 0; j < i; ++j) y[i] -= A[6 * i + j] * y[j];
   const double tol = 2.2250738585072014e-308;
   for (int i = 0; i < 6; ++i) y[i] = (fabs(A[7 * i]) > tol) ? y[i] / A[7 * i] : 0.0;
-  // L^T z = y
-  for (int i = 4; i >= 0; --i) {
-    double v = y[i];
-    for (int j = i + 1; j < 6; ++j) v -= A[6 * j + i] * y[j];
-    y[i] = v;
-  }
+  for (int i = 4; i >= 0; --i)           // L^T z = y
+    for (int j = i + 1; j < 6; ++j) y[i] -= A[6 * j + i] * y[j];
   if (!zero_diag)
     for (int k = 5; k >= 0; --k) {
       const int p = (perm_packed >> (3 * k)) & 7;

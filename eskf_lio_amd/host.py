@@ -55,8 +55,30 @@ def load_library() -> C.CDLL:
     lib.host_preprocessor_process.argtypes = [vp, sz, dp, dp, sz, dp, dp, dp, C.POINTER(sz)]
     lib.host_preprocessor_destroy.argtypes = [vp]
     lib.host_preprocessor_downsample.argtypes = [vp, sz, dp, dp, dp, C.POINTER(sz)]
+    lib.host_math_ldlt6_solve.argtypes = [dp, dp, dp]
+    lib.host_math_ldlt6_solve.restype = None
+    lib.host_math_se3_exp.argtypes = [dp, dp]
+    lib.host_math_se3_exp.restype = None
     _lib = lib
     return lib
+
+
+def math_ldlt6_solve(JTJ, b) -> np.ndarray:
+    """csrc/vgicp_math.h's pivoted LDLT (the kernels' fallback solve) compiled for the host: A x = b with A a
+    6x6 (row, col) array of which the lower triangle is read."""
+    A = np.asarray(JTJ, dtype=np.float64).reshape(6, 6)
+    low = np.ascontiguousarray([A[r, c] for r in range(6) for c in range(r + 1)], dtype=np.float64)
+    rhs = np.ascontiguousarray(b, dtype=np.float64).reshape(6)
+    x = np.zeros(6)
+    load_library().host_math_ldlt6_solve(_dp(low), _dp(rhs), _dp(x))
+    return x
+
+
+def math_se3_exp(xi) -> np.ndarray:
+    v = np.ascontiguousarray(xi, dtype=np.float64).reshape(6)
+    out = np.zeros(16)
+    load_library().host_math_se3_exp(_dp(v), _dp(out))
+    return out.reshape(4, 4).T.copy()
 
 
 def _dp(a):

@@ -13,6 +13,7 @@
 
 #include "../../include/eskf_lio_shim/CloudPreprocessor.hpp"
 #include "../../include/eskf_lio_shim/Registration.hpp"
+#include "../csrc/vgicp_math.h"
 
 using ESKF_LIO::CloudPreprocessor;
 using ESKF_LIO::ICP;
@@ -246,6 +247,23 @@ int host_preprocessor_process(
       }
       if (!meas->pointTime.empty()) {throw std::runtime_error("process() must clear pointTime");}
     });
+}
+
+// The module's own 6x6 solve (csrc/vgicp_math.h, the code the kernels run as their pivoted fallback),
+// compiled for the host: lets a CPU-only test pin its operation order against the oracle's LDLT.
+// lower21: packed lower triangle row by row; b: right-hand side; x: solution.
+void host_math_ldlt6_solve(const double * lower21, const double * b, double * x)
+{
+  double work[vgicp::kLdltWork];
+  vgicp::ldlt6_solve(lower21, b, x, work);
+}
+
+// Utils::se3ToSE3 as the module's host math states it -> column-major 4x4.
+void host_math_se3_exp(const double * xi, double * out16)
+{
+  vgicp::Pose T;
+  vgicp::se3_exp(xi, T);
+  vgicp::pose_to_mat4(T, out16);
 }
 
 }  // extern "C"

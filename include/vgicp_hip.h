@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGICP_ABI_VERSION 1
+#define VGICP_ABI_VERSION 2
 
 typedef struct vgicp_ctx vgicp_ctx;
 
@@ -152,6 +152,17 @@ int vgicp_align_resident(vgicp_ctx* ctx, const double guess[16], const vgicp_par
  * JTJ is written as a full column-major 6x6 (mirrored from its lower triangle). Local rank only. */
 int vgicp_accumulate(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
                      const double pose[16], double JTJ[36], double JTr[6], uint64_t* count);
+/* The tail of one round on given normal equations, run on the device by the same code the loop kernels
+ * inline: se3 = JTJ.ldlt().solve(-JTr) (src/Registration.cpp:78), step = Utils::se3ToSE3(se3)
+ * (src/Registration.cpp:79, src/Utils.cpp:40-63; column-major 4x4) and ICP::convergenceCheck(step)
+ * (src/Registration.cpp:37-50).  JTJ is a column-major 6x6 of which only the lower triangle is read (as
+ * Eigen's LDLT does).  The device first tries an unpivoted LDL^T that is valid for safely positive
+ * definite systems and otherwise runs the pivoted, Eigen-faithful one (pseudo-inverted D);
+ * VGICP_SOLVE_FORCE_PIVOTED selects the latter unconditionally.  used_pivoted / converged are optional. */
+#define VGICP_SOLVE_FORCE_PIVOTED 1u
+int vgicp_solve_step(vgicp_ctx* ctx, const double JTJ[36], const double JTr[6], double cosine_threshold,
+                     double translation_sq_threshold, uint32_t flags, double se3[6], double step[16],
+                     int32_t* used_pivoted, int32_t* converged);
 /* LocalMap::correspondenceMatching (src/LocalMap.cpp:78-112) on points/covs given in the MAP frame:
  * materialises (srcPoints, srcCovs, mapPoints, mapCovs) in ascending point order. Output arrays hold
  * n entries each; src_index (optional) receives the matched point indices. */

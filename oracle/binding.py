@@ -69,6 +69,8 @@ def load() -> C.CDLL:
     lib.oracle_deskew.restype = C.c_int64
     lib.oracle_deskew.argtypes = [sz, dp, dp, sz, dp]
     lib.oracle_max_threads.restype = C.c_int
+    lib.oracle_set_threads.argtypes = [C.c_int]
+    lib.oracle_set_threads.restype = None
     _lib = lib
     return lib
 
@@ -213,6 +215,10 @@ def transform(points, covs, T):
 
 def max_threads() -> int:
     return load().oracle_max_threads()
+
+
+def set_threads(threads: int) -> None:
+    load().oracle_set_threads(int(threads))
 
 
 def preprocess(points, voxel_size: float, knn: int = 30):

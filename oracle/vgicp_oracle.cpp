@@ -823,5 +823,6 @@ int64_t oracle_deskew(size_t n, double* points, const double* point_time, size_t
 }
 
 int oracle_max_threads(void) { return omp_get_max_threads(); }
+void oracle_set_threads(int threads) { if (threads > 0) omp_set_num_threads(threads); }
 
 }  // extern "C"

@@ -110,6 +110,8 @@ int64_t oracle_deskew(size_t n, double* points, const double* point_time, size_t
                       const double* states);
 
 int oracle_max_threads(void);
+/* OpenMP thread count of the following calls (the CPU-baseline thread sweep of bench.py). */
+void oracle_set_threads(int threads);
 
 #ifdef __cplusplus
 }

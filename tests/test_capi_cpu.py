@@ -30,12 +30,12 @@ def test_library_exports_every_declared_symbol():
     from eskf_lio_amd import capi
     lib = capi.load_library()
     declared = header_symbols()
-    assert len(declared) == 26 and set(declared) == set(capi.EXPORTS)
+    assert len(declared) == 27 and set(declared) == set(capi.EXPORTS)
     out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True,
                          check=True).stdout
     exported = set(re.findall(r" T (vgicp_[a-z_0-9]+)", out))
     assert set(declared) <= exported
-    assert lib.vgicp_abi_version() == 1
+    assert lib.vgicp_abi_version() == 2
 
 
 def test_library_is_a_gfx950_code_object_without_torch_or_oracle():
@@ -128,3 +128,35 @@ def test_bench_refuses_to_run_without_a_gpu_and_prices_bytes_as_designed():
     c5 = bench.measured_traffic(1_000_000, 1, "persistent_kernel")
     assert c2 is not None and c5 is not None and c5 > 50 * c2        # per launch of 20 rounds
     assert bench.measured_traffic(100_000, 8, "persistent_kernel") is None
+
+
+def test_module_fallback_solve_is_the_oracles_ldlt_bit_for_bit(oracle):
+    """csrc/vgicp_math.h's ldlt6_solve — what the kernels run when the normal equations are not safely
+    positive definite — compiled for the host, against the oracle's restatement of Eigen's pivoted LDLT
+    (reference call site src/Registration.cpp:78) on well-conditioned, indefinite and rank-deficient
+    systems with noise pivots: same operation order, no contraction, hence the same bits."""
+    from eskf_lio_amd import host
+    rng = np.random.default_rng(5)
+    for trial in range(600):
+        kind = trial % 4
+        if kind == 0:
+            Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+            A = (Q * np.geomspace(1.0, 10.0 ** rng.uniform(0, 10), 6)) @ Q.T
+        elif kind == 1:
+            Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+            A = (Q * rng.normal(size=6)) @ Q.T
+        elif kind == 2:
+            B = rng.normal(size=(6, 3))
+            A = B @ B.T
+        else:
+            B = rng.integers(-3, 4, size=(6, int(rng.integers(1, 6)))).astype(np.float64)
+            A = B @ B.T
+        A = 0.5 * (A + A.T)
+        b = rng.normal(size=6)
+        ours = host.math_ldlt6_solve(A, -b)
+        theirs, _ = oracle.solve_step(A, b)
+        assert np.array_equal(ours, theirs, equal_nan=True), trial
+    assert np.array_equal(host.math_ldlt6_solve(np.zeros((6, 6)), np.zeros(6)), np.zeros(6))   # K3
+    for xi in ([0.1, -0.2, 0.3, 0.0, 0.0, 0.0], [0.1, -0.2, 0.3, 6e-8, 0.0, 8e-8], [0, 0, 0, 0, 0, np.pi / 2],
+               [1.0, 2.0, 3.0, 0.3, -0.4, 1.2]):
+        assert np.allclose(host.math_se3_exp(xi), oracle.se3_to_SE3(np.array(xi, dtype=np.float64)), rtol=0, atol=1e-15)

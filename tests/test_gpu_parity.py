@@ -273,18 +273,125 @@ def test_empty_scan_empty_map_and_zero_iterations(gpu_ctx, c1_inputs):
         gpu_ctx.map_reset(-1.0, 0)
 
 
-def test_degenerate_system_is_reported_not_thrown(gpu_ctx):
-    """One correspondence: JTJ has rank 3. The reference is unguarded here (Registration.cpp:78); the
-    module returns whatever the pivoted LDLT yields and flags a non-finite pose with a status code."""
+def test_degenerate_system_is_reported_not_thrown(gpu_ctx, oracle):
+    """One correspondence: JTJ has rank 3. The reference is unguarded here (Registration.cpp:78): Eigen's
+    pivoted LDLT divides by whatever rounding noise the last three pivots hold. The device's fallback solve
+    follows the same operation order without contraction, so it returns the oracle's se3 bit for bit and
+    the whole align follows the oracle; a non-finite pose comes back as a status code, never as a throw."""
     from eskf_lio_amd import capi
     gpu_ctx.map_reset(0.3, 0)
     mu = np.array([[0.95, 2.05, 3.1]])
     gpu_ctx.map_upsert(np.floor(mu / 0.3).astype(np.int32), mu, np.eye(3).reshape(1, 9))
-    r = gpu_ctx.align(np.array([[1.0, 2.0, 3.0]]), np.eye(3).reshape(1, 9), np.eye(4), 3, 1e-6, 0.9999,
-                      allow_degenerate=True)
+    p = np.array([[1.0, 2.0, 3.0]])
+    om = oracle.OracleMap(0.3, 1)
+    om.insert(mu, np.eye(3).reshape(1, 9))
+    ref = om.align(p, np.eye(3).reshape(1, 9), np.eye(4), 3, 1e-6, 0.9999)
+    r = gpu_ctx.align(p, np.eye(3).reshape(1, 9), np.eye(4), 3, 1e-6, 0.9999, allow_degenerate=True)
     assert r.status in (capi.OK, capi.ERR_DEGENERATE)
+    assert (r.status == capi.OK) == bool(np.isfinite(ref.pose).all())
+    assert r.iterations == ref.iterations and np.array_equal(r.corr_count, ref.corr_count)
     if r.status == capi.OK:
-        assert np.isfinite(r.pose).all()
+        assert np.allclose(r.pose, ref.pose, rtol=1e-9, atol=1e-9)
+    # the first round's system through the solve hook: the fallback is taken and equals the oracle's bits
+    JTJ, JTr, cnt = gpu_ctx.accumulate(p, np.eye(3).reshape(1, 9), np.eye(4))
+    assert cnt == 1
+    se3, step, pivoted, _ = gpu_ctx.solve_step(JTJ, JTr)
+    ose3, ostep = oracle.solve_step(JTJ, JTr)
+    assert pivoted and np.array_equal(se3, ose3, equal_nan=True)
+    if np.isfinite(ose3).all():
+        assert np.allclose(step, ostep, rtol=1e-12, atol=1e-15)
+
+
+def _random_spd6(rng, cond=1e3):
+    Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+    A = (Q * np.geomspace(1.0, cond, 6)) @ Q.T
+    return 0.5 * (A + A.T)
+
+
+def test_solve_step_matches_oracle(c1_gpu, c1_inputs, oracle):
+    """The device's solve / exponential / convergence test on given normal equations against
+    oracle_solve_step (reference src/Registration.cpp:37-50,78-79, src/Utils.cpp:40-63)."""
+    from eskf_lio_amd import synth
+    rng = np.random.default_rng(77)
+    ctx = c1_gpu
+    vmap, pts, covs = c1_inputs
+    # (1) a real, well-conditioned system: fast path, agreement to rounding
+    JTJ, JTr, _ = ctx.accumulate(pts, covs, synth.default_guess())
+    se3, step, pivoted, _ = ctx.solve_step(JTJ, JTr)
+    ose3, ostep = oracle.solve_step(JTJ, JTr)
+    assert not pivoted
+    assert np.allclose(se3, ose3, rtol=1e-10, atol=1e-16) and np.allclose(step, ostep, rtol=1e-12, atol=1e-15)
+    # the same system through the pivoted solve: the oracle's bits
+    se3p, _, pivoted, _ = ctx.solve_step(JTJ, JTr, force_pivoted=True)
+    assert pivoted and np.array_equal(se3p, ose3)
+    # (2) random SPD systems, both paths
+    for _ in range(20):
+        A, b = _random_spd6(rng, 10.0 ** rng.uniform(0, 8)), rng.normal(size=6)
+        ose3, ostep = oracle.solve_step(A, b)
+        se3, step, pivoted, _ = ctx.solve_step(A, b)
+        assert not pivoted and np.allclose(se3, ose3, rtol=1e-7, atol=1e-14)
+        se3p, stepp, _, _ = ctx.solve_step(A, b, force_pivoted=True)
+        assert np.array_equal(se3p, ose3) and np.allclose(stepp, ostep, rtol=1e-12, atol=1e-15)
+    # (3) indefinite and rank-deficient systems: never the fast path, always the oracle's bits
+    for trial in range(20):
+        Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+        ev = np.abs(rng.normal(size=6)) * 10.0 ** rng.uniform(-3, 3, size=6)
+        ev[rng.integers(0, 6)] *= -1.0                                # one negative eigenvalue
+        A = (Q * ev) @ Q.T
+        A = 0.5 * (A + A.T)
+        b = rng.normal(size=6)
+        se3, step, pivoted, _ = ctx.solve_step(A, b)
+        ose3, ostep = oracle.solve_step(A, b)
+        assert pivoted and np.array_equal(se3, ose3)
+    B = rng.integers(-3, 4, size=(6, 3)).astype(np.float64)           # rank 3, noise pivots afterwards
+    A = B @ B.T
+    b = -(A @ rng.normal(size=6))
+    se3, _, pivoted, _ = ctx.solve_step(A, b)
+    ose3, _ = oracle.solve_step(A, b)
+    assert pivoted and np.array_equal(se3, ose3, equal_nan=True)
+    # exactly singular in exact arithmetic: zero pivots are skipped, D is pseudo-inverted
+    A = np.zeros((6, 6))
+    A[:2, :2] = [[4.0, 2.0], [2.0, 1.0]]
+    A[2, 2], A[5, 5] = 2.0, 1.0
+    b = np.array([-4.0, -2.0, -6.0, 5.0, 7.0, -3.0])
+    se3, _, pivoted, _ = ctx.solve_step(A, b)
+    ose3, _ = oracle.solve_step(A, b)
+    assert pivoted and np.array_equal(se3, ose3) and np.isfinite(se3).all() and se3[3] == 0.0 and se3[4] == 0.0
+    # (4) the all-zero system of "no correspondences" (K3): zero step, identity, converged
+    se3, step, pivoted, conv = ctx.solve_step(np.zeros((6, 6)), np.zeros(6))
+    assert pivoted and conv and np.array_equal(se3, np.zeros(6)) and np.array_equal(step, np.eye(4))
+    # (5) se3ToSE3 edge cases (K4) through the device: JTJ = I, JTr = -xi solves to xi exactly
+    for xi in ([0.1, -0.2, 0.3, 0.0, 0.0, 0.0],                       # phi = 0: R = I, t = rho
+               [0.1, -0.2, 0.3, 6e-8, 0.0, 8e-8],                     # |phi| = 1e-7 < 1e-6: J_l = I
+               [0.1, -0.2, 0.3, 0.0, 0.0, np.pi / 2],                 # 90 degrees about z
+               [0.0, 0.0, 0.0, 1e-6, 0.0, 0.0],                       # exactly at the 1e-6 branch
+               [1.0, 2.0, 3.0, 0.3, -0.4, 1.2]):
+        xi = np.array(xi)
+        se3, step, pivoted, _ = ctx.solve_step(np.eye(6), -xi)
+        assert not pivoted and np.array_equal(se3, xi)
+        ostep = oracle.se3_to_SE3(xi)
+        assert np.allclose(step, ostep, rtol=0, atol=4e-16 * max(1.0, np.abs(xi[:3]).max()))
+        if np.linalg.norm(xi[3:]) < 1e-6:
+            assert np.array_equal(step[:3, 3], xi[:3])
+    # (6) convergenceCheck (K5): equality with a threshold counts as converged, one ulp beyond does not.
+    # A step along x only: |t|^2 = tx * tx whatever the device contracts.
+    xi = np.array([3e-4, 0.0, 0.0, 0.0, 0.0, 0.0])
+    _, step, _, _ = ctx.solve_step(np.eye(6), -xi)
+    assert step[1, 3] == 0.0 and step[2, 3] == 0.0
+    cos = 0.5 * (((step[0, 0] + step[1, 1]) + step[2, 2]) - 1.0)
+    t2 = float(step[0, 3]) * float(step[0, 3])
+    for cthr, tthr in ((cos, t2), (np.nextafter(cos, 2.0), t2), (cos, np.nextafter(t2, 0.0)),
+                       (np.nextafter(cos, 0.0), np.nextafter(t2, 1.0)), (0.9999, 1e-6), (2.0, 1e-6)):
+        _, _, _, conv = ctx.solve_step(np.eye(6), -xi, cosine_threshold=cthr, translation_sq_threshold=tthr)
+        assert conv == oracle.convergence_check(step, cthr, tthr), (cthr, tthr)
+    assert ctx.solve_step(np.eye(6), -xi, cosine_threshold=cos, translation_sq_threshold=t2)[3]
+    assert not ctx.solve_step(np.eye(6), -xi, cosine_threshold=cos, translation_sq_threshold=np.nextafter(t2, 0.0))[3]
+    # a rotation: equality with the cosine threshold converges, one ulp above does not
+    xi = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 2e-3])
+    _, step, _, _ = ctx.solve_step(np.eye(6), -xi)
+    cos = 0.5 * (((step[0, 0] + step[1, 1]) + step[2, 2]) - 1.0)
+    assert ctx.solve_step(np.eye(6), -xi, cosine_threshold=cos, translation_sq_threshold=1e-6)[3]
+    assert not ctx.solve_step(np.eye(6), -xi, cosine_threshold=np.nextafter(cos, 2.0), translation_sq_threshold=1e-6)[3]
 
 
 def test_ragged_scan_sizes(c1_gpu, c1_inputs, c1_oracle_map):
@@ -601,6 +708,75 @@ def test_c2_full_size_properties(gpu_ctx, oracle):
     om.insert(vmap.means, vmap.covs)
     ref = om.align(pts, covs, g, 20, 1e-6, 2.0)
     assert_align_parity(a, ref)
+
+
+def test_sharded_loop_on_one_device_matches_the_single_gpu_log(gpu_ctx):
+    """SURVEY.md 8(e) parity expectation at C2 size without a second GPU: the scan cut by shard_bounds into
+    G in {2, 4, 8} contiguous shards, every round each shard accumulated on the device at the current pose
+    (vgicp_accumulate), the G rows summed on the host in rank order as the exchange does, solved on the
+    device (vgicp_solve_step) and composed. Every round's 27-vector and count against the single-GPU log:
+    counts identical, sums equal up to the grouping of the additions."""
+    from eskf_lio_amd import synth
+    from eskf_lio_amd.distributed import shard_bounds
+    vmap = synth.make_map(1_000_000)
+    pts, covs = synth.make_uniform_scan(100_000, vmap)
+    gpu_ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+    gpu_ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+    g = synth.default_guess()
+    rounds = 8
+    single = gpu_ctx.align(pts, covs, g, rounds, 1e-6, 2.0)
+    assert single.iterations == rounds
+    for G in (2, 4, 8):
+        pose = g.copy()
+        for r in range(rounds):
+            JTJ, JTr, count = np.zeros((6, 6)), np.zeros(6), 0
+            for rank in range(G):
+                lo, hi = shard_bounds(pts.shape[0], G, rank)
+                a, b, c = gpu_ctx.accumulate(pts[lo:hi], covs[lo:hi], pose)
+                JTJ, JTr, count = JTJ + a, JTr + b, count + c
+            assert count == int(single.corr_count[r]), (G, r)
+            scale = np.abs(single.JTJ[r]).max()
+            assert np.allclose(JTJ, single.JTJ[r], rtol=1e-11, atol=1e-12 * scale), (G, r)
+            assert np.allclose(JTr, single.JTr[r], rtol=1e-9, atol=1e-12 * scale), (G, r)
+            _, step, _, _ = gpu_ctx.solve_step(JTJ, JTr, cosine_threshold=2.0)
+            pose = step @ pose
+        dt, dr = pose_error(pose, single.pose)
+        assert dt <= 1e-11 and dr <= 1e-11, (G, dt, dr)
+
+
+def test_c5_full_size_parity(gpu_ctx, oracle):
+    """BASELINE config C5 on one GPU: 1M-point scan vs 10M-voxel map (8.6 GB table, beyond the Infinity
+    Cache), 3 forced iterations, against the oracle's deterministic mode at the full size; the persistent
+    single launch (a thread owns ~9 points there) and the one-launch-per-round loop. Identical counts, the
+    contractual 1e-4 and the tight 1e-9."""
+    from eskf_lio_amd import capi, synth
+    vmap = synth.make_map(10_000_000)
+    pts, covs = synth.make_uniform_scan(1_000_000, vmap)
+    g = synth.default_guess()
+    om = oracle.OracleMap(vmap.voxel_size, 1)
+    om.insert(vmap.means, vmap.covs)
+    ref = om.align(pts, covs, g, 3, 1e-6, 2.0)
+    del om
+    gpu_ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+    gpu_ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+    assert gpu_ctx.map_size()[0] == 10_000_000
+    gpu_ctx.scan_upload(pts, covs)
+    one = gpu_ctx.align_resident(g, 3, 1e-6, 2.0)
+    assert one.launches == 1
+    assert_align_parity(one, ref)
+    loop = gpu_ctx.align_resident(g, 3, 1e-6, 2.0, flags=capi.FLAG_NO_PERSISTENT)
+    assert loop.launches > 1
+    assert_align_parity(loop, ref)
+    scale = np.abs(ref.JTJ).max()
+    for r in range(3):
+        assert np.allclose(one.JTJ[r], ref.JTJ[r], rtol=1e-9, atol=1e-12 * scale)
+        assert np.allclose(one.JTr[r], ref.JTr[r], rtol=1e-7, atol=1e-12 * scale)
+    # 12 rounds of the persistent launch: what a thread remembers about its points between rounds is
+    # exercised over many rounds and must agree with the loop that looks every point up every round
+    many = gpu_ctx.align_resident(g, 12, 1e-6, 2.0)
+    many_loop = gpu_ctx.align_resident(g, 12, 1e-6, 2.0, flags=capi.FLAG_NO_PERSISTENT)
+    assert many.launches == 1 and np.array_equal(many.corr_count, many_loop.corr_count)
+    assert np.abs(many.pose - many_loop.pose).max() < 1e-11
 
 
 # ---- N2: scan preparation on the device (CloudPreprocessor.cpp:76-127) ----------------------------
