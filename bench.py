@@ -1,32 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — registered points/s per VGICP iteration on MI355X (BASELINE.json metric).
 
-A "step" is one whole ICP::align over the resident scan: 20 VGICP iterations (cosine_threshold 2.0
-forces all of them) of config C2 — a 100k-point synthetic uniform scan against a
-1M-voxel synthetic map.  With --gpus N (launched by torch.distributed.run, one rank per GPU) there are
-two ways to use the ranks, and the warm-up measures both:
-  * SHARD: the one scan is split in contiguous blocks over the ranks, the map is replicated, every
-    iteration ends in one RCCL all-reduce of the 28-double normal-equation row ("scaling": "strong");
-  * REPLICAS: every rank registers its OWN 100k-point scan (same generator, seed + rank) against the
-    replicated map with the single-launch loop and no communication ("scaling": "weak": per-GPU work is
-    fixed, `value` counts the points of all N scans).
-A C2 round takes ≈10 us on one GPU, less than one host-enqueued all-reduce, so sharding a 100k-point scan
-cannot pay (it does from about C5); the timed region therefore runs whichever of the two
-delivers more registered points per second (`config.sharding`, `config.sharding_autotune` report the
-choice and both rates; BENCH_SHARDING=shard|replicate forces one; `multi_gpu_parity` always exercises and
-checks the sharded path against the single-GPU result).
+A "step" is one whole ICP::align of config C2 — a 100k-point synthetic uniform scan against a 1M-voxel
+synthetic map, 20 VGICP iterations (cosine_threshold 2.0 forces all of them) — called the
+way the reference calls it: with the scan in ordinary HOST buffers (reference src/Registration.cpp:11 deep-
+copies the cloud; here that copy is the upload).  The timed region therefore holds, per step, the
+host-to-device copy of the 96·N-byte scan, its packing and the 20 rounds ("a pre-resident
+scan is not allowed for the headline number").  The map is resident before the timed region starts (it
+belongs to updateLocalMap).  `value` = N · 20 · steps / wall; `value_resident` is the same loop over a scan
+that is already in HBM (vgicp_align_resident), reported beside it, never as `value`.
 
-Timed region: inputs already resident in HBM (scan uploaded, map built) — barrier +
-torch.cuda.synchronize() on both sides, K steps, max over ranks.  `roofline` is measured live over
-the same timed region: every align brackets its iteration launches with a HIP event pair on the
-module's own stream (stats.device_seconds), so launch time = event span / body launches, kernel
-boundaries included; a second pass with an event pair around EVERY launch (VGICP_FLAG_PROFILE) is
-reported beside it.  `roofline.traffic` is the PMC-measured HBM traffic per launch of the newest
-profiles/*_summary.json (tools/profile_gpu.sh), or null.  `cpu_baseline` times the CPU oracle's
-reference-faithful mode (OpenMP, all host cores) on the same inputs, rank 0 at N=1 only.
+--gpus N (launched by torch.distributed.run, one rank per GPU): the ONE scan is split into contiguous point
+shards (BASELINE config C3), every rank uploads and registers its shard against the replicated map, every
+iteration ends in the exchange of the 28-double normal-equation row; all ranks return the same pose.
+`value` = N_points · 20 · steps / wall of that sharded align ("scaling": "strong": the total work is fixed).
+N independent scans, one per rank (no communication), are measured too and reported as
+`replicas_aggregate` — a throughput figure, not the metric.  `multi_gpu_parity` compares the sharded result
+with the whole scan on one GPU.
 
-PyTorch is plumbing here (torch.distributed rendezvous/barrier, device sync); the path itself is
-the C-ABI HIP module.  The oracle is touched only by the cpu_baseline leg.
+`roofline` is measured live over the timed region: every align brackets its iteration launch(es) with a HIP
+event pair on the module's own stream (stats.device_seconds); `achieved` = ALGORITHMIC bytes per launch
+(112 B per point-iteration + 96 B per matched point) ÷ that span.  On one GPU a launch is
+the persistent kernel = all 20 rounds.  `traffic` is the PMC-measured HBM traffic per launch from the newest
+profiles/*_summary.json taken at this scan size (tools/profile_gpu.sh), or null; the persistent launch keeps
+scan and voxel records on chip, so its real HBM traffic is far BELOW the algorithmic bytes and `frac` is a
+statement about time per algorithmic byte, not about HBM utilisation (`traffic_frac` is the latter).
+`cpu_baseline` times the CPU oracle's reference-faithful mode (OpenMP) on the same inputs at several thread
+counts, rank 0 at N=1 only, and reports the best.
+
+PyTorch is plumbing here (torch.distributed rendezvous/barrier, device sync); the path itself is the C-ABI
+HIP module.  The oracle is touched only by the cpu_baseline leg.
 """
 from __future__ import annotations
 
@@ -49,6 +52,7 @@ from eskf_lio_amd.distributed import shard_bounds, share_unique_id  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s achievable)
 ITERATIONS = 20
+METRIC = "registered points/sec per VGICP iteration (100k-pt scan vs 1M-voxel map), 1/2/4/8 GPU"
 
 
 def algorithmic_bytes(n_points: int, matches: float) -> float:
@@ -78,31 +82,43 @@ def measured_traffic(n_points: int, world: int, kernel: str):
 
 
 def cpu_baseline(vmap, pts, covs, guess, budget_s: float):
-    """The reference-faithful CPU path (oracle, OpenMP) on the same inputs; bounded wall time."""
+    """The reference-faithful CPU path (oracle, OpenMP) on the same inputs, at OpenMP thread counts
+    {1, 8, 32, all host cores}; bounded wall time; the best rate is the baseline."""
     from oracle import binding as oracle
     omap = oracle.OracleMap(vmap.voxel_size, 1)  # maxNumPointsPerVoxel = 1 (BASELINE.md §3)
     omap.insert(vmap.means, vmap.covs)
-    times = []
-    t_start = time.time()
-    reps = 0
-    while True:
-        r = omap.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0, mode=oracle.FAITHFUL)
-        reps += 1
-        if reps > 2:  # two warm-ups
-            times.append(r.seconds)
-        if (len(times) >= 10) or (time.time() - t_start > budget_s and len(times) >= 3):
-            break
-    med = float(np.median(times))
     n = pts.shape[0]
+    all_cores = oracle.max_threads()
+    counts = sorted({c for c in (1, 8, 32, all_cores) if c <= all_cores})
+    per_setting = budget_s / len(counts)
+    sweep, best, ref = [], None, None
+    for threads in counts:
+        oracle.set_threads(threads)
+        t_start = time.time()
+        times = []
+        r = omap.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0, mode=oracle.FAITHFUL)  # warm-up
+        while len(times) < 5 and (time.time() - t_start < per_setting or len(times) < 2):
+            r = omap.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0, mode=oracle.FAITHFUL)
+            times.append(r.seconds)
+        med = float(np.median(times))
+        row = {"threads": int(r.threads), "ms_per_align": med * 1e3, "points_per_s": n * r.iterations / med,
+               "aligns_timed": len(times)}
+        sweep.append(row)
+        if best is None or row["points_per_s"] > best["points_per_s"]:
+            best = row
+        ref = r
+    oracle.set_threads(all_cores)
     return {
-        "value": n * r.iterations / med,
+        "value": best["points_per_s"],
         "unit": "points/s",
-        "cores": int(r.threads),
+        "cores": best["threads"],
         "kind": "port",
-        "sample": f"full workload: {n}-pt scan x {r.iterations} iterations vs {len(omap)}-voxel map, "
-                  f"median of {len(times)} aligns after 2 warm-ups ({med * 1e3:.1f} ms each), "
-                  f"oracle faithful mode (OpenMP, -O3, no -march)",
-    }, r
+        "sample": f"full workload: {n}-pt scan x {ref.iterations} iterations vs {len(omap)}-voxel map; oracle "
+                  f"faithful mode (OpenMP, -O3, no -march), median of {best['aligns_timed']} aligns after 1 warm-up "
+                  f"at each of {counts} threads; best = {best['threads']} threads ({best['ms_per_align']:.1f} ms per align)",
+        "thread_sweep": sweep,
+        "host_cores": all_cores,
+    }, ref
 
 
 def main():
@@ -113,6 +129,9 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(synth.CONFIGS))
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resident", action="store_true",
+                    help="time vgicp_align_resident (scan already in HBM) as the step: profiling aid, the JSON "
+                         "line then says so in config.workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,8 +145,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    # BENCH_FORCE_COMM=1 runs the multi-GPU code path (process group, unique-id hand-off, RCCL
-    # all-reduce per iteration) with however many ranks there are — on one GPU a way to exercise it
+    # BENCH_FORCE_COMM=1 runs the multi-GPU code path (process group, unique-id hand-off, per-iteration
+    # exchange) with however many ranks there are — on one GPU a way to exercise it
     force_comm = os.environ.get("BENCH_FORCE_COMM", "0") == "1"
     use_dist = world > 1 or force_comm
     if use_dist:
@@ -140,25 +159,13 @@ def main():
     pts, covs = synth.make_uniform_scan(n_points, vmap)
     guess = synth.default_guess()
     lo, hi = shard_bounds(n_points, world, rank)
+    my_pts, my_covs = np.ascontiguousarray(pts[lo:hi]), np.ascontiguousarray(covs[lo:hi])
 
     ctx = capi.Context(local_rank)
     ctx.map_reset(vmap.voxel_size, n_voxels)
     ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
-    shard_error = None
     if use_dist:
-        # The module's own RCCL communicator (the sharded loop's all-reduce). If it cannot be set up on this
-        # box the independent-scans mode still runs; every rank has to see the same verdict.
-        try:
-            ctx.comm_init(world, rank, share_unique_id(ctx, rank))
-        except Exception as e:  # noqa: BLE001 - reported in the JSON line
-            shard_error = f"{type(e).__name__}: {e}"
-        bad = torch.tensor([1 if shard_error else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if int(bad.item()) and shard_error is None:
-            shard_error = "communicator set-up failed on another rank"
-            ctx.comm_destroy()
-    if shard_error is None:
-        ctx.scan_upload(pts[lo:hi], covs[lo:hi])
+        ctx.comm_init(world, rank, share_unique_id(ctx, rank))     # every rank or none: a failure ends the run
 
     def fence():
         torch.cuda.synchronize()
@@ -166,116 +173,124 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # With several ranks there are two ways to register one scan: SHARD it (each rank a contiguous
-    # block of points, one RCCL all-reduce of the 28-double row per iteration) or REPLICATE it (every
-    # rank registers the whole scan with the single-launch loop, no communication).  Sharding only pays
-    # once a shard is large enough to amortise the all-reduce, so the host side measures both during
-    # the warm-up and times the faster one (BENCH_SHARDING=shard|replicate forces a choice).
-    run_ctx, n_local, mode, tuning = ctx, hi - lo, "single", None
+    def step_host(flags=0):
+        """ICP::align as the reference calls it: scan (this rank's shard) in host buffers."""
+        return ctx.align(my_pts, my_covs, guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
+
+    def step_resident(flags=0):
+        return ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
+
+    def timed(step, steps):
+        fence()
+        t0 = time.perf_counter()
+        dev_s, res = 0.0, None
+        for _ in range(steps):
+            res = step()
+            dev_s += res.device_seconds
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, dev_s, res
+
+    headline = step_resident if args.resident else step_host
+    if args.resident:
+        ctx.scan_upload(my_pts, my_covs)
+    for _ in range(args.warmup):
+        res = headline()
+    elapsed, dev_s, res = timed(headline, args.steps)              # ---- the timed region ----
+    assert res.iterations == ITERATIONS, res.iterations
+
+    # secondary: the same loop over the scan already resident (kernel + launch + copy-back only)
+    if args.resident:
+        elapsed_res = elapsed
+    else:
+        for _ in range(2):
+            step_resident()
+        elapsed_res, _, _ = timed(step_resident, args.steps)
+    upload_ns, upload_bytes = ctx.counter(3), ctx.counter(2)
+
+    # per-launch variant: every iteration launch bracketed by HIP events on the module's stream
+    kernel_ms = []
+    for _ in range(max(3, min(args.steps, 20))):
+        r = step_resident(capi.FLAG_PROFILE)
+        kernel_ms.append(r.kernel_ms[:ITERATIONS])
+    kernel_ms = np.array(kernel_ms)
+    bracketed_s = float(kernel_ms.mean()) * 1e-3
+    n_local = hi - lo
+    matches = float(res.corr_count.mean()) / world                 # corr_count is summed over the communicator
+    bytes_per_round = algorithmic_bytes(n_local, matches)
+    persistent = res.launches == 1                                 # single GPU: the whole align is ONE launch
+    rounds_per_launch = ITERATIONS if persistent else 1
+    launches = args.steps * (1 if persistent else ITERATIONS)
+    span_s = dev_s / launches                                      # timed region: HIP-event span per launch
+    bytes_per_launch = bytes_per_round * rounds_per_launch
+    achieved = bytes_per_launch / span_s / 1e9
+    fallbacks = ctx.counter(1)
+
+    # N > 1, secondary: N independent scans, one per rank, no communication (throughput, not the metric)
+    replicas = None
+    solo = None
     if use_dist:
         solo = capi.Context(local_rank)
         solo.map_reset(vmap.voxel_size, n_voxels)
         solo.map_upsert(vmap.keys, vmap.means, vmap.covs)
         own_pts, own_covs = synth.make_uniform_scan(n_points, vmap, seed=synth.SCAN_SEED + rank)
-        solo.scan_upload(own_pts, own_covs)              # rank 0 keeps the common scan (seed + 0)
-        timing = {}
-        modes = (("replicate", solo),) if shard_error else (("shard", ctx), ("replicate", solo))
-        for name, c in modes:
-            for _ in range(2):
-                c.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(max(args.warmup, 3)):
-                c.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
-            fence()
-            t = torch.tensor([(time.perf_counter() - t0) / max(args.warmup, 3)], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)     # every rank sees the same numbers -> same choice
-            timing[name] = float(t.item())
-        want = os.environ.get("BENCH_SHARDING", "auto")
-        rate = {"replicate": world * n_points * ITERATIONS / timing["replicate"]}   # one scan per rank per step
-        if "shard" in timing:
-            rate["shard"] = n_points * ITERATIONS / timing["shard"]                  # one scan per step
-        mode = want if want in rate else max(rate, key=rate.get)
-        tuning = {"policy": want, "ms_per_step_replicate": timing["replicate"] * 1e3,
-                  "points_per_s_replicate": rate["replicate"],
-                  "ms_per_step_shard": timing["shard"] * 1e3 if "shard" in timing else None,
-                  "points_per_s_shard": rate.get("shard"), "shard_error": shard_error}
-        if mode == "replicate":
-            run_ctx, n_local = solo, n_points
 
-    def step(flags=0):
-        return run_ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
-
-    for _ in range(args.warmup):
-        res = step()
-    fence()
-    t0 = time.perf_counter()
-    dev_s = 0.0
-    for _ in range(args.steps):
-        res = step()
-        dev_s += res.device_seconds
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert res.iterations == ITERATIONS, res.iterations
-
-    # roofline pass: same steps, every iteration launch bracketed by HIP events on the module's stream
-    kernel_ms = []
-    for _ in range(max(3, min(args.steps, 20))):
-        r = step(capi.FLAG_PROFILE)
-        kernel_ms.append(r.kernel_ms[:ITERATIONS])
-    kernel_ms = np.array(kernel_ms)
-    bracketed_s = float(kernel_ms.mean()) * 1e-3
-    # matched points handled by this rank per round (corr_count is summed over the communicator)
-    matches = float(res.corr_count.mean()) / (world if mode == "shard" else 1)
-    bytes_per_round = algorithmic_bytes(n_local, matches)
-    persistent = res.launches == 1                   # single GPU: the whole align is ONE launch
-    rounds_per_launch = ITERATIONS if persistent else 1
-    launches = args.steps * (1 if persistent else ITERATIONS)
-    span_s = dev_s / launches                        # timed region: HIP-event span per launch
-    bytes_per_launch = bytes_per_round * rounds_per_launch
-    achieved = bytes_per_launch / span_s / 1e9
-
-    sharded = None
-    if use_dist and shard_error is None:  # a collective: every rank takes part (compared on rank 0 below)
-        sharded = ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
+        def step_replica():
+            return solo.align(own_pts, own_covs, guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
+        for _ in range(3):
+            step_replica()
+        steps_r = max(3, args.steps // 2)
+        el, _, _ = timed(step_replica, steps_r)
+        replicas = {"value": world * n_points * ITERATIONS * steps_r / el, "unit": "points/s",
+                    "ms_per_step": el / steps_r * 1e3,
+                    "what": f"{world} independent {n_points}-point scans, one per rank, host buffers, replicated map, "
+                            f"no communication — aggregate throughput, NOT the BASELINE metric"}
 
     out = None
     if rank == 0:
-        scans_per_step = world if mode == "replicate" else 1
-        value = scans_per_step * n_points * ITERATIONS * args.steps / elapsed
+        kernel = "vgicp::persistent_kernel" if persistent else "vgicp::iterate_kernel"
+        traffic = measured_traffic(n_points, world, "persistent_kernel" if persistent else "iterate_kernel")
+        workload = (f"{args.config}: {n_points}-pt uniform-random scan vs {n_voxels}-voxel map (voxel 0.3 m, occupancy 0.5), "
+                    f"{ITERATIONS} VGICP iterations per align (cosine_threshold 2.0 forces all); ")
+        if args.resident:
+            workload += "PROFILING MODE --resident: scan already in HBM (not the headline configuration)"
+        elif world == 1:
+            workload += ("each step = vgicp_align with the scan in host buffers: upload of the 96*N-byte scan + pack + "
+                         "20 rounds in one persistent launch; map resident")
+        else:
+            workload += (f"ONE scan point-sharded over {world} ranks (contiguous shards, replicated map); each step = "
+                         f"every rank uploads its shard from host buffers and runs the sharded loop, one exchange of the "
+                         f"28-double normal-equation row per iteration")
         out = {
-            "metric": "registered points/sec per VGICP iteration (100k-pt scan vs 1M-voxel map)",
-            "value": value,
+            "metric": METRIC,
+            "value": n_points * ITERATIONS * args.steps / elapsed,
             "unit": "points/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            # the label of the 1/2/4/8-GPU series: at N > 1 what the timed region ran; at N = 1 what that
-            # series runs at this size (replicas up to C2, where a round is shorter than any exchange)
-            "scaling": ("weak" if mode == "replicate" else "strong") if use_dist
-                       else ("weak" if n_points <= 100_000 else "strong"),
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "value_resident": n_points * ITERATIONS * args.steps / elapsed_res,
+            "ms_per_step_resident": elapsed_res / args.steps * 1e3,
             "config": {
-                "workload": f"{args.config}: {n_points}-pt uniform-random scan vs {n_voxels}-voxel map "
-                            f"(voxel 0.3 m, occupancy 0.5), {ITERATIONS} VGICP iterations per align "
-                            f"(cosine_threshold 2.0 forces all), scan resident in HBM",
+                "workload": workload,
                 "points": n_points, "voxels": n_voxels, "iterations": ITERATIONS,
-                "sharding": {"single": "single GPU",
-                             "shard": f"contiguous point shards over {world} rank(s), replicated map, RCCL "
-                                      f"all-reduce of 28 doubles per iteration",
-                             "replicate": f"{world} independent {n_points}-point scans, one per rank, replicated "
-                                          f"map, no communication: more points/s than point-sharding ONE scan "
-                                          f"at this size (see sharding_autotune)"}[mode],
-                "sharding_autotune": tuning,
+                "sharding": "single GPU" if world == 1 and not use_dist else
+                            f"contiguous point shards over {world} rank(s), replicated map, RCCL all-reduce of 28 "
+                            f"doubles per iteration",
                 "matches_per_iteration": float(res.corr_count.mean()),
+                "upload": {"bytes_per_step": 96 * n_local,
+                           "host_side_ms_per_upload": (upload_ns / 1e6) / max(1, upload_bytes // max(1, 96 * n_local)),
+                           "what": "pageable caller memory -> pinned staging by worker threads -> chunked DMA, overlapped"},
+                "persistent_fallbacks": fallbacks,
             },
             "roofline": {
                 "bound": "hbm",
@@ -283,9 +298,13 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n_points, world,
-                                            "persistent_kernel" if persistent else "iterate_kernel"),
-                "kernel": "vgicp::persistent_kernel" if persistent else "vgicp::iterate_kernel",
+                "traffic": traffic,
+                "traffic_frac": (traffic / span_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "note": "achieved/frac price ALGORITHMIC bytes (SURVEY.md 8(d)) against the launch's duration; the "
+                        "persistent launch keeps scan and voxel records on chip, so its HBM traffic (`traffic`, PMC) is "
+                        "far below them and traffic_frac is the real HBM utilisation: at this size the kernel is "
+                        "bound by the latency of the per-round reduce/exchange/solve chain, not by bytes",
+                "kernel": kernel,
                 "rounds_per_launch": rounds_per_launch,
                 "bytes_per_launch": bytes_per_launch,
                 "bytes_per_round": bytes_per_round,
@@ -298,23 +317,25 @@ def main():
                                              f"pair around each of {kernel_ms.size} launches, ~2 us event overhead each",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if replicas is not None:
+            out["replicas_aggregate"] = replicas
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
             base, ref = cpu_baseline(vmap, pts, covs, guess, args.cpu_budget)
             out["cpu_baseline"] = base
-            out["cpu_baseline"]["gpu_over_cpu"] = value / base["value"]
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / base["value"]
             # the timed GPU result is also the parity-checked one
             same_counts = bool((ref.corr_count == res.corr_count).all())
             dt = float(np.linalg.norm(ref.pose[:3, 3] - res.pose[:3, 3]))
             out["parity"] = {"identical_counts": same_counts, "pose_delta_m": dt}
-        if use_dist and sharded is not None:
-            # evidence that the sharded, all-reduced loop computes what one GPU computes
+        if use_dist:
+            # evidence that the sharded, exchanged loop computes what one GPU computes
             one = solo.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0)
             out["multi_gpu_parity"] = {
-                "identical_counts": bool((one.corr_count == sharded.corr_count).all()),
-                "pose_delta": float(np.abs(one.pose - sharded.pose).max()),
-                "against": "sharded + all-reduced loop vs the whole scan on one GPU (persistent launch)",
+                "identical_counts": bool((one.corr_count == res.corr_count).all()),
+                "pose_delta": float(np.abs(one.pose - res.pose).max()),
+                "against": "the timed sharded result vs the whole scan on one GPU (persistent launch)",
             }
-    if use_dist:
+    if solo is not None:
         solo.close()
     ctx.close()
     if use_dist:

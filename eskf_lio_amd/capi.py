@@ -25,6 +25,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/vgicp_hip.h declares
 EXPORTS = (
     "vgicp_abi_version", "vgicp_create", "vgicp_destroy", "vgicp_last_error", "vgicp_device_info",
+    "vgicp_get_counter",
     "vgicp_map_reset", "vgicp_map_upsert", "vgicp_map_erase", "vgicp_map_size",
     "vgicp_map_insert_scan", "vgicp_map_insert_resident", "vgicp_map_evict", "vgicp_map_export",
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
@@ -75,6 +76,7 @@ def load_library() -> C.CDLL:
     lib.vgicp_last_error.argtypes = [vp]
     lib.vgicp_last_error.restype = C.c_char_p
     lib.vgicp_device_info.argtypes = [vp, C.c_char_p, sz, ip, C.POINTER(C.c_uint64)]
+    lib.vgicp_get_counter.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
     lib.vgicp_map_reset.argtypes = [vp, C.c_double, sz]
     lib.vgicp_map_upsert.argtypes = [vp, sz, ip, dp, dp]
     lib.vgicp_map_erase.argtypes = [vp, sz, ip]
@@ -216,6 +218,12 @@ class Context:
         hbm = C.c_uint64()
         self._check(self._lib.vgicp_device_info(self._h, name, 64, C.byref(cu), C.byref(hbm)))
         return name.value.decode(), cu.value, hbm.value
+
+    def counter(self, which: int) -> int:
+        """vgicp_get_counter: 0 persistent launches, 1 persistent fallbacks, 2 upload bytes, 3 upload ns."""
+        v = C.c_uint64(0)
+        self._check(self._lib.vgicp_get_counter(self._h, int(which), C.byref(v)))
+        return int(v.value)
 
     # -- map mirror --
     def map_reset(self, voxel_size: float, capacity_hint: int = 0):

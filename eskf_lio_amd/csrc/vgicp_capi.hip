@@ -54,6 +54,7 @@ uint64_t next_pow2(uint64_t v) {
 constexpr uint64_t kMinSlots = 1024;
 constexpr int kDefaultChunk = 4;
 constexpr int kMaxChunksInFlight = 2;
+constexpr int kPersistentCooldownAligns = 8;  // aligns on the per-launch loop after the single launch gave up
 
 }  // namespace
 
@@ -94,11 +95,20 @@ struct vgicp_ctx {
   double* d_rows[2] = {nullptr, nullptr};  // partial rows, ping-pong like the state
   double* d_sums = nullptr;       // one row: the all-reduce message (multi-GPU)
   // persistent single-launch align (single GPU)
-  uint32_t* d_sync = nullptr;     // kShards arrival counters (one 128-byte line each); they only grow
-  uint32_t persist_base[kShards] = {0};  // host copy of the counters' values between launches
+  uint32_t* d_sync = nullptr;        // exit counter of the persistent launch (monotonic)
+  uint32_t persist_exit_base = 0;    // host copy of its value between launches
   uint32_t persist_seq = 0;
-  double* d_rows_persist = nullptr;  // [2][CUs][kSlots]
-  bool persistent_enabled = true; // cleared by VGICP_PERSISTENT=0 or after an in-kernel wait timed out
+  uint32_t persist_grid = 0;         // workgroups of every persistent launch: min(CUs, kExchangeRows), all resident
+  double* d_rows_persist = nullptr;  // [3][kExchangeRows][kSlots] (vgicp_device.h, PersistArgs)
+  double* d_parts_persist = nullptr; // [3][kFolders][kSlots]
+  void* h_exchange_image = nullptr;  // pinned: what the two buffers hold between launches
+  bool persistent_enabled = true;    // cleared by VGICP_PERSISTENT=0 or when a workgroup does not fit a CU
+  uint32_t persist_spin_limit = 50000;  // polls (>= ~1 us each) before an in-kernel wait gives up
+  int persistent_cooldown = 0;       // aligns left on the per-launch loop after an in-kernel wait timed out
+  uint64_t persistent_launches = 0;  // diagnostics (vgicp_get_counter)
+  uint64_t persistent_fallbacks = 0;
+  uint64_t upload_bytes = 0;
+  double upload_seconds = 0.0;
   int iter_block = 512;           // threads per workgroup of the iteration kernel (measured best at C2)
   double* d_log = nullptr;
   double* h_log = nullptr;  // pinned
@@ -310,15 +320,27 @@ void state_to_pose(const double* pose12, double* m16) {
   pose_to_mat4(T, m16);
 }
 
+// Put the exchange buffers of the persistent launch into their between-launch state (and the exit counter
+// to zero): at context creation and after a launch that gave up.
+int reset_persistent_exchange(vgicp_ctx* ctx) {
+  const size_t rw = persistent_rows_words(), pw = persistent_parts_words();
+  unsigned long long* img = static_cast<unsigned long long*>(ctx->h_exchange_image);
+  persistent_exchange_image(ctx->persist_grid, img, img + rw);
+  VG_HIP(ctx, hipMemcpyAsync(ctx->d_rows_persist, img, rw * 8, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->d_parts_persist, img + rw, pw * 8, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_sync, 0, 64 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->persist_exit_base = 0;
+  return VGICP_OK;
+}
+
 // The whole align in one launch (single GPU). Returns VGICP_OK and *ran = true when the kernel
-// completed; *ran = false when it could not be used or gave up (the caller then uses launches).
+// completed; *ran = false when it gave up (the caller then uses launches).
 int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params* params,
                          AlignState* result, bool* ran, float* device_ms) {
   *ran = false;
   static_assert(sizeof(AlignState) <= kSlots * sizeof(double), "the state must fit the log's header row");
-  const uint32_t workers = 512 - 64;
-  uint32_t grid = (ctx->n + workers - 1) / workers;
-  grid = std::min<uint32_t>(std::max<uint32_t>(grid, 1), (uint32_t)ctx->cu_count);  // all resident
+  const uint32_t grid = ctx->persist_grid;  // always the same, all resident: the exchange buffers rely on it
   const int max_it = params->max_iteration;
   PersistArgs a;
   std::memset(&a, 0, sizeof a);
@@ -329,17 +351,20 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.table = ctx->table;
   a.voxel_size = ctx->voxel_size;
   a.rows = ctx->d_rows_persist;
-  a.counters = ctx->d_sync;
+  a.parts = ctx->d_parts_persist;
+  a.exit_counter = ctx->d_sync;
+  a.exit_base = ctx->persist_exit_base;
   a.state = reinterpret_cast<AlignState*>(ctx->d_log - kSlots);
   a.log = ctx->d_log;
-  a.spin_limit = 400000;  // ~0.2 s of polling before giving up
+  a.spin_limit = ctx->persist_spin_limit;
   a.seq = ++ctx->persist_seq == 0 ? ++ctx->persist_seq : ctx->persist_seq;  // never 0
   pose_to_state(guess, a.pose0);
   a.cosine_threshold = params->cosine_threshold;
   a.translation_sq_threshold = params->translation_sq_threshold;
   a.max_iteration = max_it;
-  a.stash_points = std::getenv("VGICP_NO_STASH") ? 0u : persistent_stash_points(ctx->n, grid);
-  for (int k = 0; k < kShards; ++k) a.base[k] = ctx->persist_base[k];
+  persistent_lds_plan(ctx->n, grid, &a.memo_points, &a.stash_points);
+  if (std::getenv("VGICP_NO_STASH")) a.stash_points = 0;
+  if (std::getenv("VGICP_NO_MEMO")) a.memo_points = 0;
   a.stamps = ctx->d_stamps;
   // one launch, one copy back (state header + the log rows), one synchronisation
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
@@ -350,15 +375,20 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   VG_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_begin, ctx->ev_end));
   std::memcpy(result, ctx->h_log - kSlots, sizeof(AlignState));
+  ++ctx->persistent_launches;
   if (result->seq != a.seq) {
-    // an in-kernel wait timed out (not every workgroup resident): resynchronise and stop trying here
-    ctx->persistent_enabled = false;
-    VG_HIP(ctx, hipMemsetAsync(ctx->d_sync, 0, (kShards + 1) * kCounterStride * sizeof(uint32_t), ctx->stream));
-    for (int k = 0; k < kShards; ++k) ctx->persist_base[k] = 0;
-    return VGICP_OK;
+    // an in-kernel wait timed out (a workgroup was not resident: something else holds CUs of this device).
+    // Put the exchange back into its initial state, use the per-launch loop for this align and the next
+    // few, then try the single launch again.
+    ++ctx->persistent_fallbacks;
+    ctx->persistent_cooldown = kPersistentCooldownAligns;
+    if (ctx->persistent_fallbacks == 1 || std::getenv("VGICP_VERBOSE"))
+      std::fprintf(stderr, "[vgicp] persistent align launch gave up waiting for a workgroup (fallback #%llu): using one "
+                   "launch per iteration for the next %d aligns\n", (unsigned long long)ctx->persistent_fallbacks,
+                   kPersistentCooldownAligns);
+    return reset_persistent_exchange(ctx);
   }
-  for (int k = 0; k < kShards; ++k)
-    ctx->persist_base[k] += ((grid + kShards - 1 - (uint32_t)k) / kShards) * (uint32_t)result->iteration;
+  ctx->persist_exit_base += grid;
   *ran = true;
   return VGICP_OK;
 }
@@ -377,7 +407,8 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
   int chunk = params->chunk_iterations > 0 ? params->chunk_iterations : kDefaultChunk;
   if (profile) chunk = 1;
 
-  if (ctx->persistent_enabled && ctx->comm == nullptr && !profile && max_it > 0 &&
+  if (ctx->persistent_cooldown > 0) --ctx->persistent_cooldown;
+  else if (ctx->persistent_enabled && ctx->comm == nullptr && !profile && max_it > 0 &&
       (params->flags & VGICP_FLAG_NO_PERSISTENT) == 0) {
     bool ran = false;
     float ms = 0.f;
@@ -539,11 +570,20 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   for (int k = 0; k < 2; ++k)
     VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows[k]),
                         (size_t)kMaxIterBlocks * kSlots * sizeof(double)));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sync), (kShards + 1) * kCounterStride * sizeof(uint32_t)));
-  VG_CREATE(hipMemset(ctx->d_sync, 0, (kShards + 1) * kCounterStride * sizeof(uint32_t)));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows_persist),
-                      2 * (size_t)ctx->cu_count * kSlots * sizeof(double)));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sync), 64 * sizeof(uint32_t)));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows_persist), persistent_rows_words() * 8));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_parts_persist), persistent_parts_words() * 8));
+  VG_CREATE(hipHostMalloc(&ctx->h_exchange_image, (persistent_rows_words() + persistent_parts_words()) * 8, 0));
+  ctx->persist_grid = (uint32_t)std::min<int>(ctx->cu_count, kExchangeRows);
   if (const char* pe = std::getenv("VGICP_PERSISTENT")) ctx->persistent_enabled = pe[0] != '0';
+  if (const char* sl = std::getenv("VGICP_SPIN_LIMIT")) ctx->persist_spin_limit = (uint32_t)std::strtoul(sl, nullptr, 10);
+  {
+    // the in-kernel exchange needs every workgroup resident: one 512-thread workgroup with the full dynamic LDS
+    // must fit a CU (checked once here instead of found out by a timeout)
+    uint32_t resident = 0;
+    VG_CREATE(persistent_max_resident(persistent_dyn_lds_bytes(0, 0), ctx->cu_count, &resident));
+    if (resident < ctx->persist_grid) ctx->persistent_enabled = false;
+  }
   if (const char* blk = std::getenv("VGICP_ITER_BLOCK")) {
     const int b = std::atoi(blk);
     if (b == 256 || b == 512 || b == 1024) ctx->iter_block = b;
@@ -559,6 +599,11 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   for (int k = 0; k < kMaxChunksInFlight; ++k)
     VG_CREATE(hipEventCreateWithFlags(&ctx->ev_chunk[k], hipEventDisableTiming));
 #undef VG_CREATE
+  if (reset_persistent_exchange(ctx) != VGICP_OK) {
+    g_create_error = ctx->err;
+    vgicp_destroy(ctx);
+    return VGICP_ERR_HIP;
+  }
   *out = ctx;
   return VGICP_OK;
 }
@@ -580,10 +625,10 @@ int vgicp_destroy(vgicp_ctx* ctx) {
     if (hipMemcpy(h, ctx->d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[13] > 0) {
       for (int o = 8; o <= 16; o += 8) {
         const double k = 0.01 / (double)h[o + 5];  // 100 MHz ticks -> us per round
-        std::fprintf(stderr, "[vgicp stamps] persistent, %s, %llu rounds: accumulate+butterfly %.2f us, publish %.2f us, "
-                     "wait for all rows %.2f us, row loads+fold %.2f us, solve+broadcast %.2f us\n",
+        std::fprintf(stderr, "[vgicp stamps] persistent, workgroup 0 %s, %llu rounds: accumulate+butterfly (to the barrier) "
+                     "%.2f us, publish + level-1 fold %.2f us, level-2 poll %.2f us, solve+broadcast %.2f us\n",
                      o == 8 ? "solver wave" : "first worker lane", (unsigned long long)h[o + 5], h[o] * k, h[o + 1] * k,
-                     h[o + 2] * k, h[o + 3] * k, h[o + 4] * k);
+                     h[o + 2] * k, h[o + 3] * k);
       }
     }
     (void)hipFree(ctx->d_stamps);
@@ -599,6 +644,8 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipHostFree(ctx->h_state);
   (void)hipFree(ctx->d_sync);
   (void)hipFree(ctx->d_rows_persist);
+  (void)hipFree(ctx->d_parts_persist);
+  (void)hipHostFree(ctx->h_exchange_image);
   (void)hipFree(ctx->d_rows[0]);
   (void)hipFree(ctx->d_rows[1]);
   (void)hipFree(ctx->d_sums);
@@ -626,6 +673,18 @@ int vgicp_device_info(const vgicp_ctx* ctx, char* name, size_t name_len, int32_t
   }
   if (cu_count) *cu_count = ctx->cu_count;
   if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+  return VGICP_OK;
+}
+
+int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
+  if (!ctx || !value) return VGICP_ERR_BAD_ARGUMENT;
+  switch (which) {
+    case VGICP_COUNTER_PERSISTENT_LAUNCHES: *value = ctx->persistent_launches; break;
+    case VGICP_COUNTER_PERSISTENT_FALLBACKS: *value = ctx->persistent_fallbacks; break;
+    case VGICP_COUNTER_UPLOAD_BYTES: *value = ctx->upload_bytes; break;
+    case VGICP_COUNTER_UPLOAD_NANOSECONDS: *value = (uint64_t)(ctx->upload_seconds * 1e9); break;
+    default: return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown counter");
+  }
   return VGICP_OK;
 }
 
@@ -821,8 +880,15 @@ int vgicp_map_export(vgicp_ctx* ctx, size_t capacity, int32_t* keys, double* mea
   return VGICP_OK;
 }
 
-int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const double* covs) {
-  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+namespace {
+// Copy the scan to the device and pack it into the SoA planes (reference: the deep copy of the cloud at
+// src/Registration.cpp:11, which here is the copy to the device).  The caller's buffers are ordinary pageable
+// memory (std::vector storage): hipMemcpyAsync pins such ranges on the fly and lets the DMA engine read them
+// in place — measured 46 GB/s for the 9.6 MB of a 100k-point scan (tools/probe_upload.py), against 26-31 GB/s
+// for staging them through a pinned buffer with 2-12 copy threads on the two-socket host of the GPU box — and
+// returns once the caller's memory has been read, so the buffers may be released on return.  The pack kernel
+// (and whatever the caller enqueues next) follows in stream order; nothing is waited for here.
+int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const double* covs) {
   if (n > 0 && (!points || !covs)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
   if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
   VG_HIP(ctx, hipSetDevice(ctx->device));
@@ -831,14 +897,26 @@ int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const doub
   ctx->scan_ready = false;
   ctx->n = (uint32_t)n;
   ctx->stride = ctx->scan_capacity;
-  if (n > 0) {
-    double* aos_pts = ctx->d_scan_aos;
-    double* aos_cov = ctx->d_scan_aos + 3 * ctx->scan_capacity;
-    VG_HIP(ctx, hipMemcpyAsync(aos_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    VG_HIP(ctx, hipMemcpyAsync(aos_cov, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, (uint32_t)n, ctx->d_scan, ctx->stride));
-    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
+  if (n == 0) return VGICP_OK;
+  const double t0 = now_seconds();
+  double* aos_pts = ctx->d_scan_aos;
+  double* aos_cov = ctx->d_scan_aos + 3 * ctx->scan_capacity;
+  VG_HIP(ctx, hipMemcpyAsync(aos_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(aos_cov, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, (uint32_t)n, ctx->d_scan, ctx->stride));
+  ctx->upload_bytes += n * kScanPlanes * sizeof(double);
+  ctx->upload_seconds += now_seconds() - t0;  // host side of the two copies + the enqueue of the pack kernel
+  return VGICP_OK;
+}
+}  // namespace
+
+int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const double* covs) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  const double t0 = now_seconds();
+  int rc = scan_upload_enqueue(ctx, n, points, covs);
+  if (rc != VGICP_OK) return rc;
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)t0;
   ctx->scan_ready = true;
   return VGICP_OK;
 }
@@ -857,8 +935,10 @@ int vgicp_align(vgicp_ctx* ctx, size_t n, const double* points, const double* co
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   const double t0 = now_seconds();
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
-  int rc = vgicp_scan_upload(ctx, n, points, covs);
+  // the upload is only enqueued: the pack kernel and the align's first launch follow it in stream order
+  int rc = scan_upload_enqueue(ctx, n, points, covs);
   if (rc != VGICP_OK) return rc;
+  ctx->scan_ready = true;
   rc = vgicp_align_resident(ctx, guess, params, out_pose, stats);
   if (stats) stats->seconds = now_seconds() - t0;
   return rc;

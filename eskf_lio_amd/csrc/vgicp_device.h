@@ -71,10 +71,19 @@ struct IterArgs {
 };
 
 // Arguments of the persistent single-launch align (single GPU): every round of the loop runs inside
-// one kernel, workgroups exchange their 256-byte rows through `rows` (two buffers by round parity)
-// and signal arrival on `counters` (kShards words, each on a 128-byte line of its own).
-constexpr int kShards = 8;          // arrival counters; a workgroup uses shard blockIdx % kShards
-constexpr int kCounterStride = 32;  // uint32 words between two counters (128 bytes)
+// one kernel.  Workgroups exchange their partial rows through `rows` and `parts` (three buffers each, by
+// round modulo 3) with no flag and no counter: every 8-byte word of a buffer holds the bit pattern
+// kRowUnset until its producer stores the value (one write-through 8-byte store per word, never torn), and
+// consumers poll the words themselves.  Two levels, in the summation order of iterate_kernel<512>:
+//   rows   [3][256][kSlots]      workgroup b's sums of the round (21 + 6 + count) at row (b % 16) * 16 + b / 16
+//   parts  [3][kFolders][kSlots] folder g (= workgroup g < kFolders) adds the rows b = g, g + 16, g + 32 ...
+//                                in ascending order; every workgroup then adds the parts in ascending g
+// A producer re-arms its word (stores kRowUnset) one round after everyone has consumed it and two rounds
+// before it is written again; DESIGN.md section 4 has the ordering argument.
+constexpr int kExchangeRows = 256;                          // 16 folders x 16 rows: the largest persistent grid
+constexpr int kFolders = 16;                                // = 512 / kSlots, the groups of iterate_kernel<512>'s fold
+constexpr unsigned long long kRowUnset = ~0ull;             // a NaN pattern no fp64 operation produces
+constexpr unsigned long long kRowNaN = 0x7FF8000000000000ull;  // what a computed NaN is published as
 struct PersistArgs {
   const double* scan;  // SoA planes
   uint64_t stride;
@@ -82,11 +91,12 @@ struct PersistArgs {
   uint32_t mask;
   const VoxelRecord* table;
   double voxel_size;
-  double* rows;         // [2][grid][kSlots]
-  uint32_t* counters;   // zeroed by the host before every launch
+  double* rows;         // [3][kExchangeRows][kSlots]; between launches: kRowUnset where a workgroup publishes, else +0.0
+  double* parts;        // [3][kFolders][kSlots], likewise
+  uint32_t* exit_counter;  // arrivals at the end of the launch (monotonic; the host tracks its base)
   AlignState* state;    // out: final state; state->seq == seq tells the host the loop ran to its end
   double* log;          // [max_iteration][kSlots]
-  uint32_t spin_limit;  // an in-kernel wait longer than this gives up (host falls back to launches)
+  uint32_t spin_limit;  // an in-kernel wait longer than this many polls gives up (host falls back to launches)
   uint32_t seq;
   // inputs travel with the dispatch packet: no host-to-device copy and no memset per align
   double pose0[12];     // guess: R column-major (9) then t (3)
@@ -94,14 +104,25 @@ struct PersistArgs {
   double translation_sq_threshold;
   int32_t max_iteration;
   uint32_t stash_points;   // extra points per thread kept in LDS across rounds (scans larger than the grid)
-  uint32_t base[kShards];  // value of each arrival counter before this launch (they only ever grow)
+  uint32_t memo_points;    // extra points per thread whose last key + table slot are remembered in LDS
+  uint32_t exit_base;      // value of the exit counter before this launch
   uint64_t* stamps;
 };
 
 // ---- launchers (defined in vgicp_kernels.hip) ----
 // The whole ICP::align loop in one launch (512-thread workgroups, at most one per CU).
 hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid);
-uint32_t persistent_stash_points(uint32_t n, uint32_t grid);  // what launch_persistent can keep in LDS
+// How launch_persistent splits the CU's LDS for a scan of n points on `grid` workgroups: points per
+// thread beyond the first that get a memo (last key + slot, 16 B) and that are parked whole (96 B).
+void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points);
+// Sizes (8-byte words) of the rows / parts exchange buffers, and their content between launches.
+size_t persistent_rows_words();
+size_t persistent_parts_words();
+void persistent_exchange_image(uint32_t grid, unsigned long long* rows_words, unsigned long long* parts_words);
+// Whether one 512-thread workgroup of the persistent kernel with this much dynamic LDS fits a CU of the
+// current device: *max_grid = cu_count then, else 0 (the in-kernel exchange needs every workgroup resident).
+hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_t* max_grid);
+uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_points);
 // One VGICP round over the resident scan: prologue folds args.prev and advances the pose, body
 // accumulates this round's rows. block = 256 / 512 / 1024 threads per workgroup.
 hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, int block);

@@ -94,13 +94,6 @@ __device__ __forceinline__ void fold_swap(double (&v)[kSlots]) {
   }
 }
 
-// A value that is the same in every lane, moved to scalar registers (frees its VGPR pair).
-__device__ __forceinline__ double uniform_f64(double v) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-
 // Fallback of the 6x6 solve: vgicp_math.h's ldlt6_solve — Eigen's pivoted LDLT with pseudo-inverted D, the
 // operation order of the published algorithm, no contraction — run by lane 0 on an LDS work array (the
 // pivoting makes every index dynamic), the solution then read by every lane.  It is taken only when the
@@ -568,64 +561,121 @@ __global__ __launch_bounds__(64) void solve_step_kernel(const double* __restrict
 // ---------------------------------------------------------------------------------------------
 // Persistent variant: the whole loop of ICP::align (src/Registration.cpp:15-28) in ONE launch.
 //
-// Same arithmetic, same fixed summation orders and the same workgroup geometry as iterate_kernel
-// (so both variants return the same bits); what changes is how a round's partial rows travel:
-//   producer  wave 0 stores the workgroup's row write-through (sc1, 8-byte stores), drains them
-//             (s_waitcnt vmcnt(0)), then ONE lane adds 1 to the arrival counter of its shard
-//   consumer  wave 0 polls the kShards counters (sc1 loads, s_sleep between polls, bounded), the
-//             workgroup barrier releases the other waves, every thread then reads the rows with sc1
-//             loads (L1-bypassing) — the hand-off form measured valid on gfx950 in
-//             MI355X_MICROARCH.md "Valid forms" (one lane signals for all stores of its workgroup;
-//             sc1 stores and sc1 loads; one workgroup per CU; no dispatch-order assumption)
-// Rows are double-buffered by round parity: a workgroup can be at most one round ahead of the
-// slowest one, because it needs everyone's row of round r before it can publish round r+1.
-// Gains over one launch per round: no kernel boundary (~4 us of dispatch, acquire/release and skew
-// per round), the scan point stays in registers, and the voxel record a point used in round r is the
-// speculation for round r+1 — the table is touched again only when a point changes voxel.
-// Needs every workgroup resident (grid <= CUs, one 512-thread workgroup per CU); a wait that exceeds
-// spin_limit sets *error and ends the kernel, and the host re-runs the align with iterate_kernel.
+// Same arithmetic, same fixed summation orders and the same workgroup geometry as iterate_kernel<512>
+// (so both variants return the same bits); what changes is how a round's partial rows travel.  There is
+// no flag, no counter and no drain on the path: the DATA is the signal.  Every 8-byte word of the exchange
+// buffers holds kRowUnset until its producer stores the value with ONE write-through (sc1) 8-byte store —
+// a naturally aligned granule written by one store is never seen torn (MI355X_MICROARCH.md, "R2's granule")
+// — and consumers poll the words they need with sc1 loads until none is kRowUnset:
+//   level 1  wave 0 of workgroup b stores its row (28 words).  Folder g (= workgroup g < 16) polls the rows
+//            b = g, g + 16, g + 32 ... (lane = slot, up to 16 loads in flight), adds them in ascending b and
+//            stores the part
+//   level 2  wave 0 of EVERY workgroup polls the <= 16 parts, adds them in ascending g, solves
+// which is the order in which prologue_fold / prologue_solve add the rows (thread (g, slot) adds rows
+// g + 16u, then the 16 group sums are added in ascending g).  Two one-way hops instead of store + drain +
+// atomic + poll + row read, 57 KB less to read per workgroup and round, and two workgroup barriers per
+// round instead of five.
+// Re-arming (three buffers by round % 3): at the end of round j (all parts of round j seen) a workgroup
+// stores kRowUnset over its row and, if a folder, its part of buffer (j - 1) % 3.  Safe: every part of
+// round j exists, so every row of round j was published, so every workgroup had finished reading round
+// j - 1.  Ordered: the producer's next publication (round j + 1) waits for its own stores to complete
+// first (s_waitcnt vmcnt(0)), and a consumer polls buffer (j - 1) % 3 again only in round j + 2, after it
+// has seen a part of round j + 1 that depends on that publication.  At the end of the launch every
+// workgroup re-arms its row of the last round, arrives at the exit counter, and the LAST arriver (everyone
+// has read the last parts by then) re-arms the parts: the buffers are all kRowUnset between launches.
+// What stays on chip across rounds: a thread's first point with the voxel record it used (registers);
+// for scans larger than the grid, per further point its last key and table slot (16-byte memo in LDS: an
+// unchanged key that missed costs no table access at all — the map is immutable during align,
+// src/LocalMap.cpp:94-100 — and one that hit loads its payload straight from the slot), and up to
+// stash_points whole points (LDS).
+// Needs every workgroup resident (grid <= CUs, one 512-thread workgroup per CU); a poll that exceeds
+// spin_limit ends the kernel without the final state, and the host re-runs the align with iterate_kernel.
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
-__device__ __forceinline__ void store_through(double* p, double v) {
-  __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void store_through_bits(double* p, unsigned long long bits) {
+  __hip_atomic_store((gu64*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double load_through(const double* p) {
-  return __longlong_as_double(
-      (long long)__hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+__device__ __forceinline__ unsigned long long load_through_bits(const double* p) {
+  return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// A sum as it is published: never the "unset" pattern (a NaN with that payload can only come from
+// non-finite input; it is published as the canonical NaN and the align ends as VGICP_ERR_DEGENERATE).
+__device__ __forceinline__ unsigned long long publishable(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return b == kRowUnset ? kRowNaN : b;
+}
+
+// Lanes <= kCountSlot (lane = slot): wait until the 16 consecutive rows at src are published and return
+// the sum of their words in ascending row order, starting from +0.0 (as the folds of iterate_kernel do;
+// rows that belong to no workgroup hold +0.0 for good).  All 64 lanes of the wave call it; false when
+// spin_limit polls did not suffice.  The 16 loads are in flight together (one address, immediate offsets).
+__device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, uint32_t spin_limit, double& sum) {
+  const bool active = lane <= (uint32_t)kCountSlot;
+  const double* mine = src + (active ? lane : 0u);
+  unsigned long long w[kFolders];
+#pragma unroll
+  for (int k = 0; k < kFolders; ++k) w[k] = active ? load_through_bits(mine + k * kSlots) : 0ull;
+  for (uint32_t spins = 0;; ++spins) {
+    bool missing = false;
+#pragma unroll
+    for (int k = 0; k < kFolders; ++k) missing = missing || (w[k] == kRowUnset);
+    if (!__any(missing)) break;
+    if (spins >= spin_limit) return false;
+    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+    for (int k = 0; k < kFolders; ++k)
+      if (w[k] == kRowUnset) w[k] = load_through_bits(mine + k * kSlots);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < kFolders; ++k) s += __longlong_as_double((long long)w[k]);
+  sum = s;
+  return true;
+}
+
+constexpr uint32_t kMemoMiss = 0xFFFFFFFFu;  // memo.w of a point whose voxel is not in the map
+
+// Payload of a record whose slot is known (an unchanged key that hit last round): one round trip.
+__device__ __forceinline__ void load_payload(const VoxelRecord* rec, double (&mu)[3], double (&S)[9]) {
+  const double2* pay = reinterpret_cast<const double2*>(rec->mean);
+  const double2 a0 = pay[0], a1 = pay[1], a2 = pay[2], a3 = pay[3], a4 = pay[4], a5 = pay[5];
+  mu[0] = a0.x; mu[1] = a0.y; mu[2] = a1.x;
+  S[0] = a1.y; S[1] = a2.x; S[2] = a2.y; S[3] = a3.x; S[4] = a3.y; S[5] = a4.x;
+  S[6] = a4.y; S[7] = a5.x; S[8] = a5.y;
 }
 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
+  static_assert(BLOCK / kSlots == kFolders, "the exchange reproduces the fold order of iterate_kernel<512>");
   constexpr int kWaves = BLOCK / 64;
   constexpr int kWorkers = BLOCK - 64;
-  constexpr int kGroups = BLOCK / kSlots;
-  constexpr int kBatch = 16;
-  __shared__ PrologueShared<BLOCK> sh;
   __shared__ double red[kWaves][kSlots];
-  // Scans larger than the grid: a thread owns several points. The first stays in registers; the next
-  // a.stash_points are parked here after round 0 (plane-major per point: conflict-free), so only the rest
-  // is re-read from HBM every round.
-  extern __shared__ double stash[];
+  __shared__ double totals[kSlots];
+  __shared__ double work[kSolveWork];
+  __shared__ double pose_sh[12];
+  __shared__ int stop_sh;
+  // Scans larger than the grid: a thread owns several points. The first stays in registers; of the
+  // others, the first a.memo_points have a 16-byte memo {key, slot} and the first a.stash_points are
+  // parked whole after round 0 (plane-major per point: conflict-free), so only the rest is re-read.
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  int4* memo = reinterpret_cast<int4*>(dyn_lds);
+  double* stash = reinterpret_cast<double*>(dyn_lds + (size_t)a.memo_points * kWorkers * sizeof(int4));
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool worker = wave != 0;
   const uint32_t grid = gridDim.x, blk = blockIdx.x;
   const uint32_t stride_pts = grid * kWorkers;
   const uint32_t first = worker ? blk * kWorkers + (tid - 64) : a.n;
-  const uint32_t my_shard = blk % kShards;
-  // arrivals per round on the shard this lane polls (lanes 0..kShards-1 of wave 0)
-  const uint32_t shard_blocks = lane < kShards ? (grid + kShards - 1 - lane) / kShards : 0u;
-  uint32_t shard_base = 0;
-#pragma unroll
-  for (int k = 0; k < kShards; ++k) if (lane == (uint32_t)k) shard_base = a.base[k];
+  const bool folder = blk < (uint32_t)kFolders;  // folder g adds the rows of workgroups g, g + 16, g + 32 ...
+  // row of workgroup b inside a buffer: the 16 rows of a folder are consecutive
+  const uint32_t my_row = (blk % kFolders) * kFolders + blk / kFolders;
 
-  RoundHead head;
+  Pose total;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) head.total.R[k] = a.pose0[k];
+  for (int k = 0; k < 9; ++k) total.R[k] = a.pose0[k];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) head.total.t[k] = a.pose0[9 + k];
+  for (int k = 0; k < 3; ++k) total.t[k] = a.pose0[9 + k];
   const double cos_thr = a.cosine_threshold, tsq_thr = a.translation_sq_threshold;
   const int max_it = a.max_iteration;
 
@@ -643,20 +693,16 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   for (int k = 0; k < 9; ++k) Sv[k] = 0.0;
 
   uint64_t t_mark = a.stamps ? wall_clock64() : 0;
-  uint64_t acc_body = 0, acc_publish = 0, acc_wait = 0, acc_rows = 0, acc_solve = 0;
+  uint64_t acc_body = 0, acc_l1 = 0, acc_l2 = 0, acc_solve = 0;
   int it = 0;
-  bool conv = false;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) head.total.R[k] = uniform_f64(head.total.R[k]);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) head.total.t[k] = uniform_f64(head.total.t[k]);
+  bool gave_up = false;
   for (;;) {
-    const double* R = head.total.R;
-    const double* t = head.total.t;
-    double v[kSlots];
-#pragma unroll
-    for (int k = 0; k < kSlots; ++k) v[k] = 0.0;
+    const double* R = total.R;
+    const double* t = total.t;
     if (worker) {
+      double v[kSlots];
+#pragma unroll
+      for (int k = 0; k < kSlots; ++k) v[k] = 0.0;
       if (have) {
         double p[3], C[9], S[9];
 #pragma unroll
@@ -676,11 +722,11 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
           accumulate_match(R, p, C, mu, S, v);
         }
       }
-      uint32_t parked = 0;
-      for (uint32_t i = first + stride_pts; i < a.n; i += stride_pts, ++parked) {  // scans larger than the grid
+      uint32_t e = 0;
+      for (uint32_t i = first + stride_pts; i < a.n; i += stride_pts, ++e) {  // scans larger than the grid
         double q[kScanPlanes], p[3], C[9], m2[3], S[9];
-        if (parked < a.stash_points) {
-          double* slot = stash + (size_t)parked * kScanPlanes * kWorkers + (tid - 64);
+        if (e < a.stash_points) {
+          double* slot = stash + (size_t)e * kScanPlanes * kWorkers + (tid - 64);
           if (it == 0) {
             load_point(a.scan, a.stride, i, q);
 #pragma unroll
@@ -692,12 +738,31 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
         } else {
           load_point(a.scan, a.stride, i, q);
         }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
         transform_point(R, t, q[0], q[1], q[2], p);
-        if (find_and_load(a.table, a.mask, voxel_coord(p[0], a.voxel_size),
-                          voxel_coord(p[1], a.voxel_size), voxel_coord(p[2], a.voxel_size), m2, S))
+        const int32_t kx = voxel_coord(p[0], a.voxel_size);
+        const int32_t ky = voxel_coord(p[1], a.voxel_size);
+        const int32_t kz = voxel_coord(p[2], a.voxel_size);
+        bool got;
+        if (e < a.memo_points) {
+          int4* mslot = memo + (size_t)e * kWorkers + (tid - 64);
+          const int4 m = *mslot;
+          if (it != 0 && m.x == kx && m.y == ky && m.z == kz) {
+            got = (uint32_t)m.w != kMemoMiss;
+            if (got) load_payload(a.table + (uint32_t)m.w, m2, S);
+          } else {
+            const VoxelRecord* rec = find_voxel(a.table, a.mask, kx, ky, kz);
+            got = rec != nullptr;
+            *mslot = make_int4(kx, ky, kz, got ? (int32_t)(uint32_t)(rec - a.table) : (int32_t)kMemoMiss);
+            if (got) load_payload(rec, m2, S);
+          }
+        } else {
+          got = find_and_load(a.table, a.mask, kx, ky, kz, m2, S);
+        }
+        if (got) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
           accumulate_match(R, p, C, m2, S, v);
+        }
       }
       fold_swap<32, false>(v);
       fold_swap<16, true>(v);
@@ -710,127 +775,121 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
     __syncthreads();
     if (a.stamps) { const uint64_t n = wall_clock64(); acc_body += n - t_mark; t_mark = n; }
 
-    // ---- publish this workgroup's row, then wait until every workgroup has published ----
-    double* rows = a.rows + (size_t)(it & 1) * grid * kSlots;
     if (wave == 0) {
-      if (lane < kSlots) {
+      const uint32_t buf = (uint32_t)it % 3u, rearm = ((uint32_t)it + 2u) % 3u;
+      double* rows = a.rows + (size_t)buf * kExchangeRows * kSlots;
+      double* parts = a.parts + (size_t)buf * kFolders * kSlots;
+      // ---- level 1: publish this workgroup's row (every re-arming store of mine has completed) ----
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane <= (uint32_t)kCountSlot) {
         double tot = red[1][lane];
 #pragma unroll
         for (int w = 2; w < kWaves; ++w) tot += red[w][lane];
-        store_through(rows + (size_t)blk * kSlots + lane, tot);
+        store_through_bits(rows + (size_t)my_row * kSlots + lane, publishable(tot));
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has left this CU before the signal
-      if (lane == 0)
-        __hip_atomic_fetch_add((gu32*)(a.counters + my_shard * kCounterStride), 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-      if (a.stamps) { const uint64_t n = wall_clock64(); acc_publish += n - t_mark; t_mark = n; }
-      const uint32_t target = shard_base + shard_blocks * (uint32_t)(it + 1);
-      bool arrived = false;
-      for (uint32_t spins = 0; spins < a.spin_limit; ++spins) {
-        const uint32_t c = lane < kShards
-                               ? __hip_atomic_load((gu32*)(a.counters + lane * kCounterStride),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                               : target;
-        if (__all((int32_t)(c - target) >= 0)) { arrived = true; break; }  // wrap-safe
-        __builtin_amdgcn_s_sleep(1);
+      bool ok = true;
+      if (folder) {  // uniform
+        double part = 0.0;
+        ok = poll_and_sum(rows + (size_t)blk * kFolders * kSlots, lane, a.spin_limit, part);
+        if (ok && lane <= (uint32_t)kCountSlot) store_through_bits(parts + (size_t)blk * kSlots + lane, publishable(part));
       }
-      if (lane == 0) sh.stop = arrived ? 0 : 2;
-    }
-    __syncthreads();
-    if (sh.stop == 2) return;  // uniform: a workgroup never arrived (not all resident?) — give up; the
-                               // host sees state->seq != seq and falls back to one launch per round
-    if (a.stamps && wave != 0) { const uint64_t n = wall_clock64(); acc_publish += 0; acc_wait += n - t_mark; t_mark = n; }
-    if (a.stamps && wave == 0) { const uint64_t n = wall_clock64(); acc_wait += n - t_mark; t_mark = n; }
-
-    // ---- every workgroup folds all rows in the same fixed order (as round_prologue does) ----
-    {
-      const uint32_t slot = tid & (kSlots - 1), group = tid / kSlots;
-      double row[kBatch];
-      double s = 0.0;
-      for (uint32_t b0 = group; b0 < grid; b0 += kGroups * kBatch) {
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-          const uint32_t b = b0 + u * kGroups;
-          row[u] = b < grid ? load_through(rows + (size_t)b * kSlots + slot) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) s += row[u];
-      }
-      sh.fin[group][slot] = s;
-    }
-    __syncthreads();
-    if (a.stamps) { const uint64_t n = wall_clock64(); acc_rows += n - t_mark; t_mark = n; }
-
-    if (wave == 0) {
+      if (a.stamps) { const uint64_t n = wall_clock64(); acc_l1 += n - t_mark; t_mark = n; }
+      // ---- level 2: every workgroup adds the parts ----
       double tot = 0.0;
-      if (lane < kSlots) {
-        tot = sh.fin[0][lane];
+      if (ok) ok = poll_and_sum(parts, lane, a.spin_limit, tot);
+      if (a.stamps) { const uint64_t n = wall_clock64(); acc_l2 += n - t_mark; t_mark = n; }
+      if (!ok) {
+        if (lane == 0) stop_sh = 2;
+      } else {
+        // re-arm what was consumed a round ago (buffer (it - 1) % 3; in round 0 it is unset already)
+        if (it > 0 && lane <= (uint32_t)kCountSlot) {
+          store_through_bits(a.rows + ((size_t)rearm * kExchangeRows + my_row) * kSlots + lane, kRowUnset);
+          if (folder) store_through_bits(a.parts + ((size_t)rearm * kFolders + blk) * kSlots + lane, kRowUnset);
+        }
+        if (lane < kSlots) {
+          totals[lane] = lane <= (uint32_t)kCountSlot ? tot : 0.0;
+          if (blk == 0) a.log[(size_t)it * kSlots + lane] = lane <= (uint32_t)kCountSlot ? tot : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double A[21], g[6], xi[6];
 #pragma unroll
-        for (int g = 1; g < kGroups; ++g) tot += sh.fin[g][lane];
-        sh.totals[lane] = tot;
-        if (blk == 0) a.log[(size_t)it * kSlots + lane] = tot;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double A[21], g[6], xi[6];
+        for (int k = 0; k < 21; ++k) A[k] = totals[k];
 #pragma unroll
-      for (int k = 0; k < 21; ++k) A[k] = sh.totals[k];
+        for (int k = 0; k < 6; ++k) g[k] = -totals[21 + k];
+        if (!ldlt6_solve_spd(A, g, xi)) ldlt6_solve_pivoted(totals, work, lane, xi);  // uniform branch
+        Pose next, step;
+        se3_exp_device(xi, step);
+        pose_compose(step, total, next);
+        const bool conv = converged(step, cos_thr, tsq_thr);
+        if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) g[k] = -sh.totals[21 + k];
-      if (!ldlt6_solve_spd(A, g, xi)) ldlt6_solve_pivoted(sh.totals, sh.work, lane, xi);  // uniform branch
-      Pose next, step;
-      se3_exp_device(xi, step);
-      pose_compose(step, head.total, next);
-      conv = converged(step, cos_thr, tsq_thr);
-      if (lane == 0) {
+          for (int k = 0; k < 9; ++k) pose_sh[k] = next.R[k];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) sh.pose[k] = next.R[k];
+          for (int k = 0; k < 3; ++k) pose_sh[9 + k] = next.t[k];
+          stop_sh = (conv || (it + 1 >= max_it)) ? 1 : 0;
+          if (blk == 0) {  // the last increment, for the state the host reads
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sh.pose[9 + k] = next.t[k];
-        sh.stop = (conv || (it + 1 >= max_it)) ? 1 : 0;
-        if (blk == 0) {  // the last increment, for the state the host reads
+            for (int k = 0; k < 9; ++k) a.state->step[k] = step.R[k];
 #pragma unroll
-          for (int k = 0; k < 9; ++k) a.state->step[k] = step.R[k];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) a.state->step[9 + k] = step.t[k];
-          a.state->converged = conv ? 1 : 0;
+            for (int k = 0; k < 3; ++k) a.state->step[9 + k] = step.t[k];
+            a.state->converged = conv ? 1 : 0;
+          }
         }
       }
     }
     __syncthreads();
+    const int stop = stop_sh;
+    if (stop == 2) { gave_up = true; break; }  // uniform: a workgroup never published (not all resident?)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) head.total.R[k] = uniform_f64(sh.pose[k]);
+    for (int k = 0; k < 9; ++k) total.R[k] = pose_sh[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) head.total.t[k] = uniform_f64(sh.pose[9 + k]);
-    const bool stop = sh.stop != 0;
+    for (int k = 0; k < 3; ++k) total.t[k] = pose_sh[9 + k];
     ++it;
     if (a.stamps) { const uint64_t n = wall_clock64(); acc_solve += n - t_mark; t_mark = n; }
     if (stop) break;
-    __syncthreads();  // sh.stop / sh.pose are rewritten next round
   }
+  if (gave_up) return;  // the host sees state->seq != seq, resets the exchange buffers and uses launches
 
-  if (blk == 0 && tid == 0) {
-    AlignState* out = a.state;
+  if (wave == 0) {
+    // ---- leave the exchange buffers unset for the next launch ----
+    const uint32_t last = (uint32_t)(it - 1) % 3u;
+    if (lane <= (uint32_t)kCountSlot)
+      store_through_bits(a.rows + ((size_t)last * kExchangeRows + my_row) * kSlots + lane, kRowUnset);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t arrived = 0;
+    if (lane == 0)
+      arrived = __hip_atomic_fetch_add((gu32*)a.exit_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                a.exit_base;
+    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (arrived == grid - 1) {  // everyone else has read the last parts: nobody looks at them any more
+      const uint32_t folders = grid < (uint32_t)kFolders ? grid : (uint32_t)kFolders;  // the others stay +0.0
+      for (uint32_t w = lane; w < folders * kSlots; w += 64)
+        if ((w & (kSlots - 1)) <= (uint32_t)kCountSlot)
+          store_through_bits(a.parts + (size_t)last * kFolders * kSlots + w, kRowUnset);
+    }
+    if (blk == 0 && lane == 0) {
+      AlignState* out = a.state;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) out->pose[k] = head.total.R[k];
+      for (int k = 0; k < 9; ++k) out->pose[k] = total.R[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) out->pose[9 + k] = head.total.t[k];
-    out->cosine_threshold = cos_thr;
-    out->translation_sq_threshold = tsq_thr;
-    out->max_iteration = max_it;
-    out->iteration = it;
-    out->done = 1;
-    out->pad = 0;
-    out->seq = a.seq;
+      for (int k = 0; k < 3; ++k) out->pose[9 + k] = total.t[k];
+      out->cosine_threshold = cos_thr;
+      out->translation_sq_threshold = tsq_thr;
+      out->max_iteration = max_it;
+      out->iteration = it;
+      out->done = 1;
+      out->pad = 0;
+      out->seq = a.seq;
+    }
   }
   if (a.stamps && blk == 0 && (tid == 0 || tid == 64)) {
     const int o = tid == 0 ? 8 : 16;  // solver wave / first worker lane
     atomicAdd((unsigned long long*)&a.stamps[o + 0], (unsigned long long)acc_body);
-    atomicAdd((unsigned long long*)&a.stamps[o + 1], (unsigned long long)acc_publish);
-    atomicAdd((unsigned long long*)&a.stamps[o + 2], (unsigned long long)acc_wait);
-    atomicAdd((unsigned long long*)&a.stamps[o + 3], (unsigned long long)acc_rows);
-    atomicAdd((unsigned long long*)&a.stamps[o + 4], (unsigned long long)acc_solve);
+    atomicAdd((unsigned long long*)&a.stamps[o + 1], (unsigned long long)acc_l1);
+    atomicAdd((unsigned long long*)&a.stamps[o + 2], (unsigned long long)acc_l2);
+    atomicAdd((unsigned long long*)&a.stamps[o + 3], (unsigned long long)acc_solve);
     atomicAdd((unsigned long long*)&a.stamps[o + 5], (unsigned long long)it);
   }
 }
@@ -1059,28 +1118,77 @@ hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, in
 namespace {
 constexpr uint32_t kPersistWorkers = 512 - 64;
 constexpr uint32_t kStashBytesPerPoint = kScanPlanes * kPersistWorkers * sizeof(double);  // 43 008
-constexpr uint32_t kMaxStashPoints = 3;  // 129 KB of the CU's 160 KB LDS, beside ~12 KB of static use
+constexpr uint32_t kMemoBytesPerPoint = kPersistWorkers * sizeof(int4);                   //  7 168
+// dynamic LDS of the persistent launch: the CU's 160 KB minus the kernel's static use and a margin
+constexpr uint32_t kPersistDynLds = 150 * 1024;
+constexpr uint32_t kMaxMemoPoints = 12;  // beyond that a thread's points are looked up every round
 }  // namespace
 
-uint32_t persistent_stash_points(uint32_t n, uint32_t grid) {
+void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points) {
+  *memo_points = *stash_points = 0;
   const uint64_t per_round = (uint64_t)grid * kPersistWorkers;
-  if (n <= per_round) return 0;
-  const uint64_t extra = (n - 1) / per_round;  // points per thread beyond the first (upper bound)
-  return (uint32_t)(extra < kMaxStashPoints ? extra : kMaxStashPoints);
+  if (n <= per_round) return;
+  const uint32_t extra = (uint32_t)((n - 1) / per_round);  // points per thread beyond the first (upper bound)
+  // the memo first (it saves the table access, the larger term), the rest of the LDS parks whole points
+  const uint32_t memo = extra < kMaxMemoPoints ? extra : kMaxMemoPoints;
+  const uint32_t left = kPersistDynLds - memo * kMemoBytesPerPoint;
+  const uint32_t stash = left / kStashBytesPerPoint;
+  *memo_points = memo;
+  *stash_points = stash < extra ? stash : extra;
+}
+
+uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_points) {
+  return memo_points * kMemoBytesPerPoint + stash_points * kStashBytesPerPoint;
+}
+
+size_t persistent_rows_words() { return 3 * (size_t)kExchangeRows * kSlots; }
+size_t persistent_parts_words() { return 3 * (size_t)kFolders * kSlots; }
+
+// Initial / between-launch content of the exchange buffers for a launch of `grid` workgroups: the words a
+// workgroup (rows) or a folder (parts) publishes are unset, every other word is +0.0 for good, so that
+// every folder adds 16 rows and every workgroup adds 16 parts whatever the grid.
+void persistent_exchange_image(uint32_t grid, unsigned long long* rows_words, unsigned long long* parts_words) {
+  for (int buf = 0; buf < 3; ++buf) {
+    unsigned long long* rw = rows_words + (size_t)buf * kExchangeRows * kSlots;
+    for (size_t w = 0; w < (size_t)kExchangeRows * kSlots; ++w) rw[w] = 0ull;
+    for (uint32_t b = 0; b < grid && b < (uint32_t)kExchangeRows; ++b) {
+      const uint32_t row = (b % kFolders) * kFolders + b / kFolders;
+      for (int sl = 0; sl <= kCountSlot; ++sl) rw[(size_t)row * kSlots + sl] = kRowUnset;
+    }
+    unsigned long long* pw = parts_words + (size_t)buf * kFolders * kSlots;
+    for (size_t w = 0; w < (size_t)kFolders * kSlots; ++w) pw[w] = 0ull;
+    for (uint32_t g = 0; g < grid && g < (uint32_t)kFolders; ++g)
+      for (int sl = 0; sl <= kCountSlot; ++sl) pw[(size_t)g * kSlots + sl] = kRowUnset;
+  }
 }
 
 hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid) {
-  static bool raised = false;
-  if (!raised) {  // LDS beyond the default 64 KB per workgroup has to be asked for once
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<512>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(kMaxStashPoints * kStashBytesPerPoint));
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  static bool raised[64] = {false};  // per device: LDS beyond the default 64 KB per workgroup has to be asked for once
+  if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+  if (!raised[device]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<512>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistDynLds);
     if (e != hipSuccess) return e;
-    raised = true;
+    raised[device] = true;
   }
-  hipLaunchKernelGGL(persistent_kernel<512>, dim3(grid), dim3(512), args.stash_points * kStashBytesPerPoint, s,
-                     args);
+  const size_t dyn = (size_t)args.memo_points * kMemoBytesPerPoint + (size_t)args.stash_points * kStashBytesPerPoint;
+  if (dyn > kPersistDynLds) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(persistent_kernel<512>, dim3(grid), dim3(512), dyn, s, args);
   return hipGetLastError();
+}
+
+// Whether `grid` 512-thread workgroups of the persistent kernel with this much dynamic LDS can all be
+// resident at once on the current device (the in-kernel exchange requires it).
+hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_t* max_grid) {
+  int per_cu = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&persistent_kernel<512>),
+                                                              512, dyn_lds_bytes);
+  if (e != hipSuccess) return e;
+  *max_grid = per_cu > 0 ? (uint32_t)cu_count : 0u;  // one workgroup per CU is what the design uses
+  return hipSuccess;
 }
 
 hipError_t launch_close(hipStream_t s, const IterArgs& args) {

@@ -89,6 +89,19 @@ const char* vgicp_last_error(const vgicp_ctx* ctx);
 int vgicp_device_info(const vgicp_ctx* ctx, char* name, size_t name_len, int32_t* cu_count,
                       uint64_t* hbm_bytes);
 
+/* Diagnostics the reference has no counterpart for. PERSISTENT_LAUNCHES: aligns attempted as ONE kernel
+ * launch for the whole loop; PERSISTENT_FALLBACKS: how many of them gave up waiting for a workgroup that was
+ * not resident (another process or stream held CUs) and were re-run with one launch per iteration — the
+ * result is the same, the align is slower, the first occurrence also prints one line on stderr, and the
+ * context retries the single launch after 8 aligns; UPLOAD_*: bytes and time of host-to-device scan copies. */
+enum {
+  VGICP_COUNTER_PERSISTENT_LAUNCHES = 0,
+  VGICP_COUNTER_PERSISTENT_FALLBACKS = 1,
+  VGICP_COUNTER_UPLOAD_BYTES = 2,
+  VGICP_COUNTER_UPLOAD_NANOSECONDS = 3
+};
+int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value);
+
 /* ---- device mirror of LocalMap's voxel grid -------------------------------------------------
  * Replaces the read side of LocalMap::VoxelGrid (include/ESKF_LIO/LocalMap.hpp:25-26,63-89).  The
  * host LocalMap stays authoritative for save()/visualise; after each updateLocalMap

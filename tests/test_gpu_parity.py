@@ -276,8 +276,8 @@ def test_empty_scan_empty_map_and_zero_iterations(gpu_ctx, c1_inputs):
 def test_degenerate_system_is_reported_not_thrown(gpu_ctx, oracle):
     """One correspondence: JTJ has rank 3. The reference is unguarded here (Registration.cpp:78): Eigen's
     pivoted LDLT divides by whatever rounding noise the last three pivots hold. The device's fallback solve
-    follows the same operation order without contraction, so it returns the oracle's se3 bit for bit and
-    the whole align follows the oracle; a non-finite pose comes back as a status code, never as a throw."""
+    follows the same operation order without contraction, so on the same normal equations it returns the
+    oracle's se3 bit for bit; a non-finite pose comes back as a status code, never as a throw."""
     from eskf_lio_amd import capi
     gpu_ctx.map_reset(0.3, 0)
     mu = np.array([[0.95, 2.05, 3.1]])
@@ -290,8 +290,8 @@ def test_degenerate_system_is_reported_not_thrown(gpu_ctx, oracle):
     assert r.status in (capi.OK, capi.ERR_DEGENERATE)
     assert (r.status == capi.OK) == bool(np.isfinite(ref.pose).all())
     assert r.iterations == ref.iterations and np.array_equal(r.corr_count, ref.corr_count)
-    if r.status == capi.OK:
-        assert np.allclose(r.pose, ref.pose, rtol=1e-9, atol=1e-9)
+    # (the poses themselves need not agree: the last three pivots are rounding noise of sums that the device
+    #  and the CPU add in different orders, and the solve amplifies that noise along the null space)
     # the first round's system through the solve hook: the fallback is taken and equals the oracle's bits
     JTJ, JTr, cnt = gpu_ctx.accumulate(p, np.eye(3).reshape(1, 9), np.eye(4))
     assert cnt == 1
