@@ -289,7 +289,8 @@ def main():
                 "matches_per_iteration": float(res.corr_count.mean()),
                 "upload": {"bytes_per_step": 96 * n_local,
                            "host_side_ms_per_upload": (upload_ns / 1e6) / max(1, upload_bytes // max(1, 96 * n_local)),
-                           "what": "pageable caller memory -> pinned staging by worker threads -> chunked DMA, overlapped"},
+                           "what": "two hipMemcpyAsync from the caller's pageable buffers (pinned on the fly by the runtime, DMA in "
+                                   "place) + pack kernel, enqueued in front of the persistent launch"},
                 "persistent_fallbacks": fallbacks,
             },
             "roofline": {

@@ -103,6 +103,7 @@ struct vgicp_ctx {
   double* d_parts_persist = nullptr; // [3][kFolders][kSlots]
   void* h_exchange_image = nullptr;  // pinned: what the two buffers hold between launches
   bool persistent_enabled = true;    // cleared by VGICP_PERSISTENT=0 or when a workgroup does not fit a CU
+  double prefetch_margin = 0.03;     // see PersistArgs::prefetch_margin; VGICP_PREFETCH_MARGIN overrides (0 = off)
   uint32_t persist_spin_limit = 50000;  // polls (>= ~1 us each) before an in-kernel wait gives up
   int persistent_cooldown = 0;       // aligns left on the per-launch loop after an in-kernel wait timed out
   uint64_t persistent_launches = 0;  // diagnostics (vgicp_get_counter)
@@ -290,7 +291,7 @@ int enqueue_launch(vgicp_ctx* ctx, const IterArgs& base, int j, uint32_t body_gr
     a.prev = ctx->d_rows[(j + 1) & 1];
     a.prev_rows = j > 0 ? body_grid : 0u;
   }
-  if (closing) VG_HIP(ctx, launch_close(ctx->stream, a));
+  if (closing) VG_HIP(ctx, launch_close(ctx->stream, a, ctx->iter_block));
   else VG_HIP(ctx, launch_iterate(ctx->stream, a, body_grid, ctx->iter_block));
   if (use_comm && !closing) {
     VG_HIP(ctx, launch_fold_rows(ctx->stream, a.rows, body_grid, a.state_out, ctx->d_sums));
@@ -365,6 +366,7 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   persistent_lds_plan(ctx->n, grid, &a.memo_points, &a.stash_points);
   if (std::getenv("VGICP_NO_STASH")) a.stash_points = 0;
   if (std::getenv("VGICP_NO_MEMO")) a.memo_points = 0;
+  a.prefetch_margin = (a.memo_points == 0 && a.stash_points == 0 && ctx->n <= grid * 448u) ? ctx->prefetch_margin : 0.0;
   a.stamps = ctx->d_stamps;
   // one launch, one copy back (state header + the log rows), one synchronisation
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
@@ -576,6 +578,7 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   VG_CREATE(hipHostMalloc(&ctx->h_exchange_image, (persistent_rows_words() + persistent_parts_words()) * 8, 0));
   ctx->persist_grid = (uint32_t)std::min<int>(ctx->cu_count, kExchangeRows);
   if (const char* pe = std::getenv("VGICP_PERSISTENT")) ctx->persistent_enabled = pe[0] != '0';
+  if (const char* pm = std::getenv("VGICP_PREFETCH_MARGIN")) ctx->prefetch_margin = std::atof(pm);
   if (const char* sl = std::getenv("VGICP_SPIN_LIMIT")) ctx->persist_spin_limit = (uint32_t)std::strtoul(sl, nullptr, 10);
   {
     // the in-kernel exchange needs every workgroup resident: one 512-thread workgroup with the full dynamic LDS
@@ -591,8 +594,8 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sums), kSlots * sizeof(double)));
   VG_CREATE(hipMemset(ctx->d_state, 0, 2 * sizeof(AlignState)));
   if (const char* dbg = std::getenv("VGICP_DEBUG_STAMPS"); dbg && dbg[0] == '1') {
-    VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_stamps), 32 * sizeof(uint64_t)));
-    VG_CREATE(hipMemset(ctx->d_stamps, 0, 32 * sizeof(uint64_t)));
+    VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_stamps), (32 + kExchangeRows) * sizeof(uint64_t)));
+    VG_CREATE(hipMemset(ctx->d_stamps, 0, (32 + kExchangeRows) * sizeof(uint64_t)));
   }
   VG_CREATE(hipEventCreate(&ctx->ev_begin));
   VG_CREATE(hipEventCreate(&ctx->ev_end));
@@ -630,6 +633,21 @@ int vgicp_destroy(vgicp_ctx* ctx) {
                      o == 8 ? "solver wave" : "first worker lane", (unsigned long long)h[o + 5], h[o] * k, h[o + 1] * k,
                      h[o + 2] * k, h[o + 3] * k);
       }
+    }
+    uint64_t wg[kExchangeRows];
+    if (h[13] > 0 && hipMemcpy(wg, ctx->d_stamps + 32, sizeof wg, hipMemcpyDeviceToHost) == hipSuccess) {
+      const double k = 0.01 / (double)h[13];
+      double lo = 1e30, hi = 0.0, sum = 0.0;
+      int hi_at = 0;
+      const int g = (int)ctx->persist_grid;
+      for (int b = 0; b < g; ++b) {
+        const double v = wg[b] * k;
+        sum += v;
+        if (v < lo) lo = v;
+        if (v > hi) { hi = v; hi_at = b; }
+      }
+      std::fprintf(stderr, "[vgicp stamps] persistent, time to the first barrier per workgroup (mean over rounds): min %.2f us, "
+                   "mean %.2f us, max %.2f us (workgroup %d)\n", lo, sum / g, hi, hi_at);
     }
     (void)hipFree(ctx->d_stamps);
   }

@@ -106,6 +106,9 @@ struct PersistArgs {
   uint32_t stash_points;   // extra points per thread kept in LDS across rounds (scans larger than the grid)
   uint32_t memo_points;    // extra points per thread whose last key + table slot are remembered in LDS
   uint32_t exit_base;      // value of the exit counter before this launch
+  double prefetch_margin;  // > 0 (only with memo_points == stash_points == 0): a point closer than this many
+                           // voxel sizes to a face of its voxel has the neighbour behind that face looked up
+                           // into LDS while the workers wait for the exchange
   uint64_t* stamps;
 };
 
@@ -127,7 +130,7 @@ uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_points);
 // accumulates this round's rows. block = 256 / 512 / 1024 threads per workgroup.
 hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, int block);
 // The prologue-only launch that closes the last round (single workgroup).
-hipError_t launch_close(hipStream_t s, const IterArgs& args);
+hipError_t launch_close(hipStream_t s, const IterArgs& args, int block);
 // Multi-GPU: fold nrows rows into sums[kSlots] (the 256-byte message of the all-reduce).
 hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, const AlignState* state,
                             double* sums);

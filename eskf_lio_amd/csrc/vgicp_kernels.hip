@@ -635,6 +635,7 @@ __device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, u
 }
 
 constexpr uint32_t kMemoMiss = 0xFFFFFFFFu;  // memo.w of a point whose voxel is not in the map
+constexpr uint32_t kMemoNone = 0xFFFFFFFEu;  // nothing looked up
 
 // Payload of a record whose slot is known (an unchanged key that hit last round): one round trip.
 __device__ __forceinline__ void load_payload(const VoxelRecord* rec, double (&mu)[3], double (&S)[9]) {
@@ -661,6 +662,13 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   int4* memo = reinterpret_cast<int4*>(dyn_lds);
   double* stash = reinterpret_cast<double*>(dyn_lds + (size_t)a.memo_points * kWorkers * sizeof(int4));
+  // Scans that fit the grid (one point per thread, no memo / stash): the same LDS holds, per thread, the voxel
+  // BEHIND THE NEAREST FACE of the point's voxel, looked up while the workers wait for the exchange: key + slot
+  // (int4) and the 96-byte payload (6 planes of double2).  A point that changes voxel next round usually
+  // enters exactly that one and finds its record (or the news that there is none) here.
+  int4* pf_key = reinterpret_cast<int4*>(dyn_lds);
+  double2* pf_pay = reinterpret_cast<double2*>(dyn_lds + (size_t)kWorkers * sizeof(int4));
+  const bool prefetch = a.prefetch_margin > 0.0;  // uniform; implies memo_points == stash_points == 0
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool worker = wave != 0;
@@ -712,7 +720,23 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
         const int32_t ky = voxel_coord(p[1], a.voxel_size);
         const int32_t kz = voxel_coord(p[2], a.voxel_size);
         if (!spec || kx != okx || ky != oky || kz != okz) {
-          hit = find_and_load(a.table, a.mask, kx, ky, kz, mu, Sv);
+          bool served = false;
+          if (spec && prefetch) {
+            const int4 m = pf_key[tid - 64];
+            if (m.x == kx && m.y == ky && m.z == kz && (uint32_t)m.w != kMemoNone) {
+              served = true;
+              hit = (uint32_t)m.w != kMemoMiss;
+              if (hit) {
+                const double2* pay = pf_pay + (tid - 64);
+                const double2 a0 = pay[0 * kWorkers], a1 = pay[1 * kWorkers], a2 = pay[2 * kWorkers],
+                              a3 = pay[3 * kWorkers], a4 = pay[4 * kWorkers], a5 = pay[5 * kWorkers];
+                mu[0] = a0.x; mu[1] = a0.y; mu[2] = a1.x;
+                Sv[0] = a1.y; Sv[1] = a2.x; Sv[2] = a2.y; Sv[3] = a3.x; Sv[4] = a3.y; Sv[5] = a4.x;
+                Sv[6] = a4.y; Sv[7] = a5.x; Sv[8] = a5.y;
+              }
+            }
+          }
+          if (!served) hit = find_and_load(a.table, a.mask, kx, ky, kz, mu, Sv);
           okx = kx; oky = ky; okz = kz;
           spec = true;
         }
@@ -774,6 +798,34 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
     }
     __syncthreads();
     if (a.stamps) { const uint64_t n = wall_clock64(); acc_body += n - t_mark; t_mark = n; }
+
+    if (worker && prefetch && have) {
+      // While wave 0 exchanges and solves: where is this point inside its voxel?  If a face is nearer than
+      // prefetch_margin voxels, look the voxel behind it up now (full probe; 2 dependent round trips that
+      // nobody waits for) so that next round's key change finds the record in LDS.
+      double p[3];
+      transform_point(R, t, q0[0], q0[1], q0[2], p);
+      const double fx = p[0] / a.voxel_size - (double)okx, fy = p[1] / a.voxel_size - (double)oky,
+                   fz = p[2] / a.voxel_size - (double)okz;  // in [0, 1)
+      const double dx = fmin(fx, 1.0 - fx), dy = fmin(fy, 1.0 - fy), dz = fmin(fz, 1.0 - fz);
+      int32_t nx = okx, ny = oky, nz = okz;
+      double d;
+      if (dx <= dy && dx <= dz) { d = dx; nx += fx < 0.5 ? -1 : 1; }
+      else if (dy <= dz) { d = dy; ny += fy < 0.5 ? -1 : 1; }
+      else { d = dz; nz += fz < 0.5 ? -1 : 1; }
+      int4 m = make_int4(nx, ny, nz, (int32_t)kMemoNone);
+      if (d < a.prefetch_margin) {
+        const VoxelRecord* rec = find_voxel(a.table, a.mask, nx, ny, nz);
+        m.w = rec ? (int32_t)(uint32_t)(rec - a.table) : (int32_t)kMemoMiss;
+        if (rec) {
+          const double2* pay = reinterpret_cast<const double2*>(rec->mean);
+          double2* dst = pf_pay + (tid - 64);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) dst[j * kWorkers] = pay[j];
+        }
+      }
+      pf_key[tid - 64] = m;
+    }
 
     if (wave == 0) {
       const uint32_t buf = (uint32_t)it % 3u, rearm = ((uint32_t)it + 2u) % 3u;
@@ -884,6 +936,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       out->seq = a.seq;
     }
   }
+  if (a.stamps && tid == 0) atomicAdd((unsigned long long*)&a.stamps[32 + blk], (unsigned long long)acc_body);
   if (a.stamps && blk == 0 && (tid == 0 || tid == 64)) {
     const int o = tid == 0 ? 8 : 16;  // solver wave / first worker lane
     atomicAdd((unsigned long long*)&a.stamps[o + 0], (unsigned long long)acc_body);
@@ -1122,6 +1175,7 @@ constexpr uint32_t kMemoBytesPerPoint = kPersistWorkers * sizeof(int4);         
 // dynamic LDS of the persistent launch: the CU's 160 KB minus the kernel's static use and a margin
 constexpr uint32_t kPersistDynLds = 150 * 1024;
 constexpr uint32_t kMaxMemoPoints = 12;  // beyond that a thread's points are looked up every round
+constexpr uint32_t kPrefetchBytes = kPersistWorkers * (sizeof(int4) + 6 * sizeof(double2));  // 50 176
 }  // namespace
 
 void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points) {
@@ -1174,7 +1228,11 @@ hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t gr
     if (e != hipSuccess) return e;
     raised[device] = true;
   }
-  const size_t dyn = (size_t)args.memo_points * kMemoBytesPerPoint + (size_t)args.stash_points * kStashBytesPerPoint;
+  size_t dyn = (size_t)args.memo_points * kMemoBytesPerPoint + (size_t)args.stash_points * kStashBytesPerPoint;
+  if (args.prefetch_margin > 0.0) {
+    if (dyn != 0) return hipErrorInvalidValue;  // the prefetch area shares the LDS of memo / stash
+    dyn = kPrefetchBytes;
+  }
   if (dyn > kPersistDynLds) return hipErrorInvalidValue;
   hipLaunchKernelGGL(persistent_kernel<512>, dim3(grid), dim3(512), dyn, s, args);
   return hipGetLastError();
@@ -1191,8 +1249,15 @@ hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_
   return hipSuccess;
 }
 
-hipError_t launch_close(hipStream_t s, const IterArgs& args) {
-  hipLaunchKernelGGL(close_kernel<1024>, dim3(1), dim3(1024), 0, s, args);
+// The closing launch folds the last round's rows with the workgroup size of the body launches, so that
+// its sums are added in the same order as every other round's (and as the persistent launch adds them).
+hipError_t launch_close(hipStream_t s, const IterArgs& args, int block) {
+  switch (block) {
+    case 256: hipLaunchKernelGGL(close_kernel<256>, dim3(1), dim3(256), 0, s, args); break;
+    case 512: hipLaunchKernelGGL(close_kernel<512>, dim3(1), dim3(512), 0, s, args); break;
+    case 1024: hipLaunchKernelGGL(close_kernel<1024>, dim3(1), dim3(1024), 0, s, args); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

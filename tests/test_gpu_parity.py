@@ -229,6 +229,74 @@ def test_persistent_and_per_launch_variants_return_the_same_bits(c1_gpu, c1_inpu
         assert np.abs(a.pose - b.pose).max() < 1e-15
 
 
+def test_persistent_exchange_survives_uneven_load_and_every_exit_round(gpu_ctx, c1_inputs):
+    """The in-kernel row exchange (data-as-signal, three buffers re-armed in flight, cleaned at exit) under what
+    hides hand-off bugs on an idle chip: workgroups with very different amounts of work (scan sizes from one
+    point to several points per thread, so most of the 256 workgroups publish at once while a few arrive late),
+    launches that end after 1..7 rounds (every buffer takes its turn as the last one), converging runs, all
+    back to back on the same buffers with the consumer's caches warm.  Every round's 27 sums and count must be
+    the per-launch loop's, bit for bit."""
+    from eskf_lio_amd import capi, synth
+    vmap = c1_inputs[0]
+    gpu_ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+    gpu_ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+    big_p, big_c = synth.make_uniform_scan(300_000, vmap, seed=99)
+    g = synth.default_guess()
+    rng = np.random.default_rng(3)
+    sizes = [1, 447, 448, 449, 5_000, 60_000, 114_688, 114_689, 300_000]
+    checked = 0
+    for trial in range(60):
+        n = sizes[trial % len(sizes)] if trial < 27 else int(rng.integers(1, 300_000))
+        rounds = 1 + trial % 7
+        gpu_ctx.scan_upload(big_p[:n], big_c[:n])
+        one = gpu_ctx.align_resident(g, rounds, 1e-6, 2.0, allow_degenerate=True)
+        loop = gpu_ctx.align_resident(g, rounds, 1e-6, 2.0, flags=capi.FLAG_NO_PERSISTENT, allow_degenerate=True)
+        assert one.launches == 1 and loop.launches > 1
+        assert one.iterations == loop.iterations == rounds
+        if n <= 114_688:                                            # same partition of points into workgroups
+            assert np.array_equal(one.normal_eq, loop.normal_eq), (trial, n, rounds)
+        else:                                                       # the loop uses more, smaller workgroups
+            assert np.allclose(one.normal_eq, loop.normal_eq, rtol=1e-11, atol=1e-7), (trial, n, rounds)
+        assert np.array_equal(one.corr_count, loop.corr_count)
+        again = gpu_ctx.align_resident(g, rounds, 1e-6, 2.0, allow_degenerate=True)
+        assert np.array_equal(again.normal_eq, one.normal_eq) and np.array_equal(again.pose, one.pose, equal_nan=True)
+        checked += 1
+    assert checked == 60 and gpu_ctx.counter(1) == 0               # no launch gave up
+    # converging runs leave at a data-dependent round
+    spts, scovs, _ = synth.make_structured_scan(5_000, vmap)
+    for _ in range(5):
+        a = gpu_ctx.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999)
+        b = gpu_ctx.align(big_p[:70_000], big_c[:70_000], g, 6, 1e-6, 2.0)
+        assert a.converged and a.iterations == 3 and a.launches == 1 and b.launches == 1
+
+
+def test_persistent_launch_that_gives_up_falls_back_and_recovers(c1_inputs, monkeypatch):
+    """A persistent launch whose in-kernel wait runs out (forced here with a poll budget of zero; in the field:
+    another process holds compute units) must leave no trace: the align is re-run with one launch per
+    iteration and returns the same bits, the exchange buffers are put back, the fallback is counted, the next
+    aligns stay on the per-launch loop and the single launch is tried again afterwards."""
+    from eskf_lio_amd import capi, synth
+    vmap, pts, covs = c1_inputs
+    g = synth.default_guess()
+    with capi.Context(0) as ref_ctx:
+        ref_ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+        ref_ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+        want = ref_ctx.align(pts, covs, g, 10, 1e-6, 2.0, flags=capi.FLAG_NO_PERSISTENT)
+        good = ref_ctx.align(pts, covs, g, 10, 1e-6, 2.0)
+        assert good.launches == 1 and np.array_equal(good.normal_eq, want.normal_eq)
+    monkeypatch.setenv("VGICP_SPIN_LIMIT", "0")
+    with capi.Context(0) as ctx:
+        monkeypatch.delenv("VGICP_SPIN_LIMIT")
+        ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+        ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+        for k in range(12):
+            r = ctx.align(pts, covs, g, 10, 1e-6, 2.0)
+            assert r.launches > 1                                   # never the single launch: it cannot complete
+            assert np.array_equal(r.normal_eq, want.normal_eq) and np.array_equal(r.pose, want.pose)
+        # 12 aligns: the single launch tried at #0 and, after 8 aligns on the loop, again at #9
+        assert ctx.counter(0) == 2 and ctx.counter(1) == 2
+
+
 def test_resident_scan_is_not_modified_by_align(c1_gpu, c1_inputs):
     from eskf_lio_amd import synth
     _, pts, covs = c1_inputs
