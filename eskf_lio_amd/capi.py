@@ -21,6 +21,7 @@ FLAG_PROFILE = 1
 FLAG_NO_PERSISTENT = 2
 SOLVE_FORCE_PIVOTED = 1
 UNIQUE_ID_BYTES = 128
+PEER_HANDLE_BYTES = 64
 
 # every symbol include/vgicp_hip.h declares
 EXPORTS = (
@@ -32,6 +33,7 @@ EXPORTS = (
     "vgicp_accumulate", "vgicp_solve_step", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_scan_prepare", "vgicp_scan_download",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
+    "vgicp_peer_export", "vgicp_peer_connect", "vgicp_peer_disconnect",
 )
 
 
@@ -101,6 +103,9 @@ def load_library() -> C.CDLL:
     lib.vgicp_comm_unique_id.argtypes = [vp, vp]
     lib.vgicp_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.vgicp_comm_destroy.argtypes = [vp]
+    lib.vgicp_peer_export.argtypes = [vp, vp]
+    lib.vgicp_peer_connect.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.vgicp_peer_disconnect.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("vgicp_last_error",):
@@ -444,3 +449,20 @@ class Context:
 
     def comm_destroy(self):
         self._check(self._lib.vgicp_comm_destroy(self._h))
+
+    def peer_export(self) -> bytes:
+        """IPC handle (64 bytes) of this context's mailbox for the device-initiated exchange."""
+        buf = C.create_string_buffer(PEER_HANDLE_BYTES)
+        self._check(self._lib.vgicp_peer_export(self._h, buf))
+        return buf.raw
+
+    def peer_connect(self, world_size: int, rank: int, handles: bytes):
+        """handles: the world_size exported handles concatenated in rank order. The caller runs a barrier of its
+        own transport after every rank has connected, before the first align."""
+        if len(handles) != world_size * PEER_HANDLE_BYTES:
+            raise ValueError("handles must hold world_size x 64 bytes")
+        buf = C.create_string_buffer(handles, len(handles))
+        self._check(self._lib.vgicp_peer_connect(self._h, int(world_size), int(rank), buf))
+
+    def peer_disconnect(self):
+        self._check(self._lib.vgicp_peer_disconnect(self._h))

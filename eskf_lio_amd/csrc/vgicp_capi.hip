@@ -34,10 +34,12 @@ struct RcclApi {
   int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 constexpr int kNcclDouble = 8;  // ncclFloat64, rccl.h
 constexpr int kNcclSum = 0;
+constexpr int kNcclChar = 0;   // ncclInt8
 
 thread_local std::string g_create_error;
 
@@ -118,6 +120,15 @@ struct vgicp_ctx {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_chunk[kMaxChunksInFlight] = {nullptr, nullptr};
   std::vector<hipEvent_t> ev_prof;
+
+  // device-initiated exchange between GPUs: peer-mapped mailboxes (vgicp_peer_*)
+  double* d_mail = nullptr;            // this rank's mailbox, fine-grained device memory, [3][kMaxRanks][kSlots]
+  double* peer_mail[kMaxRanks] = {nullptr};  // every rank's mailbox as mapped here ([peer_rank] = d_mail)
+  double** d_mail_table = nullptr;     // device copy of peer_mail
+  int peer_world = 1, peer_rank = 0;
+  bool peers_connected = false;
+  bool peer_enabled = true;            // cleared for good when a launch gave up waiting for a peer
+  uint32_t mail_round0 = 0;            // rounds executed through the mailboxes so far (same on every rank)
 
   // RCCL
   RcclApi rccl;
@@ -256,6 +267,7 @@ int load_rccl(vgicp_ctx* ctx) {
   api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(lib, "ncclAllGather"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce)
     return fail(ctx, VGICP_ERR_RCCL, "librccl lacks a required symbol");
@@ -368,6 +380,11 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   if (std::getenv("VGICP_NO_MEMO")) a.memo_points = 0;
   a.prefetch_margin = (a.memo_points == 0 && a.stash_points == 0 && ctx->n <= grid * 448u) ? ctx->prefetch_margin : 0.0;
   a.stamps = ctx->d_stamps;
+  const bool multi = ctx->peers_connected && ctx->peer_world > 1;
+  a.world = multi ? (uint32_t)ctx->peer_world : 1u;
+  a.rank = multi ? (uint32_t)ctx->peer_rank : 0u;
+  a.mail = ctx->d_mail_table;
+  a.mail_round0 = ctx->mail_round0;
   // one launch, one copy back (state header + the log rows), one synchronisation
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
   VG_HIP(ctx, launch_persistent(ctx->stream, a, grid));
@@ -384,6 +401,13 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
     // few, then try the single launch again.
     ++ctx->persistent_fallbacks;
     ctx->persistent_cooldown = kPersistentCooldownAligns;
+    if (multi) {
+      // a peer did not deliver: its kernel may still be writing into this mailbox, so the mailboxes are not
+      // touched again — this communicator stays on the host-enqueued collective from here on
+      ctx->peer_enabled = false;
+      std::fprintf(stderr, "[vgicp] rank %d: the in-kernel exchange between GPUs gave up waiting for a peer; this "
+                   "communicator continues with one launch + one RCCL all-reduce per iteration\n", ctx->peer_rank);
+    }
     if (ctx->persistent_fallbacks == 1 || std::getenv("VGICP_VERBOSE"))
       std::fprintf(stderr, "[vgicp] persistent align launch gave up waiting for a workgroup (fallback #%llu): using one "
                    "launch per iteration for the next %d aligns\n", (unsigned long long)ctx->persistent_fallbacks,
@@ -391,6 +415,7 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
     return reset_persistent_exchange(ctx);
   }
   ctx->persist_exit_base += grid;
+  if (multi) ctx->mail_round0 += (uint32_t)result->iteration;
   *ran = true;
   return VGICP_OK;
 }
@@ -409,9 +434,11 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
   int chunk = params->chunk_iterations > 0 ? params->chunk_iterations : kDefaultChunk;
   if (profile) chunk = 1;
 
-  if (ctx->persistent_cooldown > 0) --ctx->persistent_cooldown;
-  else if (ctx->persistent_enabled && ctx->comm == nullptr && !profile && max_it > 0 &&
-      (params->flags & VGICP_FLAG_NO_PERSISTENT) == 0) {
+  const bool peer_path = ctx->peers_connected && ctx->peer_enabled && ctx->peer_world > 1;
+  const bool alone = ctx->comm == nullptr && !ctx->peers_connected;
+  if (ctx->persistent_cooldown > 0 && !peer_path) --ctx->persistent_cooldown;
+  else if (ctx->persistent_enabled && (alone || peer_path) && !profile && max_it > 0 &&
+           (params->flags & VGICP_FLAG_NO_PERSISTENT) == 0) {
     bool ran = false;
     float ms = 0.f;
     AlignState* hf = &ctx->h_state[0];
@@ -423,7 +450,7 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
       if (stats) {
         stats->iterations = hf->iteration;
         stats->converged = hf->converged;
-        stats->world_size = 1;
+        stats->world_size = peer_path ? ctx->peer_world : 1;
         stats->launches = 1;
         stats->device_seconds = ms * 1e-3;
         for (int it = 0; it < hf->iteration; ++it) {
@@ -438,6 +465,9 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
     }
   }
 
+  if (ctx->peers_connected && ctx->peer_world > 1 && ctx->comm == nullptr)
+    return fail(ctx, VGICP_ERR_RCCL, "the in-kernel exchange between GPUs is not available for this align (gave up earlier, "
+                "profiling or VGICP_FLAG_NO_PERSISTENT) and there is no RCCL communicator to fall back to");
   AlignState* h0 = &ctx->h_state[0];
   std::memset(h0, 0, sizeof(AlignState));
   pose_to_state(guess, h0->pose);
@@ -527,6 +557,28 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
 
 }  // namespace
 
+namespace {
+constexpr size_t kMailWords = 3 * (size_t)kMaxRanks * kSlots;
+
+int ensure_mailbox(vgicp_ctx* ctx) {
+  if (ctx->d_mail) return VGICP_OK;
+  // fine-grained: stores of another GPU's kernel become visible to this GPU's running kernel
+  VG_HIP(ctx, hipExtMallocWithFlags(reinterpret_cast<void**>(&ctx->d_mail), kMailWords * 8, hipDeviceMallocFinegrained));
+  VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mail_table), kMaxRanks * sizeof(double*)));
+  return VGICP_OK;
+}
+
+void close_peers(vgicp_ctx* ctx) {
+  for (int r = 0; r < kMaxRanks; ++r) {
+    if (ctx->peer_mail[r] && ctx->peer_mail[r] != ctx->d_mail) (void)hipIpcCloseMemHandle(ctx->peer_mail[r]);
+    ctx->peer_mail[r] = nullptr;
+  }
+  ctx->peers_connected = false;
+  ctx->peer_world = 1;
+  ctx->peer_rank = 0;
+}
+}  // namespace
+
 extern "C" {
 
 int vgicp_abi_version(void) { return VGICP_ABI_VERSION; }
@@ -577,6 +629,10 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_parts_persist), persistent_parts_words() * 8));
   VG_CREATE(hipHostMalloc(&ctx->h_exchange_image, (persistent_rows_words() + persistent_parts_words()) * 8, 0));
   ctx->persist_grid = (uint32_t)std::min<int>(ctx->cu_count, kExchangeRows);
+  if (const char* pg = std::getenv("VGICP_PERSIST_GRID")) {  // fewer workgroups: several contexts sharing one device
+    const long v = std::atol(pg);
+    if (v >= 1 && v <= (long)ctx->persist_grid) ctx->persist_grid = (uint32_t)v;
+  }
   if (const char* pe = std::getenv("VGICP_PERSISTENT")) ctx->persistent_enabled = pe[0] != '0';
   if (const char* pm = std::getenv("VGICP_PREFETCH_MARGIN")) ctx->prefetch_margin = std::atof(pm);
   if (const char* sl = std::getenv("VGICP_SPIN_LIMIT")) ctx->persist_spin_limit = (uint32_t)std::strtoul(sl, nullptr, 10);
@@ -615,6 +671,9 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   if (!ctx) return VGICP_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  close_peers(ctx);
+  if (ctx->d_mail) (void)hipFree(ctx->d_mail);
+  if (ctx->d_mail_table) (void)hipFree(ctx->d_mail_table);
   if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
   if (ctx->d_stamps) {
     uint64_t h[32] = {0};
@@ -827,7 +886,7 @@ int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t
   if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload first");
   if (!transform) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
   if (max_points_per_voxel == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "max_points_per_voxel must be >= 1");
-  if (ctx->comm) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "resident scan is a shard: use vgicp_map_insert_scan with the whole scan");
+  if (ctx->comm || ctx->peers_connected) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "resident scan is a shard: use vgicp_map_insert_scan with the whole scan");
   const size_t n = ctx->n;
   if (n == 0) return VGICP_OK;
   VG_HIP(ctx, hipSetDevice(ctx->device));
@@ -1326,7 +1385,7 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
   if (deskewed) *deskewed = 0;
   int rc = check_preprocess_args(ctx, n, voxel_size, knn);
   if (rc != VGICP_OK) return rc;
-  if (ctx->comm) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the prepared scan is whole: not available on a communicator (shards)");
+  if (ctx->comm || ctx->peers_connected) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the prepared scan is whole: not available on a communicator (shards)");
   if (n > 0 && !points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
   const bool with_deskew = n > 0 && num_states > 0;
   if (with_deskew && (!point_time || !states)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
@@ -1401,6 +1460,70 @@ int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double*
   return VGICP_OK;
 }
 
+int vgicp_peer_export(vgicp_ctx* ctx, void* handle64) {
+  if (!ctx || !handle64) return VGICP_ERR_BAD_ARGUMENT;
+  static_assert(sizeof(hipIpcMemHandle_t) == VGICP_PEER_HANDLE_BYTES, "handle size");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_mailbox(ctx);
+  if (rc != VGICP_OK) return rc;
+  hipIpcMemHandle_t h;
+  VG_HIP(ctx, hipIpcGetMemHandle(&h, ctx->d_mail));
+  std::memcpy(handle64, &h, sizeof h);
+  return VGICP_OK;
+}
+
+int vgicp_peer_connect(vgicp_ctx* ctx, int world_size, int rank, const void* handles) {
+  if (!ctx || !handles) return VGICP_ERR_BAD_ARGUMENT;
+  if (world_size < 1 || world_size > kMaxRanks || rank < 0 || rank >= world_size)
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "bad world_size / rank (at most 16 ranks)");
+  if (ctx->peers_connected) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "peers already connected");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_mailbox(ctx);
+  if (rc != VGICP_OK) return rc;
+  // this rank's mailbox: the rows the ranks write are unset, the others +0.0 for good
+  std::vector<unsigned long long> img(kMailWords, 0ull);
+  for (int buf = 0; buf < 3; ++buf)
+    for (int r = 0; r < world_size; ++r)
+      for (int sl = 0; sl <= kCountSlot; ++sl) img[((size_t)buf * kMaxRanks + r) * kSlots + sl] = kRowUnset;
+  VG_HIP(ctx, hipMemcpy(ctx->d_mail, img.data(), kMailWords * 8, hipMemcpyHostToDevice));
+  for (int r = 0; r < world_size; ++r) {
+    if (r == rank) {
+      ctx->peer_mail[r] = ctx->d_mail;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, static_cast<const char*>(handles) + (size_t)r * VGICP_PEER_HANDLE_BYTES, sizeof h);
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      close_peers(ctx);
+      return fail_hip(ctx, e, "hipIpcOpenMemHandle(peer mailbox)");
+    }
+    ctx->peer_mail[r] = static_cast<double*>(p);
+  }
+  VG_HIP(ctx, hipMemcpy(ctx->d_mail_table, ctx->peer_mail, kMaxRanks * sizeof(double*), hipMemcpyHostToDevice));
+  ctx->peer_world = world_size;
+  ctx->peer_rank = rank;
+  ctx->world_size = world_size;
+  ctx->rank = rank;
+  ctx->mail_round0 = 0;
+  ctx->peer_enabled = true;
+  ctx->peers_connected = true;
+  return VGICP_OK;
+}
+
+int vgicp_peer_disconnect(vgicp_ctx* ctx) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  close_peers(ctx);
+  if (!ctx->comm) {
+    ctx->world_size = 1;
+    ctx->rank = 0;
+  }
+  return VGICP_OK;
+}
+
 int vgicp_comm_unique_id(vgicp_ctx* ctx, void* id128) {
   if (!ctx || !id128) return VGICP_ERR_BAD_ARGUMENT;
   int rc = load_rccl(ctx);
@@ -1428,11 +1551,70 @@ int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128)
   ctx->comm = comm;
   ctx->world_size = world_size;
   ctx->rank = rank;
+  // Device-initiated exchange on top: every rank's mailbox handle travels through ONE RCCL all-gather, peers
+  // are mapped, and one all-reduce makes sure every mailbox is initialised before any kernel writes into one.
+  // Any failure leaves the communicator on the host-enqueued all-reduce (VGICP_PEER_EXCHANGE=0 asks for that).
+  const char* want = std::getenv("VGICP_PEER_EXCHANGE");
+  if (world_size > 1 && world_size <= kMaxRanks && !(want && want[0] == '0') && ctx->rccl.AllGather &&
+      !ctx->peers_connected) {
+    std::string why;
+    char mine[VGICP_PEER_HANDLE_BYTES];
+    char* d_all = nullptr;
+    std::vector<char> all((size_t)world_size * VGICP_PEER_HANDLE_BYTES);
+    bool ok = vgicp_peer_export(ctx, mine) == VGICP_OK;
+    if (!ok) why = ctx->err;
+    // every rank must take part in the collectives whatever happened locally: a failed export sends zeros
+    if (!ok) std::memset(mine, 0, sizeof mine);
+    if (hipMalloc(reinterpret_cast<void**>(&d_all), all.size() + VGICP_PEER_HANDLE_BYTES) == hipSuccess) {
+      char* d_mine = d_all + all.size();
+      bool coll = hipMemcpyAsync(d_mine, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                  ctx->rccl.AllGather(d_mine, d_all, VGICP_PEER_HANDLE_BYTES, kNcclChar, ctx->comm, ctx->stream) == 0 &&
+                  hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                  hipStreamSynchronize(ctx->stream) == hipSuccess;
+      if (!coll) { ok = false; why = "handle all-gather failed"; }
+      bool any_zero = false;
+      for (int r = 0; r < world_size && coll; ++r) {
+        bool zero = true;
+        for (int k = 0; k < VGICP_PEER_HANDLE_BYTES; ++k) zero = zero && all[(size_t)r * VGICP_PEER_HANDLE_BYTES + k] == 0;
+        any_zero = any_zero || zero;
+      }
+      if (any_zero) { ok = false; why = "a rank could not export its mailbox"; }
+      if (ok && vgicp_peer_connect(ctx, world_size, rank, all.data()) != VGICP_OK) { ok = false; why = ctx->err; }
+      // agreement + barrier: the sum of the ranks' verdicts; the peer path is used only if all of them connected
+      double verdict = ok ? 1.0 : 0.0;
+      double* d_v = reinterpret_cast<double*>(d_all);
+      if (coll && hipMemcpyAsync(d_v, &verdict, sizeof verdict, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+          ctx->rccl.AllReduce(d_v, d_v, 1, kNcclDouble, kNcclSum, ctx->comm, ctx->stream) == 0 &&
+          hipMemcpyAsync(&verdict, d_v, sizeof verdict, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+          hipStreamSynchronize(ctx->stream) == hipSuccess) {
+        if (verdict != (double)world_size) {
+          if (ctx->peers_connected) close_peers(ctx);
+          ctx->world_size = world_size;
+          ctx->rank = rank;
+          if (why.empty()) why = "another rank could not connect";
+        }
+      } else if (ctx->peers_connected) {
+        close_peers(ctx);
+        ctx->world_size = world_size;
+        ctx->rank = rank;
+      }
+      (void)hipFree(d_all);
+    }
+    if (!ctx->peers_connected && std::getenv("VGICP_VERBOSE"))
+      std::fprintf(stderr, "[vgicp] rank %d: no device-initiated exchange (%s); using RCCL all-reduce per iteration\n", rank,
+                   why.c_str());
+    ctx->err.clear();
+  }
   return VGICP_OK;
 }
 
 int vgicp_comm_destroy(vgicp_ctx* ctx) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->peers_connected) {
+    VG_HIP(ctx, hipSetDevice(ctx->device));
+    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    close_peers(ctx);
+  }
   if (ctx->comm) {
     VG_HIP(ctx, hipSetDevice(ctx->device));
     VG_HIP(ctx, hipStreamSynchronize(ctx->stream));

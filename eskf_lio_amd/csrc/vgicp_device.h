@@ -81,6 +81,7 @@ struct IterArgs {
 // A producer re-arms its word (stores kRowUnset) one round after everyone has consumed it and two rounds
 // before it is written again; DESIGN.md section 4 has the ordering argument.
 constexpr int kExchangeRows = 256;                          // 16 folders x 16 rows: the largest persistent grid
+constexpr int kMaxRanks = 16;                               // mailbox rows; = kFolders so one poll routine serves both
 constexpr int kFolders = 16;                                // = 512 / kSlots, the groups of iterate_kernel<512>'s fold
 constexpr unsigned long long kRowUnset = ~0ull;             // a NaN pattern no fp64 operation produces
 constexpr unsigned long long kRowNaN = 0x7FF8000000000000ull;  // what a computed NaN is published as
@@ -106,6 +107,14 @@ struct PersistArgs {
   uint32_t stash_points;   // extra points per thread kept in LDS across rounds (scans larger than the grid)
   uint32_t memo_points;    // extra points per thread whose last key + table slot are remembered in LDS
   uint32_t exit_base;      // value of the exit counter before this launch
+  // multi-GPU (world > 1): the rank totals travel through peer-mapped mailboxes, written by the ranks'
+  // kernels themselves over xGMI (no host-enqueued collective between launches)
+  uint32_t world, rank;
+  uint32_t mail_round0;    // rounds all ranks have executed on this communicator before this launch
+  uint32_t pad_;
+  double* const* mail;     // device array of kMaxRanks pointers; mail[r]: rank r's mailbox as mapped into THIS
+                           // process, [3][kMaxRanks][kSlots] words: by round % 3, row = sender rank (rows >=
+                           // world hold +0.0 for good)
   double prefetch_margin;  // > 0 (only with memo_points == stash_points == 0): a point closer than this many
                            // voxel sizes to a face of its voxel has the neighbour behind that face looked up
                            // into LDS while the workers wait for the exchange

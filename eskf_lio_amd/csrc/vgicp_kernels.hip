@@ -599,6 +599,13 @@ __device__ __forceinline__ void store_through_bits(double* p, unsigned long long
 __device__ __forceinline__ unsigned long long load_through_bits(const double* p) {
   return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Mailbox words live in fine-grained memory of this or another GPU: system scope (sc0 sc1) both ways.
+__device__ __forceinline__ void store_system_bits(double* p, unsigned long long bits) {
+  __hip_atomic_store((gu64*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long load_system_bits(const double* p) {
+  return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // A sum as it is published: never the "unset" pattern (a NaN with that payload can only come from
 // non-finite input; it is published as the canonical NaN and the align ends as VGICP_ERR_DEGENERATE).
 __device__ __forceinline__ unsigned long long publishable(double v) {
@@ -610,12 +617,14 @@ __device__ __forceinline__ unsigned long long publishable(double v) {
 // the sum of their words in ascending row order, starting from +0.0 (as the folds of iterate_kernel do;
 // rows that belong to no workgroup hold +0.0 for good).  All 64 lanes of the wave call it; false when
 // spin_limit polls did not suffice.  The 16 loads are in flight together (one address, immediate offsets).
+template <bool SYSTEM>
 __device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, uint32_t spin_limit, double& sum) {
   const bool active = lane <= (uint32_t)kCountSlot;
   const double* mine = src + (active ? lane : 0u);
   unsigned long long w[kFolders];
 #pragma unroll
-  for (int k = 0; k < kFolders; ++k) w[k] = active ? load_through_bits(mine + k * kSlots) : 0ull;
+  for (int k = 0; k < kFolders; ++k)
+    w[k] = active ? (SYSTEM ? load_system_bits(mine + k * kSlots) : load_through_bits(mine + k * kSlots)) : 0ull;
   for (uint32_t spins = 0;; ++spins) {
     bool missing = false;
 #pragma unroll
@@ -625,7 +634,7 @@ __device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, u
     __builtin_amdgcn_s_sleep(1);
 #pragma unroll
     for (int k = 0; k < kFolders; ++k)
-      if (w[k] == kRowUnset) w[k] = load_through_bits(mine + k * kSlots);
+      if (w[k] == kRowUnset) w[k] = SYSTEM ? load_system_bits(mine + k * kSlots) : load_through_bits(mine + k * kSlots);
   }
   double s = 0.0;
 #pragma unroll
@@ -646,7 +655,9 @@ __device__ __forceinline__ void load_payload(const VoxelRecord* rec, double (&mu
   S[6] = a4.y; S[7] = a5.x; S[8] = a5.y;
 }
 
-template <int BLOCK>
+// MULTI: several GPUs (the rank totals cross xGMI through mailboxes); STAMPS: in-kernel phase clocks
+// (VGICP_DEBUG_STAMPS=1).  Separate instantiations: the single-GPU production kernel carries neither.
+template <int BLOCK, bool MULTI, bool STAMPS>
 __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   static_assert(BLOCK / kSlots == kFolders, "the exchange reproduces the fold order of iterate_kernel<512>");
   constexpr int kWaves = BLOCK / 64;
@@ -700,7 +711,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) Sv[k] = 0.0;
 
-  uint64_t t_mark = a.stamps ? wall_clock64() : 0;
+  uint64_t t_mark = STAMPS ? wall_clock64() : 0;
   uint64_t acc_body = 0, acc_l1 = 0, acc_l2 = 0, acc_solve = 0;
   int it = 0;
   bool gave_up = false;
@@ -797,7 +808,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       if ((lane & 1) == 0) red[wave][lane >> 1] = wsum;
     }
     __syncthreads();
-    if (a.stamps) { const uint64_t n = wall_clock64(); acc_body += n - t_mark; t_mark = n; }
+    if (STAMPS) { const uint64_t n = wall_clock64(); acc_body += n - t_mark; t_mark = n; }
 
     if (worker && prefetch && have) {
       // While wave 0 exchanges and solves: where is this point inside its voxel?  If a face is nearer than
@@ -842,14 +853,37 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       bool ok = true;
       if (folder) {  // uniform
         double part = 0.0;
-        ok = poll_and_sum(rows + (size_t)blk * kFolders * kSlots, lane, a.spin_limit, part);
+        ok = poll_and_sum<false>(rows + (size_t)blk * kFolders * kSlots, lane, a.spin_limit, part);
         if (ok && lane <= (uint32_t)kCountSlot) store_through_bits(parts + (size_t)blk * kSlots + lane, publishable(part));
       }
-      if (a.stamps) { const uint64_t n = wall_clock64(); acc_l1 += n - t_mark; t_mark = n; }
+      if (STAMPS) { const uint64_t n = wall_clock64(); acc_l1 += n - t_mark; t_mark = n; }
       // ---- level 2: every workgroup adds the parts ----
       double tot = 0.0;
-      if (ok) ok = poll_and_sum(parts, lane, a.spin_limit, tot);
-      if (a.stamps) { const uint64_t n = wall_clock64(); acc_l2 += n - t_mark; t_mark = n; }
+      if (!MULTI) {
+        if (ok) ok = poll_and_sum<false>(parts, lane, a.spin_limit, tot);
+      } else {
+        // ---- several GPUs: workgroup 0 adds the parts to this rank's total and stores it into the mailbox
+        // of every rank (its own included); every workgroup then adds the ranks' totals in rank order ----
+        const uint32_t mbuf = (a.mail_round0 + (uint32_t)it) % 3u;
+        if (blk == 0) {
+          double mine = 0.0;
+          if (ok) ok = poll_and_sum<false>(parts, lane, a.spin_limit, mine);
+          if (ok && lane <= (uint32_t)kCountSlot) {
+            const unsigned long long bits = publishable(mine);
+            for (uint32_t r = 0; r < a.world; ++r)
+              store_system_bits(a.mail[r] + ((size_t)mbuf * kMaxRanks + a.rank) * kSlots + lane, bits);
+          }
+        }
+        if (ok) ok = poll_and_sum<true>(a.mail[a.rank] + (size_t)mbuf * kMaxRanks * kSlots, lane, a.spin_limit, tot);
+        // re-arm the mailbox buffer everyone (on every rank) finished with a round ago; the running round
+        // number carries over from launch to launch, so there is no clean-up at the end of a launch
+        if (ok && blk == 0 && lane <= (uint32_t)kCountSlot) {
+          const uint32_t old = (a.mail_round0 + (uint32_t)it + 2u) % 3u;
+          for (uint32_t r = 0; r < a.world; ++r)
+            store_system_bits(a.mail[a.rank] + ((size_t)old * kMaxRanks + r) * kSlots + lane, kRowUnset);
+        }
+      }
+      if (STAMPS) { const uint64_t n = wall_clock64(); acc_l2 += n - t_mark; t_mark = n; }
       if (!ok) {
         if (lane == 0) stop_sh = 2;
       } else {
@@ -899,7 +933,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) total.t[k] = pose_sh[9 + k];
     ++it;
-    if (a.stamps) { const uint64_t n = wall_clock64(); acc_solve += n - t_mark; t_mark = n; }
+    if (STAMPS) { const uint64_t n = wall_clock64(); acc_solve += n - t_mark; t_mark = n; }
     if (stop) break;
   }
   if (gave_up) return;  // the host sees state->seq != seq, resets the exchange buffers and uses launches
@@ -936,8 +970,8 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       out->seq = a.seq;
     }
   }
-  if (a.stamps && tid == 0) atomicAdd((unsigned long long*)&a.stamps[32 + blk], (unsigned long long)acc_body);
-  if (a.stamps && blk == 0 && (tid == 0 || tid == 64)) {
+  if (STAMPS && tid == 0) atomicAdd((unsigned long long*)&a.stamps[32 + blk], (unsigned long long)acc_body);
+  if (STAMPS && blk == 0 && (tid == 0 || tid == 64)) {
     const int o = tid == 0 ? 8 : 16;  // solver wave / first worker lane
     atomicAdd((unsigned long long*)&a.stamps[o + 0], (unsigned long long)acc_body);
     atomicAdd((unsigned long long*)&a.stamps[o + 1], (unsigned long long)acc_l1);
@@ -1216,34 +1250,45 @@ void persistent_exchange_image(uint32_t grid, unsigned long long* rows_words, un
   }
 }
 
+namespace {
+template <bool MULTI, bool STAMPS>
+hipError_t launch_persistent_as(hipStream_t s, const PersistArgs& args, uint32_t grid, size_t dyn, int device) {
+  static bool raised[64] = {false};  // per device: LDS beyond the default 64 KB per workgroup has to be asked for once
+  const void* fn = reinterpret_cast<const void*>(&persistent_kernel<512, MULTI, STAMPS>);
+  if (!raised[device]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistDynLds);
+    if (e != hipSuccess) return e;
+    raised[device] = true;
+  }
+  hipLaunchKernelGGL((persistent_kernel<512, MULTI, STAMPS>), dim3(grid), dim3(512), dyn, s, args);
+  return hipGetLastError();
+}
+}  // namespace
+
 hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid) {
   int device = 0;
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
-  static bool raised[64] = {false};  // per device: LDS beyond the default 64 KB per workgroup has to be asked for once
   if (device < 0 || device >= 64) return hipErrorInvalidDevice;
-  if (!raised[device]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<512>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistDynLds);
-    if (e != hipSuccess) return e;
-    raised[device] = true;
-  }
   size_t dyn = (size_t)args.memo_points * kMemoBytesPerPoint + (size_t)args.stash_points * kStashBytesPerPoint;
   if (args.prefetch_margin > 0.0) {
     if (dyn != 0) return hipErrorInvalidValue;  // the prefetch area shares the LDS of memo / stash
     dyn = kPrefetchBytes;
   }
   if (dyn > kPersistDynLds) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(persistent_kernel<512>, dim3(grid), dim3(512), dyn, s, args);
-  return hipGetLastError();
+  const bool multi = args.world > 1, stamps = args.stamps != nullptr;
+  if (multi) return stamps ? launch_persistent_as<true, true>(s, args, grid, dyn, device)
+                           : launch_persistent_as<true, false>(s, args, grid, dyn, device);
+  return stamps ? launch_persistent_as<false, true>(s, args, grid, dyn, device)
+                : launch_persistent_as<false, false>(s, args, grid, dyn, device);
 }
 
 // Whether `grid` 512-thread workgroups of the persistent kernel with this much dynamic LDS can all be
 // resident at once on the current device (the in-kernel exchange requires it).
 hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_t* max_grid) {
   int per_cu = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&persistent_kernel<512>),
-                                                              512, dyn_lds_bytes);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+      &per_cu, reinterpret_cast<const void*>(&persistent_kernel<512, true, false>), 512, dyn_lds_bytes);
   if (e != hipSuccess) return e;
   *max_grid = per_cu > 0 ? (uint32_t)cu_count : 0u;  // one workgroup per CU is what the design uses
   return hipSuccess;

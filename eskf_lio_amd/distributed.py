@@ -41,6 +41,21 @@ def share_bytes(payload_on_rank0: Callable[[], bytes], rank: int, nbytes: int, g
     return bytes(buf.cpu().tolist())
 
 
+def gather_bytes(payload: bytes, world_size: int, group=None) -> bytes:
+    """All-gather one equally sized byte string per rank; returns them concatenated in rank order (what
+    vgicp_peer_connect takes when the mailboxes of the device-initiated exchange are wired by hand;
+    vgicp_comm_init does the same through RCCL by itself)."""
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = torch.tensor(list(payload), dtype=torch.uint8, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(world_size)]
+    dist.all_gather(parts, mine, group=group)
+    return b"".join(bytes(p.cpu().tolist()) for p in parts)
+
+
 def share_unique_id(ctx, rank: int, group=None) -> bytes:
     """Rank 0 asks the HIP module for an RCCL unique id; everyone receives the same 128 bytes."""
     from . import capi

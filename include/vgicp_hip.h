@@ -240,8 +240,28 @@ int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double*
  * upsert/erase batches. */
 #define VGICP_UNIQUE_ID_BYTES 128
 int vgicp_comm_unique_id(vgicp_ctx* ctx, void* id128);
+/* Besides the RCCL communicator, vgicp_comm_init sets up the device-initiated exchange below by itself (the
+ * mailbox handles travel through one RCCL all-gather); where that is not possible, or with
+ * VGICP_PEER_EXCHANGE=0 in the environment, the communicator uses one RCCL all-reduce per iteration. */
 int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128);
 int vgicp_comm_destroy(vgicp_ctx* ctx);
+
+/* ---- multi-GPU: device-initiated exchange over xGMI --------------------------------------------
+ * The same merge (src/Registration.cpp:71-75) without a host-enqueued collective between kernel launches:
+ * every rank owns a small mailbox in fine-grained device memory, maps the mailboxes of all ranks (HIP IPC),
+ * and the ONE persistent kernel launch that runs the whole ICP::align loop on each GPU stores the rank's
+ * 28-double row of every iteration straight into all mailboxes and adds the rows it receives in rank order
+ * (identical bits on every rank, hence the same pose and the same break decision everywhere).
+ * Hand-wiring for hosts that do not use vgicp_comm_init: every rank exports its handle, the host side ships
+ * the world_size x 64 bytes to every rank in rank order (any transport), every rank connects, and the host
+ * side runs a barrier of its own before the first align (a mailbox must be initialised before a peer's kernel
+ * writes into it).  At most 16 ranks.  If a launch ever gives up waiting for a peer, the align is re-run
+ * through the RCCL communicator when there is one (and the communicator stays on it), else it fails with
+ * VGICP_ERR_RCCL. */
+#define VGICP_PEER_HANDLE_BYTES 64
+int vgicp_peer_export(vgicp_ctx* ctx, void* handle64);
+int vgicp_peer_connect(vgicp_ctx* ctx, int world_size, int rank, const void* handles);
+int vgicp_peer_disconnect(vgicp_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -747,6 +747,56 @@ def test_rccl_path_world_size_one(c1_gpu, c1_inputs):
         c1_gpu.comm_destroy()
 
 
+def test_two_gpu_sharded_align():
+    """Two ranks on two GPUs through vgicp_comm_init (RCCL + the device-initiated exchange where the GPUs can
+    map each other): each registers its shard, both return the single-GPU result. Needs a second device."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the round's boxes have one); the 8-GPU scaling run is the driver's")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    worker = os.path.join(os.path.dirname(__file__), "multigpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_peer_exchange_two_processes_one_device(tmp_path):
+    """The device-initiated exchange between ranks (vgicp_peer_*: HIP IPC mailboxes written by the ranks'
+    persistent kernels) with two PROCESSES on the one device of this box — what crosses xGMI on a multi-GPU
+    node crosses the device's own memory here; protocol, mapping and ordering are the same.  Each rank
+    registers its shard; every rank must obtain the same bits, equal to the whole scan on one context up to
+    the grouping of the sums.  The two persistent launches have to be resident together, so each uses 100 of
+    the 256 compute units (VGICP_PERSIST_GRID).  Spins are bounded: a launch that gives up ends its process
+    with a non-zero code.  Unmeasured on 8 GPUs (no such node was available to the build)."""
+    import subprocess
+    import sys
+    world, n, rounds = 2, 40_000, 8
+    env = dict(os.environ, VGICP_PERSIST_GRID="100")
+    worker = os.path.join(os.path.dirname(__file__), "peer_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path), str(n), str(rounds)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    a, b = (np.load(os.path.join(tmp_path, f"result{r}.npz")) for r in range(world))
+    assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["normal_eq"], b["normal_eq"])
+    assert np.array_equal(a["half_pose"], b["half_pose"])
+
+
 # ---- BASELINE's full size (C2): size-independent properties ------------------------------------
 def test_c2_full_size_properties(gpu_ctx, oracle):
     from eskf_lio_amd import synth
