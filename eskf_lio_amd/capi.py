@@ -14,7 +14,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvgicp_hip.so")
+# VGICP_LIB_PATH: a developer's A/B aid (two builds of the module timed in one session on one box)
+LIB_PATH = os.environ.get("VGICP_LIB_PATH") or os.path.join(_HERE, "lib", "libvgicp_hip.so")
 
 OK, ERR_BAD_ARGUMENT, ERR_HIP, ERR_RCCL, ERR_TABLE_FULL, ERR_DEGENERATE, ERR_NO_DEVICE, ERR_NOT_READY = range(8)
 FLAG_PROFILE = 1

@@ -435,7 +435,7 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
   if (profile) chunk = 1;
 
   const bool peer_path = ctx->peers_connected && ctx->peer_enabled && ctx->peer_world > 1;
-  const bool alone = ctx->comm == nullptr && !ctx->peers_connected;
+  const bool alone = ctx->world_size == 1;  // also a communicator of one rank: nothing to exchange
   if (ctx->persistent_cooldown > 0 && !peer_path) --ctx->persistent_cooldown;
   else if (ctx->persistent_enabled && (alone || peer_path) && !profile && max_it > 0 &&
            (params->flags & VGICP_FLAG_NO_PERSISTENT) == 0) {

@@ -22,6 +22,31 @@ __device__ __forceinline__ int32_t voxel_coord(double x, double voxel_size) {
   return (int32_t)floor(x / voxel_size);
 }
 
+// The same key without the division on the common path.  k = floor(x * fl(1/h)) can differ from the
+// reference's floor(fl(x / h)) only when the exact quotient lies within a few ulps of an integer.  The
+// remainder r = x - k h (one FMA, so its sign is exact) locates the quotient inside [k, k + 1): outside
+// (r < 0 or r >= h) the guess was off by one; close to the upper end, (h - r) / h <= 2^-53 (|k| + 1), the
+// correctly rounded division may round UP to k + 1 and the reference then takes k + 1.  All of these go to
+// the real division (rare, and bit for bit the reference's value); everywhere else the guess IS
+// floor(fl(x / h)).  NaN / infinite / huge x fail the tests and take the division, too.  *rem receives r.
+__device__ __forceinline__ int32_t voxel_coord_fast(double x, double h, double inv_h, double* rem) {
+  const double q = x * inv_h;
+  const double kf = floor(q);
+  const double r = fma(-kf, h, x);
+  const double margin = (fabs(kf) + 4.0) * 0x1p-52 * h;
+  if (fabs(q) < 0x1p30 && r >= 0.0 && (h - r) > margin) {
+    *rem = r;
+    return (int32_t)kf;
+  }
+  const double ks = floor(x / h);
+  *rem = fma(-ks, h, x);
+  return (int32_t)ks;
+}
+__device__ __forceinline__ int32_t voxel_coord_fast(double x, double h, double inv_h) {
+  double r;
+  return voxel_coord_fast(x, h, inv_h, &r);
+}
+
 // q = R p + t evaluated as Open3D's homogeneous product does (left to right, no FMA contraction),
 // so the first round reproduces the CPU path's voxel keys bit for bit.
 __device__ __forceinline__ void transform_point(const double* R, const double* t, double x, double y,

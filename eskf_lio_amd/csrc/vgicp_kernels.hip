@@ -117,6 +117,52 @@ __device__ __forceinline__ void ldlt6_solve_pivoted(const double* packed, double
   for (int k = 0; k < 6; ++k) x[k] = sol[k];
 }
 
+// 1 / d for a normal, finite d by v_rcp_f64 + two Newton steps (FMA): ~1 ulp, a third of the dependent
+// instructions of the correctly rounded division.  Only on the solver wave's serial chain (pivots of the
+// natural-order LDL^T, 1 / angle), where a last-bit difference is below the solve's own rounding.
+__device__ __forceinline__ double rcp_newton(double d) {
+#ifdef VGICP_AB_EXACT_DIV
+  return 1.0 / d;
+#endif
+  double y = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);
+  return fma(y, e, y);
+}
+
+// sin and cos of a SMALL angle (|a| <= 0.5 rad; Gauss-Newton steps are far smaller) by their Taylor series in
+// Horner form: truncation below 5e-17 relative, no argument reduction, ~20 dependent FMAs instead of the
+// library's ~100 instructions.  Larger angles take the library call.
+__device__ __forceinline__ void sincos_step(double a, double* s, double* c) {
+#ifdef VGICP_AB_LIB_SINCOS
+  sincos(a, s, c);
+  return;
+#endif
+  if (fabs(a) > 0.5) {  // uniform on the solver wave
+    sincos(a, s, c);
+    return;
+  }
+  const double z = a * a;
+  double ps = -1.0 / 1307674368000.0;   // -1/15!
+  ps = fma(ps, z, 1.0 / 6227020800.0);  //  1/13!
+  ps = fma(ps, z, -1.0 / 39916800.0);   // -1/11!
+  ps = fma(ps, z, 1.0 / 362880.0);      //  1/9!
+  ps = fma(ps, z, -1.0 / 5040.0);       // -1/7!
+  ps = fma(ps, z, 1.0 / 120.0);         //  1/5!
+  ps = fma(ps, z, -1.0 / 6.0);          // -1/3!
+  *s = fma(a * z, ps, a);
+  double pc = 1.0 / 20922789888000.0;   //  1/16!
+  pc = fma(pc, z, -1.0 / 87178291200.0);  // -1/14!
+  pc = fma(pc, z, 1.0 / 479001600.0);   //  1/12!
+  pc = fma(pc, z, -1.0 / 3628800.0);    // -1/10!
+  pc = fma(pc, z, 1.0 / 40320.0);       //  1/8!
+  pc = fma(pc, z, -1.0 / 720.0);        // -1/6!
+  pc = fma(pc, z, 1.0 / 24.0);          //  1/4!
+  pc = fma(pc, z, -0.5);                // -1/2!
+  *c = fma(pc, z, 1.0);
+}
+
 // Fast path of the 6x6 solve: LDL^T in natural order, fully unrolled, everything in registers with
 // static indices (about 130 fp64 operations and 6 reciprocals; every lane of the wave runs the same
 // scalar program).  For a symmetric positive definite system any elimination order is backward
@@ -133,8 +179,8 @@ __device__ __forceinline__ bool ldlt6_solve_spd(const double (&A)[21], const dou
     double d = A[tri6(j, j)];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= L[j][k] * W[j][k];
-    ok = ok && (d > 1e-13 * A[tri6(j, j)]) && (d < 1.0e300);  // also false for NaN
-    inv[j] = 1.0 / d;
+    ok = ok && (d > 1e-13 * A[tri6(j, j)]) && (d < 1.0e300) && (d > 1.0e-290);  // also false for NaN
+    inv[j] = rcp_newton(d);
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double t = A[tri6(i, j)];
@@ -169,9 +215,9 @@ __device__ __forceinline__ void se3_exp_device(const double* xi, Pose& T) {
   const double n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   const double angle = sqrt(n2);
   double s, c;
-  sincos(angle, &s, &c);
+  sincos_step(angle, &s, &c);
   double k[3] = {r[0], r[1], r[2]};
-  const double inv_angle = 1.0 / angle;
+  const double inv_angle = (n2 > 1.0e-280) ? rcp_newton(angle) : 1.0 / angle;
   if (n2 > 0.0) { k[0] = r[0] * inv_angle; k[1] = r[1] * inv_angle; k[2] = r[2] * inv_angle; }
   const double sx = s * k[0], sy = s * k[1], sz = s * k[2];
   const double cx = (1.0 - c) * k[0], cy = (1.0 - c) * k[1], cz = (1.0 - c) * k[2];
@@ -404,6 +450,7 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool worker = wave != 0;
   const uint32_t stride_pts = gridDim.x * kWorkers;
+  const double inv_voxel = 1.0 / a.voxel_size;
   uint32_t i = worker ? blockIdx.x * kWorkers + (tid - 64) : a.n;
 
   double q[kScanPlanes];
@@ -429,9 +476,9 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
     if (i < a.n) {
       double p[3];
       transform_point(head.total.R, head.total.t, q[0], q[1], q[2], p);
-      okx = voxel_coord(p[0], a.voxel_size);
-      oky = voxel_coord(p[1], a.voxel_size);
-      okz = voxel_coord(p[2], a.voxel_size);
+      okx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
+      oky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
+      okz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
       hit = find_and_load(a.table, a.mask, okx, oky, okz, mu, S);
     }
   } else if (solving) {
@@ -468,9 +515,9 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
 
     double p[3];
     transform_point(R, t, x, y, z, p);
-    const int32_t kx = voxel_coord(p[0], a.voxel_size);
-    const int32_t ky = voxel_coord(p[1], a.voxel_size);
-    const int32_t kz = voxel_coord(p[2], a.voxel_size);
+    const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
+    const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
+    const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
     if (!first || kx != okx || ky != oky || kz != okz)
       hit = find_and_load(a.table, a.mask, kx, ky, kz, mu, S);
     first = false;
@@ -631,7 +678,10 @@ __device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, u
     for (int k = 0; k < kFolders; ++k) missing = missing || (w[k] == kRowUnset);
     if (!__any(missing)) break;
     if (spins >= spin_limit) return false;
-    __builtin_amdgcn_s_sleep(1);
+#ifndef VGICP_AB_SLEEP
+#define VGICP_AB_SLEEP 1
+#endif
+    __builtin_amdgcn_s_sleep(VGICP_AB_SLEEP);
 #pragma unroll
     for (int k = 0; k < kFolders; ++k)
       if (w[k] == kRowUnset) w[k] = SYSTEM ? load_system_bits(mine + k * kSlots) : load_through_bits(mine + k * kSlots);
@@ -657,7 +707,10 @@ __device__ __forceinline__ void load_payload(const VoxelRecord* rec, double (&mu
 
 // MULTI: several GPUs (the rank totals cross xGMI through mailboxes); STAMPS: in-kernel phase clocks
 // (VGICP_DEBUG_STAMPS=1).  Separate instantiations: the single-GPU production kernel carries neither.
-template <int BLOCK, bool MULTI, bool STAMPS>
+// MANY: a thread owns several points (scan larger than grid x 448); all of them go through the memo / stash in LDS
+// and nothing point-specific stays in registers.  !MANY: one point per thread, kept in registers together with the
+// voxel record it used, plus the neighbour prefetch.  Separate instantiations keep both within 256 VGPRs.
+template <int BLOCK, bool MULTI, bool STAMPS, bool MANY>
 __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   static_assert(BLOCK / kSlots == kFolders, "the exchange reproduces the fold order of iterate_kernel<512>");
   constexpr int kWaves = BLOCK / 64;
@@ -679,7 +732,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   // enters exactly that one and finds its record (or the news that there is none) here.
   int4* pf_key = reinterpret_cast<int4*>(dyn_lds);
   double2* pf_pay = reinterpret_cast<double2*>(dyn_lds + (size_t)kWorkers * sizeof(int4));
-  const bool prefetch = a.prefetch_margin > 0.0;  // uniform; implies memo_points == stash_points == 0
+  const bool prefetch = !MANY && a.prefetch_margin > 0.0;  // uniform
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool worker = wave != 0;
@@ -697,11 +750,12 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   for (int k = 0; k < 3; ++k) total.t[k] = a.pose0[9 + k];
   const double cos_thr = a.cosine_threshold, tsq_thr = a.translation_sq_threshold;
   const int max_it = a.max_iteration;
+  const double inv_voxel = 1.0 / a.voxel_size;
 
   double q0[kScanPlanes];
 #pragma unroll
   for (int k = 0; k < kScanPlanes; ++k) q0[k] = 0.0;
-  const bool have = first < a.n;
+  const bool have = !MANY && first < a.n;
   if (have) load_point(a.scan, a.stride, first, q0);
 
   // what the first point used last round: key, hit flag, voxel payload (raw)
@@ -722,81 +776,84 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       double v[kSlots];
 #pragma unroll
       for (int k = 0; k < kSlots; ++k) v[k] = 0.0;
-      if (have) {
-        double p[3], C[9], S[9];
+      if constexpr (!MANY) {
+        if (have) {
+          double p[3], C[9], S[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) C[k] = q0[3 + k];
-        transform_point(R, t, q0[0], q0[1], q0[2], p);
-        const int32_t kx = voxel_coord(p[0], a.voxel_size);
-        const int32_t ky = voxel_coord(p[1], a.voxel_size);
-        const int32_t kz = voxel_coord(p[2], a.voxel_size);
-        if (!spec || kx != okx || ky != oky || kz != okz) {
-          bool served = false;
-          if (spec && prefetch) {
-            const int4 m = pf_key[tid - 64];
-            if (m.x == kx && m.y == ky && m.z == kz && (uint32_t)m.w != kMemoNone) {
-              served = true;
-              hit = (uint32_t)m.w != kMemoMiss;
-              if (hit) {
-                const double2* pay = pf_pay + (tid - 64);
-                const double2 a0 = pay[0 * kWorkers], a1 = pay[1 * kWorkers], a2 = pay[2 * kWorkers],
-                              a3 = pay[3 * kWorkers], a4 = pay[4 * kWorkers], a5 = pay[5 * kWorkers];
-                mu[0] = a0.x; mu[1] = a0.y; mu[2] = a1.x;
-                Sv[0] = a1.y; Sv[1] = a2.x; Sv[2] = a2.y; Sv[3] = a3.x; Sv[4] = a3.y; Sv[5] = a4.x;
-                Sv[6] = a4.y; Sv[7] = a5.x; Sv[8] = a5.y;
+          for (int k = 0; k < 9; ++k) C[k] = q0[3 + k];
+          transform_point(R, t, q0[0], q0[1], q0[2], p);
+          const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
+          const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
+          const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
+          if (!spec || kx != okx || ky != oky || kz != okz) {
+            bool served = false;
+            if (spec && prefetch) {
+              const int4 m = pf_key[tid - 64];
+              if (m.x == kx && m.y == ky && m.z == kz && (uint32_t)m.w != kMemoNone) {
+                served = true;
+                hit = (uint32_t)m.w != kMemoMiss;
+                if (hit) {
+                  const double2* pay = pf_pay + (tid - 64);
+                  const double2 a0 = pay[0 * kWorkers], a1 = pay[1 * kWorkers], a2 = pay[2 * kWorkers],
+                                a3 = pay[3 * kWorkers], a4 = pay[4 * kWorkers], a5 = pay[5 * kWorkers];
+                  mu[0] = a0.x; mu[1] = a0.y; mu[2] = a1.x;
+                  Sv[0] = a1.y; Sv[1] = a2.x; Sv[2] = a2.y; Sv[3] = a3.x; Sv[4] = a3.y; Sv[5] = a4.x;
+                  Sv[6] = a4.y; Sv[7] = a5.x; Sv[8] = a5.y;
+                }
               }
             }
+            if (!served) hit = find_and_load(a.table, a.mask, kx, ky, kz, mu, Sv);
+            okx = kx; oky = ky; okz = kz;
+            spec = true;
           }
-          if (!served) hit = find_and_load(a.table, a.mask, kx, ky, kz, mu, Sv);
-          okx = kx; oky = ky; okz = kz;
-          spec = true;
-        }
-        if (hit) {
+          if (hit) {
 #pragma unroll
-          for (int k = 0; k < 9; ++k) S[k] = Sv[k];
-          accumulate_match(R, p, C, mu, S, v);
+            for (int k = 0; k < 9; ++k) S[k] = Sv[k];
+            accumulate_match(R, p, C, mu, S, v);
+          }
         }
-      }
-      uint32_t e = 0;
-      for (uint32_t i = first + stride_pts; i < a.n; i += stride_pts, ++e) {  // scans larger than the grid
-        double q[kScanPlanes], p[3], C[9], m2[3], S[9];
-        if (e < a.stash_points) {
-          double* slot = stash + (size_t)e * kScanPlanes * kWorkers + (tid - 64);
-          if (it == 0) {
+      } else {
+        uint32_t e = 0;
+        for (uint32_t i = first; i < a.n; i += stride_pts, ++e) {
+          double q[kScanPlanes], p[3], C[9], m2[3], S[9];
+          if (e < a.stash_points) {
+            double* slot = stash + (size_t)e * kScanPlanes * kWorkers + (tid - 64);
+            if (it == 0) {
+              load_point(a.scan, a.stride, i, q);
+#pragma unroll
+              for (int k = 0; k < kScanPlanes; ++k) slot[k * kWorkers] = q[k];
+            } else {
+#pragma unroll
+              for (int k = 0; k < kScanPlanes; ++k) q[k] = slot[k * kWorkers];
+            }
+          } else {
             load_point(a.scan, a.stride, i, q);
-#pragma unroll
-            for (int k = 0; k < kScanPlanes; ++k) slot[k * kWorkers] = q[k];
-          } else {
-#pragma unroll
-            for (int k = 0; k < kScanPlanes; ++k) q[k] = slot[k * kWorkers];
           }
-        } else {
-          load_point(a.scan, a.stride, i, q);
-        }
-        transform_point(R, t, q[0], q[1], q[2], p);
-        const int32_t kx = voxel_coord(p[0], a.voxel_size);
-        const int32_t ky = voxel_coord(p[1], a.voxel_size);
-        const int32_t kz = voxel_coord(p[2], a.voxel_size);
-        bool got;
-        if (e < a.memo_points) {
-          int4* mslot = memo + (size_t)e * kWorkers + (tid - 64);
-          const int4 m = *mslot;
-          if (it != 0 && m.x == kx && m.y == ky && m.z == kz) {
-            got = (uint32_t)m.w != kMemoMiss;
-            if (got) load_payload(a.table + (uint32_t)m.w, m2, S);
+          transform_point(R, t, q[0], q[1], q[2], p);
+          const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
+          const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
+          const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
+          bool got;
+          if (e < a.memo_points) {
+            int4* mslot = memo + (size_t)e * kWorkers + (tid - 64);
+            const int4 m = *mslot;
+            if (it != 0 && m.x == kx && m.y == ky && m.z == kz) {
+              got = (uint32_t)m.w != kMemoMiss;
+              if (got) load_payload(a.table + (uint32_t)m.w, m2, S);
+            } else {
+              const VoxelRecord* rec = find_voxel(a.table, a.mask, kx, ky, kz);
+              got = rec != nullptr;
+              *mslot = make_int4(kx, ky, kz, got ? (int32_t)(uint32_t)(rec - a.table) : (int32_t)kMemoMiss);
+              if (got) load_payload(rec, m2, S);
+            }
           } else {
-            const VoxelRecord* rec = find_voxel(a.table, a.mask, kx, ky, kz);
-            got = rec != nullptr;
-            *mslot = make_int4(kx, ky, kz, got ? (int32_t)(uint32_t)(rec - a.table) : (int32_t)kMemoMiss);
-            if (got) load_payload(rec, m2, S);
+            got = find_and_load(a.table, a.mask, kx, ky, kz, m2, S);
           }
-        } else {
-          got = find_and_load(a.table, a.mask, kx, ky, kz, m2, S);
-        }
-        if (got) {
+          if (got) {
 #pragma unroll
-          for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
-          accumulate_match(R, p, C, m2, S, v);
+            for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
+            accumulate_match(R, p, C, m2, S, v);
+          }
         }
       }
       fold_swap<32, false>(v);
@@ -810,22 +867,24 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
     __syncthreads();
     if (STAMPS) { const uint64_t n = wall_clock64(); acc_body += n - t_mark; t_mark = n; }
 
-    if (worker && prefetch && have) {
+    if (!MANY && worker && prefetch && have) {
       // While wave 0 exchanges and solves: where is this point inside its voxel?  If a face is nearer than
       // prefetch_margin voxels, look the voxel behind it up now (full probe; 2 dependent round trips that
       // nobody waits for) so that next round's key change finds the record in LDS.
-      double p[3];
+      double p[3], rx, ry, rz;  // r*: distance of the point from the lower face of its voxel, in [0, voxel)
       transform_point(R, t, q0[0], q0[1], q0[2], p);
-      const double fx = p[0] / a.voxel_size - (double)okx, fy = p[1] / a.voxel_size - (double)oky,
-                   fz = p[2] / a.voxel_size - (double)okz;  // in [0, 1)
-      const double dx = fmin(fx, 1.0 - fx), dy = fmin(fy, 1.0 - fy), dz = fmin(fz, 1.0 - fz);
+      (void)voxel_coord_fast(p[0], a.voxel_size, inv_voxel, &rx);
+      (void)voxel_coord_fast(p[1], a.voxel_size, inv_voxel, &ry);
+      (void)voxel_coord_fast(p[2], a.voxel_size, inv_voxel, &rz);
+      const double half = 0.5 * a.voxel_size;
+      const double dx = fmin(rx, a.voxel_size - rx), dy = fmin(ry, a.voxel_size - ry), dz = fmin(rz, a.voxel_size - rz);
       int32_t nx = okx, ny = oky, nz = okz;
       double d;
-      if (dx <= dy && dx <= dz) { d = dx; nx += fx < 0.5 ? -1 : 1; }
-      else if (dy <= dz) { d = dy; ny += fy < 0.5 ? -1 : 1; }
-      else { d = dz; nz += fz < 0.5 ? -1 : 1; }
+      if (dx <= dy && dx <= dz) { d = dx; nx += rx < half ? -1 : 1; }
+      else if (dy <= dz) { d = dy; ny += ry < half ? -1 : 1; }
+      else { d = dz; nz += rz < half ? -1 : 1; }
       int4 m = make_int4(nx, ny, nz, (int32_t)kMemoNone);
-      if (d < a.prefetch_margin) {
+      if (d < a.prefetch_margin * a.voxel_size) {
         const VoxelRecord* rec = find_voxel(a.table, a.mask, nx, ny, nz);
         m.w = rec ? (int32_t)(uint32_t)(rec - a.table) : (int32_t)kMemoMiss;
         if (rec) {
@@ -1105,8 +1164,10 @@ __global__ void voxel_index_kernel(const double* __restrict__ pts, uint32_t n, d
                                    int32_t* __restrict__ keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  // the division-free form the loop kernels use (exact, see voxel_coord_fast): this hook is how tests pin it
+  const double inv_voxel = 1.0 / voxel_size;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) keys[3 * (size_t)i + k] = voxel_coord(pts[3 * (size_t)i + k], voxel_size);
+  for (int k = 0; k < 3; ++k) keys[3 * (size_t)i + k] = voxel_coord_fast(pts[3 * (size_t)i + k], voxel_size, inv_voxel);
 }
 
 // ---- correspondence materialisation: count per block, scan block counts, compact ----
@@ -1215,14 +1276,14 @@ constexpr uint32_t kPrefetchBytes = kPersistWorkers * (sizeof(int4) + 6 * sizeof
 void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points) {
   *memo_points = *stash_points = 0;
   const uint64_t per_round = (uint64_t)grid * kPersistWorkers;
-  if (n <= per_round) return;
-  const uint32_t extra = (uint32_t)((n - 1) / per_round);  // points per thread beyond the first (upper bound)
+  if (n <= per_round) return;  // one point per thread: registers (and the neighbour prefetch area)
+  const uint32_t per_thread = (uint32_t)((n + per_round - 1) / per_round);  // points per thread (upper bound)
   // the memo first (it saves the table access, the larger term), the rest of the LDS parks whole points
-  const uint32_t memo = extra < kMaxMemoPoints ? extra : kMaxMemoPoints;
+  const uint32_t memo = per_thread < kMaxMemoPoints ? per_thread : kMaxMemoPoints;
   const uint32_t left = kPersistDynLds - memo * kMemoBytesPerPoint;
   const uint32_t stash = left / kStashBytesPerPoint;
   *memo_points = memo;
-  *stash_points = stash < extra ? stash : extra;
+  *stash_points = stash < per_thread ? stash : per_thread;
 }
 
 uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_points) {
@@ -1251,16 +1312,16 @@ void persistent_exchange_image(uint32_t grid, unsigned long long* rows_words, un
 }
 
 namespace {
-template <bool MULTI, bool STAMPS>
+template <bool MULTI, bool STAMPS, bool MANY>
 hipError_t launch_persistent_as(hipStream_t s, const PersistArgs& args, uint32_t grid, size_t dyn, int device) {
   static bool raised[64] = {false};  // per device: LDS beyond the default 64 KB per workgroup has to be asked for once
-  const void* fn = reinterpret_cast<const void*>(&persistent_kernel<512, MULTI, STAMPS>);
+  const void* fn = reinterpret_cast<const void*>(&persistent_kernel<512, MULTI, STAMPS, MANY>);
   if (!raised[device]) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistDynLds);
     if (e != hipSuccess) return e;
     raised[device] = true;
   }
-  hipLaunchKernelGGL((persistent_kernel<512, MULTI, STAMPS>), dim3(grid), dim3(512), dyn, s, args);
+  hipLaunchKernelGGL((persistent_kernel<512, MULTI, STAMPS, MANY>), dim3(grid), dim3(512), dyn, s, args);
   return hipGetLastError();
 }
 }  // namespace
@@ -1277,10 +1338,17 @@ hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t gr
   }
   if (dyn > kPersistDynLds) return hipErrorInvalidValue;
   const bool multi = args.world > 1, stamps = args.stamps != nullptr;
-  if (multi) return stamps ? launch_persistent_as<true, true>(s, args, grid, dyn, device)
-                           : launch_persistent_as<true, false>(s, args, grid, dyn, device);
-  return stamps ? launch_persistent_as<false, true>(s, args, grid, dyn, device)
-                : launch_persistent_as<false, false>(s, args, grid, dyn, device);
+  const bool many = (uint64_t)args.n > (uint64_t)grid * kPersistWorkers;
+  if (many) {
+    if (multi) return stamps ? launch_persistent_as<true, true, true>(s, args, grid, dyn, device)
+                             : launch_persistent_as<true, false, true>(s, args, grid, dyn, device);
+    return stamps ? launch_persistent_as<false, true, true>(s, args, grid, dyn, device)
+                  : launch_persistent_as<false, false, true>(s, args, grid, dyn, device);
+  }
+  if (multi) return stamps ? launch_persistent_as<true, true, false>(s, args, grid, dyn, device)
+                           : launch_persistent_as<true, false, false>(s, args, grid, dyn, device);
+  return stamps ? launch_persistent_as<false, true, false>(s, args, grid, dyn, device)
+                : launch_persistent_as<false, false, false>(s, args, grid, dyn, device);
 }
 
 // Whether `grid` 512-thread workgroups of the persistent kernel with this much dynamic LDS can all be
@@ -1288,7 +1356,7 @@ hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t gr
 hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_t* max_grid) {
   int per_cu = 0;
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-      &per_cu, reinterpret_cast<const void*>(&persistent_kernel<512, true, false>), 512, dyn_lds_bytes);
+      &per_cu, reinterpret_cast<const void*>(&persistent_kernel<512, true, false, true>), 512, dyn_lds_bytes);
   if (e != hipSuccess) return e;
   *max_grid = per_cu > 0 ? (uint32_t)cu_count : 0u;  // one workgroup per CU is what the design uses
   return hipSuccess;

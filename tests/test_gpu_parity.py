@@ -71,6 +71,29 @@ def test_voxel_index_is_bit_exact(gpu_ctx, oracle):
     for p in (rnd, on_face, edge):
         assert np.array_equal(gpu_ctx.voxel_index(p), oracle.voxel_index(0.3, p))
     assert gpu_ctx.voxel_index(edge)[0].tolist() == [-1, 0, 1]     # floor, not truncation
+    # The loop kernels take the key without dividing (x * (1 / h), remainder test, real division only near
+    # an integer quotient): coordinates within a few ulps of every kind of cell boundary, for several voxel
+    # sizes, must give the reference's floor(x / h) exactly — including where the correctly rounded quotient
+    # rounds UP to the next integer.
+    for h in (0.3, 0.1, 0.7, 1.0, 0.05, 2.5, 1.0 / 3.0):
+        gpu_ctx.map_reset(h, 0)
+        k = np.concatenate([np.arange(-2_000, 2_000), rng.integers(-2**29, 2**29, size=4_000),
+                            rng.integers(-70_000, 70_000, size=6_000)]).astype(np.float64)
+        base = k * h
+        cols = [base]
+        for ulps in (1, 2, 3, 5, 17):
+            up = base.copy()
+            dn = base.copy()
+            for _ in range(ulps):
+                up = np.nextafter(up, np.inf)
+                dn = np.nextafter(dn, -np.inf)
+            cols += [up, dn]
+        near = np.concatenate(cols)
+        near = near[: (near.size // 3) * 3].reshape(-1, 3)
+        assert np.array_equal(gpu_ctx.voxel_index(near), oracle.voxel_index(h, near)), h
+        far = rng.uniform(-1e5, 1e5, size=(30_000, 3))
+        assert np.array_equal(gpu_ctx.voxel_index(far), oracle.voxel_index(h, far)), h
+    gpu_ctx.map_reset(0.3, 0)
 
 
 def test_match_equals_oracle_correspondences(c1_gpu, c1_inputs, c1_oracle_map, oracle):
@@ -735,13 +758,16 @@ def test_rccl_path_world_size_one(c1_gpu, c1_inputs):
     single = c1_gpu.align(pts, covs, g, 20, 1e-6, 2.0)
     c1_gpu.comm_init(1, 0, c1_gpu.comm_unique_id())
     try:
-        viacomm = c1_gpu.align(pts, covs, g, 20, 1e-6, 2.0)        # fold kernel + ncclAllReduce + prologue
-        assert viacomm.world_size == 1 and viacomm.iterations == 20
+        NP = 2                                                     # VGICP_FLAG_NO_PERSISTENT
+        viacomm = c1_gpu.align(pts, covs, g, 20, 1e-6, 2.0, flags=NP)   # fold kernel + ncclAllReduce + prologue
+        assert viacomm.world_size == 1 and viacomm.iterations == 20 and viacomm.launches == 21
+        same = c1_gpu.align(pts, covs, g, 20, 1e-6, 2.0)          # one rank: nothing to exchange, the single launch
+        assert same.launches == 1 and np.array_equal(same.pose, single.pose)
         assert np.array_equal(viacomm.corr_count, single.corr_count)
         dt, dr = pose_error(viacomm.pose, single.pose)
         assert dt <= 1e-12 and dr <= 1e-12
         spts, scovs, _ = synth.make_structured_scan(5_000, c1_inputs[0])
-        r = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999)
+        r = c1_gpu.align(spts, scovs, np.eye(4), 100, 1e-6, 0.9999, flags=NP)
         assert r.converged and r.iterations == 3
     finally:
         c1_gpu.comm_destroy()
