@@ -1176,6 +1176,10 @@ int preprocess_on_device(vgicp_ctx* ctx, const double* d_pts, size_t n, double v
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t m = ctx->h_counters[0], cells = ctx->h_counters[1];
+  if (ctx->h_counters[3] != 0) {
+    *kept = 0;
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "a point lies beyond the search grid (more than 2^17 voxel sizes from the origin)");
+  }
   *kept = m;
   if (m > capacity) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "output capacity smaller than the number of occupied voxels");
   const uint64_t entries = preprocess_cell_entries(cells);

@@ -88,13 +88,24 @@ __device__ __forceinline__ uint32_t cell_hash(unsigned long long key) {
   return (uint32_t)key;
 }
 
+// A finite coordinate whose finest cell lies outside the 2^20 cells per axis the Morton codes span (+-2^17
+// voxel sizes): the clamped code would merge distinct far voxels and break the bounds of the neighbour search,
+// so such a scan is refused (counters[3] flags it; vgicp_preprocess returns VGICP_ERR_BAD_ARGUMENT).
+__device__ __forceinline__ bool beyond_grid(double v, double fine) {
+  const double c = floor(v / fine);
+  return c < -(double)kCoordOffset || c > (double)(kCoordMax - kCoordOffset);  // false for NaN / infinity
+}
+
 __global__ void morton_kernel(const double* __restrict__ pts, uint32_t n, double fine,
-                              unsigned long long* __restrict__ codes, uint32_t* __restrict__ idx) {
+                              unsigned long long* __restrict__ codes, uint32_t* __restrict__ idx,
+                              uint32_t* __restrict__ counters) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  codes[i] = morton3(cell_coord(pts[3 * (size_t)i], fine), cell_coord(pts[3 * (size_t)i + 1], fine),
-                     cell_coord(pts[3 * (size_t)i + 2], fine));
+  const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+  codes[i] = morton3(cell_coord(x, fine), cell_coord(y, fine), cell_coord(z, fine));
   idx[i] = i;
+  const bool is_finite = x - x == 0.0 && y - y == 0.0 && z - z == 0.0;
+  if (is_finite && (beyond_grid(x, fine) || beyond_grid(y, fine) || beyond_grid(z, fine))) counters[3] = 1u;
 }
 
 // One pass over the sorted codes: voxel-level run starts are flagged, the points are copied into sorted
@@ -704,7 +715,7 @@ hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, 
   auto* rank_p = reinterpret_cast<uint32_t*>(b + L.rank_p);
   auto* queries = reinterpret_cast<uint32_t*>(b + L.queries);
   const double fine = h / (double)(1 << kFineShift);
-  hipLaunchKernelGGL(morton_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, fine, codes_in, idx_in);
+  hipLaunchKernelGGL(morton_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, fine, codes_in, idx_in, counters);
   size_t cub_bytes = L.cub_bytes;
   hipError_t e = hipcub::DeviceRadixSort::SortPairs(b + L.cub, cub_bytes, codes_in, codes_out, idx_in, idx_out,
                                                     (int)n, 0, 3 * kCoordBits, s);

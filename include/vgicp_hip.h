@@ -197,8 +197,10 @@ int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* k
  * them in unordered_map iteration order, which callers must not rely on.  *kept receives the number
  * of voxels occupied; if it exceeds capacity nothing is written and VGICP_ERR_BAD_ARGUMENT is
  * returned with *kept set, so the caller can retry (capacity = n always suffices).
- * The search grid spans +-2^17 voxel_size per axis (39 km at 0.3 m); points beyond are clamped onto
- * its border cells, which only costs speed. */
+ * The search grid spans +-2^17 voxel_size per axis (39 km at 0.3 m); a scan with a finite coordinate beyond
+ * it is refused with VGICP_ERR_BAD_ARGUMENT (*kept = 0, nothing written).  Non-finite coordinates are not
+ * detected: such a point never enters a neighbourhood and its own covariance is garbage, as in the
+ * reference's KD-tree. */
 int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxel_size, int knn,
                      size_t capacity, double* out_points, double* out_covs, uint64_t* out_index,
                      size_t* kept);

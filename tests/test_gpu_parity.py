@@ -1157,6 +1157,22 @@ def test_align_randomised_configurations(gpu_ctx, oracle, seed):
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and dt < 1e-7 and dr < 1e-9
 
 
+def test_preprocess_refuses_points_beyond_the_search_grid(gpu_ctx):
+    """The Morton grid of the neighbour search spans +-2^17 voxel sizes; a finite coordinate beyond it would be
+    clamped onto a border cell (distinct far voxels merged, search bounds void), so the scan is refused."""
+    from eskf_lio_amd import capi, synth
+    pts = synth.make_lidar_scan(2_000, seed=21)
+    far = pts.copy()
+    far[7, 0] = 0.3 * (2 ** 17) + 10.0
+    with pytest.raises(capi.VgicpError) as e:
+        gpu_ctx.preprocess(far, 0.3, 30)
+    assert e.value.code == capi.ERR_BAD_ARGUMENT and "search grid" in str(e.value)
+    edge = pts.copy()
+    edge[7, 0] = 0.3 * (2 ** 17) - 1.0                              # just inside: accepted
+    gp, gc, gi = gpu_ctx.preprocess(edge, 0.3, 30)
+    assert len(gi) > 0
+
+
 def test_preprocess_survives_non_finite_points(gpu_ctx, oracle):
     """NaN / infinite coordinates are garbage in, garbage out — but never a hang or a crash, and the finite part
     of the scan is prepared as if the bad points were not neighbours of anything."""
