@@ -1191,18 +1191,9 @@ int preprocess_on_device(vgicp_ctx* ctx, const double* d_pts, size_t n, double v
   if (debug) {
     VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (debug == 2)
-      std::fprintf(stderr, "[vgicp prep] tile kernel, 10 ns ticks summed over %u tiles (mean us per tile): bounds + range pass %.1f, "
-                   "cell set + lookups %.1f, offsets + pass 1 %.1f, pass 2 %.1f, selection + output %.1f\n", (m + 63) / 64,
-                   ctx->h_counters[3] * 0.01 / ((m + 63) / 64), ctx->h_counters[4] * 0.01 / ((m + 63) / 64),
-                   ctx->h_counters[5] * 0.01 / ((m + 63) / 64), ctx->h_counters[6] * 0.01 / ((m + 63) / 64),
-                   ctx->h_counters[7] * 0.01 / ((m + 63) / 64));
-    else
-    std::fprintf(stderr, "[vgicp prep] kept %u cells %u | tile search: queries handed to the wave-per-query kernel %u (of them "
-                 "by lanes inside staged tiles %u), tiles given up: dense range %u / population %u / cells %u, candidates per staged tile (sum / all tiles) %.0f, longest list %u\n",
-                 m, cells, ctx->h_counters[2], ctx->h_counters[6], ctx->h_counters[4] & 0x3FF, (ctx->h_counters[4] >> 10) & 0x3FF,
-                 ctx->h_counters[4] >> 20,
-                 ctx->h_counters[5] / (double)((m + 63) / 64 ? (m + 63) / 64 : 1), ctx->h_counters[7]);
+    std::fprintf(stderr, "[vgicp prep] kept %u cells %u queries that spilled %u | point batches total %u (%.1f/query) max %u | cells taken total %u (%.1f/query) max %u | queries starting above the voxel level: %u\n",
+                 m, cells, ctx->h_counters[2], ctx->h_counters[3], ctx->h_counters[3] / (double)(m ? m : 1), ctx->h_counters[4],
+                 ctx->h_counters[5], ctx->h_counters[5] / (double)(m ? m : 1), ctx->h_counters[6], ctx->h_counters[7]);
   }
   return VGICP_OK;
 }

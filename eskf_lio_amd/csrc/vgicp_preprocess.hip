@@ -30,8 +30,6 @@
 // distances, sums and rotations round as they do on the CPU.
 #include <hipcub/hipcub.hpp>
 
-#include <cstdlib>
-
 #include "vgicp_device.h"
 #include "vgicp_device_fn.h"
 
@@ -234,25 +232,20 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     const double* __restrict__ spts, const uint32_t* __restrict__ sorted_idx, uint32_t n, double h, int knn,
     const CellEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ queries,
     const uint32_t* __restrict__ slot_of_index, uint32_t m, uint32_t* __restrict__ nbr,
-    double* __restrict__ out_pts, unsigned long long* __restrict__ out_idx, uint32_t* counters, int debug,
-    const uint32_t* __restrict__ todo_list, const uint32_t* __restrict__ todo_count) {
+    double* __restrict__ out_pts, unsigned long long* __restrict__ out_idx, uint32_t* counters, int debug) {
   __shared__ float pool_d[kSearchBlock / 64][kPool];   // cell distances rounded DOWN: ordering and pruning stay safe
   __shared__ unsigned long long pool_key[kSearchBlock / 64][kPool];
   __shared__ uint32_t pool_start[kSearchBlock / 64][kPool];
   __shared__ uint32_t pool_end[kSearchBlock / 64][kPool];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  // With a to-do list (the queries the tile kernel passed on): wave w of the launch takes entries w, w + waves, ...
-  const uint32_t todo = todo_list ? *todo_count : 1u;
-  for (uint32_t turn = todo_list ? blockIdx.x * (kSearchBlock / 64) + wave : 0u; turn < todo;
-       turn += gridDim.x * (kSearchBlock / 64)) {
   // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous
   // eighth of the Morton-ordered queries, so that neighbouring queries (same cells, same points) share an L2.
   constexpr uint32_t kXcds = 8;
   const uint32_t per_xcd = (m + kXcds - 1) / kXcds;
   const uint32_t slot_in_xcd = (blockIdx.x / kXcds) * (kSearchBlock / 64) + wave;
-  const uint32_t qrank = todo_list ? todo_list[turn] : (blockIdx.x % kXcds) * per_xcd + slot_in_xcd;
-  if (!todo_list && (slot_in_xcd >= per_xcd || qrank >= m)) return;  // whole waves leave; nothing below synchronises across waves
+  const uint32_t qrank = (blockIdx.x % kXcds) * per_xcd + slot_in_xcd;
+  if (slot_in_xcd >= per_xcd || qrank >= m) return;  // whole waves leave; nothing below synchronises across waves
   volatile float* pd = pool_d[wave];
   volatile unsigned long long* pk = pool_key[wave];
   volatile uint32_t* ps = pool_start[wave];
@@ -482,7 +475,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     }
     spills += 1000000u;
   }
-  (void)spills;
+  if (lane == 0 && spills && debug) atomicAdd(&counters[2], 1u);
   const uint32_t qi = uniform_u32(sorted_idx[qj]);
   const uint32_t o = uniform_u32(slot_of_index[qi]);
   if (lane < kMaxKnn) nbr[(size_t)o * kMaxKnn + lane] = lj;
@@ -495,372 +488,6 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       atomicAdd(&counters[5], pops);
       atomicMax(&counters[6], pops);
       if (level > kFineShift) atomicAdd(&counters[7], 1u);
-    }
-  }
-  }  // to-do list
-}
-
-// ---- the tile search: 64 Morton-adjacent kept points per wave, one per LANE -------------------------------
-// The wave-per-query kernel above spends ~8 000 instructions per query, most of them keeping 64 lanes busy with
-// one query's bookkeeping.  Here a wave takes 64 consecutive queries of the Morton-ordered list (one surface
-// patch of ~64 voxels), stages nothing, and lets every lane measure EVERY candidate of the patch's surroundings
-// under uniform control flow — a candidate's coordinates are the same address for all lanes:
-//   1. per lane, the same two upper bounds on the k-th distance as above (K consecutive sorted points around
-//      the query; the finest cell around it that holds K points) -> radius r
-//   2. the box of the patch's balls picks the octree level at which it spans <= 4 cells per axis; lane c looks
-//      up cell c of that 4 x 4 x 4 block: the candidates are those <= 64 runs of the sorted points
-//   3. pass 1: a 32-bucket histogram of d^2 in [0, bound] per lane (LDS); the first bucket B at which the count
-//      reaches K bounds the k-th distance tightly
-//   4. pass 2: the candidates with bucket <= B (K plus a few) go to the lane's list in LDS
-//   5. K selection passes over that list give the neighbours in ascending (d^2, index) order — what the
-//      covariance kernel's summation order needs to return the oracle's bits
-// Exact by construction (every point within a lane's ball lies in an enumerated cell; the same d^2 expression
-// in both passes).  Whatever does not fit — a patch whose box is too wide or too populated (the Morton curve
-// jumped), a list that overflows, a non-finite query — is appended to a to-do list for the kernel above.
-constexpr int kTileListCap = 48;
-constexpr int kTileBuckets = 32;
-constexpr uint32_t kTilePointCap = 3072;  // candidates per patch: beyond, the patch would hold its SIMD for > 100 us
-constexpr uint32_t kTileRangeCap = 1536;  // sorted points between the patch's first and last query (+ margins)
-constexpr int kTileCells = 1024;          // hash set of the cells a patch touches (at most half full)
-constexpr int kTileWindow = 64;           // sorted-order margin either side of the patch for the first bound
-
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
-  return v;
-}
-
-__global__ __launch_bounds__(64) void knn_tile_kernel(
-    const double* __restrict__ spts, const uint32_t* __restrict__ sorted_idx,
-    const uint32_t* __restrict__ pos_of_index, uint32_t n, double h, int knn, const CellEntry* __restrict__ table,
-    uint32_t mask, const uint32_t* __restrict__ queries, const uint32_t* __restrict__ slot_of_index, uint32_t m,
-    uint32_t* __restrict__ nbr, double* __restrict__ out_pts, unsigned long long* __restrict__ out_idx,
-    uint32_t* __restrict__ todo_list, uint32_t* __restrict__ todo_count, uint32_t* counters, int debug) {
-  __shared__ uint32_t hist[kTileBuckets][64];
-  __shared__ double list_d[kTileListCap][64];
-  __shared__ uint32_t list_id[kTileListCap][64];
-  __shared__ unsigned long long cell_set[kTileCells];  // cell keys, then (packed to the front) start | end << 32
-  const int lane = threadIdx.x;
-  const unsigned long long lanes_below = (1ull << lane) - 1ull;
-  constexpr uint32_t kXcds = 8;  // a contiguous eighth of the Morton-ordered tiles per XCD (shared L2), as above
-  const uint32_t tiles = (m + 63u) / 64u;
-  const uint32_t per_xcd = (tiles + kXcds - 1) / kXcds;
-  const uint32_t t_in = blockIdx.x / kXcds;
-  const uint32_t tile = (blockIdx.x % kXcds) * per_xcd + t_in;
-  if (t_in >= per_xcd || tile >= tiles) return;
-  const uint32_t qrank = tile * 64u + (uint32_t)lane;
-  const bool valid = qrank < m;
-  const uint32_t qj = valid ? queries[qrank] : queries[tile * 64u];
-  const double qx = spts[3 * (size_t)qj], qy = spts[3 * (size_t)qj + 1], qz = spts[3 * (size_t)qj + 2];
-  const int K = knn < (int)n ? knn : (int)n;
-  const double fine = h / (double)(1 << kFineShift);
-  auto dist2 = [&](uint32_t j) {
-    const double dx = spts[3 * (size_t)j] - qx, dy = spts[3 * (size_t)j + 1] - qy, dz = spts[3 * (size_t)j + 2] - qz;
-    return dx * dx + dy * dy + dz * dz;
-  };
-  auto pass_on = [&](bool who) {  // these lanes' queries go to the wave-per-query kernel
-    if (who) todo_list[atomicAdd(todo_count, 1u)] = qrank;
-  };
-  auto lds_sync = [&]() {  // one wave per workgroup: order the LDS accesses of its lanes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  };
-  auto give_up = [&](uint32_t why) {
-    pass_on(valid);
-    if (debug == 1 && lane == 0) atomicAdd(&counters[4], why);
-  };
-  bool ok = valid && (qx - qx == 0.0) && (qy - qy == 0.0) && (qz - qz == 0.0);
-  uint64_t t_prev = debug == 2 ? wall_clock64() : 0;
-  auto phase = [&](int which) {  // developer aid (VGICP_DEBUG_PREP=2): 10 ns ticks per phase, summed over the tiles
-    if (debug == 2) {
-      const uint64_t now = wall_clock64();
-      if (lane == 0) atomicAdd(&counters[which], (uint32_t)(now - t_prev));
-      t_prev = now;
-    }
-  };
-  // Every lane looks at every candidate: the candidates are fetched 64 at a time, one per lane (coalesced where
-  // the sorted positions are consecutive), the next 64 while the current ones are being used, and handed round
-  // with v_readlane — no memory latency inside the loop over candidates.  index_of(g): sorted position of
-  // candidate g; use(x, y, z, j): what every lane does with it.
-  auto sweep = [&](uint32_t total, auto&& index_of, auto&& use) {
-    uint32_t j = (uint32_t)lane < total ? index_of((uint32_t)lane) : 0u;
-    double px = spts[3 * (size_t)j], py = spts[3 * (size_t)j + 1], pz = spts[3 * (size_t)j + 2];
-    for (uint32_t base = 0; base < total; base += 64u) {
-      const uint32_t g = base + 64u + (uint32_t)lane;
-      const uint32_t nj = g < total ? index_of(g) : 0u;
-      const double nx = spts[3 * (size_t)nj], ny = spts[3 * (size_t)nj + 1], nz = spts[3 * (size_t)nj + 2];
-      const int here = total - base < 64u ? (int)(total - base) : 64;
-      for (int c = 0; c < here; ++c)
-        use(readlane_f64(px, c), readlane_f64(py, c), readlane_f64(pz, c), (uint32_t)__builtin_amdgcn_readlane((int)j, c));
-      j = nj; px = nx; py = ny; pz = nz;
-    }
-  };
-  auto d2_to = [&](double x, double y, double z) {  // the same expression as dist2()
-    const double dx = x - qx, dy = y - qy, dz = z - qz;
-    return dx * dx + dy * dy + dz * dz;
-  };
-
-  // 1a. upper bounds on the k-th distance as in the wave-per-query kernel: the farthest of K consecutive sorted
-  // points around the query, and the diagonal of the finest cell around it that holds K points
-  double bound = 0.0;
-  {
-    const uint32_t half = (uint32_t)K / 2;
-    uint32_t w0 = qj > half ? qj - half : 0;
-    if (w0 + (uint32_t)K > n) w0 = n - (uint32_t)K;
-#pragma unroll 6
-    for (int i = 0; i < K; ++i) bound = fmax(bound, dist2(w0 + (uint32_t)i));
-  }
-  if (ok) {
-    const uint32_t cx = cell_coord(qx, fine), cy = cell_coord(qy, fine), cz = cell_coord(qz, fine);
-    for (int l = 0; l < kLevels; ++l) {
-      const CellEntry* e = find_cell(table, mask, cell_key(morton3(cx >> l, cy >> l, cz >> l), l));
-      if (e && e->end - e->start >= (uint32_t)K) {
-        const double size = fine * (double)(1u << l);
-        bound = fmin(bound, 3.0 * size * size * (1.0 + 1e-9));
-        break;
-      }
-    }
-  }
-  ok = ok && bound - bound == 0.0;
-  if (!__any(ok)) {
-    pass_on(valid);
-    return;
-  }
-
-  // The histogram step, used three times: 32 buckets of d^2 over [0, limit] per lane; the first bucket at which
-  // the count reaches K.  d^2 -> bucket is the same expression wherever it is evaluated.
-  double scale = 0.0;
-  auto bucket = [&](double d2) {
-    const int b = (int)(d2 * scale);
-    return b >= kTileBuckets ? kTileBuckets - 1 : b;
-  };
-  auto clear_hist = [&]() {
-#pragma unroll
-    for (int b = 0; b < kTileBuckets; ++b) hist[b][lane] = 0u;
-  };
-  auto kth_bucket = [&](int& last, uint32_t& upto) {  // false: fewer than K counted
-    bool reached = false;
-    last = kTileBuckets - 1;
-    upto = 0;
-#pragma unroll
-    for (int b = 0; b < kTileBuckets; ++b) {
-      const uint32_t c = hist[b][lane];
-      if (!reached) {
-        upto += c;
-        if (upto >= (uint32_t)K) { reached = true; last = b; }
-      }
-    }
-    return reached;
-  };
-
-  // 1b. tighten: the patch's queries are consecutive voxels of the sorted order, so the sorted points from a
-  // little before its first query to a little after its last are one contiguous range that holds every lane's
-  // sorted-order neighbours; every lane measures all of it (one address for all lanes) and keeps the bucket
-  // edge at which it has seen K points.  Typically 1.5x the true k-th distance instead of 3x.
-  {
-    const uint32_t jlo = wave_min_u32(valid ? qj : 0xFFFFFFFFu), jhi = wave_max_u32(valid ? qj : 0u);
-    const uint32_t r0 = jlo > (uint32_t)kTileWindow ? jlo - kTileWindow : 0u;
-    const uint32_t r1 = jhi + kTileWindow + 1u < n ? jhi + kTileWindow + 1u : n;
-    if (r1 - r0 > kTileRangeCap) {  // uniform: very dense voxels — leave the patch to the other kernel
-      give_up(1u);
-      return;
-    }
-    scale = (ok && bound > 0.0) ? (double)kTileBuckets / bound : 0.0;
-    clear_hist();
-    sweep(r1 - r0, [&](uint32_t g) { return r0 + g; }, [&](double x, double y, double z, uint32_t) {
-      const double d2 = d2_to(x, y, z);
-      if (ok && d2 <= bound) hist[bucket(d2)][lane] += 1u;
-    });
-    int last;
-    uint32_t upto;
-    if (ok && kth_bucket(last, upto) && scale > 0.0)
-      bound = fmin(bound, ((double)(last + 1) / scale) * (1.0 + 1e-12));  // >= K points have d^2 below this edge
-  }
-  const double r = ok ? sqrt(bound) * (1.0 + 1e-9) : 0.0;
-  phase(3);
-
-  // 2. the cells the balls touch.  Level of the patch: cells at least half as wide as the radius of three
-  // quarters of its lanes; a lane with a wider ball (an isolated point between surfaces) would blow the
-  // candidate set up for all 64 and is passed on instead.  Every lane enters the cells its ball reaches (box
-  // test against the cell) into a hash set in LDS — neighbouring queries share most of them — then the distinct
-  // cells are looked up in the octree table, one per lane and turn, and their runs of the sorted points are
-  // packed to the front of the same LDS array for the two passes.
-  int my_level = 0;
-  while (my_level < kLevels && 2.0 * fine * (double)(1u << my_level) < r) ++my_level;
-  const int lanes_ok = __builtin_popcountll(__ballot(ok));
-  int level = 0;
-  while (level < kLevels - 1 && 4 * __builtin_popcountll(__ballot(ok && my_level <= level)) < 3 * lanes_ok) ++level;
-  if (ok && my_level > level) ok = false;
-  for (int i = lane; i < kTileCells; i += 64) cell_set[i] = kEmptyCell;
-  lds_sync();
-  if (ok) {
-    const double size = fine * (double)(1u << level);
-    auto low_cell = [&](double v) {
-      long long c = (long long)floor(v / fine) - 1 + kCoordOffset;
-      return (int)(c < 0 ? 0 : (c > kCoordMax ? kCoordMax : c)) >> level;
-    };
-    auto high_cell = [&](double v) {
-      long long c = (long long)floor(v / fine) + 1 + kCoordOffset;
-      return (int)(c < 0 ? 0 : (c > kCoordMax ? kCoordMax : c)) >> level;
-    };
-    const int x0 = low_cell(qx - r), x1 = high_cell(qx + r), y0 = low_cell(qy - r), y1 = high_cell(qy + r),
-              z0 = low_cell(qz - r), z1 = high_cell(qz + r);
-    for (int z = z0; z <= z1; ++z) {
-      const double lz = (double)(((long long)z << level) - kCoordOffset) * fine;
-      const double ez = fmax(fmax(lz - qz, qz - (lz + size)), 0.0);
-      for (int y = y0; y <= y1; ++y) {
-        const double ly = (double)(((long long)y << level) - kCoordOffset) * fine;
-        const double ey = fmax(fmax(ly - qy, qy - (ly + size)), 0.0);
-        for (int x = x0; x <= x1; ++x) {
-          const double lx = (double)(((long long)x << level) - kCoordOffset) * fine;
-          const double ex = fmax(fmax(lx - qx, qx - (lx + size)), 0.0);
-          if ((ex * ex + ey * ey + ez * ez) * (1.0 - 1e-9) > bound) continue;  // the ball does not reach this cell
-          const unsigned long long key = cell_key(morton3((uint32_t)x, (uint32_t)y, (uint32_t)z), level);
-          uint32_t at = cell_hash(key) & (kTileCells - 1);
-          for (int probes = 0; probes < kTileCells; ++probes) {  // the set never fills: see the count below
-            const unsigned long long seen = atomicCAS(&cell_set[at], kEmptyCell, key);
-            if (seen == kEmptyCell || seen == key) break;
-            at = (at + 1) & (kTileCells - 1);
-          }
-        }
-      }
-    }
-  }
-  lds_sync();
-  uint32_t population = 0, distinct = 0;
-  int runs = 0;
-  for (int base = 0; base < kTileCells; base += 64) {
-    const unsigned long long key = cell_set[base + lane];
-    uint32_t s0 = 0, e0 = 0;
-    if (key != kEmptyCell) {
-      ++distinct;
-      const CellEntry* e = find_cell(table, mask, key);
-      if (e) { s0 = e->start; e0 = e->end; }
-    }
-    const unsigned long long who = __ballot(e0 > s0);
-    if (e0 > s0) cell_set[runs + __builtin_popcountll(who & lanes_below)] = (unsigned long long)s0 | ((unsigned long long)e0 << 32);
-    runs += __builtin_popcountll(who);
-    population += e0 - s0;
-  }
-  population = wave_sum_u32(population);
-  distinct = wave_sum_u32(distinct);
-  // a set more than half full may have dropped a cell (probing gave up): such a patch is too wide as well
-  if (population > kTilePointCap || distinct > (uint32_t)kTileCells / 2) {  // uniform
-    give_up(population > kTilePointCap ? 0x400u : 0x100000u);
-    return;
-  }
-  phase(4);
-  // start of every run in the list of all candidates (exclusive prefix sums, kept in the free upper half of
-  // the LDS array); candidate g then is position g - run_off[r] of the run r that a binary search finds
-  uint32_t* run_off = reinterpret_cast<uint32_t*>(cell_set + kTileCells / 2);
-  {
-    uint32_t carry = 0;
-    for (int base = 0; base < runs; base += 64) {
-      const unsigned long long run = base + lane < runs ? cell_set[base + lane] : 0ull;
-      const uint32_t len = (uint32_t)(run >> 32) - (uint32_t)run;
-      uint32_t incl = len;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-        if (lane >= o) incl += up;
-      }
-      if (base + lane < runs) run_off[base + lane] = carry + incl - len;
-      carry += (uint32_t)__shfl((int)incl, 63, 64);
-    }
-    if (lane == 0) run_off[runs] = carry;
-  }
-  lds_sync();
-  auto candidate = [&](uint32_t g) {
-    int lo = 0, hi = runs;  // run_off[lo] <= g < run_off[hi]
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (run_off[mid] <= g) lo = mid; else hi = mid;
-    }
-    return (uint32_t)cell_set[lo] + (g - run_off[lo]);
-  };
-
-  // 3. pass 1: histogram of d^2 over [0, bound] -> the bucket that holds the k-th distance
-  scale = (ok && bound > 0.0) ? (double)kTileBuckets / bound : 0.0;
-  clear_hist();
-  sweep(population, candidate, [&](double x, double y, double z, uint32_t) {
-    const double d2 = d2_to(x, y, z);
-    if (ok && d2 <= bound) hist[bucket(d2)][lane] += 1u;
-  });
-  int last;
-  uint32_t upto;
-  // fewer than K inside the bound cannot happen for a true upper bound; more than the list holds can
-  if (!kth_bucket(last, upto) || upto > (uint32_t)kTileListCap) ok = false;
-  phase(5);
-
-  // 4. pass 2: the candidates of the buckets up to `last` into the lane's list
-  uint32_t cnt = 0;
-  sweep(population, candidate, [&](double x, double y, double z, uint32_t j) {
-    const double d2 = d2_to(x, y, z);
-    if (ok && d2 <= bound && bucket(d2) <= last) {
-      list_d[cnt][lane] = d2;
-      list_id[cnt][lane] = j;  // sorted position for now; the tie-break below needs the original index
-      ++cnt;
-    }
-  });
-
-  phase(6);
-  // 5. the list into registers (statically indexed), then K selection passes in ascending (d^2, original
-  // index) order: each takes the smallest entry that is larger than the previous one, nothing is written back
-  const uint32_t qi = sorted_idx[qj];
-  const uint32_t slot = ok ? slot_of_index[qi] : 0u;
-  double ed[kTileListCap];
-  uint32_t ej[kTileListCap], ei[kTileListCap];
-#pragma unroll
-  for (int e = 0; e < kTileListCap; ++e) {
-    const bool have = (uint32_t)e < cnt;
-    ed[e] = have ? list_d[e][lane] : INFINITY;
-    ej[e] = have ? list_id[e][lane] : 0u;
-  }
-#pragma unroll
-  for (int e = 0; e < kTileListCap; ++e) ei[e] = (uint32_t)e < cnt ? sorted_idx[ej[e]] : 0xFFFFFFFFu;
-  double prev = -1.0;
-  uint32_t prev_id = 0u;
-  for (int p = 0; p < K; ++p) {
-    double best = INFINITY;
-    uint32_t best_id = 0xFFFFFFFFu, best_j = 0u;
-#pragma unroll
-    for (int e = 0; e < kTileListCap; ++e) {
-      const bool after = ed[e] > prev || (ed[e] == prev && ei[e] > prev_id);
-      const bool better = ed[e] < best || (ed[e] == best && ei[e] < best_id);
-      if (after && better) { best = ed[e]; best_id = ei[e]; best_j = ej[e]; }
-    }
-    prev = best;
-    prev_id = best_id;
-    if (ok) nbr[(size_t)slot * kMaxKnn + p] = best_j;
-  }
-  if (ok) {
-    out_pts[3 * (size_t)slot] = qx; out_pts[3 * (size_t)slot + 1] = qy; out_pts[3 * (size_t)slot + 2] = qz;
-    out_idx[slot] = qi;
-  }
-  pass_on(valid && !ok);  // non-finite query or bound, a ball wider than the patch's level, a list that would overflow
-  phase(7);
-  if (debug == 1) {
-    const uint32_t handed = (uint32_t)__builtin_popcountll(__ballot(valid && !ok));
-    if (lane == 0) {
-      atomicAdd(&counters[5], population);
-      atomicAdd(&counters[6], handed);
-      atomicMax(&counters[7], wave_max_u32(cnt));
     }
   }
 }
@@ -1129,26 +756,9 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
                      table_entries);
   hipLaunchKernelGGL(cell_start_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
   hipLaunchKernelGGL(cell_end_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
-  const char* force = std::getenv("VGICP_PREP_SEARCH");  // "wave": the wave-per-query kernel for everything
-  const bool tiles = n >= 4096 && m >= 256 && !(force && force[0] == 'w');
-  if (tiles) {
-    // the tile kernel takes 64 Morton-adjacent queries per wave; what it cannot stage goes to a to-do list
-    // (in keep_p's storage, dead by now; its length is counters[2]) for the wave-per-query kernel
-    auto* todo_list = reinterpret_cast<uint32_t*>(b + L.keep_p);
-    auto* pos_i = reinterpret_cast<uint32_t*>(b + L.pos_i);
-    const uint32_t tile_count = (m + 63u) / 64u;
-    hipLaunchKernelGGL(knn_tile_kernel, dim3(8 * ((tile_count + 7) / 8)), dim3(64), 0, s, spts, idx_out, pos_i, n, h, knn,
-                       table, mask, queries, rank_i, m, nbr, out_pts, out_idx, todo_list, counters + 2, counters, debug);
-    const uint32_t waves = m < 16384u ? m : 16384u;
-    hipLaunchKernelGGL(knn_search_kernel, dim3(blocks_for(waves, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts,
-                       idx_out, n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug,
-                       todo_list, counters + 2);
-  } else {
-    // 8 XCDs x ceil(m / 8) queries each (see the kernel's query mapping)
-    hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((m + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts,
-                       idx_out, n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-  }
+  // 8 XCDs x ceil(m / 8) queries each (see the kernel's query mapping)
+  hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((m + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
+                     n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
   const int found = knn < (int)n ? knn : (int)n;
   hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, spts, nbr, m, found, out_covs);
   return hipGetLastError();
