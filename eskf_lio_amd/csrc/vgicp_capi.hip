@@ -1569,7 +1569,11 @@ int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128)
     if (!ok) why = ctx->err;
     // every rank must take part in the collectives whatever happened locally: a failed export sends zeros
     if (!ok) std::memset(mine, 0, sizeof mine);
-    if (hipMalloc(reinterpret_cast<void**>(&d_all), all.size() + VGICP_PEER_HANDLE_BYTES) == hipSuccess) {
+    // (a rank that could not even allocate these few bytes cannot take part in the collectives below and fails
+    // the whole call; its peers would wait for it inside RCCL as they would for any rank that died)
+    if (hipMalloc(reinterpret_cast<void**>(&d_all), all.size() + VGICP_PEER_HANDLE_BYTES) != hipSuccess)
+      return fail(ctx, VGICP_ERR_HIP, "hipMalloc(handle exchange) failed");
+    {
       char* d_mine = d_all + all.size();
       bool coll = hipMemcpyAsync(d_mine, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                   ctx->rccl.AllGather(d_mine, d_all, VGICP_PEER_HANDLE_BYTES, kNcclChar, ctx->comm, ctx->stream) == 0 &&

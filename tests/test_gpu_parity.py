@@ -792,18 +792,19 @@ def test_two_gpu_sharded_align():
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
 
-def test_peer_exchange_two_processes_one_device(tmp_path):
+@pytest.mark.parametrize("world,grid", [(2, 100), (4, 60)])
+def test_peer_exchange_two_processes_one_device(tmp_path, world, grid):
     """The device-initiated exchange between ranks (vgicp_peer_*: HIP IPC mailboxes written by the ranks'
-    persistent kernels) with two PROCESSES on the one device of this box — what crosses xGMI on a multi-GPU
+    persistent kernels) with two or four PROCESSES on the one device of this box — what crosses xGMI on a multi-GPU
     node crosses the device's own memory here; protocol, mapping and ordering are the same.  Each rank
     registers its shard; every rank must obtain the same bits, equal to the whole scan on one context up to
-    the grouping of the sums.  The two persistent launches have to be resident together, so each uses 100 of
-    the 256 compute units (VGICP_PERSIST_GRID).  Spins are bounded: a launch that gives up ends its process
+    the grouping of the sums.  The ranks' persistent launches have to be resident together, so each uses 100
+    (60 with four ranks) of the 256 compute units (VGICP_PERSIST_GRID).  Spins are bounded: a launch that gives up ends its process
     with a non-zero code.  Unmeasured on 8 GPUs (no such node was available to the build)."""
     import subprocess
     import sys
-    world, n, rounds = 2, 40_000, 8
-    env = dict(os.environ, VGICP_PERSIST_GRID="100")
+    n, rounds = 40_000, 8
+    env = dict(os.environ, VGICP_PERSIST_GRID=str(grid))
     worker = os.path.join(os.path.dirname(__file__), "peer_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path), str(n), str(rounds)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -818,9 +819,11 @@ def test_peer_exchange_two_processes_one_device(tmp_path):
             raise
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    a, b = (np.load(os.path.join(tmp_path, f"result{r}.npz")) for r in range(world))
-    assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["normal_eq"], b["normal_eq"])
-    assert np.array_equal(a["half_pose"], b["half_pose"])
+    results = [np.load(os.path.join(tmp_path, f"result{r}.npz")) for r in range(world)]
+    for other in results[1:]:
+        assert np.array_equal(results[0]["pose"], other["pose"])
+        assert np.array_equal(results[0]["normal_eq"], other["normal_eq"])
+        assert np.array_equal(results[0]["half_pose"], other["half_pose"])
 
 
 # ---- BASELINE's full size (C2): size-independent properties ------------------------------------

@@ -17,6 +17,19 @@ __device__ __forceinline__ void store_flag(unsigned* p, unsigned v) {
   __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, SCOPE);
 }
 
+// MIXED (scope -1): the writer stores PLAIN (the line stays in its XCD's L2) and drains (s_waitcnt vmcnt(0)), the
+// reader polls with sc1 loads (L1 bypassed, L2 served): a candidate fast path between workgroups of one XCD.
+constexpr int kMixed = -1;
+template <>
+__device__ __forceinline__ unsigned load_flag<kMixed>(unsigned* p) {
+  return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <>
+__device__ __forceinline__ void store_flag<kMixed>(unsigned* p, unsigned v) {
+  *(volatile unsigned*)p = v;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // workgroups a and b bounce a counter `rounds` times; everybody else leaves at once
 template <int SCOPE>
 __global__ void pingpong(unsigned* flags, int a, int b, int rounds, unsigned long long* ticks, unsigned* xcc) {
@@ -64,7 +77,8 @@ int main() {
     (void)hipMemset(flags, 0, 4096);
     (void)hipMemset(ticks, 0, 8);
     (void)hipMemset(xcc, 0, grid * 4);
-    if (scope == 0) hipLaunchKernelGGL(pingpong<__HIP_MEMORY_SCOPE_WORKGROUP>, dim3(grid), dim3(64), 0, 0, flags, a, b, rounds, ticks, xcc);
+    if (scope == -1) hipLaunchKernelGGL(pingpong<kMixed>, dim3(grid), dim3(64), 0, 0, flags, a, b, rounds, ticks, xcc);
+    else if (scope == 0) hipLaunchKernelGGL(pingpong<__HIP_MEMORY_SCOPE_WORKGROUP>, dim3(grid), dim3(64), 0, 0, flags, a, b, rounds, ticks, xcc);
     else hipLaunchKernelGGL(pingpong<__HIP_MEMORY_SCOPE_AGENT>, dim3(grid), dim3(64), 0, 0, flags, a, b, rounds, ticks, xcc);
     if (hipDeviceSynchronize() != hipSuccess) { std::printf("%s: launch failed\n", what); return; }
     unsigned long long t = 0;
@@ -77,6 +91,9 @@ int main() {
   run(1, 0, 8, "agent scope (sc1), 8 apart");
   run(0, 0, 8, "workgroup scope (sc0), 8 apart");
   run(0, 0, 16, "workgroup scope (sc0), 16 apart");
+  run(-1, 0, 8, "plain store + drain / sc1 load, 8 apart (same XCD)");
+  run(-1, 0, 16, "plain store + drain / sc1 load, 16 apart (same XCD)");
+  run(-1, 0, 1, "plain store + drain / sc1 load, neighbours (different XCDs)");
   std::printf("xcc ids of workgroups 0..15:");
   for (int i = 0; i < 16; ++i) std::printf(" %u", hx[i] & 0xF);
   std::printf("\n");
