@@ -245,6 +245,15 @@ __device__ __forceinline__ void se3_exp_device(const double* xi, Pose& T) {
   mat3_vec(J, xi, T.t);
 }
 
+// Fixed-shape pairwise sum of N values: (first half) + (second half), recursively.  The order every fold of the
+// partial sums uses, in both loop variants (hence the same bits), instead of a left-to-right chain: a dependent
+// fp64 add costs ~32 cycles on one wave (tools/micro/valu_chain.hip), so 16 values take 4 steps instead of 15.
+template <int N>
+__device__ __forceinline__ double tree_sum(const double* v) {
+  if constexpr (N == 1) return v[0];
+  else return tree_sum<N / 2>(v) + tree_sum<N - N / 2>(v + N / 2);
+}
+
 // What every wave needs to run a round: the total pose, or the news that the loop has ended.
 struct RoundHead {
   Pose total;
@@ -300,17 +309,14 @@ __device__ __forceinline__ RoundHead prologue_fold(const IterArgs& a, PrologueSh
     if (blockIdx.x == 0 && tid == 0) *a.state_out = *in;
     return head;
   }
-  double s = 0.0;
-#pragma unroll
-  for (int u = 0; u < kBatch; ++u) s += row[u];
+  double s = tree_sum<kBatch>(row);  // rows group, group + kGroups, ...: the 16 rows a folder of the persistent launch adds
   for (uint32_t b0 = group + kBatch * kGroups; b0 < a.prev_rows; b0 += kGroups * kBatch) {
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       const uint32_t b = b0 + u * kGroups;
       row[u] = b < a.prev_rows ? a.prev[(size_t)b * kSlots + slot] : 0.0;
     }
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) s += row[u];
+    s += tree_sum<kBatch>(row);
   }
   sh.fin[group][slot] = s;
   return head;
@@ -323,9 +329,10 @@ __device__ __forceinline__ void prologue_solve(const IterArgs& a, PrologueShared
   constexpr int kGroups = BLOCK / kSlots;
   double tot = 0.0;
   if (lane < kSlots) {
-    tot = sh.fin[0][lane];
+    double part[kGroups];
 #pragma unroll
-    for (int g = 1; g < kGroups; ++g) tot += sh.fin[g][lane];
+    for (int g = 0; g < kGroups; ++g) part[g] = sh.fin[g][lane];
+    tot = tree_sum<kGroups>(part);
   }
   // the 27 sums to every lane (same wave wrote them: LDS is in order within a wave)
   if (lane < kSlots) sh.totals[lane] = tot;
@@ -538,10 +545,10 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
   __syncthreads();
   // ---- workgroup: fixed-order sum over the worker waves, one plain 256-byte row per workgroup ----
   if (tid < kSlots) {
-    double tot = red[1][tid];
+    double w_sum[kWaves - 1];
 #pragma unroll
-    for (int w = 2; w < kWaves; ++w) tot += red[w][tid];
-    a.rows[(size_t)blockIdx.x * kSlots + tid] = tot;
+    for (int w = 1; w < kWaves; ++w) w_sum[w - 1] = red[w][tid];
+    a.rows[(size_t)blockIdx.x * kSlots + tid] = tree_sum<kWaves - 1>(w_sum);
   }
   if (a.stamps && blockIdx.x == 0 && tid == 64) {
     const uint64_t t_end = wall_clock64();
@@ -661,8 +668,8 @@ __device__ __forceinline__ unsigned long long publishable(double v) {
 }
 
 // Lanes <= kCountSlot (lane = slot): wait until the 16 consecutive rows at src are published and return
-// the sum of their words in ascending row order, starting from +0.0 (as the folds of iterate_kernel do;
-// rows that belong to no workgroup hold +0.0 for good).  All 64 lanes of the wave call it; false when
+// the sum of their words as the pairwise tree over ascending rows (tree_sum<16>, as the folds of iterate_kernel
+// do; rows that belong to no workgroup hold +0.0 for good).  All 64 lanes of the wave call it; false when
 // spin_limit polls did not suffice.  The 16 loads are in flight together (one address, immediate offsets).
 template <bool SYSTEM>
 __device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, uint32_t spin_limit, double& sum) {
@@ -686,10 +693,10 @@ __device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, u
     for (int k = 0; k < kFolders; ++k)
       if (w[k] == kRowUnset) w[k] = SYSTEM ? load_system_bits(mine + k * kSlots) : load_through_bits(mine + k * kSlots);
   }
-  double s = 0.0;
+  double x[kFolders];
 #pragma unroll
-  for (int k = 0; k < kFolders; ++k) s += __longlong_as_double((long long)w[k]);
-  sum = s;
+  for (int k = 0; k < kFolders; ++k) x[k] = __longlong_as_double((long long)w[k]);
+  sum = tree_sum<kFolders>(x);
   return true;
 }
 
@@ -904,10 +911,10 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       // ---- level 1: publish this workgroup's row (every re-arming store of mine has completed) ----
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane <= (uint32_t)kCountSlot) {
-        double tot = red[1][lane];
+        double w_sum[kWaves - 1];
 #pragma unroll
-        for (int w = 2; w < kWaves; ++w) tot += red[w][lane];
-        store_through_bits(rows + (size_t)my_row * kSlots + lane, publishable(tot));
+        for (int w = 1; w < kWaves; ++w) w_sum[w - 1] = red[w][lane];
+        store_through_bits(rows + (size_t)my_row * kSlots + lane, publishable(tree_sum<kWaves - 1>(w_sum)));
       }
       bool ok = true;
       if (folder) {  // uniform
