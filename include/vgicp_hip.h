@@ -252,7 +252,7 @@ int vgicp_comm_destroy(vgicp_ctx* ctx);
  * The same merge (src/Registration.cpp:71-75) without a host-enqueued collective between kernel launches:
  * every rank owns a small mailbox in fine-grained device memory, maps the mailboxes of all ranks (HIP IPC),
  * and the ONE persistent kernel launch that runs the whole ICP::align loop on each GPU stores the rank's
- * 28-double row of every iteration straight into all mailboxes and adds the rows it receives in rank order
+ * 28-double row of every iteration straight into all mailboxes and adds the rows it receives in one fixed order
  * (identical bits on every rank, hence the same pose and the same break decision everywhere).
  * Hand-wiring for hosts that do not use vgicp_comm_init: every rank exports its handle, the host side ships
  * the world_size x 64 bytes to every rank in rank order (any transport), every rank connects, and the host
