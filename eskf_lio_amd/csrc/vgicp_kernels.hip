@@ -94,6 +94,20 @@ __device__ __forceinline__ void fold_swap(double (&v)[kSlots]) {
   }
 }
 
+// 1 / d for a normal, finite d by v_rcp_f64 + two Newton steps (FMA): ~1 ulp, a third of the dependent
+// instructions of the correctly rounded division.  Only on the solver wave's serial chain (pivots of the
+// natural-order LDL^T, 1 / angle), where a last-bit difference is below the solve's own rounding.
+__device__ __forceinline__ double rcp_newton(double d) {
+#ifdef VGICP_AB_EXACT_DIV
+  return 1.0 / d;
+#endif
+  double y = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);
+  return fma(y, e, y);
+}
+
 // Fallback of the 6x6 solve: vgicp_math.h's ldlt6_solve — Eigen's pivoted LDLT with pseudo-inverted D, the
 // operation order of the published algorithm, no contraction — run by lane 0 on an LDS work array (the
 // pivoting makes every index dynamic), the solution then read by every lane.  It is taken only when the
@@ -115,20 +129,6 @@ __device__ __forceinline__ void ldlt6_solve_pivoted(const double* packed, double
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
   for (int k = 0; k < 6; ++k) x[k] = sol[k];
-}
-
-// 1 / d for a normal, finite d by v_rcp_f64 + two Newton steps (FMA): ~1 ulp, a third of the dependent
-// instructions of the correctly rounded division.  Only on the solver wave's serial chain (pivots of the
-// natural-order LDL^T, 1 / angle), where a last-bit difference is below the solve's own rounding.
-__device__ __forceinline__ double rcp_newton(double d) {
-#ifdef VGICP_AB_EXACT_DIV
-  return 1.0 / d;
-#endif
-  double y = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-d, y, 1.0);
-  return fma(y, e, y);
 }
 
 // sin and cos of a SMALL angle (|a| <= 0.5 rad; Gauss-Newton steps are far smaller) by their Taylor series in
@@ -384,6 +384,10 @@ __device__ __forceinline__ void load_point(const double* scan, uint64_t stride, 
 
 // One correspondence: p (already in the map frame), scan covariance C, voxel mean / covariance.
 // ICP::computeJTJAndJTr in structured form (J = [I | -[p]x]); S holds C_voxel on entry.
+// FIRST: v holds nothing yet (the thread's first match of the round): the 28 values are stored, not added to
+// zeros — 28 dependent-latency adds less per round in the one-point-per-thread case.  Both loop variants make the
+// same choice for the same point, so they still agree bit for bit.
+template <bool FIRST>
 __device__ __forceinline__ void accumulate_match(const double* R, const double (&p)[3],
                                                  const double (&C)[9], const double (&mu)[3],
                                                  double (&S)[9], double (&v)[kSlots]) {
@@ -400,8 +404,20 @@ __device__ __forceinline__ void accumulate_match(const double* R, const double (
     for (int r = 0; r < 3; ++r)
       S[r + 3 * c] += RC[r] * R[c] + RC[r + 3] * R[c + 3] + RC[r + 6] * R[c + 6];
 
+  // W = S^-1 by cofactors as Eigen's fixed-size inverse (vgicp_math.h inv3), the one division replaced by
+  // v_rcp_f64 + two Newton steps (~1 ulp; a third of the dependent instructions)
   double W[9];
-  inv3(S, W);
+  {
+    const double c00 = S[4] * S[8] - S[7] * S[5], c10 = S[5] * S[6] - S[8] * S[3], c20 = S[3] * S[7] - S[6] * S[4];
+    const double det = c00 * S[0] + c10 * S[1] + c20 * S[2];
+    const double id = rcp_newton(det);
+    const double c01 = S[7] * S[2] - S[1] * S[8], c11 = S[8] * S[0] - S[2] * S[6], c21 = S[6] * S[1] - S[0] * S[7];
+    const double c02 = S[1] * S[5] - S[4] * S[2], c12 = S[2] * S[3] - S[5] * S[0], c22 = S[0] * S[4] - S[3] * S[1];
+    W[0] = c00 * id; W[3] = c10 * id; W[6] = c20 * id;
+    W[1] = c01 * id; W[4] = c11 * id; W[7] = c21 * id;
+    W[2] = c02 * id; W[5] = c12 * id; W[8] = c22 * id;
+  }
+  auto acc = [](double& dst, double x) { if (FIRST) dst = x; else dst += x; };
   const double e0 = p[0] - mu[0], e1 = p[1] - mu[1], e2 = p[2] - mu[2];
   // Q = [p]x W  (rows 3..5, columns 0..2 of J^T Sigma^-1 J)
   double Q[9];  // Q[r + 3c]
@@ -412,26 +428,26 @@ __device__ __forceinline__ void accumulate_match(const double* R, const double (
     Q[2 + 3 * c] = p[0] * W[1 + 3 * c] - p[1] * W[0 + 3 * c];
   }
   // lower triangle of J^T Sigma^-1 J, row by row
-  v[0] += W[0];
-  v[1] += W[1]; v[2] += W[4];
-  v[3] += W[2]; v[4] += W[5]; v[5] += W[8];
+  acc(v[0], W[0]);
+  acc(v[1], W[1]); acc(v[2], W[4]);
+  acc(v[3], W[2]); acc(v[4], W[5]); acc(v[5], W[8]);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int base = (3 + r) * (4 + r) / 2;
     const double q0 = Q[r], q1 = Q[r + 3], q2 = Q[r + 6];
-    v[base + 0] += q0; v[base + 1] += q1; v[base + 2] += q2;
-    v[base + 3] += q2 * p[1] - q1 * p[2];
-    if (r >= 1) v[base + 4] += q0 * p[2] - q2 * p[0];
-    if (r >= 2) v[base + 5] += q1 * p[0] - q0 * p[1];
+    acc(v[base + 0], q0); acc(v[base + 1], q1); acc(v[base + 2], q2);
+    acc(v[base + 3], q2 * p[1] - q1 * p[2]);
+    if (r >= 1) acc(v[base + 4], q0 * p[2] - q2 * p[0]);
+    if (r >= 2) acc(v[base + 5], q1 * p[0] - q0 * p[1]);
   }
   // J^T Sigma^-1 r
-  v[21] += W[0] * e0 + W[3] * e1 + W[6] * e2;
-  v[22] += W[1] * e0 + W[4] * e1 + W[7] * e2;
-  v[23] += W[2] * e0 + W[5] * e1 + W[8] * e2;
-  v[24] += Q[0] * e0 + Q[3] * e1 + Q[6] * e2;
-  v[25] += Q[1] * e0 + Q[4] * e1 + Q[7] * e2;
-  v[26] += Q[2] * e0 + Q[5] * e1 + Q[8] * e2;
-  v[kCountSlot] += 1.0;
+  acc(v[21], W[0] * e0 + W[3] * e1 + W[6] * e2);
+  acc(v[22], W[1] * e0 + W[4] * e1 + W[7] * e2);
+  acc(v[23], W[2] * e0 + W[5] * e1 + W[8] * e2);
+  acc(v[24], Q[0] * e0 + Q[3] * e1 + Q[6] * e2);
+  acc(v[25], Q[1] * e0 + Q[4] * e1 + Q[7] * e2);
+  acc(v[26], Q[2] * e0 + Q[5] * e1 + Q[8] * e2);
+  acc(v[kCountSlot], 1.0);
 }
 
 // One VGICP round.  Launch j reads state j&1 and the rows launch j-1 wrote, writes state (j+1)&1
@@ -527,8 +543,11 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
     const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
     if (!first || kx != okx || ky != oky || kz != okz)
       hit = find_and_load(a.table, a.mask, kx, ky, kz, mu, S);
+    if (hit) {
+      if (first) accumulate_match<true>(R, p, C, mu, S, v);  // the thread's first point of the round
+      else accumulate_match<false>(R, p, C, mu, S, v);
+    }
     first = false;
-    if (hit) accumulate_match(R, p, C, mu, S, v);
   }
   const uint64_t t_loop = a.stamps ? wall_clock64() : 0;
 
@@ -816,7 +835,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
           if (hit) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) S[k] = Sv[k];
-            accumulate_match(R, p, C, mu, S, v);
+            accumulate_match<true>(R, p, C, mu, S, v);
           }
         }
       } else {
@@ -859,7 +878,8 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
           if (got) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
-            accumulate_match(R, p, C, m2, S, v);
+            if (e == 0) accumulate_match<true>(R, p, C, m2, S, v);  // the thread's first point of the round
+            else accumulate_match<false>(R, p, C, m2, S, v);
           }
         }
       }
