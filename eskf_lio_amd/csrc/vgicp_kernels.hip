@@ -384,6 +384,9 @@ __device__ __forceinline__ void load_point(const double* scan, uint64_t stride, 
 
 // One correspondence: p (already in the map frame), scan covariance C, voxel mean / covariance.
 // ICP::computeJTJAndJTr in structured form (J = [I | -[p]x]); S holds C_voxel on entry.
+template <bool B>
+struct Flag { static constexpr bool value = B; };
+
 // FIRST: v holds nothing yet (the thread's first match of the round): the 28 values are stored, not added to
 // zeros — 28 dependent-latency adds less per round in the one-point-per-thread case.  Both loop variants make the
 // same choice for the same point, so they still agree bit for bit.
@@ -781,7 +784,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   double q0[kScanPlanes];
 #pragma unroll
   for (int k = 0; k < kScanPlanes; ++k) q0[k] = 0.0;
-  const bool have = !MANY && first < a.n;
+  const bool have = first < a.n;
   if (have) load_point(a.scan, a.stride, first, q0);
 
   // what the first point used last round: key, hit flag, voxel payload (raw)
@@ -839,22 +842,9 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
           }
         }
       } else {
-        uint32_t e = 0;
-        for (uint32_t i = first; i < a.n; i += stride_pts, ++e) {
-          double q[kScanPlanes], p[3], C[9], m2[3], S[9];
-          if (e < a.stash_points) {
-            double* slot = stash + (size_t)e * kScanPlanes * kWorkers + (tid - 64);
-            if (it == 0) {
-              load_point(a.scan, a.stride, i, q);
-#pragma unroll
-              for (int k = 0; k < kScanPlanes; ++k) slot[k * kWorkers] = q[k];
-            } else {
-#pragma unroll
-              for (int k = 0; k < kScanPlanes; ++k) q[k] = slot[k * kWorkers];
-            }
-          } else {
-            load_point(a.scan, a.stride, i, q);
-          }
+        // one point: transform, key, the memo of point e (if it has one), accumulate
+        auto one_point = [&](const double (&q)[kScanPlanes], uint32_t e, auto first_of_round) {
+          double p[3], C[9], m2[3], S[9];
           transform_point(R, t, q[0], q[1], q[2], p);
           const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
           const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
@@ -878,9 +868,29 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
           if (got) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
-            if (e == 0) accumulate_match<true>(R, p, C, m2, S, v);  // the thread's first point of the round
-            else accumulate_match<false>(R, p, C, m2, S, v);
+            accumulate_match<decltype(first_of_round)::value>(R, p, C, m2, S, v);
           }
+        };
+        // the thread's first point stays in registers (its voxel record does not: the memo finds it), the next
+        // a.stash_points are parked in LDS after round 0, the rest is re-read from HBM every round
+        if (have) one_point(q0, 0u, Flag<true>{});
+        uint32_t e = 1;
+        for (uint32_t i = first + stride_pts; i < a.n; i += stride_pts, ++e) {
+          double q[kScanPlanes];
+          if (e <= a.stash_points) {
+            double* slot = stash + (size_t)(e - 1) * kScanPlanes * kWorkers + (tid - 64);
+            if (it == 0) {
+              load_point(a.scan, a.stride, i, q);
+#pragma unroll
+              for (int k = 0; k < kScanPlanes; ++k) slot[k * kWorkers] = q[k];
+            } else {
+#pragma unroll
+              for (int k = 0; k < kScanPlanes; ++k) q[k] = slot[k * kWorkers];
+            }
+          } else {
+            load_point(a.scan, a.stride, i, q);
+          }
+          one_point(q, e, Flag<false>{});
         }
       }
       fold_swap<32, false>(v);
@@ -1310,7 +1320,7 @@ void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint3
   const uint32_t left = kPersistDynLds - memo * kMemoBytesPerPoint;
   const uint32_t stash = left / kStashBytesPerPoint;
   *memo_points = memo;
-  *stash_points = stash < per_thread ? stash : per_thread;
+  *stash_points = stash < per_thread - 1 ? stash : per_thread - 1;  // the first point of a thread lives in registers
 }
 
 uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_points) {
