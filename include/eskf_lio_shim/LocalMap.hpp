@@ -318,7 +318,9 @@ public:
   bool visualizeLocalMap() const {return true;}
 
   // reference: src/LocalMap.cpp:156-167 writes a .pcd through Open3D and a PinholeCameraTrajectory
-  // JSON. Written here without Open3D: ASCII PCD v0.7 of every stored point, and the 4x4 poses as a
+  // JSON. Written here without Open3D: ASCII PCD v0.7 — of every stored point when the host map is
+  // authoritative (as the reference writes), of ONE point per voxel (its mean, read back with
+  // vgicp_map_export) in deviceResident mode, where the raw points are not kept — and the 4x4 poses as a
   // JSON array of column-major "extrinsic" arrays (the field Open3D's trajectory reader uses).
   void save(const std::string & cloud_path, const std::string & trajectory_path) const
   {
