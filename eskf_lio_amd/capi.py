@@ -304,23 +304,29 @@ class Context:
         p = Params(int(max_iteration), int(chunk), float(translation_sq_threshold),
                    float(cosine_threshold), int(flags), 0)
         cap = max(int(max_iteration), 1)
-        counts = np.zeros(cap, dtype=np.uint64)
-        neq = np.zeros((cap, 27))
-        kms = np.zeros(cap, dtype=np.float32)
-        st = Stats()
-        st.corr_count = counts.ctypes.data_as(C.POINTER(C.c_uint64))
-        st.normal_eq = _dp(neq)
-        st.kernel_ms = kms.ctypes.data_as(C.POINTER(C.c_float))
-        out = np.zeros(16)
-        rc = call(p, out, st)
+        # output buffers are kept per context and reused (a call in a frame loop should not pay for a dozen
+        # numpy allocations); the result holds copies of the filled parts
+        scratch = getattr(self, "_scratch", None)
+        if scratch is None or scratch[0] < cap:
+            counts = np.zeros(cap, dtype=np.uint64)
+            neq = np.zeros((cap, 27))
+            kms = np.zeros(cap, dtype=np.float32)
+            st = Stats()
+            st.corr_count = counts.ctypes.data_as(C.POINTER(C.c_uint64))
+            st.normal_eq = _dp(neq)
+            st.kernel_ms = kms.ctypes.data_as(C.POINTER(C.c_float))
+            out = np.zeros(16)
+            scratch = self._scratch = (cap, counts, neq, kms, st, out, _dp(out))
+        _, counts, neq, kms, st, out, out_p = scratch
+        rc = call(p, out_p, st)
         allow = (ERR_DEGENERATE,) if allow_degenerate else ()
         self._check(rc, allow)
         it = st.iterations
         return AlignResult(pose=pose_from_abi(out), iterations=it, converged=bool(st.converged),
                            world_size=st.world_size, launches=st.launches, seconds=st.seconds,
-                           device_seconds=st.device_seconds, corr_count=counts[:it],
-                           normal_eq=neq[:it],
-                           kernel_ms=kms[:st.launches] if flags & FLAG_PROFILE else None,
+                           device_seconds=st.device_seconds, corr_count=counts[:it].copy(),
+                           normal_eq=neq[:it].copy(),
+                           kernel_ms=kms[:st.launches].copy() if flags & FLAG_PROFILE else None,
                            status=rc, message=self.last_error() if rc else "")
 
     def align(self, points, covs, guess, max_iteration, translation_sq_threshold, cosine_threshold,
@@ -330,7 +336,7 @@ class Context:
             raise ValueError("points / covs disagree in length")
         g = pose_to_abi(guess)
         return self._run(lambda p, out, st: self._lib.vgicp_align(
-            self._h, points.shape[0], _dp(points), _dp(covs), _dp(g), C.byref(p), _dp(out), C.byref(st)),
+            self._h, points.shape[0], _dp(points), _dp(covs), _dp(g), C.byref(p), out, C.byref(st)),
             max_iteration, translation_sq_threshold, cosine_threshold, chunk_iterations, flags,
             allow_degenerate)
 
@@ -339,7 +345,7 @@ class Context:
                        allow_degenerate: bool = False) -> AlignResult:
         g = pose_to_abi(guess)
         return self._run(lambda p, out, st: self._lib.vgicp_align_resident(
-            self._h, _dp(g), C.byref(p), _dp(out), C.byref(st)),
+            self._h, _dp(g), C.byref(p), out, C.byref(st)),
             max_iteration, translation_sq_threshold, cosine_threshold, chunk_iterations, flags,
             allow_degenerate)
 
