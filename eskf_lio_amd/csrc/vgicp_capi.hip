@@ -369,7 +369,9 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.exit_base = ctx->persist_exit_base;
   a.state = reinterpret_cast<AlignState*>(ctx->d_log - kSlots);
   a.log = ctx->d_log;
-  a.spin_limit = ctx->persist_spin_limit;
+  // between GPUs the ranks' host threads reach the launch at slightly different times: a rank waits much longer
+  // for a peer (~1 s) than for a workgroup of its own device (~50 ms) before it gives up
+  a.spin_limit = (ctx->peers_connected && ctx->peer_world > 1) ? ctx->persist_spin_limit * 20u : ctx->persist_spin_limit;
   a.seq = ++ctx->persist_seq == 0 ? ++ctx->persist_seq : ctx->persist_seq;  // never 0
   pose_to_state(guess, a.pose0);
   a.cosine_threshold = params->cosine_threshold;
