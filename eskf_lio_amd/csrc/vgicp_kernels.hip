@@ -98,9 +98,6 @@ __device__ __forceinline__ void fold_swap(double (&v)[kSlots]) {
 // instructions of the correctly rounded division.  Only on the solver wave's serial chain (pivots of the
 // natural-order LDL^T, 1 / angle), where a last-bit difference is below the solve's own rounding.
 __device__ __forceinline__ double rcp_newton(double d) {
-#ifdef VGICP_AB_EXACT_DIV
-  return 1.0 / d;
-#endif
   double y = __builtin_amdgcn_rcp(d);
   double e = fma(-d, y, 1.0);
   y = fma(y, e, y);
@@ -135,10 +132,6 @@ __device__ __forceinline__ void ldlt6_solve_pivoted(const double* packed, double
 // Horner form: truncation below 5e-17 relative, no argument reduction, ~20 dependent FMAs instead of the
 // library's ~100 instructions.  Larger angles take the library call.
 __device__ __forceinline__ void sincos_step(double a, double* s, double* c) {
-#ifdef VGICP_AB_LIB_SINCOS
-  sincos(a, s, c);
-  return;
-#endif
   if (fabs(a) > 0.5) {  // uniform on the solver wave
     sincos(a, s, c);
     return;
@@ -707,10 +700,7 @@ __device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, u
     for (int k = 0; k < kFolders; ++k) missing = missing || (w[k] == kRowUnset);
     if (!__any(missing)) break;
     if (spins >= spin_limit) return false;
-#ifndef VGICP_AB_SLEEP
-#define VGICP_AB_SLEEP 1
-#endif
-    __builtin_amdgcn_s_sleep(VGICP_AB_SLEEP);
+    __builtin_amdgcn_s_sleep(1);
 #pragma unroll
     for (int k = 0; k < kFolders; ++k)
       if (w[k] == kRowUnset) w[k] = SYSTEM ? load_system_bits(mine + k * kSlots) : load_through_bits(mine + k * kSlots);

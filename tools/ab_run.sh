@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: r02_ab.sh <outdir> <config> <reps> name1 name2 ...   ("tree" = the in-tree build)
+# Times builds made with tools/ab_build.sh against each other in ONE session on ONE box (probe.py, two passes).
+# usage: ab_run.sh <outdir under gpurun_out> <C2|C5> <reps> name1 name2 ...   ("tree" = the in-tree build)
 OUT=gpurun_out/$1; CFG=$2; REPS=$3; shift 3; mkdir -p $OUT
 for round in 1 2; do
 for name in "$@"; do

@@ -1,4 +1,7 @@
 #!/bin/bash
+# One gpurun call for the evidence of a round: the default bench line, the three rocprofv3 passes at C2 and C5
+# (tools/profile_gpu.sh -> gpurun_out/<tag>_c2, <tag>_c5; reduce with tools/summarize_profile.py) and the upload probe.
+# usage: gpurun -- bash tools/round_evidence.sh <tag>
 set -u
 T=${1:-r02f}
 mkdir -p gpurun_out/$T
