@@ -100,6 +100,103 @@ def test_filter_prediction_follows_the_imu():
     assert len(kf.getStates()) == before
 
 
+def _inject(state, err):
+    """ErrorStateKF::injectError (src/ErrorStateKF.cpp:166-174) on a copy."""
+    s = state.copy()
+    s.position = s.position + err[0:3]
+    s.velocity = s.velocity + err[3:6]
+    s.attitude = replay.quat_multiply(s.attitude, replay.rotation_vector_to_quat(err[6:9]))
+    s.biasAccel = s.biasAccel + err[9:12]
+    s.biasGyro = s.biasGyro + err[12:15]
+    s.gravity = s.gravity + err[15:18]
+    return s
+
+
+def _error_between(a, b):
+    """The 18-vector e with a (+) e = b, to first order."""
+    e = np.zeros(18)
+    e[0:3] = b.position - a.position
+    e[3:6] = b.velocity - a.velocity
+    e[6:9] = replay.rotation_matrix_to_vector(replay.quat_to_matrix(a.attitude).T @ replay.quat_to_matrix(b.attitude))
+    e[9:12] = b.biasAccel - a.biasAccel
+    e[12:15] = b.biasGyro - a.biasGyro
+    e[15:18] = b.gravity - a.gravity
+    return e
+
+
+def test_filter_transition_matrix_is_the_jacobian_of_its_own_prediction():
+    """An independent check of the estimator restatement (it drives the GPU run AND the oracle run, so an error
+    in it would cancel in their comparison): the error-state transition matrix F that ErrorStateKF::process
+    uses for the covariance (src/ErrorStateKF.cpp:99-110) must be the Jacobian of the nominal prediction it
+    performs on the state (:84-97) — perturb the state by an error vector, predict both, and compare the
+    resulting error with F times the perturbation, block by block."""
+    rng = np.random.default_rng(3)
+    kf = replay.ErrorStateKF(replay.DEFAULT_CONFIG, align=None)
+    base = kf.getStates()[0]
+    base.timestamp = 10.0
+    base.position = rng.normal(size=3)
+    base.velocity = rng.normal(size=3)
+    base.attitude = replay.rotation_vector_to_quat(np.array([0.3, -0.5, 0.8]))
+    base.biasAccel = 0.05 * rng.normal(size=3)
+    base.biasGyro = 0.01 * rng.normal(size=3)
+    dt = 1.0 / 400.0
+    imu = replay.ImuMeasurement(base.timestamp + dt, np.array([0.2, -0.4, 0.3]), np.array([0.5, -1.0, 9.6]))
+    kf.process(imu)
+    nominal = kf.getStates()[-1]
+    F = kf.F_x_.copy()
+    assert np.allclose(nominal.P, F @ base.P @ F.T + kf.F_i_ @ (kf.Q_ * np.r_[[dt * dt] * 6, [dt] * 6][:, None] *
+                                                                np.eye(12)) @ kf.F_i_.T)
+    eps = 1e-6
+    J = np.zeros((18, 18))
+    for k in range(18):
+        e = np.zeros(18)
+        e[k] = eps
+        other = replay.ErrorStateKF(replay.DEFAULT_CONFIG, align=None)
+        other.states_[0] = _inject(base, e)
+        other.process(imu)
+        J[:, k] = _error_between(nominal, other.getStates()[-1]) / eps
+    # F is first order in dt: the prediction's 0.5 a dt^2 terms (position <- attitude / biases / gravity) are not
+    # in it; everything else agrees to the finite-difference error
+    tol = np.full((18, 18), 2e-6)
+    tol[0:3, 6:18] = 0.5 * 12.0 * dt * dt + 2e-6
+    tol[3:6, 6:9] += 12.0 * dt * np.linalg.norm(imu.angularVelocity) * dt     # R(t + dt) vs R(t) in the velocity row
+    assert (np.abs(J - F) <= tol).all(), np.abs(J - F).max()
+    # and the blocks themselves (Sola's error-state kinematics): identities where states do not interact
+    assert np.allclose(F[0:3, 3:6], np.eye(3) * dt) and np.allclose(F[3:6, 15:18], np.eye(3) * dt)
+    assert np.allclose(F[6:9, 12:15], -np.eye(3) * dt) and np.allclose(F[9:18, 9:18], np.eye(9))
+
+
+def test_filter_update_moves_the_state_onto_a_trusted_observation():
+    """ErrorStateKF::update (src/ErrorStateKF.cpp:116-164): with the measurement noise far below the prior
+    covariance the posterior pose is the observed pose, the covariance of the observed states collapses to V,
+    unobserved ones shrink only through their correlations, P stays symmetric positive definite — properties
+    the restatement must have whatever `align` returns."""
+    rng = np.random.default_rng(4)
+    T_obs = synth.se3_to_SE3(np.array([0.3, -0.2, 0.1, 0.02, -0.03, 0.04]))
+    kf = replay.ErrorStateKF(replay.DEFAULT_CONFIG, align=lambda p, c, guess: T_obs)
+    kf.initialize(0.0)
+    for k in range(1, 41):                                            # 0.1 s of prediction so that P is full
+        kf.process(replay.ImuMeasurement(k / 400.0, 0.05 * rng.normal(size=3), np.array([0.0, 0.0, -9.805]) + 0.1 * rng.normal(size=3)))
+    prior = kf.getStates()[-1].copy()
+    lidar = replay.LidarMeasurement(np.zeros((1, 3)), np.array([0.1]))
+    lidar.covariances = np.zeros((1, 9))
+    lidar.endTime = 0.1
+    pose = kf.update(lidar)
+    post = [s for s in kf.getStates() if s.timestamp == 0.1][-1]
+    V = kf.V_
+    assert np.allclose(pose[:3, 3], T_obs[:3, 3], atol=1e-4) and np.abs(pose[:3, :3] - T_obs[:3, :3]).max() < 1e-4
+    assert np.allclose(post.P, post.P.T, atol=1e-12) and np.all(np.linalg.eigvalsh(0.5 * (post.P + post.P.T)) > 0)
+    assert np.all(np.diag(post.P)[0:3] <= 1.01 * (np.diag(V)[0:3] + 1e-12) + 1e-9)          # observed: down to the noise
+    assert np.all(np.diag(post.P)[6:9] <= 1.01 * (np.diag(V)[3:6] + 1e-12) + 1e-9)
+    assert np.all(np.diag(post.P) <= np.diag(prior.P) * (1 + 1e-9) + 1e-12)                 # nothing grows in an update
+    # the gain is the textbook one: K = P H^T (H P H^T + V)^-1 reproduces the correction that was applied
+    S = kf.H_ @ prior.P @ kf.H_.T + V
+    K = prior.P @ kf.H_.T @ np.linalg.inv(S)
+    guess = prior.pose()
+    r = np.r_[T_obs[:3, 3] - guess[:3, 3], replay.rotation_matrix_to_vector(guess[:3, :3].T @ T_obs[:3, :3])]
+    assert np.allclose(post.velocity - prior.velocity, (K @ r)[3:6], atol=1e-12)
+
+
 def test_oracle_driven_replay_tracks_the_motion(stream, oracle_run, tmp_path):
     _, truth = stream
     traj, backend = oracle_run
