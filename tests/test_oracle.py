@@ -48,6 +48,93 @@ def test_k1_general_covariance_matches_dense_formula(oracle):
 
 
 # ---- K2: exact structured scan recovers the motion ------------------------------------------
+def test_k11_one_round_in_exact_rational_arithmetic(oracle):
+    """A pin that shares no floating-point code with the oracle or the numpy restatement: one round of the
+    path on a handful of correspondences evaluated with exact rationals (fractions.Fraction) — transform of the
+    point and R C R^T (Open3D), Sigma = R C R^T + C_voxel, its inverse by cofactors, J = [I | -[p]x],
+    J^T Sigma^-1 J and J^T Sigma^-1 (p - mu), summed (src/Registration.cpp:52-102) — on inputs that are exactly
+    representable, so the exact result is THE result and the oracle must reproduce it to rounding."""
+    from fractions import Fraction as Fr
+    rng = np.random.default_rng(11)
+    h = 0.5
+    n = 6
+    # a rotation with rational entries (Cayley transform of a small skew matrix), exact in Fractions; points,
+    # means and covariances on a dyadic grid
+    a, b, c = Fr(1, 8), Fr(-1, 16), Fr(3, 32)
+    A = [[Fr(0), -c, b], [c, Fr(0), -a], [-b, a, Fr(0)]]
+    eye = [[Fr(int(i == j)) for j in range(3)] for i in range(3)]
+
+    def mat(f):
+        return [[f(i, j) for j in range(3)] for i in range(3)]
+
+    def mul(X, Y):
+        return mat(lambda i, j: sum(X[i][k] * Y[k][j] for k in range(3)))
+
+    def inv(M):
+        cof = mat(lambda i, j: M[(i + 1) % 3][(j + 1) % 3] * M[(i + 2) % 3][(j + 2) % 3]
+                  - M[(i + 1) % 3][(j + 2) % 3] * M[(i + 2) % 3][(j + 1) % 3])
+        det = sum(M[0][j] * cof[0][j] for j in range(3))
+        return mat(lambda i, j: cof[j][i] / det)
+
+    R = mul(inv(mat(lambda i, j: eye[i][j] - A[i][j])), mat(lambda i, j: eye[i][j] + A[i][j]))   # (I - A)^-1 (I + A)
+    t = [Fr(1, 4), Fr(-1, 8), Fr(1, 16)]
+    Rf = np.array([[float(x) for x in row] for row in R])
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = Rf, [float(x) for x in t]
+    # the float rotation is not the exact rational one; rebuild the exact inputs FROM the floats the oracle gets
+    Rq = [[Fr(float(Rf[i, j])) for j in range(3)] for i in range(3)]
+    cells = rng.integers(-4, 5, size=(n, 3))
+    means = (cells + rng.integers(1, 8, size=(n, 3)) / 8.0) * h
+    pts_map = (cells + rng.integers(1, 8, size=(n, 3)) / 8.0) * h                   # where the points must land
+    def dyadic_spd():
+        L = np.tril(rng.integers(-3, 4, size=(3, 3)) / 4.0) + np.eye(3)
+        return L @ L.T
+    cov_v = np.array([dyadic_spd() for _ in range(n)])
+    cov_s = np.array([dyadic_spd() for _ in range(n)])
+    # source points: exact pre-images are not representable in general, so choose scan points on a dyadic grid
+    # and let the EXACT arithmetic tell where they land and whether they still hit the intended voxel
+    pts = rng.integers(-40, 41, size=(n, 3)) / 16.0
+    JTJ_x = [[Fr(0)] * 6 for _ in range(6)]
+    JTr_x = [Fr(0)] * 6
+    keep_means, count = [], 0
+    om = oracle.OracleMap(h, 1)
+    used = set()
+    for i in range(n):
+        p = [Fr(float(v)) for v in pts[i]]
+        q = [sum(Rq[r][k] * p[k] for k in range(3)) + Fr(float(T[r, 3])) for r in range(3)]
+        key = tuple(int(np.floor(float(qq) / h)) for qq in q)
+        if key in used:
+            continue
+        used.add(key)
+        mu = [(Fr(key[r]) + Fr(int(rng.integers(1, 8)), 8)) * Fr(h) for r in range(3)]   # a voxel mean inside that voxel
+        keep_means.append(([float(m) for m in mu], cov_v[i].T.reshape(9)))
+        C = [[Fr(float(cov_s[i][r][k])) for k in range(3)] for r in range(3)]
+        Cv = [[Fr(float(cov_v[i][r][k])) for k in range(3)] for r in range(3)]
+        Rt = mat(lambda r, k: Rq[k][r])
+        S = mul(mul(Rq, C), Rt)
+        S = mat(lambda r, k: S[r][k] + Cv[r][k])
+        W = inv(S)
+        J = [[Fr(int(r == k)) for k in range(3)] + [Fr(0)] * 3 for r in range(3)]
+        J[0][4], J[0][5] = q[2], -q[1]                                   # -[q]x
+        J[1][3], J[1][5] = -q[2], q[0]
+        J[2][3], J[2][4] = q[1], -q[0]
+        e = [q[r] - mu[r] for r in range(3)]
+        JT_W = [[sum(J[k][r] * W[k][cidx] for k in range(3)) for cidx in range(3)] for r in range(6)]
+        for r in range(6):
+            JTr_x[r] += sum(JT_W[r][k] * e[k] for k in range(3))
+            for cc in range(6):
+                JTJ_x[r][cc] += sum(JT_W[r][k] * J[k][cc] for k in range(3))
+        count += 1
+    om.insert(np.array([m for m, _ in keep_means]), np.array([cv for _, cv in keep_means]))
+    tp, tc = oracle.transform(pts, cov_s.transpose(0, 2, 1).reshape(n, 9), T)
+    JTJ, JTr, m = om.accumulate(tp, tc)
+    assert m == count >= 4
+    exact_J = np.array([[float(x) for x in row] for row in JTJ_x])
+    exact_r = np.array([float(x) for x in JTr_x])
+    assert np.allclose(JTJ, exact_J, rtol=1e-12, atol=1e-12 * np.abs(exact_J).max())
+    assert np.allclose(JTr, exact_r, rtol=1e-11, atol=1e-12 * np.abs(exact_J).max())
+
+
 def test_k2_noise_free_structured_scan_recovers_pose(oracle):
     vmap = synth.make_map(4_000, seed=11)
     pts, covs, T_true = synth.make_structured_scan(1_500, vmap, seed=12, noise=0.0)
