@@ -115,6 +115,7 @@ struct vgicp_ctx {
   int iter_block = 512;           // threads per workgroup of the iteration kernel (measured best at C2)
   double* d_log = nullptr;
   double* h_log = nullptr;  // pinned
+  double* h_log_dev = nullptr;  // the same memory as the device addresses it (the persistent launch writes state + log there)
   int log_capacity = 0;     // iterations
   uint64_t* d_stamps = nullptr;  // only with VGICP_DEBUG_STAMPS=1
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -226,8 +227,11 @@ int ensure_log(vgicp_ctx* ctx, int iterations) {
   VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), (size_t)(cap + 1) * kSlots * sizeof(double)));
   VG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&h), (size_t)(cap + 1) * kSlots * sizeof(double), 0));
   VG_HIP(ctx, hipMemset(d, 0, kSlots * sizeof(double)));
+  void* hd = nullptr;
+  VG_HIP(ctx, hipHostGetDevicePointer(&hd, h, 0));
   ctx->d_log = d + kSlots;
   ctx->h_log = h + kSlots;
+  ctx->h_log_dev = static_cast<double*>(hd) + kSlots;
   ctx->log_capacity = cap;
   return VGICP_OK;
 }
@@ -367,8 +371,10 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.parts = ctx->d_parts_persist;
   a.exit_counter = ctx->d_sync;
   a.exit_base = ctx->persist_exit_base;
-  a.state = reinterpret_cast<AlignState*>(ctx->d_log - kSlots);
-  a.log = ctx->d_log;
+  // final state and per-round log go straight into pinned host memory (posted PCIe writes, 5.4 KB per align):
+  // no copy-back to enqueue after the launch
+  a.state = reinterpret_cast<AlignState*>(ctx->h_log_dev - kSlots);
+  a.log = ctx->h_log_dev;
   // between GPUs the ranks' host threads reach the launch at slightly different times: a rank waits much longer
   // for a peer (~1 s) than for a workgroup of its own device (~50 ms) before it gives up
   a.spin_limit = (ctx->peers_connected && ctx->peer_world > 1) ? ctx->persist_spin_limit * 20u : ctx->persist_spin_limit;
@@ -387,12 +393,10 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.rank = multi ? (uint32_t)ctx->peer_rank : 0u;
   a.mail = ctx->d_mail_table;
   a.mail_round0 = ctx->mail_round0;
-  // one launch, one copy back (state header + the log rows), one synchronisation
+  // one launch, one synchronisation
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
   VG_HIP(ctx, launch_persistent(ctx->stream, a, grid));
   VG_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(ctx->h_log - kSlots, ctx->d_log - kSlots,
-                             (size_t)(max_it + 1) * kSlots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   VG_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_begin, ctx->ev_end));
   std::memcpy(result, ctx->h_log - kSlots, sizeof(AlignState));
