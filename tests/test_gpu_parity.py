@@ -293,6 +293,32 @@ def test_persistent_exchange_survives_uneven_load_and_every_exit_round(gpu_ctx, 
         assert a.converged and a.iterations == 3 and a.launches == 1 and b.launches == 1
 
 
+@pytest.mark.parametrize("grid", [1, 5, 16, 17, 100, 255])
+def test_persistent_launch_on_fewer_workgroups(c1_inputs, monkeypatch, grid):
+    """The persistent launch on a part of the device (VGICP_PERSIST_GRID: contexts of several processes sharing
+    one GPU, or a partitioned one): fewer workgroups than exchange rows, fewer than folders, one more than
+    folders; scans that fit the grid and scans that give every thread several points. Same counts as the
+    per-launch loop, sums equal to rounding (the partition of the points differs), run to run the same bits."""
+    from eskf_lio_amd import capi, synth
+    vmap, pts, covs = c1_inputs
+    g = synth.default_guess()
+    monkeypatch.setenv("VGICP_PERSIST_GRID", str(grid))
+    with capi.Context(0) as ctx:
+        monkeypatch.delenv("VGICP_PERSIST_GRID")
+        ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+        ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+        for n in (1, 300, 5_000):
+            for rounds in (1, 4, 7):
+                a = ctx.align(pts[:n], covs[:n], g, rounds, 1e-6, 2.0, allow_degenerate=True)
+                b = ctx.align(pts[:n], covs[:n], g, rounds, 1e-6, 2.0, flags=capi.FLAG_NO_PERSISTENT, allow_degenerate=True)
+                again = ctx.align(pts[:n], covs[:n], g, rounds, 1e-6, 2.0, allow_degenerate=True)
+                assert a.launches == 1 and b.launches > 1
+                assert np.array_equal(a.corr_count, b.corr_count)
+                assert np.allclose(a.normal_eq, b.normal_eq, rtol=1e-11, atol=1e-9)
+                assert np.array_equal(a.normal_eq, again.normal_eq) and np.array_equal(a.pose, again.pose, equal_nan=True)
+        assert ctx.counter(1) == 0
+
+
 def test_persistent_launch_that_gives_up_falls_back_and_recovers(c1_inputs, monkeypatch):
     """A persistent launch whose in-kernel wait runs out (forced here with a poll budget of zero; in the field:
     another process holds compute units) must leave no trace: the align is re-run with one launch per
