@@ -124,8 +124,8 @@ def cpu_baseline(vmap, pts, covs, guess, budget_s: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)      # 500 x 0.37 ms: a timed region long enough to be seen
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C2", choices=sorted(synth.CONFIGS))
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
