@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(synth.CONFIGS))
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the secondary C5 (1M points / 10M voxels) leg")
     ap.add_argument("--resident", action="store_true",
                     help="time vgicp_align_resident (scan already in HBM) as the step: profiling aid, the JSON "
                          "line then says so in config.workload")
@@ -181,7 +182,10 @@ def main():
         return ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
 
     def timed(step, steps):
+        import gc
         fence()
+        gc.collect()
+        gc.disable()                  # no collector pauses of the host language inside the timed region
         t0 = time.perf_counter()
         dev_s, res = 0.0, None
         for _ in range(steps):
@@ -189,6 +193,7 @@ def main():
             dev_s += res.device_seconds
         fence()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -338,6 +343,40 @@ def main():
             }
     if solo is not None:
         solo.close()
+        solo = None
+
+    # Secondary leg (never `value`): BASELINE config C5 — 1M-point scan vs 10M-voxel map, the bandwidth regime —
+    # on the same ranks: the scan point-sharded, the map replicated, scan resident, 20 forced rounds per align.
+    # On one GPU this puts the C5 figures into the same record as the headline; on N GPUs it is the curve of the
+    # regime that sharding is for.  Any failure is reported in the field, never raised.
+    c5 = None
+    if args.config == "C2" and not args.no_c5:
+        try:
+            n5, v5 = synth.CONFIGS["C5"]
+            map5 = synth.make_map(v5)
+            pts5, covs5 = synth.make_uniform_scan(n5, map5)
+            lo5, hi5 = shard_bounds(n5, world, rank)
+            ctx.map_reset(map5.voxel_size, v5)
+            ctx.map_upsert(map5.keys, map5.means, map5.covs)
+            ctx.scan_upload(np.ascontiguousarray(pts5[lo5:hi5]), np.ascontiguousarray(covs5[lo5:hi5]))
+            del map5, pts5, covs5
+            for _ in range(3):
+                r5 = step_resident()
+            steps5 = 10
+            el5, dev5, r5 = timed(step_resident, steps5)
+            per_rank_bytes = algorithmic_bytes(hi5 - lo5, float(r5.corr_count.mean()) / world) * ITERATIONS
+            launches5 = r5.launches
+            c5 = {"value": n5 * ITERATIONS * steps5 / el5, "unit": "points/s", "ms_per_step": el5 / steps5 * 1e3,
+                  "us_per_round": dev5 / steps5 / ITERATIONS * 1e6,
+                  "achieved_GBs_per_gpu": per_rank_bytes / (dev5 / steps5) / 1e9,
+                  "frac_of_8TBs_per_gpu": per_rank_bytes / (dev5 / steps5) / 1e9 / HBM_PEAK_GBS,
+                  "single_launch": launches5 == 1, "matches_per_iteration": float(r5.corr_count.mean()),
+                  "workload": f"C5: {n5}-pt scan vs {v5}-voxel map, {ITERATIONS} rounds per align, scan resident, "
+                              f"point-sharded over {world} rank(s); algorithmic bytes of a rank / its event span"}
+        except Exception as e:  # noqa: BLE001 - reported in the JSON line
+            c5 = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0 and out is not None:
+            out["c5_resident"] = c5
     ctx.close()
     if use_dist:
         dist.barrier()

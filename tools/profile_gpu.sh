@@ -10,7 +10,7 @@ TAG=${1:-r01}; shift || true
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="--steps 30 --warmup 3 --no-cpu-baseline $*"
+ARGS="--steps 30 --warmup 3 --no-cpu-baseline --no-c5 $*"
 python3 bench.py $ARGS > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
