@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   // every lane brings one candidate (valid, d, id, j); the passing ones are inserted one after the other
   auto offer = [&](bool valid, double d, uint32_t id, uint32_t j) {
     ++batches;
-    bool pass = valid && d <= bound && (found < K || d < kth || (d == kth && id < kth_id));
+    const bool pass = valid & (d <= bound) & ((found < K) | (d < kth) | ((d == kth) & (id < kth_id)));
     unsigned long long todo = __ballot(pass);
     while (todo) {
       const int src = __builtin_ctzll(todo);
@@ -294,12 +294,16 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
       const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)j, src);
       if (found == K && !(cd < kth || (cd == kth && ci < kth_id))) continue;  // the list moved on
-      const bool less = lane < found && (ld < cd || (ld == cd && li < ci));
+      // branch-free on purpose (bitwise & | on the lane masks, selects): with short-circuit && || the compiler
+      // emits a nest of exec-mask saves and branches per insertion, and this kernel is bound by instruction issue
+      const bool less = (lane < found) & ((ld < cd) | ((ld == cd) & (li < ci)));
       const int p = __builtin_popcountll(__ballot(less));
       const double ud = lane_below_f64(ld);
       const uint32_t ui = (uint32_t)lane_below_i32((int)li), uj = (uint32_t)lane_below_i32((int)lj);
-      if (lane == p) { ld = cd; li = ci; lj = cj; }
-      else if (lane > p) { ld = ud; li = ui; lj = uj; }
+      const bool here = lane == p, above = lane > p;
+      ld = here ? cd : (above ? ud : ld);
+      li = here ? ci : (above ? ui : li);
+      lj = here ? cj : (above ? uj : lj);
       if (found < K) ++found;
       if (found == K) {
         kth = readlane_f64(ld, K - 1);
