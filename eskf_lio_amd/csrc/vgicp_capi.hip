@@ -74,7 +74,7 @@ struct vgicp_ctx {
   uint64_t slots = 0;
   uint64_t voxels = 0;      // FULL records
   uint64_t tombstones = 0;
-  uint32_t* d_counters = nullptr;  // 8 words
+  uint32_t* d_counters = nullptr;  // 8 words + 64 of developer histograms (VGICP_DEBUG_PREP=2)
   uint32_t* h_counters = nullptr;  // pinned
 
   // batch staging (upsert / erase / hooks)
@@ -622,8 +622,8 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   } while (0)
   VG_CREATE(hipSetDevice(device_id));
   VG_CREATE(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), 8 * sizeof(uint32_t)));
-  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), 8 * sizeof(uint32_t), 0));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), 72 * sizeof(uint32_t)));
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), 72 * sizeof(uint32_t), 0));
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_state), 2 * sizeof(AlignState)));
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state),
                           (1 + kMaxChunksInFlight) * sizeof(AlignState), 0));
@@ -1177,7 +1177,7 @@ int ensure_cells(vgicp_ctx* ctx, size_t need) {
 int preprocess_on_device(vgicp_ctx* ctx, const double* d_pts, size_t n, double voxel_size, int knn, void* scratch,
                          size_t capacity, double* d_out_pts, double* d_out_covs, unsigned long long* d_out_idx,
                          uint32_t* kept) {
-  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 72 * sizeof(uint32_t), ctx->stream));
   VG_HIP(ctx, launch_preprocess_sort(ctx->stream, d_pts, (uint32_t)n, voxel_size, scratch, ctx->d_counters));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1195,8 +1195,15 @@ int preprocess_on_device(vgicp_ctx* ctx, const double* d_pts, size_t n, double v
   VG_HIP(ctx, launch_preprocess_finish(ctx->stream, d_pts, (uint32_t)n, voxel_size, knn, m, scratch, ctx->d_cells,
                                        entries, d_out_pts, d_out_covs, d_out_idx, ctx->d_counters, debug));
   if (debug) {
-    VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 72 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (debug >= 2) {
+      std::fprintf(stderr, "[vgicp prep] queries by cells taken (buckets of 8):");
+      for (int i = 0; i < 32; ++i) std::fprintf(stderr, " %u", ctx->h_counters[8 + i]);
+      std::fprintf(stderr, "\n[vgicp prep] queries by time in the search (buckets of 8 us):");
+      for (int i = 0; i < 32; ++i) std::fprintf(stderr, " %u", ctx->h_counters[40 + i]);
+      std::fprintf(stderr, "\n");
+    }
     std::fprintf(stderr, "[vgicp prep] kept %u cells %u queries that spilled %u | point batches total %u (%.1f/query) max %u | cells taken total %u (%.1f/query) max %u | queries starting above the voxel level: %u\n",
                  m, cells, ctx->h_counters[2], ctx->h_counters[3], ctx->h_counters[3] / (double)(m ? m : 1), ctx->h_counters[4],
                  ctx->h_counters[5], ctx->h_counters[5] / (double)(m ? m : 1), ctx->h_counters[6], ctx->h_counters[7]);

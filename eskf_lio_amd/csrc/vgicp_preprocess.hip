@@ -219,6 +219,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  return ((unsigned long long)uniform_u32((uint32_t)(v >> 32)) << 32) | uniform_u32((uint32_t)v);
+}
 // value of the lane below (lane 0 keeps its own)
 // DPP wave_shr:1 (GFX9): one VALU move, no trip through the LDS crossbar
 __device__ __forceinline__ int lane_below_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   const double qx = uniform_f64(spts[3 * (size_t)qj]), qy = uniform_f64(spts[3 * (size_t)qj + 1]),
                qz = uniform_f64(spts[3 * (size_t)qj + 2]);
   const int K = knn < (int)n ? knn : (int)n;
+  const uint64_t t_begin = debug >= 2 ? wall_clock64() : 0;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
   // the k-list: lane l < found holds the l-th nearest so far
@@ -294,16 +298,33 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
       const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)j, src);
       if (found == K && !(cd < kth || (cd == kth && ci < kth_id))) continue;  // the list moved on
-      // branch-free on purpose (bitwise & | on the lane masks, selects): with short-circuit && || the compiler
-      // emits a nest of exec-mask saves and branches per insertion, and this kernel is bound by instruction issue
+      // branch-free on purpose (bitwise & | on the lane masks): with short-circuit && || the compiler emits a nest
+      // of exec-mask saves and branches per insertion, and this kernel is bound by instruction issue
       const bool less = (lane < found) & ((ld < cd) | ((ld == cd) & (li < ci)));
       const int p = __builtin_popcountll(__ballot(less));
-      const double ud = lane_below_f64(ld);
-      const uint32_t ui = (uint32_t)lane_below_i32((int)li), uj = (uint32_t)lane_below_i32((int)lj);
-      const bool here = lane == p, above = lane > p;
-      ld = here ? cd : (above ? ud : ld);
-      li = here ? ci : (above ? ui : li);
-      lj = here ? cj : (above ? uj : lj);
+      // lanes above p take the entry of the lane below (one DPP select per dword, lanes <= p keep theirs), then
+      // lane p is overwritten from the scalar registers (v_writelane): 9 VALU instructions for the whole shift-and-insert
+      uint32_t lo = (uint32_t)__double_as_longlong(ld), hi = (uint32_t)((unsigned long long)__double_as_longlong(ld) >> 32);
+      const unsigned long long cbits = (unsigned long long)__double_as_longlong(cd);
+      uint32_t m0_saved;
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_cmp_ge_u32_e32 vcc, %5, %6\n\t"
+          "s_mov_b32 %4, m0\n\t"
+          "s_mov_b32 m0, %5\n\t"
+          "v_cndmask_b32_dpp %0, %0, %0, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+          "v_cndmask_b32_dpp %1, %1, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+          "v_cndmask_b32_dpp %2, %2, %2, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+          "v_cndmask_b32_dpp %3, %3, %3, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+          "v_writelane_b32 %0, %7, m0\n\t"
+          "v_writelane_b32 %1, %8, m0\n\t"
+          "v_writelane_b32 %2, %9, m0\n\t"
+          "v_writelane_b32 %3, %10, m0\n\t"
+          "s_mov_b32 m0, %4"
+          : "+v"(lo), "+v"(hi), "+v"(li), "+v"(lj), "=&s"(m0_saved)
+          : "s"(p), "v"(lane), "s"((uint32_t)cbits), "s"((uint32_t)(cbits >> 32)), "s"(ci), "s"(cj)
+          : "vcc");
+      ld = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
       if (found < K) ++found;
       if (found == K) {
         kth = readlane_f64(ld, K - 1);
@@ -311,18 +332,22 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       }
     }
   };
-  // squared distance from the query to the cell (level l, Morton key mk), deflated so that the rounding
-  // between floor(p / fine) and k * fine can never hide a cell
-  auto cell_d2 = [&](int l, unsigned long long mk) {
+  // squared distance from the query to the cell (x, y, z) of level l, deflated so that the rounding between
+  // floor(p / fine) and k * fine can never hide a cell
+  auto cell_d2 = [&](int l, uint32_t x, uint32_t y, uint32_t z) {
     const double size = fine * (double)(1u << l);
-    const double lx = (double)((long long)((unsigned long long)compact21(mk) << l) - kCoordOffset) * fine;
-    const double ly = (double)((long long)((unsigned long long)compact21(mk >> 1) << l) - kCoordOffset) * fine;
-    const double lz = (double)((long long)((unsigned long long)compact21(mk >> 2) << l) - kCoordOffset) * fine;
+    const double lx = (double)((int)(x << l) - kCoordOffset) * fine;
+    const double ly = (double)((int)(y << l) - kCoordOffset) * fine;
+    const double lz = (double)((int)(z << l) - kCoordOffset) * fine;
     const double ex = fmax(fmax(lx - qx, qx - (lx + size)), 0.0);
     const double ey = fmax(fmax(ly - qy, qy - (ly + size)), 0.0);
     const double ez = fmax(fmax(lz - qz, qz - (lz + size)), 0.0);
     return (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-9);
   };
+  // where lane's child sits inside its parent: the lane number is the child's Morton digits (z y x per level)
+  const uint32_t ox1 = (uint32_t)lane & 1u, oy1 = ((uint32_t)lane >> 1) & 1u, oz1 = ((uint32_t)lane >> 2) & 1u;
+  const uint32_t ox2 = ox1 | (((uint32_t)lane >> 2) & 2u), oy2 = oy1 | (((uint32_t)lane >> 3) & 2u),
+                 oz2 = oz1 | (((uint32_t)lane >> 4) & 2u);
   int waiting = 0;
   // drop the waiting cells that the k-th distance has overtaken since they were pushed
   auto compact = [&]() {
@@ -400,7 +425,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
         mk = morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
         const CellEntry* e = find_cell(table, mask, cell_key(mk, level));
         want = e != nullptr;
-        if (e) { start = e->start; end = e->end; d2 = cell_d2(level, mk); want = d2 <= bound; }
+        if (e) { start = e->start; end = e->end; d2 = cell_d2(level, (uint32_t)x, (uint32_t)y, (uint32_t)z); want = d2 <= bound; }
       }
       push(want, d2, cell_key(mk, level), start, end);
     }
@@ -412,17 +437,34 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
         const float d = pd[i];
         if (d < mine) { mine = d; at = i; }
       }
-      float least = mine;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) least = fminf(least, __shfl_xor(least, o, 64));
+      // the distances are non-negative floats: their bit patterns order as unsigned integers. Minimum of every
+      // row of 16 lanes with four DPP rotations, then of the four rows on the scalar unit: no LDS-crossbar shuffles
+      uint32_t mbits = __builtin_bit_cast(uint32_t, mine);
+      asm volatile(  // a DPP operand written by the instruction before needs two wait states
+          "s_nop 1\n\t"
+          "v_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 0"
+          : "+v"(mbits));
+      const uint32_t least_bits =
+          min(min((uint32_t)__builtin_amdgcn_readlane((int)mbits, 0), (uint32_t)__builtin_amdgcn_readlane((int)mbits, 16)),
+              min((uint32_t)__builtin_amdgcn_readlane((int)mbits, 32), (uint32_t)__builtin_amdgcn_readlane((int)mbits, 48)));
+      const float least = __builtin_bit_cast(float, least_bits);
       const int owner = __builtin_ctzll(__ballot(mine == least));   // the lowest lane holding the minimum
       at = __builtin_amdgcn_readlane(at, owner);
-      const double best = (double)__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, least)));
+      const double best = (double)least;
       const double limit = found == K ? fmin(bound, kth) : bound;
       if (best > limit) break;  // nothing left can hold one of the K nearest
       ++pops;
-      const unsigned long long key = pk[at];
-      const uint32_t start = ps[at], end = pe[at];
+      // every lane reads the same entry; telling the compiler so (readfirstlane) keeps the list length, the k-th
+      // distance and all the loop control below in scalar registers instead of under exec masks
+      const unsigned long long key = uniform_u64(pk[at]);
+      const uint32_t start = uniform_u32(ps[at]), end = uniform_u32(pe[at]);
       --waiting;
       if (at != waiting) {  // every lane moves the same entry: a benign same-value write
         pd[at] = pd[waiting];
@@ -437,6 +479,10 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
         const int step = l >= 2 ? 2 : 1;
         const int fan = 1 << (3 * step);
         const unsigned long long cm = (mk << (3 * step)) | (unsigned long long)lane;
+        // the parent's coordinates come out of its (wave-uniform) key on the scalar unit
+        const uint32_t px = compact21(mk), py = compact21(mk >> 1), pz = compact21(mk >> 2);
+        const uint32_t chx = (px << step) | (step == 2 ? ox2 : ox1), chy = (py << step) | (step == 2 ? oy2 : oy1),
+                       chz = (pz << step) | (step == 2 ? oz2 : oz1);
         bool want = lane < fan;
         double d2 = 0.0;
         uint32_t cs = 0, ce = 0;
@@ -446,7 +492,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
           if (e) {
             cs = e->start;
             ce = e->end;
-            d2 = cell_d2(l - step, cm);
+            d2 = cell_d2(l - step, chx, chy, chz);
             want = d2 <= limit;
           }
         }
@@ -492,6 +538,11 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       atomicAdd(&counters[5], pops);
       atomicMax(&counters[6], pops);
       if (level > kFineShift) atomicAdd(&counters[7], 1u);
+      if (debug >= 2) {  // developer histograms: cells taken, and wall time of this query (100 MHz clock)
+        atomicAdd(&counters[8 + (pops / 8u < 31u ? pops / 8u : 31u)], 1u);
+        const uint32_t us8 = (uint32_t)((wall_clock64() - t_begin) / 800u);
+        atomicAdd(&counters[40 + (us8 < 31u ? us8 : 31u)], 1u);
+      }
     }
   }
 }
