@@ -83,9 +83,11 @@ __device__ __forceinline__ uint32_t cell_coord(double v, double fine) {
 __device__ __forceinline__ unsigned long long cell_key(unsigned long long morton_at_level, int level) {
   return ((unsigned long long)level << 60) | morton_at_level;
 }
+// 32-bit multiplies only (three; a 64-bit mixer costs eight, and integer multiplies run at quarter rate)
 __device__ __forceinline__ uint32_t cell_hash(unsigned long long key) {
-  key ^= key >> 33; key *= 0xFF51AFD7ED558CCDull; key ^= key >> 33; key *= 0xC4CEB9FE1A85EC53ull; key ^= key >> 33;
-  return (uint32_t)key;
+  uint32_t h = (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA77u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+  return h;
 }
 
 // A finite coordinate whose finest cell lies outside the 2^20 cells per axis the Morton codes span (+-2^17
@@ -259,37 +261,64 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
                qz = uniform_f64(spts[3 * (size_t)qj + 2]);
   const int K = knn < (int)n ? knn : (int)n;
   const uint64_t t_begin = debug >= 2 ? wall_clock64() : 0;
+#ifdef VGICP_PREP_TRACE
+  const uint64_t t_trace = wall_clock64();
+#endif
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-  // the k-list: lane l < found holds the l-th nearest so far
-  double ld = INFINITY;
-  uint32_t li = 0xFFFFFFFFu, lj = 0;
-  int found = 0;
-  double kth = INFINITY;
-  uint32_t kth_id = 0xFFFFFFFFu;
   uint32_t batches = 0, pops = 0, spills = 0;
+  const unsigned long long list_lanes = K >= 64 ? ~0ull : (1ull << K) - 1ull;
 
   auto dist2 = [&](uint32_t j) {
     const double dx = spts[3 * (size_t)j] - qx, dy = spts[3 * (size_t)j + 1] - qy, dz = spts[3 * (size_t)j + 2] - qz;
     return dx * dx + dy * dy + dz * dz;
   };
-  // Seed: K consecutive points of the sorted order around the query are real points, so the farthest of
-  // them bounds the k-th distance from above.
-  double bound;
+  // The k-list: lane l < K holds the l-th nearest so far, by (distance, index). It starts FULL: K consecutive
+  // points of the sorted order around the query (w0 .. w0 + K - 1) are real points and usually near ones, so
+  // the farthest of them bounds the k-th distance from above and most of them are never displaced. The search
+  // below skips them when it meets them again.
+  const uint32_t half = (uint32_t)K / 2;
+  uint32_t w0 = qj > half ? qj - half : 0;
+  if (w0 + (uint32_t)K > n) w0 = n - (uint32_t)K;
+  double ld = INFINITY;
+  uint32_t li = 0xFFFFFFFFu, lj = 0;
   {
-    const uint32_t half = (uint32_t)K / 2;
-    uint32_t w0 = qj > half ? qj - half : 0;
-    if (w0 + (uint32_t)K > n) w0 = n - (uint32_t)K;
-    double d = lane < K ? dist2(w0 + (uint32_t)lane) : 0.0;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) d = fmax(d, __shfl_xor(d, o, 64));
-    bound = uniform_f64(d);
+    const bool mine = lane < K;
+    double d = mine ? dist2(w0 + (uint32_t)lane) : INFINITY;
+    if (!(d < INFINITY)) d = INFINITY;  // a NaN / infinite point is a placeholder that everything finite displaces
+    const uint32_t id = mine ? sorted_idx[w0 + (uint32_t)lane] : 0xFFFFFFFFu;
+    // rank of every seed among the seeds (all distinct by index), then one trip through this wave's (still
+    // empty) pool to put lane l's entry into lane rank(l)
+    uint32_t rank = 0;
+    for (int s = 0; s < K; ++s) {
+      const double sd = readlane_f64(d, s);
+      const uint32_t si = (uint32_t)__builtin_amdgcn_readlane((int)id, s);
+      rank += ((sd < d) | ((sd == d) & (si < id))) ? 1u : 0u;
+    }
+    if (mine) {
+      pk[rank] = (unsigned long long)__double_as_longlong(d);
+      ps[rank] = id;
+      pe[rank] = w0 + (uint32_t)lane;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (mine) {
+      ld = __longlong_as_double((long long)pk[lane]);
+      li = ps[lane];
+      lj = pe[lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+  double kth = readlane_f64(ld, K - 1);
+  uint32_t kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
+  double bound = kth;
 
   // every lane brings one candidate (valid, d, id, j); the passing ones are inserted one after the other
   auto offer = [&](bool valid, double d, uint32_t id, uint32_t j) {
     ++batches;
-    const bool pass = valid & (d <= bound) & ((found < K) | (d < kth) | ((d == kth) & (id < kth_id)));
+    const bool pass = valid & (j - w0 >= (uint32_t)K) & (d <= bound) & ((d < kth) | ((d == kth) & (id < kth_id)));
     unsigned long long todo = __ballot(pass);
     while (todo) {
       const int src = __builtin_ctzll(todo);
@@ -297,13 +326,16 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       const double cd = readlane_f64(d, src);
       const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
       const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)j, src);
-      if (found == K && !(cd < kth || (cd == kth && ci < kth_id))) continue;  // the list moved on
-      // branch-free on purpose (bitwise & | on the lane masks): with short-circuit && || the compiler emits a nest
-      // of exec-mask saves and branches per insertion, and this kernel is bound by instruction issue
-      const bool less = (lane < found) & ((ld < cd) | ((ld == cd) & (li < ci)));
-      const int p = __builtin_popcountll(__ballot(less));
+      // how many entries come before the candidate (scalar mask arithmetic; equal distances are rare and take
+      // the uniform branch). Lanes >= K hold whatever was pushed out and are masked off.
+      unsigned long long before = __ballot(ld < cd);
+      const unsigned long long same = __ballot(ld == cd) & list_lanes;
+      if (same) before |= same & __ballot(li < ci);
+      const int p = __builtin_popcountll(before & list_lanes);
+      if (p >= K) continue;  // the list moved on since the batch was filtered
       // lanes above p take the entry of the lane below (one DPP select per dword, lanes <= p keep theirs), then
-      // lane p is overwritten from the scalar registers (v_writelane): 9 VALU instructions for the whole shift-and-insert
+      // lane p is overwritten from the scalar registers (v_writelane): 9 VALU instructions for the whole
+      // shift-and-insert. (A DPP operand written by the instruction before needs two wait states: s_nop 1.)
       uint32_t lo = (uint32_t)__double_as_longlong(ld), hi = (uint32_t)((unsigned long long)__double_as_longlong(ld) >> 32);
       const unsigned long long cbits = (unsigned long long)__double_as_longlong(cd);
       uint32_t m0_saved;
@@ -325,11 +357,8 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
           : "s"(p), "v"(lane), "s"((uint32_t)cbits), "s"((uint32_t)(cbits >> 32)), "s"(ci), "s"(cj)
           : "vcc");
       ld = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-      if (found < K) ++found;
-      if (found == K) {
-        kth = readlane_f64(ld, K - 1);
-        kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
-      }
+      kth = readlane_f64(ld, K - 1);
+      kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
     }
   };
   // squared distance from the query to the cell (x, y, z) of level l, deflated so that the rounding between
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   int waiting = 0;
   // drop the waiting cells that the k-th distance has overtaken since they were pushed
   auto compact = [&]() {
-    const double limit = found == K ? fmin(bound, kth) : bound;
+    const double limit = fmin(bound, kth);
     int kept = 0;
     for (int base = 0; base < waiting; base += 64) {
       const int i = base + lane;
@@ -458,7 +487,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       const int owner = __builtin_ctzll(__ballot(mine == least));   // the lowest lane holding the minimum
       at = __builtin_amdgcn_readlane(at, owner);
       const double best = (double)least;
-      const double limit = found == K ? fmin(bound, kth) : bound;
+      const double limit = fmin(bound, kth);
       if (best > limit) break;  // nothing left can hold one of the K nearest
       ++pops;
       // every lane reads the same entry; telling the compiler so (readfirstlane) keeps the list length, the k-th
@@ -532,6 +561,13 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   if (lane == 0) {
     out_pts[3 * (size_t)o] = qx; out_pts[3 * (size_t)o + 1] = qy; out_pts[3 * (size_t)o + 2] = qz;
     out_idx[o] = qi;
+#ifdef VGICP_PREP_TRACE  // developer build only (tools/ab_build.sh trace -DVGICP_PREP_TRACE): the index output carries a trace record
+    {
+      const uint64_t t_end = wall_clock64();
+      uint64_t dt = t_end - t_trace; if (dt > 0xFFFFFu) dt = 0xFFFFFu;
+      out_idx[o] = (dt << 44) | ((uint64_t)(pops > 1023u ? 1023u : pops) << 34) | ((uint64_t)(level & 15) << 30) | ((t_trace / 10u) & 0x3FFFFFFFu);
+    }
+#endif
     if (debug) {
       atomicAdd(&counters[3], batches);
       atomicMax(&counters[4], batches);
