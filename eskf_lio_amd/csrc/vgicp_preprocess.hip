@@ -251,10 +251,18 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   const uint32_t slot_in_xcd = (blockIdx.x / kXcds) * (kSearchBlock / 64) + wave;
   const uint32_t qrank = (blockIdx.x % kXcds) * per_xcd + slot_in_xcd;
   if (slot_in_xcd >= per_xcd || qrank >= m) return;  // whole waves leave; nothing below synchronises across waves
-  volatile float* pd = pool_d[wave];
-  volatile unsigned long long* pk = pool_key[wave];
-  volatile uint32_t* ps = pool_start[wave];
-  volatile uint32_t* pe = pool_end[wave];
+  // The pool is this wave's own: its lanes exchange entries through it, and a wave's LDS instructions execute in
+  // order. Plain LDS pointers (ds_read / ds_write) with a wave-scope fence wherever one lane reads what another
+  // wrote -- NOT volatile: that turns every access into a flat load with its own full wait.
+  float* pd = pool_d[wave];
+  unsigned long long* pk = pool_key[wave];
+  uint32_t* ps = pool_start[wave];
+  uint32_t* pe = pool_end[wave];
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   const double fine = h / (double)(1 << kFineShift);
   const uint32_t qj = uniform_u32(queries[qrank]);
   const double qx = uniform_f64(spts[3 * (size_t)qj]), qy = uniform_f64(spts[3 * (size_t)qj + 1]),
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
 #endif
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-  uint32_t batches = 0, pops = 0, spills = 0;
+  uint32_t batches = 0, pops = 0, spills = 0, inserts = 0;
   const unsigned long long list_lanes = K >= 64 ? ~0ull : (1ull << K) - 1ull;
 
   auto dist2 = [&](uint32_t j) {
@@ -300,16 +308,13 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       ps[rank] = id;
       pe[rank] = w0 + (uint32_t)lane;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_sync();
     if (mine) {
       ld = __longlong_as_double((long long)pk[lane]);
       li = ps[lane];
       lj = pe[lane];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
   }
   double kth = readlane_f64(ld, K - 1);
   uint32_t kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       if (same) before |= same & __ballot(li < ci);
       const int p = __builtin_popcountll(before & list_lanes);
       if (p >= K) continue;  // the list moved on since the batch was filtered
+      ++inserts;
       // lanes above p take the entry of the lane below (one DPP select per dword, lanes <= p keep theirs), then
       // lane p is overwritten from the scalar registers (v_writelane): 9 VALU instructions for the whole
       // shift-and-insert. (A DPP operand written by the instruction before needs two wait states: s_nop 1.)
@@ -459,6 +465,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       push(want, d2, cell_key(mk, level), start, end);
     }
     while (waiting > 0) {
+      wave_sync();  // what the lanes pushed, moved or compacted in the turn before
       // the nearest waiting cell
       float mine = INFINITY;
       int at = 0;
@@ -501,6 +508,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
         ps[at] = ps[waiting];
         pe[at] = pe[waiting];
       }
+      wave_sync();
       const int l = (int)(key >> 60);
       const unsigned long long mk = key & kKeyMask;
       bool measure = l == 0 || end - start <= 64u;
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     {
       const uint64_t t_end = wall_clock64();
       uint64_t dt = t_end - t_trace; if (dt > 0xFFFFFu) dt = 0xFFFFFu;
-      out_idx[o] = (dt << 44) | ((uint64_t)(pops > 1023u ? 1023u : pops) << 34) | ((uint64_t)(level & 15) << 30) | ((t_trace / 10u) & 0x3FFFFFFFu);
+      out_idx[o] = (dt << 44) | ((uint64_t)((VGICP_PREP_TRACE == 2 ? inserts : pops) > 1023u ? 1023u : (VGICP_PREP_TRACE == 2 ? inserts : pops)) << 34) | ((uint64_t)(level & 15) << 30) | ((t_trace / 10u) & 0x3FFFFFFFu);
     }
 #endif
     if (debug) {
