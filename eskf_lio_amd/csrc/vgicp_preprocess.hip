@@ -119,26 +119,37 @@ __global__ void run_count_kernel(const double* __restrict__ pts, const unsigned 
                                  uint32_t* __restrict__ pos_of_index, uint32_t* __restrict__ voxel_min,
                                  uint32_t* counters) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const unsigned long long c = codes[j];
-  const unsigned long long prev = j ? codes[j - 1] : 0ull;
-  const uint32_t i = idx[j];
-  sorted_pts[3 * (size_t)j] = pts[3 * (size_t)i];
-  sorted_pts[3 * (size_t)j + 1] = pts[3 * (size_t)i + 1];
-  sorted_pts[3 * (size_t)j + 2] = pts[3 * (size_t)i + 2];
-  uint32_t runs = 0;
+  uint32_t runs = 0, first = 0;
+  if (j < n) {
+    const unsigned long long c = codes[j];
+    const unsigned long long prev = j ? codes[j - 1] : 0ull;
+    const uint32_t i = idx[j];
+    // 32-byte records {x, y, z, original index}: the search fetches a candidate with two aligned 16-byte loads
+    double2* rec = reinterpret_cast<double2*>(sorted_pts + 4 * (size_t)j);
+    rec[0] = make_double2(pts[3 * (size_t)i], pts[3 * (size_t)i + 1]);
+    rec[1] = make_double2(pts[3 * (size_t)i + 2], __longlong_as_double((long long)i));
 #pragma unroll 1
-  for (int l = 0; l < kLevels; ++l) {
-    if (j != 0 && (c >> (3 * l)) == (prev >> (3 * l))) break;
-    ++runs;
+    for (int l = 0; l < kLevels; ++l) {
+      if (j != 0 && (c >> (3 * l)) == (prev >> (3 * l))) break;
+      ++runs;
+    }
+    first = (j == 0 || (c >> (3 * kFineShift)) != (prev >> (3 * kFineShift))) ? 1u : 0u;
+    keep_by_index[i] = 0u;
+    voxel_min[j] = 0xFFFFFFFFu;
+    pos_of_index[i] = j;
+    voxel_start[j] = first;
   }
-  const uint32_t first = (j == 0 || (c >> (3 * kFineShift)) != (prev >> (3 * kFineShift))) ? 1u : 0u;
-  keep_by_index[i] = 0u;
-  voxel_min[j] = 0xFFFFFFFFu;
-  pos_of_index[i] = j;
-  voxel_start[j] = first;
-  if (first) atomicAdd(&counters[0], 1u);
-  if (runs) atomicAdd(&counters[1], runs);
+  // one atomic per wave and counter, not one per point on the same two words
+  uint32_t firsts = first;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    runs += __shfl_xor(runs, o, 64);
+    firsts += __shfl_xor(firsts, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (firsts) atomicAdd(&counters[0], firsts);
+    if (runs) atomicAdd(&counters[1], runs);
+  }
 }
 
 // the kept point of a voxel is its FIRST point in scan order: the lowest index of the voxel's run
@@ -162,28 +173,35 @@ __global__ void query_list_kernel(const uint32_t* __restrict__ voxel_start, cons
   keep_by_index[i] = 1u;
 }
 
-// starts of the runs of every level: claim the cell's entry and store the start
-__global__ void cell_start_kernel(const unsigned long long* __restrict__ codes, uint32_t n, CellEntry* table,
+// Runs of every level in one pass: point j opens the cells whose run starts at j (its code differs from its
+// predecessor's at that level) and closes those whose run ends at j (differs from its successor's). Whichever of
+// the two comes first claims the cell's entry (CAS on the key); each stores its own field.
+__device__ __forceinline__ CellEntry* claim_cell(CellEntry* table, uint32_t mask, unsigned long long key) {
+  uint32_t slot = cell_hash(key) & mask;
+  for (;;) {  // cells are unique per (level, key) and the table holds at least eight times their number
+    const unsigned long long seen = atomicCAS(&table[slot].key, kEmptyCell, key);
+    if (seen == kEmptyCell || seen == key) return table + slot;
+    slot = (slot + 1) & mask;
+  }
+}
+__global__ void cell_build_kernel(const unsigned long long* __restrict__ codes, uint32_t n, CellEntry* table,
                                   uint32_t mask) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned long long c = codes[j];
   const unsigned long long prev = j ? codes[j - 1] : 0ull;
-#pragma unroll 1
+  const unsigned long long next = j + 1 < n ? codes[j + 1] : 0ull;
+  // codes that differ at level l differ at every finer level: the cells opened / closed here are levels 0 .. count-1
+  int opens = 0, closes = 0;
   for (int l = 0; l < kLevels; ++l) {
-    const unsigned long long m = c >> (3 * l);
-    if (j != 0 && m == (prev >> (3 * l))) break;  // same cell as the predecessor here and at every coarser level
-    const unsigned long long key = cell_key(m, l);
-    uint32_t slot = cell_hash(key) & mask;
-    for (;;) {  // cells are unique per (level, key) and the table holds twice their number
-      const unsigned long long seen = atomicCAS(&table[slot].key, kEmptyCell, key);
-      if (seen == kEmptyCell || seen == key) break;
-      slot = (slot + 1) & mask;
-    }
-    table[slot].start = j;
+    if (j == 0 || (c >> (3 * l)) != (prev >> (3 * l))) ++opens;
+    if (j + 1 == n || (c >> (3 * l)) != (next >> (3 * l))) ++closes;
   }
+#pragma unroll 1
+  for (int l = 0; l < opens; ++l) claim_cell(table, mask, cell_key(c >> (3 * l), l))->start = j;
+#pragma unroll 1
+  for (int l = 0; l < closes; ++l) claim_cell(table, mask, cell_key(c >> (3 * l), l))->end = j + 1;
 }
-
 __device__ __forceinline__ const CellEntry* find_cell(const CellEntry* table, uint32_t mask,
                                                       unsigned long long key) {
   uint32_t slot = cell_hash(key) & mask;
@@ -195,20 +213,6 @@ __device__ __forceinline__ const CellEntry* find_cell(const CellEntry* table, ui
   }
 }
 
-__global__ void cell_end_kernel(const unsigned long long* __restrict__ codes, uint32_t n, CellEntry* table,
-                                uint32_t mask) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const unsigned long long c = codes[j];
-  const unsigned long long next = j + 1 < n ? codes[j + 1] : 0ull;
-#pragma unroll 1
-  for (int l = 0; l < kLevels; ++l) {
-    const unsigned long long m = c >> (3 * l);
-    if (j + 1 < n && m == (next >> (3 * l))) break;  // not the last of its run (nor of any coarser one)
-    CellEntry* e = const_cast<CellEntry*>(find_cell(table, mask, cell_key(m, l)));
-    if (e) e->end = j + 1;
-  }
-}
 
 // ---- wave-level helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ double uniform_f64(double v) {
@@ -266,8 +270,8 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   };
   const double fine = h / (double)(1 << kFineShift);
   const uint32_t qj = uniform_u32(queries[qrank]);
-  const double qx = uniform_f64(spts[3 * (size_t)qj]), qy = uniform_f64(spts[3 * (size_t)qj + 1]),
-               qz = uniform_f64(spts[3 * (size_t)qj + 2]);
+  const double qx = uniform_f64(spts[4 * (size_t)qj]), qy = uniform_f64(spts[4 * (size_t)qj + 1]),
+               qz = uniform_f64(spts[4 * (size_t)qj + 2]);
   const int K = knn < (int)n ? knn : (int)n;
   const uint64_t t_begin = debug >= 2 ? wall_clock64() : 0;
 #ifdef VGICP_PREP_TRACE
@@ -278,8 +282,12 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   uint32_t batches = 0, pops = 0, spills = 0, inserts = 0;
   const unsigned long long list_lanes = K >= 64 ? ~0ull : (1ull << K) - 1ull;
 
-  auto dist2 = [&](uint32_t j) {
-    const double dx = spts[3 * (size_t)j] - qx, dy = spts[3 * (size_t)j + 1] - qy, dz = spts[3 * (size_t)j + 2] - qz;
+  // squared distance to sorted point j and, from the same record, its original index
+  auto dist2 = [&](uint32_t j, uint32_t& id) {
+    const double2* rec = reinterpret_cast<const double2*>(spts + 4 * (size_t)j);
+    const double2 xy = rec[0], zi = rec[1];
+    id = (uint32_t)__double_as_longlong(zi.y);
+    const double dx = xy.x - qx, dy = xy.y - qy, dz = zi.x - qz;
     return dx * dx + dy * dy + dz * dz;
   };
   // The k-list: lane l < K holds the l-th nearest so far, by (distance, index). It starts FULL: K consecutive
@@ -293,9 +301,10 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   uint32_t li = 0xFFFFFFFFu, lj = 0;
   {
     const bool mine = lane < K;
-    double d = mine ? dist2(w0 + (uint32_t)lane) : INFINITY;
+    uint32_t id = 0xFFFFFFFFu;
+    double d = INFINITY;
+    if (mine) d = dist2(w0 + (uint32_t)lane, id);
     if (!(d < INFINITY)) d = INFINITY;  // a NaN / infinite point is a placeholder that everything finite displaces
-    const uint32_t id = mine ? sorted_idx[w0 + (uint32_t)lane] : 0xFFFFFFFFu;
     // rank of every seed among the seeds (all distinct by index), then one trip through this wave's (still
     // empty) pool to put lane l's entry into lane rank(l)
     uint32_t rank = 0;
@@ -547,8 +556,9 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
         for (uint32_t base = start; base < end; base += 64u) {
           const uint32_t j = base + (uint32_t)lane;
           const bool valid = j < end;
-          const double d = valid ? dist2(j) : INFINITY;
-          const uint32_t id = valid ? sorted_idx[j] : 0xFFFFFFFFu;
+          uint32_t id = 0xFFFFFFFFu;
+          double d = INFINITY;
+          if (valid) d = dist2(j, id);
           offer(valid, d, id, j);
         }
       }
@@ -557,8 +567,9 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     for (uint32_t base = 0; base < n; base += 64u) {
       const uint32_t j = base + (uint32_t)lane;
       const bool valid = j < n;
-      const double d = valid ? dist2(j) : INFINITY;
-      const uint32_t id = valid ? sorted_idx[j] : 0xFFFFFFFFu;
+      uint32_t id = 0xFFFFFFFFu;
+      double d = INFINITY;
+      if (valid) d = dist2(j, id);
       offer(valid, d, id, j);
     }
     spills += 1000000u;
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < found; ++k) {
       const uint32_t j = nbr[(size_t)o * kMaxKnn + k];
-      const double x = spts[3 * (size_t)j], y = spts[3 * (size_t)j + 1], z = spts[3 * (size_t)j + 2];
+      const double x = spts[4 * (size_t)j], y = spts[4 * (size_t)j + 1], z = spts[4 * (size_t)j + 2];
       c[0] += x; c[1] += y; c[2] += z;
       c[3] += x * x; c[4] += x * y; c[5] += x * z;
       c[6] += y * y; c[7] += y * z; c[8] += z * z;
@@ -777,7 +788,7 @@ __host__ inline Layout layout_for(uint32_t n) {
   L.codes_out = off; off += align256((size_t)n * 8);
   L.idx_in = off; off += align256((size_t)n * 4);
   L.idx_out = off; off += align256((size_t)n * 4);
-  L.spts = off; off += align256((size_t)n * 24);
+  L.spts = off; off += align256((size_t)n * 32);
   L.keep_i = off; off += align256((size_t)n * 4);
   L.keep_p = off; off += align256((size_t)n * 4);
   L.rank_i = off; off += align256((size_t)n * 4);
@@ -857,8 +868,7 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
   const uint32_t mask = (uint32_t)(table_entries - 1);
   hipLaunchKernelGGL(cell_clear_kernel, dim3(blocks_for(table_entries, 256)), dim3(256), 0, s, table,
                      table_entries);
-  hipLaunchKernelGGL(cell_start_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
-  hipLaunchKernelGGL(cell_end_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
+  hipLaunchKernelGGL(cell_build_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
   // 8 XCDs x ceil(m / 8) queries each (see the kernel's query mapping)
   hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((m + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
                      n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
