@@ -377,17 +377,26 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
     }
   };
-  // squared distance from the query to the cell (x, y, z) of level l, deflated so that the rounding between
-  // floor(p / fine) and k * fine can never hide a cell
+  const uint32_t cx = uniform_u32(cell_coord(qx, fine)), cy = uniform_u32(cell_coord(qy, fine)),
+                 cz = uniform_u32(cell_coord(qz, fine));
+  const unsigned long long mq = morton3(cx, cy, cz);  // wave-uniform: scalar unit
+  const double fx = qx / fine - floor(qx / fine), fy = qy / fine - floor(qy / fine), fz = qz / fine - floor(qz / fine);
+  const float ffx = (float)fx, ffy = (float)fy, ffz = (float)fz;
+  const float fine2_low = __double2float_rd(fine * fine) * (1.0f - 0x1p-20f);
+  // Lower bound of the squared distance from the query to the cell (x, y, z) of level l, in single precision and
+  // in units of the finest cell: the query is (cx + fx, ...) with the SAME quotient floor(q / fine) that binned the
+  // points, so the integer part of every difference is exact; what single precision loses (2^-23 relative,
+  // 2^-24 absolute per axis) is taken off eight times over (2^-20 relative and absolute, and 2^-20 relative on the
+  // sum). The bound only orders and prunes cells; a bound that is low by a millionth costs nothing.
   auto cell_d2 = [&](int l, uint32_t x, uint32_t y, uint32_t z) {
-    const double size = fine * (double)(1u << l);
-    const double lx = (double)((int)(x << l) - kCoordOffset) * fine;
-    const double ly = (double)((int)(y << l) - kCoordOffset) * fine;
-    const double lz = (double)((int)(z << l) - kCoordOffset) * fine;
-    const double ex = fmax(fmax(lx - qx, qx - (lx + size)), 0.0);
-    const double ey = fmax(fmax(ly - qy, qy - (ly + size)), 0.0);
-    const double ez = fmax(fmax(lz - qz, qz - (lz + size)), 0.0);
-    return (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-9);
+    const float size = (float)(1u << l);
+    constexpr float kOff = 0x1p-20f, kKeep = 1.0f - 0x1p-20f;
+    const float ax = (float)(int)((x << l) - cx) - ffx, ay = (float)(int)((y << l) - cy) - ffy,
+                az = (float)(int)((z << l) - cz) - ffz;
+    const float ex = fmaxf(fmaf(fmaxf(fmaxf(ax, -ax - size), 0.0f), kKeep, -kOff), 0.0f);
+    const float ey = fmaxf(fmaf(fmaxf(fmaxf(ay, -ay - size), 0.0f), kKeep, -kOff), 0.0f);
+    const float ez = fmaxf(fmaf(fmaxf(fmaxf(az, -az - size), 0.0f), kKeep, -kOff), 0.0f);
+    return fmaf(ex, ex, fmaf(ey, ey, ez * ez)) * fine2_low;
   };
   // where lane's child sits inside its parent: the lane number is the child's Morton digits (z y x per level)
   const uint32_t ox1 = (uint32_t)lane & 1u, oy1 = ((uint32_t)lane >> 1) & 1u, oz1 = ((uint32_t)lane >> 2) & 1u;
@@ -413,11 +422,11 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     waiting = kept;
   };
   // the caller has made sure that the pool has room
-  auto push = [&](bool want, double d2, unsigned long long key, uint32_t start, uint32_t end) {
+  auto push = [&](bool want, float d2, unsigned long long key, uint32_t start, uint32_t end) {
     const unsigned long long who = __ballot(want);
     const int at = waiting + __builtin_popcountll(who & lanes_below);
     if (want) {
-      pd[at] = __double2float_rd(d2);
+      pd[at] = d2;
       pk[at] = key;
       ps[at] = start;
       pe[at] = end;
@@ -425,14 +434,13 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     waiting += __builtin_popcountll(who);
   };
 
-  const uint32_t cx = cell_coord(qx, fine), cy = cell_coord(qy, fine), cz = cell_coord(qz, fine);
   {
     // A second bound: the finest cell around the query that holds K points has them all within its
-    // diagonal (lane l asks for level l). Sorted-order neighbours can be far apart where the Morton
-    // curve jumps; this bound cannot.
+    // diagonal (lane l asks for level l: the query's Morton code, made once on the scalar unit, shifted).
+    // Sorted-order neighbours can be far apart where the Morton curve jumps; this bound cannot.
     uint32_t population = 0;
     if (lane < kLevels) {
-      const CellEntry* e = find_cell(table, mask, cell_key(morton3(cx >> lane, cy >> lane, cz >> lane), lane));
+      const CellEntry* e = find_cell(table, mask, cell_key(mq >> (3 * lane), lane));
       if (e) population = e->end - e->start;
     }
     const unsigned long long enough = __ballot(population >= (uint32_t)K);
@@ -441,21 +449,18 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       bound = fmin(bound, 3.0 * size * size * (1.0 + 1e-9));
     }
   }
-  const double fx = qx / fine - floor(qx / fine), fy = qy / fine - floor(qy / fine), fz = qz / fine - floor(qz / fine);
-  // distance from the query to the faces of the 27-cell block of level l around it
-  auto safe_radius = [&](int l) {
+  // the level whose 27-cell block covers the ball of the seed radius: everything that can be among the K
+  // nearest lies inside it. Lane l works out level l: the distance from the query to the faces of that block
+  int level;
+  {
+    const int l = lane < kLevels ? lane : kLevels - 1;
     const double sub = (double)(1u << l);
     const double px = (double)(cx & ((1u << l) - 1u)) + fx, py = (double)(cy & ((1u << l) - 1u)) + fy,
                  pz = (double)(cz & ((1u << l) - 1u)) + fz;
     const double margin = fmin(fmin(fmin(px, sub - px), fmin(py, sub - py)), fmin(pz, sub - pz));
-    return (sub + margin) * fine * (1.0 - 1e-12);
-  };
-  // the level whose 27-cell block covers the ball of the seed radius: everything that can be among the K
-  // nearest lies inside it
-  int level = 0;
-  for (; level < kLevels; ++level) {
-    const double r = safe_radius(level);
-    if (bound <= r * r) break;
+    const double r = (sub + margin) * fine * (1.0 - 1e-12);
+    const unsigned long long covers = __ballot((lane < kLevels) & (bound <= r * r));
+    level = covers ? __builtin_ctzll(covers) : kLevels;
   }
   if (level < kLevels) {
     {
@@ -463,14 +468,24 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       const int x = (int)(cx >> level) + lane % 3 - 1, y = (int)(cy >> level) + (lane / 3) % 3 - 1,
                 z = (int)(cz >> level) + lane / 9 - 1;
       bool want = lane < 27 && x >= 0 && y >= 0 && z >= 0 && x <= top && y <= top && z <= top;
-      unsigned long long mk = 0;
-      double d2 = 0.0;
+      // Morton codes of the 27 cells without spreading any bits: the block's centre is the query's code shifted
+      // (scalar), a step of +-1 along an axis is an increment / decrement of that axis' dilated digits (scalar
+      // too), and every lane picks one of three per axis
+      constexpr unsigned long long kMx = 0x1249249249249249ull, kMy = kMx << 1, kMz = kMx << 2;
+      const unsigned long long centre = mq >> (3 * level);
+      const unsigned long long bx = centre & kMx, by = centre & kMy, bz = centre & kMz;
+      const unsigned long long xi = ((bx | ~kMx) + 1ull) & kMx, xd = (bx - 1ull) & kMx;
+      const unsigned long long yi = ((by | ~kMy) + 1ull) & kMy, yd = (by - 1ull) & kMy;
+      const unsigned long long zi = ((bz | ~kMz) + 1ull) & kMz, zd = (bz - 1ull) & kMz;
+      const int sx = lane % 3, sy = (lane / 3) % 3, sz = lane / 9;
+      const unsigned long long mk = ((sx == 0 ? xd : (sx == 1 ? bx : xi)) | (sy == 0 ? yd : (sy == 1 ? by : yi)) |
+                                     (sz == 0 ? zd : (sz == 1 ? bz : zi))) & kKeyMask;
+      float d2 = 0.0f;
       uint32_t start = 0, end = 0;
       if (want) {
-        mk = morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
         const CellEntry* e = find_cell(table, mask, cell_key(mk, level));
         want = e != nullptr;
-        if (e) { start = e->start; end = e->end; d2 = cell_d2(level, (uint32_t)x, (uint32_t)y, (uint32_t)z); want = d2 <= bound; }
+        if (e) { start = e->start; end = e->end; d2 = cell_d2(level, (uint32_t)x, (uint32_t)y, (uint32_t)z); want = d2 <= __double2float_ru(bound); }
       }
       push(want, d2, cell_key(mk, level), start, end);
     }
@@ -531,7 +546,8 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
         const uint32_t chx = (px << step) | (step == 2 ? ox2 : ox1), chy = (py << step) | (step == 2 ? oy2 : oy1),
                        chz = (pz << step) | (step == 2 ? oz2 : oz1);
         bool want = lane < fan;
-        double d2 = 0.0;
+        float d2 = 0.0f;
+        const float limit_up = __double2float_ru(limit);
         uint32_t cs = 0, ce = 0;
         if (want) {
           const CellEntry* e = find_cell(table, mask, cell_key(cm, l - step));
@@ -540,7 +556,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
             cs = e->start;
             ce = e->end;
             d2 = cell_d2(l - step, chx, chy, chz);
-            want = d2 <= limit;
+            want = d2 <= limit_up;
           }
         }
         const int incoming = __builtin_popcountll(__ballot(want));
@@ -585,7 +601,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     {
       const uint64_t t_end = wall_clock64();
       uint64_t dt = t_end - t_trace; if (dt > 0xFFFFFu) dt = 0xFFFFFu;
-      out_idx[o] = (dt << 44) | ((uint64_t)((VGICP_PREP_TRACE == 2 ? inserts : pops) > 1023u ? 1023u : (VGICP_PREP_TRACE == 2 ? inserts : pops)) << 34) | ((uint64_t)(level & 15) << 30) | ((t_trace / 10u) & 0x3FFFFFFFu);
+      out_idx[o] = (dt << 44) | ((uint64_t)((VGICP_PREP_TRACE == 2 ? inserts : pops) > 1023u ? 1023u : (VGICP_PREP_TRACE == 2 ? inserts : pops)) << 34) | ((uint64_t)((VGICP_PREP_TRACE == 3 ? (int)(blockIdx.x % 8u) : level) & 15) << 30) | ((t_trace / 10u) & 0x3FFFFFFFu);
     }
 #endif
     if (debug) {

@@ -33,3 +33,24 @@ for lv in sorted(set(level.tolist())):
           f"time mean {dt[k].mean():.1f} max {dt[k].max():.1f} us, us per cell {dt[k].sum() / max(1, pops[k].sum()):.2f}")
 late = np.argsort(end)[-10:]
 print("[trace] the ten last to finish: " + "; ".join(f"start {t0[i]:.0f} dt {dt[i]:.0f} cells {pops[i]} level {level[i]}" for i in late))
+if os.environ.get("VGICP_TRACE_XCD"):  # a -DVGICP_PREP_TRACE=3 build: the level field carries blockIdx % 8 (the XCD)
+    for x in range(8):
+        k = level == x
+        print(f"[trace] xcd {x}: {k.sum()} queries, busy sum {dt[k].sum() / 1e3:.1f} ms, first start {t0[k].min():.1f}, last start {t0[k].max():.1f}, last end {end[k].max():.1f} us")
+if os.environ.get("VGICP_TRACE_SIM"):  # list scheduling of the measured durations on as many slots as ran at once
+    import heapq
+    slots = int(((t0 <= 0.5 * end.max()) & (end > 0.5 * end.max())).sum())
+    def makespan(order):
+        heap = [0.0] * slots
+        heapq.heapify(heap)
+        last = 0.0
+        for i in order:
+            t = heapq.heappop(heap) + dt[i]
+            last = max(last, t)
+            heapq.heappush(heap, t)
+        return last
+    by_start = np.argsort(t0, kind="stable")
+    print(f"[trace] {slots} slots; makespan as dispatched {makespan(by_start):.1f} us, sum/slots {dt.sum() / slots:.1f} us, "
+          f"by level descending {makespan(by_start[np.argsort(-level[by_start], kind='stable')]):.1f} us, "
+          f"by cells taken descending {makespan(np.argsort(-pops, kind='stable')):.1f} us, "
+          f"longest first {makespan(np.argsort(-dt)):.1f} us")
