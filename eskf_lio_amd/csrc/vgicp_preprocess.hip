@@ -101,9 +101,10 @@ __device__ __forceinline__ bool beyond_grid(double v, double fine) {
 
 __global__ void morton_kernel(const double* __restrict__ pts, uint32_t n, double fine,
                               unsigned long long* __restrict__ codes, uint32_t* __restrict__ idx,
-                              uint32_t* __restrict__ counters) {
+                              uint32_t* __restrict__ keep_by_index, uint32_t* __restrict__ counters) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  keep_by_index[i] = 0u;
   const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
   codes[i] = morton3(cell_coord(x, fine), cell_coord(y, fine), cell_coord(z, fine));
   idx[i] = i;
@@ -111,15 +112,31 @@ __global__ void morton_kernel(const double* __restrict__ pts, uint32_t n, double
   if (is_finite && (beyond_grid(x, fine) || beyond_grid(y, fine) || beyond_grid(z, fine))) counters[3] = 1u;
 }
 
-// One pass over the sorted codes: voxel-level run starts are flagged, the points are copied into sorted
-// order, every point learns its sorted position, and the number of runs over all levels sizes the cell table.
+// Element and operator of the segmented scan over the sorted order: count = voxel runs started so far, packed =
+// (original index << 32 | sorted position) of the LOWEST original index since the last run start. At the last
+// point of a voxel's run that is the voxel's rank (+1) and its kept point -- the first point of the voxel in scan
+// order -- with its sorted position (inside a run the sort orders by the finer cells, not by index).
+struct RunMin {
+  unsigned long long packed;
+  uint32_t count;
+  uint32_t runs;  // cells opened over all levels (plain sum: its total sizes the cell table)
+};
+struct RunMinOp {
+  __host__ __device__ __forceinline__ RunMin operator()(const RunMin& a, const RunMin& b) const {
+    RunMin r;
+    r.count = a.count + b.count;
+    r.packed = b.count ? b.packed : (a.packed < b.packed ? a.packed : b.packed);
+    r.runs = a.runs + b.runs;
+    return r;
+  }
+};
+
+// One pass over the sorted codes: the points are copied into sorted order (32-byte records), voxel-level run starts
+// become the scan's input, and the number of runs over all levels sizes the cell table.
 __global__ void run_count_kernel(const double* __restrict__ pts, const unsigned long long* __restrict__ codes,
                                  const uint32_t* __restrict__ idx, uint32_t n, double* __restrict__ sorted_pts,
-                                 uint32_t* __restrict__ keep_by_index, uint32_t* __restrict__ voxel_start,
-                                 uint32_t* __restrict__ pos_of_index, uint32_t* __restrict__ voxel_min,
-                                 uint32_t* counters) {
+                                 RunMin* __restrict__ run_in) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t runs = 0, first = 0;
   if (j < n) {
     const unsigned long long c = codes[j];
     const unsigned long long prev = j ? codes[j - 1] : 0ull;
@@ -128,49 +145,36 @@ __global__ void run_count_kernel(const double* __restrict__ pts, const unsigned 
     double2* rec = reinterpret_cast<double2*>(sorted_pts + 4 * (size_t)j);
     rec[0] = make_double2(pts[3 * (size_t)i], pts[3 * (size_t)i + 1]);
     rec[1] = make_double2(pts[3 * (size_t)i + 2], __longlong_as_double((long long)i));
+    uint32_t runs = 0;
 #pragma unroll 1
     for (int l = 0; l < kLevels; ++l) {
       if (j != 0 && (c >> (3 * l)) == (prev >> (3 * l))) break;
       ++runs;
     }
-    first = (j == 0 || (c >> (3 * kFineShift)) != (prev >> (3 * kFineShift))) ? 1u : 0u;
-    keep_by_index[i] = 0u;
-    voxel_min[j] = 0xFFFFFFFFu;
-    pos_of_index[i] = j;
-    voxel_start[j] = first;
-  }
-  // one atomic per wave and counter, not one per point on the same two words
-  uint32_t firsts = first;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    runs += __shfl_xor(runs, o, 64);
-    firsts += __shfl_xor(firsts, o, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (firsts) atomicAdd(&counters[0], firsts);
-    if (runs) atomicAdd(&counters[1], runs);
+    const uint32_t first = (j == 0 || (c >> (3 * kFineShift)) != (prev >> (3 * kFineShift))) ? 1u : 0u;
+    RunMin e;
+    e.packed = ((unsigned long long)i << 32) | j;
+    e.count = first;
+    e.runs = runs;
+    run_in[j] = e;
   }
 }
 
-// the kept point of a voxel is its FIRST point in scan order: the lowest index of the voxel's run
-// (inside a run the sort orders by the finer cells, not by index)
-__global__ void voxel_min_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ voxel_start,
-                                 const uint32_t* __restrict__ voxel_rank, uint32_t n, uint32_t* voxel_min) {
+// query list in Morton order of the voxels (sorted positions of the kept points) and the kept flags: the last
+// point of every voxel run reads the scan
+__global__ void query_list_kernel(const unsigned long long* __restrict__ codes, const RunMin* __restrict__ run_out,
+                                  uint32_t n, uint32_t* __restrict__ queries, uint32_t* __restrict__ keep_by_index,
+                                  uint32_t* __restrict__ counters) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  atomicMin(&voxel_min[voxel_rank[j] + voxel_start[j] - 1u], idx[j]);
-}
-
-// query list in Morton order of the voxels (sorted positions of the kept points) and the kept flags
-__global__ void query_list_kernel(const uint32_t* __restrict__ voxel_start, const uint32_t* __restrict__ voxel_rank,
-                                  const uint32_t* __restrict__ voxel_min, const uint32_t* __restrict__ pos_of_index,
-                                  uint32_t n, uint32_t* __restrict__ queries, uint32_t* __restrict__ keep_by_index) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n || !voxel_start[j]) return;
-  const uint32_t r = voxel_rank[j];
-  const uint32_t i = voxel_min[r];
-  queries[r] = pos_of_index[i];
-  keep_by_index[i] = 1u;
+  if (j + 1 < n && (codes[j + 1] >> (3 * kFineShift)) == (codes[j] >> (3 * kFineShift))) return;
+  const RunMin e = run_out[j];
+  if (j + 1 == n) {  // the scan's total: kept points and cells (no atomics: device-scope atomics on one word
+    counters[0] = e.count;  // from 1 500 waves cost this pipeline 35 us)
+    counters[1] = e.runs;
+  }
+  queries[e.count - 1u] = (uint32_t)e.packed;
+  keep_by_index[(uint32_t)(e.packed >> 32)] = 1u;
 }
 
 // Runs of every level in one pass: point j opens the cells whose run starts at j (its code differs from its
@@ -186,21 +190,18 @@ __device__ __forceinline__ CellEntry* claim_cell(CellEntry* table, uint32_t mask
 }
 __global__ void cell_build_kernel(const unsigned long long* __restrict__ codes, uint32_t n, CellEntry* table,
                                   uint32_t mask) {
+  // one thread per (point, level) -- blockIdx.y is the level: a point on a coarse boundary opens and closes a
+  // cell on every level, and one thread doing those two dozen atomic round trips in sequence set the pace
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = (int)blockIdx.y;
   if (j >= n) return;
-  const unsigned long long c = codes[j];
-  const unsigned long long prev = j ? codes[j - 1] : 0ull;
-  const unsigned long long next = j + 1 < n ? codes[j + 1] : 0ull;
-  // codes that differ at level l differ at every finer level: the cells opened / closed here are levels 0 .. count-1
-  int opens = 0, closes = 0;
-  for (int l = 0; l < kLevels; ++l) {
-    if (j == 0 || (c >> (3 * l)) != (prev >> (3 * l))) ++opens;
-    if (j + 1 == n || (c >> (3 * l)) != (next >> (3 * l))) ++closes;
-  }
-#pragma unroll 1
-  for (int l = 0; l < opens; ++l) claim_cell(table, mask, cell_key(c >> (3 * l), l))->start = j;
-#pragma unroll 1
-  for (int l = 0; l < closes; ++l) claim_cell(table, mask, cell_key(c >> (3 * l), l))->end = j + 1;
+  const unsigned long long c = codes[j] >> (3 * l);
+  const bool opens = j == 0 || c != (codes[j - 1] >> (3 * l));
+  const bool closes = j + 1 == n || c != (codes[j + 1] >> (3 * l));
+  if (!opens && !closes) return;
+  CellEntry* e = claim_cell(table, mask, cell_key(c, l));
+  if (opens) e->start = j;
+  if (closes) e->end = j + 1;
 }
 __device__ __forceinline__ const CellEntry* find_cell(const CellEntry* table, uint32_t mask,
                                                       unsigned long long key) {
@@ -787,7 +788,7 @@ __host__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 __host__ inline uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
 struct Layout {
-  size_t codes_in, codes_out, idx_in, idx_out, spts, keep_i, keep_p, rank_i, rank_p, queries, pos_i, vmin, nbr, cub, total;
+  size_t codes_in, codes_out, idx_in, idx_out, spts, keep_i, rank_i, queries, run_in, run_out, nbr, cub, total;
   size_t cub_bytes;
 };
 
@@ -797,8 +798,11 @@ __host__ inline Layout layout_for(uint32_t n) {
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_pairs, (const unsigned long long*)nullptr,
                                            (unsigned long long*)nullptr, (const uint32_t*)nullptr,
                                            (uint32_t*)nullptr, (int)n);
+  size_t run_scan = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+  (void)hipcub::DeviceScan::InclusiveScan(nullptr, run_scan, (const RunMin*)nullptr, (RunMin*)nullptr, RunMinOp(), (int)n);
   L.cub_bytes = sort_pairs > scan ? sort_pairs : scan;
+  if (run_scan > L.cub_bytes) L.cub_bytes = run_scan;
   size_t off = 0;
   L.codes_in = off; off += align256((size_t)n * 8);
   L.codes_out = off; off += align256((size_t)n * 8);
@@ -806,12 +810,10 @@ __host__ inline Layout layout_for(uint32_t n) {
   L.idx_out = off; off += align256((size_t)n * 4);
   L.spts = off; off += align256((size_t)n * 32);
   L.keep_i = off; off += align256((size_t)n * 4);
-  L.keep_p = off; off += align256((size_t)n * 4);
   L.rank_i = off; off += align256((size_t)n * 4);
-  L.rank_p = off; off += align256((size_t)n * 4);
   L.queries = off; off += align256((size_t)n * 4);
-  L.pos_i = off; off += align256((size_t)n * 4);
-  L.vmin = off; off += align256((size_t)n * 4);
+  L.run_in = off; off += align256((size_t)n * sizeof(RunMin));
+  L.run_out = off; off += align256((size_t)n * sizeof(RunMin));
   L.nbr = off; off += align256((size_t)n * kMaxKnn * 4);
   L.cub = off; off += align256(L.cub_bytes);
   L.total = off + 256;
@@ -840,26 +842,24 @@ hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, 
   auto* idx_out = reinterpret_cast<uint32_t*>(b + L.idx_out);
   auto* spts = reinterpret_cast<double*>(b + L.spts);
   auto* keep_i = reinterpret_cast<uint32_t*>(b + L.keep_i);
-  auto* keep_p = reinterpret_cast<uint32_t*>(b + L.keep_p);
   auto* rank_i = reinterpret_cast<uint32_t*>(b + L.rank_i);
-  auto* rank_p = reinterpret_cast<uint32_t*>(b + L.rank_p);
   auto* queries = reinterpret_cast<uint32_t*>(b + L.queries);
+  auto* run_in = reinterpret_cast<RunMin*>(b + L.run_in);
+  auto* run_out = reinterpret_cast<RunMin*>(b + L.run_out);
   const double fine = h / (double)(1 << kFineShift);
-  hipLaunchKernelGGL(morton_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, fine, codes_in, idx_in, counters);
+  hipLaunchKernelGGL(morton_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, fine, codes_in, idx_in, keep_i,
+                     counters);
   size_t cub_bytes = L.cub_bytes;
   hipError_t e = hipcub::DeviceRadixSort::SortPairs(b + L.cub, cub_bytes, codes_in, codes_out, idx_in, idx_out,
                                                     (int)n, 0, 3 * kCoordBits, s);
   if (e != hipSuccess) return e;
-  auto* pos_i = reinterpret_cast<uint32_t*>(b + L.pos_i);
-  auto* vmin = reinterpret_cast<uint32_t*>(b + L.vmin);
   hipLaunchKernelGGL(run_count_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, codes_out, idx_out, n, spts,
-                     keep_i, keep_p, pos_i, vmin, counters);
+                     run_in);
   cub_bytes = L.cub_bytes;
-  e = hipcub::DeviceScan::ExclusiveSum(b + L.cub, cub_bytes, keep_p, rank_p, (int)n, s);
+  e = hipcub::DeviceScan::InclusiveScan(b + L.cub, cub_bytes, run_in, run_out, RunMinOp(), (int)n, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(voxel_min_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, idx_out, keep_p, rank_p, n, vmin);
-  hipLaunchKernelGGL(query_list_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, keep_p, rank_p, vmin, pos_i, n,
-                     queries, keep_i);
+  hipLaunchKernelGGL(query_list_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, run_out, n, queries,
+                     keep_i, counters);
   cub_bytes = L.cub_bytes;
   e = hipcub::DeviceScan::ExclusiveSum(b + L.cub, cub_bytes, keep_i, rank_i, (int)n, s);
   if (e != hipSuccess) return e;
@@ -884,7 +884,7 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
   const uint32_t mask = (uint32_t)(table_entries - 1);
   hipLaunchKernelGGL(cell_clear_kernel, dim3(blocks_for(table_entries, 256)), dim3(256), 0, s, table,
                      table_entries);
-  hipLaunchKernelGGL(cell_build_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, n, table, mask);
+  hipLaunchKernelGGL(cell_build_kernel, dim3(blocks_for(n, 256), kLevels), dim3(256), 0, s, codes_out, n, table, mask);
   // 8 XCDs x ceil(m / 8) queries each (see the kernel's query mapping)
   hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((m + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
                      n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
