@@ -17,6 +17,24 @@ __device__ __forceinline__ uint32_t voxel_hash(int32_t x, int32_t y, int32_t z) 
   return h;
 }
 
+// Counting with ONE atomic per wave on the same word, spelled out (the compiler's atomic optimizer merges the lanes
+// of a wave as well; measured: no difference). What hurts is many WAVES on one word: device-scope atomics are
+// carried out at the memory side (eight XCDs, eight L2s), one after the other per address -- ~12 ns each; 3 000
+// of them made a 5 us kernel of the scan preparation take 38 us, so that one takes its counts from a scan instead.
+__device__ __forceinline__ void wave_count(uint32_t* counter, bool flag) {
+  const unsigned long long votes = __ballot(flag);
+  if (votes && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(votes)) atomicAdd(counter, (uint32_t)__builtin_popcountll(votes));
+}
+// Every active lane gets its own position in a list whose length is *counter: one atomic per wave.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter) {
+  const unsigned long long active = __ballot(true);
+  const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(active);
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(active));
+  base = (uint32_t)__shfl((int)base, (int)leader, 64);
+  return base + (uint32_t)__builtin_popcountll(active & ((1ull << lane) - 1ull));
+}
+
 // LocalMap::getVoxelIndex: IEEE division, floor, double -> int32.
 __device__ __forceinline__ int32_t voxel_coord(double x, double voxel_size) {
   return (int32_t)floor(x / voxel_size);

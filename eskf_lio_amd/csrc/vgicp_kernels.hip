@@ -1107,9 +1107,10 @@ __global__ void table_clear_kernel(VoxelRecord* table, uint64_t slots) {
 
 // Claim-or-update insert. Keys are unique within a batch, so a LOCKED slot always belongs to a
 // different key and is skipped; tombstones are never reused (rehash reclaims them).
-__device__ __forceinline__ bool insert_voxel(VoxelRecord* table, uint32_t mask, int32_t kx,
-                                             int32_t ky, int32_t kz, const double* mean,
-                                             const double* cov, uint64_t count, uint32_t* counters) {
+// Returns 1: new record, 0: existing record updated, -1: no free slot. The callers count (wave_count).
+__device__ __forceinline__ int insert_voxel(VoxelRecord* table, uint32_t mask, int32_t kx,
+                                            int32_t ky, int32_t kz, const double* mean,
+                                            const double* cov, uint64_t count) {
   uint32_t slot = voxel_hash(kx, ky, kz) & mask;
   for (uint32_t probes = 0; probes <= mask; ++probes) {
     VoxelRecord* rec = table + slot;
@@ -1124,20 +1125,18 @@ __device__ __forceinline__ bool insert_voxel(VoxelRecord* table, uint32_t mask, 
         rec->count = count;
         rec->reserved = 0;
         __hip_atomic_store(&rec->state, SLOT_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(&counters[0], 1u);
-        return true;
+        return 1;
       }
       state = expected;  // lost the race: look at what the winner left
     }
     if (state == SLOT_FULL && rec->key[0] == kx && rec->key[1] == ky && rec->key[2] == kz) {
       for (int k = 0; k < 3; ++k) rec->mean[k] = mean[k];
       for (int k = 0; k < 9; ++k) rec->cov[k] = cov[k];
-      return true;
+      return 0;
     }
     slot = (slot + 1) & mask;
   }
-  atomicAdd(&counters[1], 1u);
-  return false;
+  return -1;
 }
 
 __global__ void upsert_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
@@ -1149,8 +1148,10 @@ __global__ void upsert_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
   for (int k = 0; k < 3; ++k) mean[k] = means[3 * (size_t)i + k];
   for (int k = 0; k < 9; ++k) cov[k] = covs[9 * (size_t)i + k];
   // numPoints of a voxel mirrored from the host is not part of the batch: a new record starts at 1
-  insert_voxel(table, mask, keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2],
-               mean, cov, 1, counters);
+  const int r = insert_voxel(table, mask, keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2],
+                             mean, cov, 1);
+  wave_count(&counters[0], r == 1);
+  wave_count(&counters[1], r < 0);
 }
 
 __global__ void rehash_kernel(const VoxelRecord* __restrict__ old_table, uint64_t old_slots,
@@ -1162,7 +1163,9 @@ __global__ void rehash_kernel(const VoxelRecord* __restrict__ old_table, uint64_
   double mean[3], cov[9];
   for (int k = 0; k < 3; ++k) mean[k] = rec->mean[k];
   for (int k = 0; k < 9; ++k) cov[k] = rec->cov[k];
-  insert_voxel(table, mask, rec->key[0], rec->key[1], rec->key[2], mean, cov, rec->count, counters);
+  const int r = insert_voxel(table, mask, rec->key[0], rec->key[1], rec->key[2], mean, cov, rec->count);
+  wave_count(&counters[0], r == 1);
+  wave_count(&counters[1], r < 0);
 }
 
 __global__ void erase_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
@@ -1171,20 +1174,21 @@ __global__ void erase_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
   if (i >= n) return;
   const int32_t kx = keys[3 * (size_t)i], ky = keys[3 * (size_t)i + 1], kz = keys[3 * (size_t)i + 2];
   uint32_t slot = voxel_hash(kx, ky, kz) & mask;
+  bool erased = false;
   for (uint32_t probes = 0; probes <= mask; ++probes) {
     VoxelRecord* rec = table + slot;
     const int32_t state = rec->state;
-    if (state == SLOT_EMPTY) return;
+    if (state == SLOT_EMPTY) break;
     if (state == SLOT_FULL && rec->key[0] == kx && rec->key[1] == ky && rec->key[2] == kz) {
       // duplicates in the batch race here: exactly one CAS wins and counts
       int32_t expected = SLOT_FULL;
-      if (__hip_atomic_compare_exchange_strong(&rec->state, &expected, SLOT_TOMB, __ATOMIC_RELAXED,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicAdd(&counters[0], 1u);
-      return;
+      erased = __hip_atomic_compare_exchange_strong(&rec->state, &expected, SLOT_TOMB, __ATOMIC_RELAXED,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
     }
     slot = (slot + 1) & mask;
   }
+  wave_count(&counters[0], erased);
 }
 
 __global__ void voxel_index_kernel(const double* __restrict__ pts, uint32_t n, double voxel_size,

@@ -103,6 +103,7 @@ __global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double 
 
   uint32_t slot = voxel_hash(kx, ky, kz) & mask;
   uint32_t found = kNoSlot;
+  bool fresh = false;
   // `spins` bounds the waits on LOCKED words so that a bug can only fail the call, never hang the GPU
   for (uint32_t probes = 0, spins = 0; probes <= mask && spins < (1u << 22); ++spins) {
     VoxelRecord* rec = table + slot;
@@ -116,7 +117,7 @@ __global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double 
         rec->count = 0;
         rec->reserved = 0;
         __hip_atomic_store(&rec->state, SLOT_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(&counters[0], 1u);
+        fresh = true;
         found = slot;
         break;
       }
@@ -133,7 +134,8 @@ __global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double 
     slot = (slot + 1) & mask;  // other key or tombstone
     ++probes;
   }
-  if (found == kNoSlot) atomicAdd(&counters[1], 1u);
+  wave_count(&counters[0], fresh);
+  wave_count(&counters[1], found == kNoSlot);
   slot_of[i] = found;
   idx_of[i] = i;
 }
@@ -184,21 +186,19 @@ __global__ void insert_apply_kernel(VoxelRecord* table, const uint32_t* __restri
 __global__ void evict_kernel(VoxelRecord* table, uint64_t slots, double voxel_size, double px,
                              double py, double pz, double distance, uint32_t* counters) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= slots) return;
-  VoxelRecord* rec = table + i;
-  if (rec->state != SLOT_FULL) return;
-  bool far;
-  {
+  bool far = false;
+  if (i < slots && table[i].state == SLOT_FULL) {
 #pragma clang fp contract(off)
+    VoxelRecord* rec = table + i;
     const double dx = ((double)rec->key[0] + 0.5) * voxel_size - px;
     const double dy = ((double)rec->key[1] + 0.5) * voxel_size - py;
     const double dz = ((double)rec->key[2] + 0.5) * voxel_size - pz;
     far = sqrt((dx * dx + dy * dy) + dz * dz) > distance;
+    if (far) rec->state = SLOT_TOMB;
   }
-  if (far) {
-    rec->state = SLOT_TOMB;
-    atomicAdd(&counters[0], 1u);
-  }
+  // one atomic per workgroup: a mass eviction (788k of 1M voxels) was bound by 16 000 waves adding to one word
+  const int gone = __syncthreads_count(far ? 1 : 0);
+  if (threadIdx.x == 0 && gone) atomicAdd(&counters[0], (uint32_t)gone);
 }
 
 __global__ void export_kernel(const VoxelRecord* __restrict__ table, uint64_t slots, uint32_t capacity,
@@ -209,7 +209,7 @@ __global__ void export_kernel(const VoxelRecord* __restrict__ table, uint64_t sl
   if (i >= slots) return;
   const VoxelRecord* rec = table + i;
   if (rec->state != SLOT_FULL) return;
-  const uint32_t pos = atomicAdd(&counters[0], 1u);
+  const uint32_t pos = wave_append(&counters[0]);
   if (pos >= capacity) return;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
