@@ -291,13 +291,41 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     const double dx = xy.x - qx, dy = xy.y - qy, dz = zi.x - qz;
     return dx * dx + dy * dy + dz * dz;
   };
+  const uint32_t cx = uniform_u32(cell_coord(qx, fine)), cy = uniform_u32(cell_coord(qy, fine)),
+                 cz = uniform_u32(cell_coord(qz, fine));
+  const unsigned long long mq = morton3(cx, cy, cz);  // wave-uniform: scalar unit
+  const double fx = qx / fine - floor(qx / fine), fy = qy / fine - floor(qy / fine), fz = qz / fine - floor(qz / fine);
+  const float ffx = (float)fx, ffy = (float)fy, ffz = (float)fz;
+  const float fine2_low = __double2float_rd(fine * fine) * (1.0f - 0x1p-20f);
+  // The query's own cell on every level (lane l asks for level l: the query's Morton code, made once on the scalar
+  // unit, shifted). "Home" is the finest of them that holds at least K points: its points are the search's first
+  // candidates, and the K-th distance among them is already close to the final one.
+  uint32_t own_start = 0, own_end = 0;
+  if (lane < kLevels) {
+    const CellEntry* e = find_cell(table, mask, cell_key(mq >> (3 * lane), lane));
+    if (e) { own_start = e->start; own_end = e->end; }
+  }
+  const unsigned long long enough = __ballot(own_end - own_start >= (uint32_t)K);
+  const int home_level = enough ? __builtin_ctzll(enough) : 0;
+  const uint32_t home_start = (uint32_t)__builtin_amdgcn_readlane((int)own_start, home_level),
+                 home_end = (uint32_t)__builtin_amdgcn_readlane((int)own_end, home_level);
+  // (not when it is crowded -- thousands of returns in one finest cell next to the sensor: measuring all of them in
+  // sorted order costs more insertions than the best-first search needs; 64: 270 us, 128 / 256: 250 us, no cap: 308 us)
+  const bool has_home = enough != 0 && home_end - home_start <= kLeafPoints;
+
   // The k-list: lane l < K holds the l-th nearest so far, by (distance, index). It starts FULL: K consecutive
-  // points of the sorted order around the query (w0 .. w0 + K - 1) are real points and usually near ones, so
-  // the farthest of them bounds the k-th distance from above and most of them are never displaced. The search
-  // below skips them when it meets them again.
+  // points of the sorted order around the query (w0 .. w0 + K - 1, inside home when there is one) are real points
+  // and usually near ones. The search skips the points it has measured here when it meets them again
+  // (sorted positions skip_start .. skip_start + skip_count - 1).
   const uint32_t half = (uint32_t)K / 2;
   uint32_t w0 = qj > half ? qj - half : 0;
-  if (w0 + (uint32_t)K > n) w0 = n - (uint32_t)K;
+  if (has_home) {
+    if (w0 < home_start) w0 = home_start;
+    if (w0 + (uint32_t)K > home_end) w0 = home_end - (uint32_t)K;
+  } else if (w0 + (uint32_t)K > n) {
+    w0 = n - (uint32_t)K;
+  }
+  uint32_t skip_start = w0, skip_count = (uint32_t)K;
   double ld = INFINITY;
   uint32_t li = 0xFFFFFFFFu, lj = 0;
   {
@@ -334,7 +362,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   // every lane brings one candidate (valid, d, id, j); the passing ones are inserted one after the other
   auto offer = [&](bool valid, double d, uint32_t id, uint32_t j) {
     ++batches;
-    const bool pass = valid & (j - w0 >= (uint32_t)K) & (d <= bound) & ((d < kth) | ((d == kth) & (id < kth_id)));
+    const bool pass = valid & (j - skip_start >= skip_count) & (d <= bound) & ((d < kth) | ((d == kth) & (id < kth_id)));
     unsigned long long todo = __ballot(pass);
     while (todo) {
       const int src = __builtin_ctzll(todo);
@@ -378,12 +406,20 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
     }
   };
-  const uint32_t cx = uniform_u32(cell_coord(qx, fine)), cy = uniform_u32(cell_coord(qy, fine)),
-                 cz = uniform_u32(cell_coord(qz, fine));
-  const unsigned long long mq = morton3(cx, cy, cz);  // wave-uniform: scalar unit
-  const double fx = qx / fine - floor(qx / fine), fy = qy / fine - floor(qy / fine), fz = qz / fine - floor(qz / fine);
-  const float ffx = (float)fx, ffy = (float)fy, ffz = (float)fz;
-  const float fine2_low = __double2float_rd(fine * fine) * (1.0f - 0x1p-20f);
+  if (has_home) {
+    // the rest of home, then home as a whole is what the search skips; all K are now within home's diagonal
+    for (uint32_t base = home_start; base < home_end; base += 64u) {
+      const uint32_t j = base + (uint32_t)lane;
+      const bool valid = j < home_end;
+      uint32_t id = 0xFFFFFFFFu;
+      double d = INFINITY;
+      if (valid) d = dist2(j, id);
+      offer(valid, d, id, j);
+    }
+    skip_start = home_start;
+    skip_count = home_end - home_start;
+    bound = fmin(bound, kth);
+  }
   // Lower bound of the squared distance from the query to the cell (x, y, z) of level l, in single precision and
   // in units of the finest cell: the query is (cx + fx, ...) with the SAME quotient floor(q / fine) that binned the
   // points, so the integer part of every difference is exact; what single precision loses (2^-23 relative,
@@ -435,21 +471,6 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     waiting += __builtin_popcountll(who);
   };
 
-  {
-    // A second bound: the finest cell around the query that holds K points has them all within its
-    // diagonal (lane l asks for level l: the query's Morton code, made once on the scalar unit, shifted).
-    // Sorted-order neighbours can be far apart where the Morton curve jumps; this bound cannot.
-    uint32_t population = 0;
-    if (lane < kLevels) {
-      const CellEntry* e = find_cell(table, mask, cell_key(mq >> (3 * lane), lane));
-      if (e) population = e->end - e->start;
-    }
-    const unsigned long long enough = __ballot(population >= (uint32_t)K);
-    if (enough) {
-      const double size = fine * (double)(1u << __builtin_ctzll(enough));
-      bound = fmin(bound, 3.0 * size * size * (1.0 + 1e-9));
-    }
-  }
   // the level whose 27-cell block covers the ball of the seed radius: everything that can be among the K
   // nearest lies inside it. Lane l works out level l: the distance from the query to the faces of that block
   int level;
@@ -486,7 +507,12 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       if (want) {
         const CellEntry* e = find_cell(table, mask, cell_key(mk, level));
         want = e != nullptr;
-        if (e) { start = e->start; end = e->end; d2 = cell_d2(level, (uint32_t)x, (uint32_t)y, (uint32_t)z); want = d2 <= __double2float_ru(bound); }
+        if (e) {
+          start = e->start; end = e->end;
+          d2 = cell_d2(level, (uint32_t)x, (uint32_t)y, (uint32_t)z);
+          // (a cell whose whole run has been measured already has nothing to add)
+          want = (d2 <= __double2float_ru(bound)) & !((start >= skip_start) & (end <= skip_start + skip_count));
+        }
       }
       push(want, d2, cell_key(mk, level), start, end);
     }
@@ -557,7 +583,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
             cs = e->start;
             ce = e->end;
             d2 = cell_d2(l - step, chx, chy, chz);
-            want = d2 <= limit_up;
+            want = (d2 <= limit_up) & !((cs >= skip_start) & (ce <= skip_start + skip_count));
           }
         }
         const int incoming = __builtin_popcountll(__ballot(want));
