@@ -707,12 +707,30 @@ __global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict
   double cov[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   if (found >= 3) {
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < found; ++k) {
-      const uint32_t j = nbr[(size_t)o * kMaxKnn + k];
-      const double x = spts[4 * (size_t)j], y = spts[4 * (size_t)j + 1], z = spts[4 * (size_t)j + 2];
-      c[0] += x; c[1] += y; c[2] += z;
-      c[3] += x * x; c[4] += x * y; c[5] += x * z;
-      c[6] += y * y; c[7] += y * z; c[8] += z * z;
+    // eight neighbours at a time: their indices, then their points, are requested together (one thread per point
+    // is less than a wave per SIMD -- nothing else hides a load, and one neighbour after the other was 60
+    // dependent round trips); the sums stay in ascending-distance order
+    constexpr int kChunk = 8;
+    const uint4* row = reinterpret_cast<const uint4*>(nbr + (size_t)o * kMaxKnn);
+    for (int k0 = 0; k0 < found; k0 += kChunk) {
+      const uint4 ja = row[k0 / 4], jb = row[k0 / 4 + 1];
+      const uint32_t j[kChunk] = {ja.x, ja.y, ja.z, ja.w, jb.x, jb.y, jb.z, jb.w};
+      double2 xy[kChunk], zi[kChunk];
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        const double2* rec = reinterpret_cast<const double2*>(spts + 4 * (size_t)(k0 + u < found ? j[u] : 0u));
+        xy[u] = rec[0];
+        zi[u] = rec[1];
+      }
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        if (k0 + u < found) {
+          const double x = xy[u].x, y = xy[u].y, z = zi[u].x;
+          c[0] += x; c[1] += y; c[2] += z;
+          c[3] += x * x; c[4] += x * y; c[5] += x * z;
+          c[6] += y * y; c[7] += y * z; c[8] += z * z;
+        }
+      }
     }
     const double inv = (double)found;
 #pragma unroll
