@@ -1022,6 +1022,27 @@ def test_preprocess_edge_cases(gpu_ctx, oracle):
         gpu_ctx.preprocess(two, 0.0, 30)
 
 
+def test_preprocess_ties_duplicates_and_crowded_cells(gpu_ctx, oracle):
+    """What the search's shortcuts must not change: a lattice (every distance many times over: the k-th place is
+    decided by the index), exact duplicates of one point (a finest cell far more crowded than the 128 points the
+    'home cell' may hold, all at distance zero), and a scan where both meet ordinary points."""
+    from eskf_lio_amd import synth
+    rng = np.random.default_rng(17)
+    g = np.arange(-7, 8) * 0.125
+    lattice = np.stack(np.meshgrid(g, g, g[:5], indexing="ij"), axis=-1).reshape(-1, 3)   # 1 125 points, exact in binary
+    lattice = lattice[rng.permutation(len(lattice))]
+    for k in (30, 7):
+        _assert_preprocess_parity(gpu_ctx.preprocess(lattice, 0.3, k), oracle.preprocess(lattice, 0.3, k), lattice)
+    pile = np.concatenate([np.tile([[0.51, -0.23, 0.07]], (700, 1)), rng.normal(size=(300, 3)) * 0.4,
+                           np.tile([[3.0, 3.0, 3.0]], (40, 1))])
+    pile = pile[rng.permutation(len(pile))]
+    _assert_preprocess_parity(gpu_ctx.preprocess(pile, 0.3, 30), oracle.preprocess(pile, 0.3, 30), pile)
+    mixed = np.concatenate([synth.make_lidar_scan(6_000, seed=3), lattice + [2.0, 1.0, 0.5], pile + [-3.0, 2.0, 0.0]])
+    mixed = mixed[rng.permutation(len(mixed))]
+    for h in (0.3, 0.8):
+        _assert_preprocess_parity(gpu_ctx.preprocess(mixed, h, 30), oracle.preprocess(mixed, h, 30), mixed)
+
+
 def test_preprocess_feeds_the_registration(gpu_ctx, oracle):
     """Frame pipeline of LIOdometry (src/Odometry.cpp:153-175): prepare the scan, align it, insert it."""
     from eskf_lio_amd import synth
