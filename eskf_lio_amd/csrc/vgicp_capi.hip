@@ -1319,7 +1319,7 @@ namespace {
 // [state times | 12 doubles per state] for the states that can own points; false where the reference would
 // step off its deque (no state at or before the last point's time, or none after it).
 bool deskew_table(size_t n, const double* point_time, size_t num_states, const double* states,
-                  std::vector<double>& host, size_t& used) {
+                  std::vector<double>& host, size_t& used, bool& ordered) {
   const double t_end = point_time[n - 1];
   long before = (long)num_states - 1;
   while (before >= 0 && states[8 * before] > t_end) --before;
@@ -1352,6 +1352,9 @@ bool deskew_table(size_t n, const double* point_time, size_t num_states, const d
     std::memcpy(&host[used + 12 * s], T.R, 9 * sizeof(double));
     std::memcpy(&host[used + 12 * s + 9], T.t, 3 * sizeof(double));
   }
+  ordered = true;  // finite, non-decreasing state times: the device finds the segment bounds in parallel
+  for (size_t s = 0; s < used; ++s)
+    if (!(host[s] - host[s] == 0.0) || (s && host[s] < host[s - 1])) ordered = false;
   return true;
 }
 }  // namespace
@@ -1366,7 +1369,8 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
   if (n > 0x7FFFFFFFull || num_states > 0x7FFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan or state queue too large");
   std::vector<double> host;
   size_t used = 0;
-  if (!deskew_table(n, point_time, num_states, states, host, used)) {
+  bool ordered = false;
+  if (!deskew_table(n, point_time, num_states, states, host, used, ordered)) {
     *transformed = -1;
     return VGICP_OK;
   }
@@ -1374,7 +1378,7 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
   const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
   const size_t tb = (n * sizeof(double) + 255) & ~size_t(255);
   const size_t sb = (used * 13 * sizeof(double) + 255) & ~size_t(255);
-  const size_t eb = (used * sizeof(uint32_t) + 255) & ~size_t(255);
+  const size_t eb = (deskew_scratch_words((uint32_t)used) * sizeof(uint32_t) + 255) & ~size_t(255);
   int rc = ensure_stage(ctx, pb + tb + sb + eb);
   if (rc != VGICP_OK) return rc;
   char* base = static_cast<char*>(ctx->d_stage);
@@ -1385,7 +1389,7 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
   VG_HIP(ctx, hipMemcpyAsync(d_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   VG_HIP(ctx, hipMemcpyAsync(d_states, host.data(), used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  VG_HIP(ctx, launch_deskew(ctx->stream, d_pts, (uint32_t)n, d_time, d_states, (uint32_t)used, d_states + used, d_ends));
+  VG_HIP(ctx, launch_deskew(ctx->stream, d_pts, (uint32_t)n, d_time, d_states, (uint32_t)used, d_states + used, d_ends, ordered));
   VG_HIP(ctx, hipMemcpyAsync(points, d_pts, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, d_ends + (used - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1419,7 +1423,8 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
   }
   std::vector<double> host;
   size_t used = 0;
-  if (with_deskew && !deskew_table(n, point_time, num_states, states, host, used)) {
+  bool ordered = false;
+  if (with_deskew && !deskew_table(n, point_time, num_states, states, host, used, ordered)) {
     if (deskewed) *deskewed = -1;
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the IMU states do not bracket the end of the sweep");
   }
@@ -1427,7 +1432,7 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
   const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
   const size_t tb = (n * sizeof(double) + 255) & ~size_t(255);
   const size_t sb = (used * 13 * sizeof(double) + 255) & ~size_t(255);
-  const size_t eb = (used * sizeof(uint32_t) + 255) & ~size_t(255);
+  const size_t eb = (deskew_scratch_words((uint32_t)used) * sizeof(uint32_t) + 255) & ~size_t(255);
   const size_t ib = (n * sizeof(uint64_t) + 255) & ~size_t(255);
   rc = ensure_stage(ctx, pb + tb + sb + eb + ib + preprocess_scratch_bytes((uint32_t)n));
   if (rc != VGICP_OK) return rc;
@@ -1443,7 +1448,7 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
   if (with_deskew) {
     VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     VG_HIP(ctx, hipMemcpyAsync(d_states, host.data(), used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    VG_HIP(ctx, launch_deskew(ctx->stream, d_pts, (uint32_t)n, d_time, d_states, (uint32_t)used, d_states + used, d_ends));
+    VG_HIP(ctx, launch_deskew(ctx->stream, d_pts, (uint32_t)n, d_time, d_states, (uint32_t)used, d_states + used, d_ends, ordered));
     VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters + 4, d_ends + (used - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   }
   double* aos_pts = ctx->d_scan_aos;

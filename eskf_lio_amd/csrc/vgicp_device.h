@@ -182,9 +182,12 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
                                     void* scratch, void* cell_table, uint64_t table_entries, double* out_pts,
                                     double* out_covs, unsigned long long* out_idx, uint32_t* counters, int debug);
 hipError_t launch_transform_points(hipStream_t s, double* pts, uint32_t n, const double T16[16]);
-// CloudPreprocessor::deskew: ends = scratch of `states` words; poses = 12 doubles per state (R column-major, t)
+// CloudPreprocessor::deskew: ends = scratch of deskew_scratch_words(states) words (the first `states` are the
+// segment ends); poses = 12 doubles per state (R column-major, t); ordered_states: the host has checked that the
+// state times are finite and non-decreasing (the parallel bounds; otherwise the reference's walk, state by state)
+size_t deskew_scratch_words(uint32_t states);
 hipError_t launch_deskew(hipStream_t s, double* pts, uint32_t n, const double* point_time, const double* state_time,
-                         uint32_t states, const double* poses, uint32_t* ends);
+                         uint32_t states, const double* poses, uint32_t* ends, bool ordered_states);
 hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, double voxel_size,
                              const double* points_aos, const double* covs_aos, uint32_t n,
                              const double pose12[12], uint64_t max_points, void* scratch,

@@ -790,6 +790,72 @@ __global__ __launch_bounds__(kBoundsBlock) void deskew_bounds_kernel(const doubl
   }
 }
 
+// The same bounds without the walk, for state times that are finite and non-decreasing (the host checks; any IMU
+// queue is): "hit" = !(point_time < state_time) is then nested -- a point that is a hit for state s is one for
+// every earlier state -- and by induction the walk's result for s is simply the FIRST hit of s in the whole scan
+// (it cannot lie before where s-1 stopped), or, once a state has no hit at all, the last bound found. Every point
+// counts the states it is a hit for (binary search in LDS); a thread that sees its count rise at point j lowers
+// the first-hit of the states in between to j (LDS atomicMin); blocks cover contiguous parts of the scan and a
+// second small kernel takes the minimum over the blocks. 163 us -> two launches of a few us per 60k-point sweep.
+constexpr uint32_t kDeskewParts = 512;      // at most this many blocks share the scan (one load per thread: the loop is a chain)
+constexpr uint32_t kDeskewMaxStates = 4096; // LDS: 12 bytes per state; longer queues take the walk
+__global__ __launch_bounds__(256) void deskew_first_hit_kernel(const double* __restrict__ point_time, uint32_t n,
+                                                               const double* __restrict__ state_time, uint32_t states,
+                                                               uint32_t per_block, uint32_t* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char deskew_lds[];
+  double* ts = reinterpret_cast<double*>(deskew_lds);
+  uint32_t* first = reinterpret_cast<uint32_t*>(deskew_lds + (size_t)states * sizeof(double));
+  for (uint32_t s = threadIdx.x; s < states; s += blockDim.x) { ts[s] = state_time[s]; first[s] = 0xFFFFFFFFu; }
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t seen = 0;  // wave-uniform: states whose first hit this wave has already lowered (its later points come later)
+  for (uint32_t base = lo + (threadIdx.x & ~63u); base < hi; base += blockDim.x) {  // whole waves stay together
+    const uint32_t j = base + lane;
+    uint32_t a = 0;
+    if (j < hi) {
+      const double t = point_time[j];
+      // hits = number of states with !(t < ts[s]); NaN is a hit for all of them, like in the walk
+      uint32_t b = states;
+      while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        if (!(t < ts[mid])) a = mid + 1; else b = mid;
+      }
+    }
+    uint32_t most = a;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)most, o, 64); most = v > most ? v : most; }
+    // for every state not lowered yet: the first lane (= lowest j of this wave) that hits it; one lane stores
+    for (; seen < most; ++seen) {
+      const unsigned long long hit = __ballot(a > seen);
+      const uint32_t jmin = base + (uint32_t)__builtin_ctzll(hit);
+      if (lane == 0 && first[seen] > jmin) atomicMin(&first[seen], jmin);
+    }
+  }
+  __syncthreads();
+  for (uint32_t s = threadIdx.x; s < states; s += blockDim.x) part[(size_t)blockIdx.x * states + s] = first[s];
+}
+__global__ __launch_bounds__(1024) void deskew_merge_kernel(const uint32_t* __restrict__ part, uint32_t parts,
+                                                            uint32_t states, uint32_t* __restrict__ ends) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char deskew_lds[];
+  uint32_t* least = reinterpret_cast<uint32_t*>(deskew_lds);
+  __shared__ uint32_t last_found;
+  if (threadIdx.x == 0) last_found = 0u;
+  for (uint32_t s = threadIdx.x; s < states; s += blockDim.x) least[s] = 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < parts * states; k += blockDim.x) {  // all loads independent
+    const uint32_t v = part[k];
+    if (v != 0xFFFFFFFFu) atomicMin(&least[k % states], v);
+  }
+  __syncthreads();
+  // first hits are non-decreasing in s and the states without one form a tail: they keep the last bound found
+  for (uint32_t s = threadIdx.x; s < states; s += blockDim.x)
+    if (least[s] != 0xFFFFFFFFu) atomicMax(&last_found, least[s]);
+  __syncthreads();
+  const uint32_t keep = last_found;
+  for (uint32_t s = threadIdx.x; s < states; s += blockDim.x) ends[s] = least[s] != 0xFFFFFFFFu ? least[s] : keep;
+}
+
 // p <- T_s p for the state s whose segment holds the point; poses: 12 doubles per state, R column-major
 // then t. Evaluated in the order of Eigen's Isometry3d * Vector3d (this file has no FMA contraction).
 __global__ void deskew_apply_kernel(double* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ ends,
@@ -945,10 +1011,22 @@ hipError_t launch_transform_points(hipStream_t s, double* pts, uint32_t n, const
   return hipGetLastError();
 }
 
+size_t deskew_scratch_words(uint32_t states) { return (size_t)states * (1 + kDeskewParts); }
+
 hipError_t launch_deskew(hipStream_t s, double* pts, uint32_t n, const double* point_time, const double* state_time,
-                         uint32_t states, const double* poses, uint32_t* ends) {
+                         uint32_t states, const double* poses, uint32_t* ends, bool ordered_states) {
   if (n == 0 || states == 0) return hipSuccess;
-  hipLaunchKernelGGL(deskew_bounds_kernel, dim3(1), dim3(kBoundsBlock), 0, s, point_time, n, state_time, states, ends);
+  if (ordered_states && states <= kDeskewMaxStates) {
+    uint32_t parts = blocks_for(n, 256);
+    if (parts > kDeskewParts) parts = kDeskewParts;
+    const uint32_t per_block = blocks_for(n, parts);
+    uint32_t* part = ends + states;
+    hipLaunchKernelGGL(deskew_first_hit_kernel, dim3(parts), dim3(256), (size_t)states * 12, s, point_time, n,
+                       state_time, states, per_block, part);
+    hipLaunchKernelGGL(deskew_merge_kernel, dim3(1), dim3(1024), (size_t)states * 4, s, part, parts, states, ends);
+  } else {
+    hipLaunchKernelGGL(deskew_bounds_kernel, dim3(1), dim3(kBoundsBlock), 0, s, point_time, n, state_time, states, ends);
+  }
   hipLaunchKernelGGL(deskew_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, ends, states, poses);
   return hipGetLastError();
 }

@@ -1117,6 +1117,30 @@ def test_deskew_edge_cases(gpu_ctx, oracle):
     gp, done = gpu_ctx.deskew(pts, back, st)
     rp, rdone = oracle.deskew(pts, back, st)
     assert done == rdone and np.array_equal(gp, rp)
+    # point times in random order, with repeats and NaNs: first hits all over the scan (the parallel bounds)
+    rng = np.random.default_rng(8)
+    wild = rng.permutation(np.concatenate([t[:250], np.repeat(st[6, 0], 30), np.full(20, np.nan)]))
+    wild[-1] = st[-3, 0] + 1e-3
+    gp, done = gpu_ctx.deskew(pts, wild, st)
+    rp, rdone = oracle.deskew(pts, wild, st)
+    assert done == rdone and np.array_equal(gp, rp, equal_nan=True)
+    # a state queue that is NOT in time order takes the reference's walk, state by state, on the device too
+    mixed = st.copy()
+    mixed[[3, 4]] = mixed[[4, 3]]
+    for times in (t, back):
+        gp, done = gpu_ctx.deskew(pts, times, mixed)
+        rp, rdone = oracle.deskew(pts, times, mixed)
+        assert done == rdone and np.array_equal(gp, rp)
+    # a large sweep in many blocks, times with jitter across block boundaries
+    n = 150_000
+    big = synth.make_lidar_scan(n, seed=6)
+    st2 = synth.make_imu_states(60, seed=6)
+    t2 = synth.make_point_times(n, st2[1, 0] + 1e-4, st2[-3, 0] + 1e-3, seed=6)
+    t2 = t2 + rng.normal(size=n) * 2e-3
+    t2[-1] = st2[-3, 0] + 1e-3
+    gp, done = gpu_ctx.deskew(big, t2, st2)
+    rp, rdone = oracle.deskew(big, t2, st2)
+    assert done == rdone and np.array_equal(gp, rp)
 
 
 def test_host_mirror_cloud_preprocessor_process(oracle):
