@@ -15,6 +15,7 @@
 //                arithmetic of the reference sequentially, in registers, one record write at the end
 // Arithmetic is bit-exact with the CPU path (tests compare means, covariances and counts with `==`).
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include "vgicp_device.h"
 #include "vgicp_device_fn.h"
@@ -54,12 +55,18 @@ struct InsertScratch {
 
 __host__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
+// (slot, point index) pairs, stable. rocPRIM's merge sort with 2 048-item blocks: at scan sizes a launch costs as
+// much as the work it does, and hipCUB's radix-sort front end picks the same sort with half the block and one more
+// merge pass (see vgicp_preprocess.hip).
+__host__ inline hipError_t sort_slots(void* temp, size_t& temp_bytes, const uint32_t* slot_in, uint32_t* slot_out,
+                                      const uint32_t* idx_in, uint32_t* idx_out, uint32_t n, hipStream_t s) {
+  using Config = rocprim::merge_sort_config<512, 512, 4>;
+  return rocprim::merge_sort<Config>(temp, temp_bytes, slot_in, slot_out, idx_in, idx_out, (size_t)n,
+                                     rocprim::less<uint32_t>(), s);
+}
 __host__ inline size_t sort_temp_bytes(uint32_t n) {
   size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const uint32_t*>(nullptr),
-                                           static_cast<uint32_t*>(nullptr),
-                                           static_cast<const uint32_t*>(nullptr),
-                                           static_cast<uint32_t*>(nullptr), (int)n);
+  (void)sort_slots(nullptr, bytes, nullptr, nullptr, nullptr, nullptr, n, nullptr);
   return bytes;
 }
 
@@ -247,8 +254,7 @@ hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, d
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // stable: equal slots keep ascending point index = scan order
-  e = hipcub::DeviceRadixSort::SortPairs(w.cub, cub_bytes, w.slot_in, w.slot_out, w.idx_in, w.idx_out,
-                                         (int)n, 0, 32, s);
+  e = sort_slots(w.cub, cub_bytes, w.slot_in, w.slot_out, w.idx_in, w.idx_out, n, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(insert_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, w.slot_out,
                      w.idx_out, n, w.wpts, w.wcovs, max_points);
