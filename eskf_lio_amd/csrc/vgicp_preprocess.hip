@@ -238,8 +238,8 @@ __device__ __forceinline__ double lane_below_f64(double v) {
   return __hiloint2double(lane_below_i32(__double2hiint(v)), lane_below_i32(__double2loint(v)));
 }
 
-// Exact k nearest neighbours of one kept point per wave; writes the neighbours' positions in the sorted
-// order (ascending distance, ties by index) to nbr[slot * kMaxKnn + k] and the point itself to the output.
+// Exact k nearest neighbours of one kept point per wave; writes the neighbours' original indices (ascending
+// distance, ties by index) to nbr[slot * kMaxKnn + k] and the point itself to the output.
 __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     const double* __restrict__ spts, const uint32_t* __restrict__ sorted_idx, uint32_t n, double h, int knn,
     const CellEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ queries,
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   }
   uint32_t skip_start = w0, skip_count = (uint32_t)K;
   double ld = INFINITY;
-  uint32_t li = 0xFFFFFFFFu, lj = 0;
+  uint32_t li = 0xFFFFFFFFu;
   {
     const bool mine = lane < K;
     uint32_t id = 0xFFFFFFFFu;
@@ -346,13 +346,11 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     if (mine) {
       pk[rank] = (unsigned long long)__double_as_longlong(d);
       ps[rank] = id;
-      pe[rank] = w0 + (uint32_t)lane;
     }
     wave_sync();
     if (mine) {
       ld = __longlong_as_double((long long)pk[lane]);
       li = ps[lane];
-      lj = pe[lane];
     }
     wave_sync();
   }
@@ -370,7 +368,6 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       todo &= todo - 1;
       const double cd = readlane_f64(d, src);
       const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
-      const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)j, src);
       // how many entries come before the candidate (scalar mask arithmetic; equal distances are rare and take
       // the uniform branch). Lanes >= K hold whatever was pushed out and are masked off.
       unsigned long long before = __ballot(ld < cd);
@@ -380,27 +377,25 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       if (p >= K) continue;  // the list moved on since the batch was filtered
       ++inserts;
       // lanes above p take the entry of the lane below (one DPP select per dword, lanes <= p keep theirs), then
-      // lane p is overwritten from the scalar registers (v_writelane): 9 VALU instructions for the whole
+      // lane p is overwritten from the scalar registers (v_writelane): 7 VALU instructions for the whole
       // shift-and-insert. (A DPP operand written by the instruction before needs two wait states: s_nop 1.)
       uint32_t lo = (uint32_t)__double_as_longlong(ld), hi = (uint32_t)((unsigned long long)__double_as_longlong(ld) >> 32);
       const unsigned long long cbits = (unsigned long long)__double_as_longlong(cd);
       uint32_t m0_saved;
       asm volatile(
           "s_nop 1\n\t"
-          "v_cmp_ge_u32_e32 vcc, %5, %6\n\t"
-          "s_mov_b32 %4, m0\n\t"
-          "s_mov_b32 m0, %5\n\t"
+          "v_cmp_ge_u32_e32 vcc, %4, %5\n\t"
+          "s_mov_b32 %3, m0\n\t"
+          "s_mov_b32 m0, %4\n\t"
           "v_cndmask_b32_dpp %0, %0, %0, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
           "v_cndmask_b32_dpp %1, %1, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
           "v_cndmask_b32_dpp %2, %2, %2, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-          "v_cndmask_b32_dpp %3, %3, %3, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-          "v_writelane_b32 %0, %7, m0\n\t"
-          "v_writelane_b32 %1, %8, m0\n\t"
-          "v_writelane_b32 %2, %9, m0\n\t"
-          "v_writelane_b32 %3, %10, m0\n\t"
-          "s_mov_b32 m0, %4"
-          : "+v"(lo), "+v"(hi), "+v"(li), "+v"(lj), "=&s"(m0_saved)
-          : "s"(p), "v"(lane), "s"((uint32_t)cbits), "s"((uint32_t)(cbits >> 32)), "s"(ci), "s"(cj)
+          "v_writelane_b32 %0, %6, m0\n\t"
+          "v_writelane_b32 %1, %7, m0\n\t"
+          "v_writelane_b32 %2, %8, m0\n\t"
+          "s_mov_b32 m0, %3"
+          : "+v"(lo), "+v"(hi), "+v"(li), "=&s"(m0_saved)
+          : "s"(p), "v"(lane), "s"((uint32_t)cbits), "s"((uint32_t)(cbits >> 32)), "s"(ci)
           : "vcc");
       ld = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
       kth = readlane_f64(ld, K - 1);
@@ -621,7 +616,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   if (lane == 0 && spills && debug) atomicAdd(&counters[2], 1u);
   const uint32_t qi = uniform_u32(sorted_idx[qj]);
   const uint32_t o = uniform_u32(slot_of_index[qi]);
-  if (lane < kMaxKnn) nbr[(size_t)o * kMaxKnn + lane] = lj;
+  if (lane < kMaxKnn) nbr[(size_t)o * kMaxKnn + lane] = li;  // original indices: the list carries nothing else
   if (lane == 0) {
     out_pts[3 * (size_t)o] = qx; out_pts[3 * (size_t)o + 1] = qy; out_pts[3 * (size_t)o + 2] = qz;
     out_idx[o] = qi;
@@ -700,7 +695,7 @@ __device__ __forceinline__ void symmetric_eigen3(double (&A)[3][3], double (&U)[
 }
 
 // Covariance of the neighbours + regularisation, one thread per kept point.
-__global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict__ spts,
+__global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict__ pts,
                                                         const uint32_t* __restrict__ nbr, uint32_t m, int found,
                                                         double* __restrict__ out_covs) {
   const uint32_t o = blockIdx.x * kCovBlock + threadIdx.x;
@@ -716,17 +711,18 @@ __global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict
     for (int k0 = 0; k0 < found; k0 += kChunk) {
       const uint4 ja = row[k0 / 4], jb = row[k0 / 4 + 1];
       const uint32_t j[kChunk] = {ja.x, ja.y, ja.z, ja.w, jb.x, jb.y, jb.z, jb.w};
-      double2 xy[kChunk], zi[kChunk];
+      double px[kChunk], py[kChunk], pz[kChunk];
 #pragma unroll
       for (int u = 0; u < kChunk; ++u) {
-        const double2* rec = reinterpret_cast<const double2*>(spts + 4 * (size_t)(k0 + u < found ? j[u] : 0u));
-        xy[u] = rec[0];
-        zi[u] = rec[1];
+        const double* rec = pts + 3 * (size_t)(k0 + u < found ? j[u] : 0u);  // the scan as it came: original indices
+        px[u] = rec[0];
+        py[u] = rec[1];
+        pz[u] = rec[2];
       }
 #pragma unroll
       for (int u = 0; u < kChunk; ++u) {
         if (k0 + u < found) {
-          const double x = xy[u].x, y = xy[u].y, z = zi[u].x;
+          const double x = px[u], y = py[u], z = pz[u];
           c[0] += x; c[1] += y; c[2] += z;
           c[3] += x * x; c[4] += x * y; c[5] += x * z;
           c[6] += y * y; c[7] += y * z; c[8] += z * z;
@@ -1009,7 +1005,7 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
   hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((m + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
                      n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
   const int found = knn < (int)n ? knn : (int)n;
-  hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, spts, nbr, m, found, out_covs);
+  hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, pts, nbr, m, found, out_covs);
   return hipGetLastError();
 }
 
