@@ -363,6 +363,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     ++batches;
     const bool pass = valid & (j - skip_start >= skip_count) & (d <= bound) & ((d < kth) | ((d == kth) & (id < kth_id)));
     unsigned long long todo = __ballot(pass);
+    bool moved = false;
     while (todo) {
       const int src = __builtin_ctzll(todo);
       todo &= todo - 1;
@@ -398,6 +399,9 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
           : "s"(p), "v"(lane), "s"((uint32_t)cbits), "s"((uint32_t)(cbits >> 32)), "s"(ci)
           : "vcc");
       ld = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      moved = true;
+    }
+    if (moved) {  // the k-th entry is read back once per batch: inside the loop the list itself decides (p >= K)
       kth = readlane_f64(ld, K - 1);
       kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
     }
