@@ -7,21 +7,25 @@
 // Here:
 //   1. every point gets the 60-bit Morton code of its cell on a grid of voxel_size / 4 (so that
 //      code >> 6 is the Morton code of the voxel, the same floor(p / h) as the map keys); ONE stable
-//      radix sort (hipCUB) of (code, index) orders the scan so that the cells of every octree level —
-//      h/4, h/2, h, 2h, ... — are contiguous runs
+//      sort (rocPRIM merge sort) of (code, index) orders the scan so that the cells of every octree
+//      level — h/4, h/2, h, 2h, ... — are contiguous runs
 //   2. the lowest index of every voxel-level run is the first point of its voxel: that is the
-//      down-sampling; a prefix sum over scan order gives every kept point its output slot (ascending
-//      index), one over the runs the query list in Morton order
+//      down-sampling. One segmented scan over the sorted order yields, at the last point of every run,
+//      the voxel's rank, its kept point and that point's sorted position (the query list in Morton
+//      order), and in its total the number of kept points and of octree cells; a prefix sum over scan
+//      order gives every kept point its output slot (ascending index)
 //   3. a hash table of (level, cell) -> [start, end) over the sorted order is built for all levels:
 //      an octree whose nodes are contiguous runs of the sorted points
-//   4. ONE WAVE per kept point (control flow is uniform, lanes share the work): the farthest of k
-//      consecutive sorted points around the query bounds the k-th distance; the 27 cells around the
-//      query on the level whose block covers that ball seed a pool of cells; the wave repeatedly takes
-//      the nearest cell of the pool (best-first), and either lets its lanes look up the 64 cells two
-//      levels below (one each) or, for a short run, lets them measure its points (one each); passing
-//      points are inserted into the sorted k-list the lanes hold in registers. It stops when the
-//      nearest cell left is farther than the k-th distance: the result is the EXACT k nearest
-//      neighbours, ties broken by index, for work proportional to what lies inside that ball
+//   4. ONE WAVE per kept point (control flow is uniform, lanes share the work): the k-list starts
+//      full with sorted-order neighbours of the query; the finest own cell with >= k points ("home")
+//      is measured first, and the k-th distance after it picks the level whose 27-cell block covers
+//      the ball; those cells seed a pool; the wave repeatedly takes the nearest cell of the pool
+//      (best-first), and either lets its lanes look up the 64 cells two levels below (one each) or,
+//      for a short run, lets them measure its points (one each); passing points are inserted into the
+//      sorted k-list the lanes hold in registers. It stops when the nearest cell left is farther than
+//      the k-th distance: the result is the EXACT k nearest neighbours, ties broken by index, for
+//      work proportional to what lies inside that ball (DESIGN.md §9 has the measurements behind
+//      every choice in this kernel)
 //   5. one THREAD per kept point: cumulants in ascending-distance order, covariance, cyclic-Jacobi
 //      eigen-decomposition (for a symmetric positive semi-definite matrix U = V = eigenvectors),
 //      U diag(1,1,1e-2) U^T.
