@@ -58,5 +58,35 @@ with capi.Context(0) as ctx:
             bad += 1
             print(f"MISMATCH kind {kind} n {len(pts)} h {h} k {k}", flush=True)
             np.save(f"gpurun_out/soak_prep_fail_{runs}.npy", pts)
+    # the deskew's segment bounds: random point times (ordered, jittered, shuffled, with repeats), state queues of
+    # varied length, in time order and not
+    d_runs = d_bad = 0
+    t_end = time.time() + 0.25 * budget
+    while time.time() < t_end:
+        ns = int(rng.integers(6, 300))
+        st = synth.make_imu_states(ns, seed=int(rng.integers(1 << 30)))
+        n = int(rng.integers(10, 40_000))
+        pts = synth.make_lidar_scan(n, seed=int(rng.integers(1 << 30)))
+        lo, hi = st[int(rng.integers(0, ns // 2)), 0], st[int(rng.integers(ns // 2, ns - 2)), 0]
+        t = synth.make_point_times(n, lo + 1e-4, hi + 1e-3, seed=int(rng.integers(1 << 30)))
+        mode = int(rng.integers(4))
+        if mode == 1:
+            t = t + rng.normal(size=n) * float(rng.uniform(1e-4, 5e-2))
+        elif mode == 2:
+            t = rng.permutation(t)
+        elif mode == 3:
+            t[rng.integers(n, size=n // 10)] = st[rng.integers(ns, size=n // 10), 0]
+        t[-1] = hi + 1e-3
+        if rng.random() < 0.2:
+            i, j = rng.integers(ns, size=2)
+            st[[i, j]] = st[[j, i]]
+        gp, done = ctx.deskew(pts, t, st)
+        rp, rdone = oracle.deskew(pts, t, st)
+        d_runs += 1
+        if done != rdone or not np.array_equal(gp, rp):
+            d_bad += 1
+            print(f"DESKEW MISMATCH n {n} states {ns} mode {mode}", flush=True)
+    print(f"[soak deskew] {d_runs} sweeps, {d_bad} mismatches", flush=True)
+    bad += d_bad
 print(f"[soak prep] {runs} scans, {bad} mismatches", flush=True)
 sys.exit(1 if bad else 0)
