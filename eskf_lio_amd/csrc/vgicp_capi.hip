@@ -97,8 +97,7 @@ struct vgicp_ctx {
   double* d_rows[2] = {nullptr, nullptr};  // partial rows, ping-pong like the state
   double* d_sums = nullptr;       // one row: the all-reduce message (multi-GPU)
   // persistent single-launch align (single GPU)
-  uint32_t* d_sync = nullptr;        // exit counter of the persistent launch (monotonic)
-  uint32_t persist_exit_base = 0;    // host copy of its value between launches
+  uint32_t persist_round0 = 0;       // rounds the persistent launches of this context have executed, mod 3
   uint32_t persist_seq = 0;
   uint32_t persist_grid = 0;         // workgroups of every persistent launch: min(CUs, kExchangeRows), all resident
   double* d_rows_persist = nullptr;  // [3][kExchangeRows][kSlots] (vgicp_device.h, PersistArgs)
@@ -337,17 +336,16 @@ void state_to_pose(const double* pose12, double* m16) {
   pose_to_mat4(T, m16);
 }
 
-// Put the exchange buffers of the persistent launch into their between-launch state (and the exit counter
-// to zero): at context creation and after a launch that gave up.
+// Put the exchange buffers of the persistent launch into their initial state (everything unset, round 0):
+// at context creation and after a launch that gave up.
 int reset_persistent_exchange(vgicp_ctx* ctx) {
   const size_t rw = persistent_rows_words(), pw = persistent_parts_words();
   unsigned long long* img = static_cast<unsigned long long*>(ctx->h_exchange_image);
   persistent_exchange_image(ctx->persist_grid, img, img + rw);
   VG_HIP(ctx, hipMemcpyAsync(ctx->d_rows_persist, img, rw * 8, hipMemcpyHostToDevice, ctx->stream));
   VG_HIP(ctx, hipMemcpyAsync(ctx->d_parts_persist, img + rw, pw * 8, hipMemcpyHostToDevice, ctx->stream));
-  VG_HIP(ctx, hipMemsetAsync(ctx->d_sync, 0, 64 * sizeof(uint32_t), ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->persist_exit_base = 0;
+  ctx->persist_round0 = 0;
   return VGICP_OK;
 }
 
@@ -369,8 +367,7 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.voxel_size = ctx->voxel_size;
   a.rows = ctx->d_rows_persist;
   a.parts = ctx->d_parts_persist;
-  a.exit_counter = ctx->d_sync;
-  a.exit_base = ctx->persist_exit_base;
+  a.round0 = ctx->persist_round0;
   // final state and per-round log go straight into pinned host memory (posted PCIe writes, 5.4 KB per align):
   // no copy-back to enqueue after the launch
   a.state = reinterpret_cast<AlignState*>(ctx->h_log_dev - kSlots);
@@ -420,7 +417,7 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
                    kPersistentCooldownAligns);
     return reset_persistent_exchange(ctx);
   }
-  ctx->persist_exit_base += grid;
+  ctx->persist_round0 = (ctx->persist_round0 + (uint32_t)result->iteration) % 3u;
   if (multi) ctx->mail_round0 += (uint32_t)result->iteration;
   *ran = true;
   return VGICP_OK;
@@ -630,7 +627,6 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   for (int k = 0; k < 2; ++k)
     VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows[k]),
                         (size_t)kMaxIterBlocks * kSlots * sizeof(double)));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sync), 64 * sizeof(uint32_t)));
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_rows_persist), persistent_rows_words() * 8));
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_parts_persist), persistent_parts_words() * 8));
   VG_CREATE(hipHostMalloc(&ctx->h_exchange_image, (persistent_rows_words() + persistent_parts_words()) * 8, 0));
@@ -725,7 +721,6 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipFree(ctx->d_scan_aos);
   (void)hipFree(ctx->d_state);
   (void)hipHostFree(ctx->h_state);
-  (void)hipFree(ctx->d_sync);
   (void)hipFree(ctx->d_rows_persist);
   (void)hipFree(ctx->d_parts_persist);
   (void)hipHostFree(ctx->h_exchange_image);

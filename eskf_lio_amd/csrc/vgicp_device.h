@@ -92,9 +92,9 @@ struct PersistArgs {
   uint32_t mask;
   const VoxelRecord* table;
   double voxel_size;
-  double* rows;         // [3][kExchangeRows][kSlots]; between launches: kRowUnset where a workgroup publishes, else +0.0
+  double* rows;         // [3][kExchangeRows][kSlots]; kRowUnset where a workgroup publishes (between launches: all but the
+                        // buffer of the last round, which the next launch's first round re-arms), else +0.0
   double* parts;        // [3][kFolders][kSlots], likewise
-  uint32_t* exit_counter;  // arrivals at the end of the launch (monotonic; the host tracks its base)
   AlignState* state;    // out: final state; state->seq == seq tells the host the loop ran to its end
   double* log;          // [max_iteration][kSlots]
   uint32_t spin_limit;  // an in-kernel wait longer than this many polls gives up (host falls back to launches)
@@ -106,7 +106,8 @@ struct PersistArgs {
   int32_t max_iteration;
   uint32_t stash_points;   // extra points per thread kept in LDS across rounds (scans larger than the grid)
   uint32_t memo_points;    // extra points per thread whose last key + table slot are remembered in LDS
-  uint32_t exit_base;      // value of the exit counter before this launch
+  uint32_t round0;         // rounds executed on this context before this launch (mod 3 matters): the exchange
+                           // buffers rotate with round0 + it, so a launch leaves nothing to tidy up
   // multi-GPU (world > 1): the rank totals travel through peer-mapped mailboxes, written by the ranks'
   // kernels themselves over xGMI (no host-enqueued collective between launches)
   uint32_t world, rank;

@@ -925,7 +925,9 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
     }
 
     if (wave == 0) {
-      const uint32_t buf = (uint32_t)it % 3u, rearm = ((uint32_t)it + 2u) % 3u;
+      // the buffers rotate with a round number that runs on from launch to launch (a.round0: rounds executed on
+      // this context before): nothing has to be tidied up when a launch ends
+      const uint32_t buf = (a.round0 + (uint32_t)it) % 3u, rearm = (a.round0 + (uint32_t)it + 2u) % 3u;
       double* rows = a.rows + (size_t)buf * kExchangeRows * kSlots;
       double* parts = a.parts + (size_t)buf * kFolders * kSlots;
       // ---- level 1: publish this workgroup's row (every re-arming store of mine has completed) ----
@@ -973,8 +975,10 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       if (!ok) {
         if (lane == 0) stop_sh = 2;
       } else {
-        // re-arm what was consumed a round ago (buffer (it - 1) % 3; in round 0 it is unset already)
-        if (it > 0 && lane <= (uint32_t)kCountSlot) {
+        // re-arm what was consumed a round ago. In a launch's first round that is what the launch BEFORE published
+        // last: everyone has published this round, so everyone has left that launch and its reads behind. (Before
+        // the very first round of a context the buffer is unset already; storing "unset" again is harmless.)
+        if (lane <= (uint32_t)kCountSlot) {
           store_through_bits(a.rows + ((size_t)rearm * kExchangeRows + my_row) * kSlots + lane, kRowUnset);
           if (folder) store_through_bits(a.parts + ((size_t)rearm * kFolders + blk) * kSlots + lane, kRowUnset);
         }
@@ -1025,22 +1029,6 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   if (gave_up) return;  // the host sees state->seq != seq, resets the exchange buffers and uses launches
 
   if (wave == 0) {
-    // ---- leave the exchange buffers unset for the next launch ----
-    const uint32_t last = (uint32_t)(it - 1) % 3u;
-    if (lane <= (uint32_t)kCountSlot)
-      store_through_bits(a.rows + ((size_t)last * kExchangeRows + my_row) * kSlots + lane, kRowUnset);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t arrived = 0;
-    if (lane == 0)
-      arrived = __hip_atomic_fetch_add((gu32*)a.exit_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                a.exit_base;
-    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-    if (arrived == grid - 1) {  // everyone else has read the last parts: nobody looks at them any more
-      const uint32_t folders = grid < (uint32_t)kFolders ? grid : (uint32_t)kFolders;  // the others stay +0.0
-      for (uint32_t w = lane; w < folders * kSlots; w += 64)
-        if ((w & (kSlots - 1)) <= (uint32_t)kCountSlot)
-          store_through_bits(a.parts + (size_t)last * kFolders * kSlots + w, kRowUnset);
-    }
     if (blk == 0 && lane == 0) {
       AlignState* out = a.state;
 #pragma unroll
