@@ -88,13 +88,12 @@ struct Pose12 {
   double v[12];
 };
 
-__global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double voxel_size,
-                                      const double* __restrict__ pts, const double* __restrict__ covs,
-                                      uint32_t n, Pose12 pose, double* __restrict__ wpts,
-                                      double* __restrict__ wcovs, uint32_t* __restrict__ slot_of,
-                                      uint32_t* __restrict__ idx_of, uint32_t* counters) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// One point of insert_prepare_kernel: transform, key, find-or-claim the slot. fresh: this thread created the
+// voxel; returns the slot or kNoSlot (table full).
+__device__ __forceinline__ uint32_t prepare_point(VoxelRecord* table, uint32_t mask, double voxel_size,
+                                                  const double* __restrict__ pts, const double* __restrict__ covs,
+                                                  uint32_t i, const Pose12& pose, double* __restrict__ wpts,
+                                                  double* __restrict__ wcovs, bool& fresh) {
   double p[3], C[9], W[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) C[k] = covs[9 * (size_t)i + k];
@@ -110,7 +109,6 @@ __global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double 
 
   uint32_t slot = voxel_hash(kx, ky, kz) & mask;
   uint32_t found = kNoSlot;
-  bool fresh = false;
   // `spins` bounds the waits on LOCKED words so that a bug can only fail the call, never hang the GPU
   for (uint32_t probes = 0, spins = 0; probes <= mask && spins < (1u << 22); ++spins) {
     VoxelRecord* rec = table + slot;
@@ -141,10 +139,30 @@ __global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double 
     slot = (slot + 1) & mask;  // other key or tombstone
     ++probes;
   }
-  wave_count(&counters[0], fresh);
-  wave_count(&counters[1], found == kNoSlot);
-  slot_of[i] = found;
-  idx_of[i] = i;
+  return found;
+}
+
+__global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double voxel_size,
+                                      const double* __restrict__ pts, const double* __restrict__ covs,
+                                      uint32_t n, Pose12 pose, double* __restrict__ wpts,
+                                      double* __restrict__ wcovs, uint32_t* __restrict__ slot_of,
+                                      uint32_t* __restrict__ idx_of, uint32_t* counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool fresh = false, lost = false;
+  if (i < n) {
+    const uint32_t found = prepare_point(table, mask, voxel_size, pts, covs, i, pose, wpts, wcovs, fresh);
+    lost = found == kNoSlot;
+    slot_of[i] = found;
+    idx_of[i] = i;
+  }
+  // one atomic per workgroup and counter (every wave of a scan that opens new ground creates some voxel: one
+  // atomic per wave on the same word was half of this kernel's time)
+  const int created = __syncthreads_count(fresh ? 1 : 0);
+  const int failed = __syncthreads_count(lost ? 1 : 0);
+  if (threadIdx.x == 0) {
+    if (created) atomicAdd(&counters[0], (uint32_t)created);
+    if (failed) atomicAdd(&counters[1], (uint32_t)failed);
+  }
 }
 
 // Voxel(max, p, C) / Voxel::addPoint applied to the segment that starts at sorted position j.
