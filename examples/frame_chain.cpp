@@ -15,9 +15,11 @@
 //
 // build:  make -C examples   (plain g++; links eskf_lio_amd/lib/libvgicp_hip.so)
 #define ESKF_LIO_SHIM_FORCE_POD 1
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <memory>
 #include <vector>
@@ -104,12 +106,12 @@ double positionError(const double * pose16, const Pose & truth)
 }
 }  // namespace
 
-int main()
+int main(int argc, char ** argv)
 {
   try {
     const double t0 = 500.0, voxel = 0.3;
-    const int frames = 6;
-    const size_t n = 30000;
+    const int frames = argc > 1 ? std::atoi(argv[1]) : 6;             // frame_chain [frames] [points per sweep]
+    const size_t n = argc > 2 ? (size_t)std::atol(argv[2]) : 30000;
     // the state queue of the whole run: true poses at 400 Hz (what ErrorStateKF::getStates() would hold)
     std::deque<State> states;
     for (int k = -50; k <= (int)(400 * 0.1 * frames) + 20; ++k) {states.push_back(stateAt(t0, k / 400.0 + 0.00037));}
@@ -138,7 +140,8 @@ int main()
     Isometry3d estimateA = Isometry3d::Identity();
     double estimateB[16];
     std::memcpy(estimateB, shim::poseData(estimateA), sizeof estimateB);
-    int bad = 0;
+    int bad = 0, residentFrames = 0;
+    double residentMs = 0.0;
     for (int f = 0; f < frames; ++f) {
       const double end = 0.1 * f;
       LidarMeasurementPtr meas = sweep(t0, end, n, 77 + f, f > 0);
@@ -157,6 +160,7 @@ int main()
       }
 
       // ---- B: the same frame with the scan resident on the device ----
+      const auto b0 = std::chrono::steady_clock::now();
       size_t kept = 0;
       int64_t moved = 0;
       shim::check(ctx, vgicp_scan_prepare(ctx, raw.size(), raw[0].data(), times.data(), f == 0 ? 0 : states.size(),
@@ -167,6 +171,8 @@ int main()
       }
       size_t fresh = 0;
       shim::check(ctx, vgicp_map_insert_resident(ctx, estimateB, 20, &fresh), "vgicp_map_insert_resident");
+      const double frameMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
+      if (f > 0) {residentMs += frameMs; ++residentFrames;}
 
       const double errA = positionError(shim::poseData(estimateA), truth), errB = positionError(estimateB, truth);
       double gap = 0.0;
@@ -174,6 +180,10 @@ int main()
       std::printf("frame %d: %zu -> %zu points (%lld deskewed); classes: error %.2e m; resident chain: error %.2e m; "
         "difference between the two %.1e\n", f, raw.size(), kept, (long long)moved, errA, errB, gap);
       if (kept != meas->cloud->points_.size() || !(errA < 1e-2) || !(errB < 1e-2) || !(gap < 1e-9)) {++bad;}
+    }
+    if (residentFrames) {
+      std::printf("resident chain (raw sweep in, pose out, map updated): %.3f ms per %zu-point frame on average over %d frames\n",
+        residentMs / residentFrames, n, residentFrames);
     }
     vgicp_destroy(ctx);
     return bad == 0 ? 0 : 2;
