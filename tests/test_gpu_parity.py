@@ -776,6 +776,33 @@ def test_cpp_frame_chain_classes_and_resident_abi_agree():
     assert len(lines) == 6 and "deskewed" in lines[1]
 
 
+def test_bench_line_keeps_its_contract():
+    """bench.py end to end (short run): ONE JSON line with the driver's keys, BASELINE.json's metric string, the
+    roofline and cpu_baseline objects, and parity confirmed on the timed result."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--no-c5",
+                          "--cpu-budget", "4"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "points/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1e9 and abs(d["value"] - 100_000 * 20 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
+    assert d["parity"]["identical_counts"] is True and d["parity"]["pose_delta_m"] < 1e-9
+    assert d["config"]["persistent_fallbacks"] == 0
+
+
 # ---- multi-GPU code path on one device: RCCL communicator of size 1 ---------------------------
 def test_rccl_path_world_size_one(c1_gpu, c1_inputs):
     from eskf_lio_amd import synth
