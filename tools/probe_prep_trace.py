@@ -52,5 +52,6 @@ if os.environ.get("VGICP_TRACE_SIM"):  # list scheduling of the measured duratio
     by_start = np.argsort(t0, kind="stable")
     print(f"[trace] {slots} slots; makespan as dispatched {makespan(by_start):.1f} us, sum/slots {dt.sum() / slots:.1f} us, "
           f"by level descending {makespan(by_start[np.argsort(-level[by_start], kind='stable')]):.1f} us, "
+          f"by the level field ascending {makespan(by_start[np.argsort(level[by_start], kind='stable')]):.1f} us, "
           f"by cells taken descending {makespan(np.argsort(-pops, kind='stable')):.1f} us, "
           f"longest first {makespan(np.argsort(-dt)):.1f} us")
