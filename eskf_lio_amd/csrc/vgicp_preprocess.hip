@@ -235,12 +235,6 @@ __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)_
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
   return ((unsigned long long)uniform_u32((uint32_t)(v >> 32)) << 32) | uniform_u32((uint32_t)v);
 }
-// value of the lane below (lane 0 keeps its own)
-// DPP wave_shr:1 (GFX9): one VALU move, no trip through the LDS crossbar
-__device__ __forceinline__ int lane_below_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
-__device__ __forceinline__ double lane_below_f64(double v) {
-  return __hiloint2double(lane_below_i32(__double2hiint(v)), lane_below_i32(__double2loint(v)));
-}
 
 // Exact k nearest neighbours of one kept point per wave; writes the neighbours' original indices (ascending
 // distance, ties by index) to nbr[slot * kMaxKnn + k] and the point itself to the output.
