@@ -226,7 +226,8 @@ class Context:
         return name.value.decode(), cu.value, hbm.value
 
     def counter(self, which: int) -> int:
-        """vgicp_get_counter: 0 persistent launches, 1 persistent fallbacks, 2 upload bytes, 3 upload ns."""
+        """vgicp_get_counter: 0 persistent launches, 1 persistent fallbacks, 2 upload bytes, 3 upload ns,
+        4 indefinite covariances of the last scan preparation."""
         v = C.c_uint64(0)
         self._check(self._lib.vgicp_get_counter(self._h, int(which), C.byref(v)))
         return int(v.value)

@@ -111,6 +111,7 @@ struct vgicp_ctx {
   uint64_t persistent_fallbacks = 0;
   uint64_t upload_bytes = 0;
   double upload_seconds = 0.0;
+  uint64_t prep_indefinite = 0;      // kept points of the last scan preparation with an indefinite covariance
   int iter_block = 512;           // threads per workgroup of the iteration kernel (measured best at C2)
   double* d_log = nullptr;
   double* h_log = nullptr;  // pinned
@@ -619,8 +620,8 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   } while (0)
   VG_CREATE(hipSetDevice(device_id));
   VG_CREATE(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), 72 * sizeof(uint32_t)));
-  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), 72 * sizeof(uint32_t), 0));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), kCounterWords * sizeof(uint32_t)));
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), kCounterWords * sizeof(uint32_t), 0));
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_state), 2 * sizeof(AlignState)));
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state),
                           (1 + kMaxChunksInFlight) * sizeof(AlignState), 0));
@@ -761,6 +762,7 @@ int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
     case VGICP_COUNTER_PERSISTENT_FALLBACKS: *value = ctx->persistent_fallbacks; break;
     case VGICP_COUNTER_UPLOAD_BYTES: *value = ctx->upload_bytes; break;
     case VGICP_COUNTER_UPLOAD_NANOSECONDS: *value = (uint64_t)(ctx->upload_seconds * 1e9); break;
+    case VGICP_COUNTER_PREP_INDEFINITE: *value = ctx->prep_indefinite; break;
     default: return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown counter");
   }
   return VGICP_OK;
@@ -1172,7 +1174,7 @@ int ensure_cells(vgicp_ctx* ctx, size_t need) {
 int preprocess_on_device(vgicp_ctx* ctx, const double* d_pts, size_t n, double voxel_size, int knn, void* scratch,
                          size_t capacity, double* d_out_pts, double* d_out_covs, unsigned long long* d_out_idx,
                          uint32_t* kept) {
-  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 72 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, kCounterWords * sizeof(uint32_t), ctx->stream));
   VG_HIP(ctx, launch_preprocess_sort(ctx->stream, d_pts, (uint32_t)n, voxel_size, scratch, ctx->d_counters));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1247,7 +1249,10 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
   VG_HIP(ctx, hipMemcpyAsync(out_covs, d_out_covs, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (out_index)
     VG_HIP(ctx, hipMemcpyAsync(out_index, d_out_idx, (size_t)m * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters + kIndefiniteCounter, ctx->d_counters + kIndefiniteCounter, sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->prep_indefinite = ctx->h_counters[kIndefiniteCounter];
   return VGICP_OK;
 }
 
@@ -1453,7 +1458,10 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
   if (rc != VGICP_OK) return rc;
   if (with_deskew && deskewed) *deskewed = (int64_t)ctx->h_counters[4];
   if (m > 0) VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, m, ctx->d_scan, ctx->stride));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters + kIndefiniteCounter, ctx->d_counters + kIndefiniteCounter, sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->prep_indefinite = ctx->h_counters[kIndefiniteCounter];
   ctx->n = m;
   ctx->scan_ready = true;
   *kept = m;

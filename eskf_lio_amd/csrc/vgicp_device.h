@@ -173,6 +173,11 @@ uint32_t match_blocks(uint32_t n);
 size_t map_insert_scratch_bytes(uint32_t n);
 
 // vgicp_preprocess.hip — voxel down-sampling + k-NN covariances (CloudPreprocessor.cpp:76-127)
+// words of the context's counter block: [0] kept points, [1] octree cells, [2..7] developer counts, [3] also the
+// "point beyond the search grid" flag of stage A, [8..71] developer histograms, [72] kept points whose regularised
+// covariance is indefinite (a negative eigenvalue of the cumulant covariance, src/CloudPreprocessor.cpp:119-123)
+constexpr int kCounterWords = 80;
+constexpr int kIndefiniteCounter = 72;
 size_t preprocess_scratch_bytes(uint32_t n);
 int preprocess_max_knn();
 uint64_t preprocess_cell_entries(uint32_t cells);

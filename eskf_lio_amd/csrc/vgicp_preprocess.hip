@@ -644,62 +644,140 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   }
 }
 
-// Symmetric 3x3 eigen-decomposition by cyclic Jacobi; eigenvalues descending, U's columns the vectors.
-__device__ __forceinline__ void symmetric_eigen3(double (&A)[3][3], double (&U)[3][3]) {
-  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-    const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
-    if (off <= 1e-300 || off <= 1e-22 * diag) break;
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int q = p + 1; q < 3; ++q) {
-        if (A[p][q] == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - s * akq;
-          A[k][q] = s * akp + c * akq;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - s * aqk;
-          A[q][k] = s * apk + c * aqk;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
-        }
-      }
+// Eigen::JacobiSVD<Matrix3d>(A, ComputeFullU | ComputeFullV) in its published operation order (Eigen 3.4
+// src/SVD/JacobiSVD.h compute() / real_2x2_jacobi_svd(), src/Jacobi/Jacobi.h makeJacobi(), rotation product and
+// apply_rotation_in_the_plane()): what src/CloudPreprocessor.cpp:119-123 runs on every covariance.  Two-sided
+// Jacobi on A / max|A| over (p, q) = (1,0), (2,0), (2,1) until all off-diagonal pairs are below 2 eps max|diag|;
+// negative diagonal entries are folded into U, then values and columns are sorted descending (first maximum
+// wins).  For a symmetric input that leaves U.col(k) = sign(eigenvalue_k) V.col(k): a cumulant covariance with a
+// rounding-level NEGATIVE smallest eigenvalue (exact planes, lines, repeated points far from the origin) comes
+// back indefinite, as from the reference.  This file is compiled without contraction, and the tests' CPU checker
+// restates the same operations in the same order, so the two agree bit for bit.
+struct Rot { double c, s; };
+__device__ __forceinline__ double max_first(double a, double b) { return a < b ? b : a; }  // std::max
+__device__ __forceinline__ Rot make_jacobi(double x, double y, double z) {
+  const double deno = 2.0 * fabs(y);
+  if (deno < 2.2250738585072014e-308) return {1.0, 0.0};
+  const double tau = (x - z) / deno;
+  const double w = sqrt(tau * tau + 1.0);
+  const double t = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+  const double sign_t = t > 0.0 ? 1.0 : -1.0;
+  const double n = 1.0 / sqrt(t * t + 1.0);
+  return {n, -sign_t * (y / fabs(y)) * fabs(t) * n};
+}
+__device__ __forceinline__ void rotate_pair(double& x, double& y, const Rot& j) {
+  const double xi = x, yi = y;
+  x = j.c * xi + j.s * yi;
+  y = -j.s * xi + j.c * yi;
+}
+template <int P, int Q>
+__device__ __forceinline__ bool jacobi_svd_step(double (&W)[3][3], double (&U)[3][3], double (&V)[3][3], double& max_diag) {
+  const double threshold = max_first(2.2250738585072014e-308, 4.440892098500626e-16 * max_diag);
+  if (!(fabs(W[P][Q]) > threshold || fabs(W[Q][P]) > threshold)) return false;
+  double m00 = W[P][P], m01 = W[P][Q], m10 = W[Q][P], m11 = W[Q][Q];
+  Rot rot1;
+  const double t = m00 + m11, d = m10 - m01;
+  if (fabs(d) < 2.2250738585072014e-308) {
+    rot1 = {1.0, 0.0};
+  } else {
+    const double u = t / d;
+    const double tmp = sqrt(1.0 + u * u);
+    rot1 = {u / tmp, 1.0 / tmp};
   }
-  // order columns by descending eigenvalue (static index swaps)
-  double w0 = A[0][0], w1 = A[1][1], w2 = A[2][2];
-#define VG_SWAP_COL(a, b, wa, wb)                                                   \
-  if (wb > wa) {                                                                    \
-    const double tw = wa; wa = wb; wb = tw;                                         \
-    for (int k = 0; k < 3; ++k) { const double tv = V[k][a]; V[k][a] = V[k][b]; V[k][b] = tv; } \
+  if (!(rot1.c == 1.0 && rot1.s == 0.0)) {
+    rotate_pair(m00, m10, rot1);
+    rotate_pair(m01, m11, rot1);
   }
-  VG_SWAP_COL(0, 1, w0, w1)
-  VG_SWAP_COL(0, 2, w0, w2)
-  VG_SWAP_COL(1, 2, w1, w2)
-#undef VG_SWAP_COL
+  const Rot jr = make_jacobi(m00, m01, m11);
+  const Rot jrt = {jr.c, -jr.s};
+  const Rot jl = {rot1.c * jrt.c - rot1.s * jrt.s, rot1.c * jrt.s + rot1.s * jrt.c};
+  if (!(jl.c == 1.0 && jl.s == 0.0)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rotate_pair(W[P][k], W[Q][k], jl);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rotate_pair(U[k][P], U[k][Q], jl);
+  }
+  if (!(jrt.c == 1.0 && jrt.s == 0.0)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rotate_pair(W[k][P], W[k][Q], jrt);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rotate_pair(V[k][P], V[k][Q], jrt);
+  }
+  max_diag = max_first(max_diag, max_first(fabs(W[P][P]), fabs(W[Q][Q])));
+  return true;
+}
+// -> false for a non-finite input (U, V unset). `opposed` = columns with U.col(k) . V.col(k) < 0.
+__device__ __forceinline__ bool jacobi_svd3(const double (&A)[3][3], double (&U)[3][3], double (&V)[3][3], int& opposed) {
+  double scale = 0.0;
+  bool finite = true;
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) U[r][c] = V[r][c];
+    for (int c = 0; c < 3; ++c) {
+      const double v = fabs(A[r][c]);
+      if (!(v - v == 0.0)) finite = false;
+      if (v > scale) scale = v;
+    }
+  opposed = 0;
+  if (!finite) return false;
+  if (scale == 0.0) scale = 1.0;
+  double W[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      W[r][c] = A[r][c] / scale;
+      U[r][c] = V[r][c] = r == c ? 1.0 : 0.0;
+    }
+  double max_diag = max_first(fabs(W[0][0]), max_first(fabs(W[1][1]), fabs(W[2][2])));
+  bool finished = false;
+  while (!finished) {
+    finished = true;
+    if (jacobi_svd_step<1, 0>(W, U, V, max_diag)) finished = false;
+    if (jacobi_svd_step<2, 0>(W, U, V, max_diag)) finished = false;
+    if (jacobi_svd_step<2, 1>(W, U, V, max_diag)) finished = false;
+  }
+  double sv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double a = W[i][i];
+    sv[i] = fabs(a);
+    if (a < 0.0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) U[k][i] = -U[k][i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sv[i] *= scale;
+  // selection sort, descending, first maximum of the tail; stops at an all-zero tail (static indices)
+#define VG_SWAP_COLS(a, b)                                                                     \
+  {                                                                                            \
+    const double tw = sv[a]; sv[a] = sv[b]; sv[b] = tw;                                        \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                            \
+      const double tu = U[k][a]; U[k][a] = U[k][b]; U[k][b] = tu;                              \
+      const double tv = V[k][a]; V[k][a] = V[k][b]; V[k][b] = tv;                              \
+    }                                                                                          \
+  }
+  {
+    const int pos = sv[2] > (sv[1] > sv[0] ? sv[1] : sv[0]) ? 2 : (sv[1] > sv[0] ? 1 : 0);
+    const bool stop = sv[pos] == 0.0;
+    if (!stop) {
+      if (pos == 1) VG_SWAP_COLS(0, 1)
+      if (pos == 2) VG_SWAP_COLS(0, 2)
+      if (sv[2] > sv[1]) VG_SWAP_COLS(1, 2)   // (an all-zero tail ends Eigen's loop: nothing to swap then either)
+    }
+  }
+#undef VG_SWAP_COLS
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (U[0][i] * V[0][i] + U[1][i] * V[1][i] + U[2][i] * V[2][i] < 0.0) ++opposed;
+  return true;
 }
 
 // Covariance of the neighbours + regularisation, one thread per kept point.
 __global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict__ pts,
                                                         const uint32_t* __restrict__ nbr, uint32_t m, int found,
-                                                        double* __restrict__ out_covs) {
+                                                        double* __restrict__ out_covs, uint32_t* __restrict__ indefinite) {
   const uint32_t o = blockIdx.x * kCovBlock + threadIdx.x;
   if (o >= m) return;
   double cov[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
@@ -741,13 +819,17 @@ __global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict
     cov[0][2] = cov[2][0] = c[5] - c[0] * c[2];
     cov[1][2] = cov[2][1] = c[7] - c[1] * c[2];
   }
-  double U[3][3];
-  symmetric_eigen3(cov, U);
+  // svd.matrixU() * diag(1, 1, 1e-2) * svd.matrixV()^T (src/CloudPreprocessor.cpp:119-123)
+  double U[3][3], V[3][3];
+  int opposed = 0;
+  const bool ok = jacobi_svd3(cov, U, V, opposed);
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
     for (int r = 0; r < 3; ++r)
-      out_covs[9 * (size_t)o + r + 3 * cc] = U[r][0] * U[cc][0] + U[r][1] * U[cc][1] + (U[r][2] * 1e-2) * U[cc][2];
+      out_covs[9 * (size_t)o + r + 3 * cc] =
+          ok ? U[r][0] * V[cc][0] + U[r][1] * V[cc][1] + (U[r][2] * 1e-2) * V[cc][2] : __builtin_nan("");
+  if (opposed > 0) atomicAdd(indefinite, 1u);   // rare: a negative eigenvalue, the matrix written is indefinite
 }
 
 __global__ void cell_clear_kernel(CellEntry* table, uint64_t entries) {
@@ -1007,7 +1089,8 @@ hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n
   hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((m + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
                      n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
   const int found = knn < (int)n ? knn : (int)n;
-  hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, pts, nbr, m, found, out_covs);
+  hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, pts, nbr, m, found, out_covs,
+                     counters + kIndefiniteCounter);
   return hipGetLastError();
 }
 

@@ -98,7 +98,9 @@ enum {
   VGICP_COUNTER_PERSISTENT_LAUNCHES = 0,
   VGICP_COUNTER_PERSISTENT_FALLBACKS = 1,
   VGICP_COUNTER_UPLOAD_BYTES = 2,
-  VGICP_COUNTER_UPLOAD_NANOSECONDS = 3
+  VGICP_COUNTER_UPLOAD_NANOSECONDS = 3,
+  VGICP_COUNTER_PREP_INDEFINITE = 4   /* kept points of the LAST vgicp_preprocess / vgicp_scan_prepare whose
+                                         regularised covariance has a negative eigenvalue (see vgicp_preprocess) */
 };
 int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value);
 
@@ -189,8 +191,14 @@ int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* k
  * CloudPreprocessor::voxelDownsampleAndEstimateCovariances (src/CloudPreprocessor.cpp:76-127): keep the
  * first point of every voxel of size voxel_size, and give each kept point the covariance of its knn
  * nearest neighbours in the WHOLE scan (the point itself included; Open3D's cumulant estimate),
- * regularised to U diag(1, 1, 1e-2) V^T.  knn is KDTreeSearchParamKNN's (30 in the reference), at most
- * 32 here.  The neighbour search is exact (a Morton-ordered multi-level cell grid searched until the
+ * regularised to svd.matrixU() diag(1, 1, 1e-2) svd.matrixV()^T with Eigen's JacobiSVD in its published operation
+ * order.  For a symmetric matrix that is sum_k f_k sign(eigenvalue_k) q_k q_k^T ordered by |eigenvalue|: the
+ * cumulant estimate E[xx^T] - E[x]E[x]^T of an exactly planar, collinear or repeated neighbourhood far from the
+ * origin has a rounding-level smallest eigenvalue of either sign, and the reference — and therefore this call —
+ * then returns an INDEFINITE matrix (-1e-2 on the normal).  vgicp_get_counter(VGICP_COUNTER_PREP_INDEFINITE) says
+ * how many kept points of the last call were affected, so a caller can see it (the registration's Mahalanobis
+ * weight of such a point is still finite: the voxel's covariance is added before the inverse).
+ * knn is KDTreeSearchParamKNN's (30 in the reference), at most 32 here.  The neighbour search is exact (a Morton-ordered multi-level cell grid searched until the
  * k-th distance is certified), ties broken by the lower point index.
  * out_points (capacity x 3), out_covs (capacity x 9, column-major) and out_index (capacity, optional:
  * the kept points' indices in the input) are written in ascending input order — the reference emits

@@ -66,6 +66,12 @@ def load() -> C.CDLL:
                                  C.POINTER(_Stats)]
     lib.oracle_preprocess.restype = sz
     lib.oracle_preprocess.argtypes = [sz, dp, C.c_double, C.c_int, dp, dp, up]
+    lib.oracle_preprocess_ex.restype = sz
+    lib.oracle_preprocess_ex.argtypes = [sz, dp, C.c_double, C.c_int, dp, dp, up, up]
+    lib.oracle_jacobi_svd3.restype = C.c_int
+    lib.oracle_jacobi_svd3.argtypes = [dp, dp, dp, dp]
+    lib.oracle_regularize.restype = C.c_int
+    lib.oracle_regularize.argtypes = [dp, dp]
     lib.oracle_deskew.restype = C.c_int64
     lib.oracle_deskew.argtypes = [sz, dp, dp, sz, dp]
     lib.oracle_max_threads.restype = C.c_int
@@ -230,6 +236,35 @@ def preprocess(points, voxel_size: float, knn: int = 30):
     m = load().oracle_preprocess(n, _dp(points), float(voxel_size), int(knn), _dp(op), _dp(oc),
                                  ix.ctypes.data_as(C.POINTER(C.c_uint64)))
     return op[:m].copy(), oc[:m].copy(), ix[:m].copy()
+
+
+def preprocess_ex(points, voxel_size: float, knn: int = 30):
+    """preprocess() plus the number of kept points whose covariance came out INDEFINITE (the SVD negated a
+    column of U: a negative eigenvalue of the cumulant covariance, src/CloudPreprocessor.cpp:119-123)."""
+    points = _f64(points, 3)
+    n = points.shape[0]
+    op, oc = np.zeros((n, 3)), np.zeros((n, 9))
+    ix = np.zeros(n, dtype=np.uint64)
+    bad = C.c_uint64(0)
+    m = load().oracle_preprocess_ex(n, _dp(points), float(voxel_size), int(knn), _dp(op), _dp(oc),
+                                    ix.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(bad))
+    return op[:m].copy(), oc[:m].copy(), ix[:m].copy(), int(bad.value)
+
+
+def jacobi_svd3(A):
+    """Eigen::JacobiSVD<Matrix3d> restated: A (3x3, row/col numpy) -> (U, sv, V, negated columns); A = U diag(sv) V^T."""
+    a = np.ascontiguousarray(np.asarray(A, dtype=np.float64).reshape(3, 3).T).reshape(9)
+    U, V, sv = np.zeros(9), np.zeros(9), np.zeros(3)
+    neg = load().oracle_jacobi_svd3(_dp(a), _dp(U), _dp(V), _dp(sv))
+    return U.reshape(3, 3).T.copy(), sv, V.reshape(3, 3).T.copy(), int(neg)
+
+
+def regularize(cov):
+    """svd.matrixU() * diag(1, 1, 1e-2) * svd.matrixV()^T of a 3x3 -> (3x3, negated columns)."""
+    a = np.ascontiguousarray(np.asarray(cov, dtype=np.float64).reshape(3, 3).T).reshape(9)
+    out = np.zeros(9)
+    neg = load().oracle_regularize(_dp(a), _dp(out))
+    return out.reshape(3, 3).T.copy(), int(neg)
 
 
 def deskew(points, point_time, states):

@@ -616,55 +616,180 @@ int oracle_align(const oracle_map* map, size_t n, const double* points, const do
 // ---- N2: CloudPreprocessor::voxelDownsampleAndEstimateCovariances (src/CloudPreprocessor.cpp:76-127) ----
 namespace {
 
-// Eigen decomposition of a symmetric 3x3 by cyclic Jacobi rotations; eigenvalues descending, the
-// columns of U the matching unit eigenvectors.  For a symmetric positive semi-definite input this is
-// the U (= V) and the singular values Eigen::JacobiSVD returns, up to the sign of each column.
-void symmetric_eigen3(const M3& Ain, double w[3], M3& U) {
-  double A[3][3];
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) A[r][c] = Ain(r, c);
-  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    const double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
-    const double diag = std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]);
-    if (off <= 1e-300 || off <= 1e-22 * diag) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        if (A[p][q] == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {  // A <- A J
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - s * akq;
-          A[k][q] = s * akp + c * akq;
+// Eigen::JacobiSVD<Matrix3d>(A, ComputeFullU | ComputeFullV) restated in its published operation order
+// (Eigen 3.4 src/SVD/JacobiSVD.h: compute(), real_2x2_jacobi_svd(); src/Jacobi/Jacobi.h: makeJacobi(),
+// JacobiRotation product / transpose, apply_rotation_in_the_plane()).  Two-sided Jacobi on the square work
+// matrix A / max|A|: sweeps over (p, q) = (1,0), (2,0), (2,1) until every off-diagonal pair is below
+// 2 eps * max|diagonal|; each 2x2 block is first made symmetric by a left rotation (the identity while the
+// block IS symmetric), then diagonalised; U collects the left rotations, V the right ones.  Afterwards the
+// diagonal is made non-negative by negating the U column of every negative entry, and values and columns are
+// sorted descending by selection (first maximum wins).
+// What that means for the caller below (src/CloudPreprocessor.cpp:119-123): for a symmetric input the singular
+// values are |eigenvalue| and a NEGATIVE eigenvalue leaves U.col(k) = -V.col(k), so U F V^T carries
+// sign(eigenvalue_k) on its k-th term.  Open3D's cumulant covariance E[xx^T] - E[x]E[x]^T is not positive
+// semi-definite in floating point: far from the origin an exactly planar, collinear or repeated neighbourhood has
+// a smallest eigenvalue that is rounding noise of either sign, and the reference then emits an INDEFINITE
+// "covariance" (-1e-2 on the normal).  This restatement reproduces that class of result; whether a particular
+// noise-level eigenvalue comes out negative depends on every rounding of Eigen's compiled code and cannot be
+// pinned without Eigen (parity unpinned, see the header).  `negated` receives the number of columns k with
+// U.col(k) . V.col(k) < 0, i.e. of negative eigenvalues of a symmetric input (NOT the number of sign folds: a
+// rounding-level asymmetry of a 2x2 block can turn it by ~180 degrees, which negates work-matrix entries and U
+// columns together).
+// Returns false for a non-finite input (Eigen 3.4: info() == InvalidInput, U and V left unset).
+struct Rot {  // Eigen::JacobiRotation<double>
+  double c, s;
+};
+// JacobiRotation::makeJacobi(x, y, z) for the symmetric 2x2 [[x, y], [y, z]]
+inline Rot make_jacobi(double x, double y, double z) {
+  const double deno = 2.0 * std::fabs(y);
+  if (deno < std::numeric_limits<double>::min()) return {1.0, 0.0};
+  const double tau = (x - z) / deno;
+  const double w = std::sqrt(tau * tau + 1.0);
+  const double t = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+  const double sign_t = t > 0.0 ? 1.0 : -1.0;
+  const double n = 1.0 / std::sqrt(t * t + 1.0);
+  return {n, -sign_t * (y / std::fabs(y)) * std::fabs(t) * n};
+}
+// apply_rotation_in_the_plane(x, y, j): x_i <- c x_i + s y_i, y_i <- -s x_i + c y_i (skipped for the identity)
+inline void rotate_pair(double& x, double& y, const Rot& j) {
+  const double xi = x, yi = y;
+  x = j.c * xi + j.s * yi;
+  y = -j.s * xi + j.c * yi;
+}
+bool jacobi_svd3(const M3& Ain, M3& U, M3& V, double sv[3], int* negated) {
+  const double precision = 2.0 * std::numeric_limits<double>::epsilon();
+  const double consider_as_zero = std::numeric_limits<double>::min();
+  double scale = 0.0;
+  bool finite = true;
+  for (int i = 0; i < 9; ++i) {
+    const double v = std::fabs(Ain.a[i]);
+    if (!(v - v == 0.0)) finite = false;
+    if (v > scale) scale = v;
+  }
+  if (!finite) return false;
+  if (scale == 0.0) scale = 1.0;
+  M3 W;
+  for (int i = 0; i < 9; ++i) W.a[i] = Ain.a[i] / scale;
+  U = identity3();
+  V = identity3();
+  double max_diag = std::max(std::fabs(W(0, 0)), std::max(std::fabs(W(1, 1)), std::fabs(W(2, 2))));
+  bool finished = false;
+  while (!finished) {
+    finished = true;
+    for (int p = 1; p < 3; ++p)
+      for (int q = 0; q < p; ++q) {
+        const double threshold = std::max(consider_as_zero, precision * max_diag);
+        if (!(std::fabs(W(p, q)) > threshold || std::fabs(W(q, p)) > threshold)) continue;
+        finished = false;
+        // real_2x2_jacobi_svd on m = [[W(p,p), W(p,q)], [W(q,p), W(q,q)]]
+        double m00 = W(p, p), m01 = W(p, q), m10 = W(q, p), m11 = W(q, q);
+        Rot rot1;
+        const double t = m00 + m11, d = m10 - m01;
+        if (std::fabs(d) < std::numeric_limits<double>::min()) {
+          rot1 = {1.0, 0.0};
+        } else {
+          const double u = t / d;
+          const double tmp = std::sqrt(1.0 + u * u);
+          rot1 = {u / tmp, 1.0 / tmp};
         }
-        for (int k = 0; k < 3; ++k) {  // A <- J^T A
-          const double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - s * aqk;
-          A[q][k] = s * apk + c * aqk;
+        if (!(rot1.c == 1.0 && rot1.s == 0.0)) {  // m.applyOnTheLeft(0, 1, rot1)
+          rotate_pair(m00, m10, rot1);
+          rotate_pair(m01, m11, rot1);
         }
-        for (int k = 0; k < 3; ++k) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
+        const Rot jr = make_jacobi(m00, m01, m11);
+        const Rot jrt = {jr.c, -jr.s};                                         // j_right.transpose()
+        const Rot jl = {rot1.c * jrt.c - rot1.s * jrt.s, rot1.c * jrt.s + rot1.s * jrt.c};  // rot1 * j_right^T
+        const Rot jlt = {jl.c, -jl.s};
+        // m_workMatrix.applyOnTheLeft(p, q, j_left): rows p and q
+        if (!(jl.c == 1.0 && jl.s == 0.0))
+          for (int k = 0; k < 3; ++k) rotate_pair(W(p, k), W(q, k), jl);
+        // m_matrixU.applyOnTheRight(p, q, j_left.transpose()): columns p and q, rotated by (j_left^T)^T = j_left
+        if (!(jl.c == 1.0 && -jlt.s == 0.0))
+          for (int k = 0; k < 3; ++k) rotate_pair(U(k, p), U(k, q), jl);
+        // m_workMatrix.applyOnTheRight(p, q, j_right): columns p and q, rotated by j_right^T
+        if (!(jrt.c == 1.0 && jrt.s == 0.0)) {
+          for (int k = 0; k < 3; ++k) rotate_pair(W(k, p), W(k, q), jrt);
+          for (int k = 0; k < 3; ++k) rotate_pair(V(k, p), V(k, q), jrt);     // m_matrixV.applyOnTheRight
         }
+        max_diag = std::max(max_diag, std::max(std::fabs(W(p, p)), std::fabs(W(q, q))));
       }
   }
-  int order[3] = {0, 1, 2};
-  for (int i = 0; i < 2; ++i)
-    for (int j = i + 1; j < 3; ++j)
-      if (A[order[j]][order[j]] > A[order[i]][order[i]]) std::swap(order[i], order[j]);
-  for (int k = 0; k < 3; ++k) {
-    w[k] = A[order[k]][order[k]];
-    for (int r = 0; r < 3; ++r) U(r, k) = V[r][order[k]];
+  for (int i = 0; i < 3; ++i) {
+    const double a = W(i, i);
+    sv[i] = std::fabs(a);
+    if (a < 0.0)
+      for (int k = 0; k < 3; ++k) U(k, i) = -U(k, i);
   }
+  for (int i = 0; i < 3; ++i) sv[i] *= scale;
+  for (int i = 0; i < 3; ++i) {  // selection sort, descending, first maximum of the tail
+    int pos = i;
+    for (int k = i + 1; k < 3; ++k)
+      if (sv[k] > sv[pos]) pos = k;
+    if (sv[pos] == 0.0) break;
+    if (pos != i) {
+      std::swap(sv[i], sv[pos]);
+      for (int k = 0; k < 3; ++k) {
+        std::swap(U(k, i), U(k, pos));
+        std::swap(V(k, i), V(k, pos));
+      }
+    }
+  }
+  if (negated) {
+    int opposed = 0;
+    for (int i = 0; i < 3; ++i)
+      if (U(0, i) * V(0, i) + U(1, i) * V(1, i) + U(2, i) * V(2, i) < 0.0) ++opposed;
+    *negated = opposed;
+  }
+  return true;
+}
+
+// svd.matrixU() * covarianceFactor_ * svd.matrixV().transpose() (src/CloudPreprocessor.cpp:119-123) with
+// covarianceFactor_ = diag(1, 1, 1e-2) (include/ESKF_LIO/CloudPreprocessor.hpp:30-31).  U F has the columns
+// u0, u1, 1e-2 u2 (its other terms are exact zeros).  A non-finite covariance gives NaNs (the reference: unset U, V).
+inline M3 regularize(const M3& cov, int* negated) {
+  M3 U, V, R;
+  double sv[3];
+  if (!jacobi_svd3(cov, U, V, sv, negated)) {
+    if (negated) *negated = 0;
+    for (double& v : R.a) v = std::numeric_limits<double>::quiet_NaN();
+    return R;
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 3; ++cc)
+      R(r, cc) = U(r, 0) * V(cc, 0) + U(r, 1) * V(cc, 1) + (U(r, 2) * 1e-2) * V(cc, 2);
+  return R;
 }
 
 }  // namespace
 
+// Test hooks: the JacobiSVD restatement on ANY real 3x3 (column-major), and the regulariser alone.
+extern "C" int oracle_jacobi_svd3(const double A[9], double U[9], double V[9], double sv[3]) {
+  M3 a, u, v;
+  std::memcpy(a.a, A, 72);
+  int negated = 0;
+  if (!jacobi_svd3(a, u, v, sv, &negated)) return -1;
+  std::memcpy(U, u.a, 72);
+  std::memcpy(V, v.a, 72);
+  return negated;
+}
+extern "C" int oracle_regularize(const double cov[9], double out[9]) {
+  M3 c;
+  std::memcpy(c.a, cov, 72);
+  int negated = 0;
+  const M3 R = regularize(c, &negated);
+  std::memcpy(out, R.a, 72);
+  return negated;
+}
+
 extern "C" size_t oracle_preprocess(size_t n, const double* points, double voxel_size, int knn,
                                     double* out_points, double* out_covs, uint64_t* out_index) {
+  return oracle_preprocess_ex(n, points, voxel_size, knn, out_points, out_covs, out_index, nullptr);
+}
+
+extern "C" size_t oracle_preprocess_ex(size_t n, const double* points, double voxel_size, int knn,
+                                       double* out_points, double* out_covs, uint64_t* out_index,
+                                       uint64_t* indefinite) {
+  uint64_t flipped = 0;
   const V3* P = reinterpret_cast<const V3*>(points);
   // first point per voxel (src/CloudPreprocessor.cpp:87-92)
   std::unordered_map<Key, size_t, KeyHash> first;
@@ -675,7 +800,7 @@ extern "C" size_t oracle_preprocess(size_t n, const double* points, double voxel
   std::sort(kept.begin(), kept.end());
   const size_t m = kept.size();
   const size_t K = std::min<size_t>(static_cast<size_t>(knn > 0 ? knn : 0), n);
-#pragma omp parallel
+#pragma omp parallel reduction(+ : flipped)
   {
     std::vector<std::pair<double, size_t>> dist(n);
 #pragma omp for schedule(dynamic, 16)
@@ -704,20 +829,15 @@ extern "C" size_t oracle_preprocess(size_t n, const double* points, double voxel
         cov(0, 2) = cov(2, 0) = c[5] - c[0] * c[2];
         cov(1, 2) = cov(2, 1) = c[7] - c[1] * c[2];
       }
-      // U diag(1, 1, 1e-2) V^T (src/CloudPreprocessor.cpp:119-123, CloudPreprocessor.hpp:30-31)
-      double w[3];
-      M3 U;
-      symmetric_eigen3(cov, w, U);
-      const double f[3] = {1.0, 1.0, 1e-2};
-      M3 R;
-      for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc)
-          R(r, cc) = U(r, 0) * f[0] * U(cc, 0) + U(r, 1) * f[1] * U(cc, 1) + U(r, 2) * f[2] * U(cc, 2);
+      int negated = 0;
+      const M3 R = regularize(cov, &negated);
+      if (negated > 0) ++flipped;
       std::memcpy(out_points + 3 * o, &q, 24);
       std::memcpy(out_covs + 9 * o, R.a, 72);
       out_index[o] = kept[o];
     }
   }
+  if (indefinite) *indefinite = flipped;
   return m;
 }
 

@@ -91,12 +91,27 @@ int oracle_align(const oracle_map* map, size_t n, const double* points, const do
  * keep the first point (lowest index) of every voxel of size voxel_size; for every kept point the knn
  * nearest points of the FULL cloud (the point itself included, Open3D KDTreeSearchParamKNN, default 30),
  * Open3D's ComputeCovariance over them (cumulants: E[x x^T] - E[x] E[x]^T), then the regularisation
- * U diag(1, 1, 1e-2) V^T of Eigen's JacobiSVD (for a symmetric positive semi-definite matrix U = V =
- * eigenvectors, singular values descending); fewer than 3 neighbours -> identity before regularising.
+ * svd.matrixU() * diag(1, 1, 1e-2) * svd.matrixV()^T with Eigen's JacobiSVD restated in its published operation
+ * order (two-sided Jacobi, negative diagonal entries folded into U, selection sort).  For a symmetric input the
+ * k-th term carries sign(eigenvalue_k): the cumulant covariance of an exactly planar / collinear / repeated
+ * neighbourhood far from the origin has a rounding-level smallest eigenvalue of either sign, and the reference then
+ * returns an INDEFINITE matrix (-1e-2 on the normal).  The restatement reproduces that class; which noise-level
+ * eigenvalues come out negative depends on every rounding of Eigen's compiled code and is not pinned (parity
+ * unpinned).  Fewer than 3 neighbours -> identity before regularising.  A non-finite covariance -> NaNs.
  * Output order: ascending original index (the reference emits unordered_map iteration order).
- * out_points m x 3, out_covs m x 9 column-major, out_index m; returns m. Brute-force neighbour search. */
+ * out_points m x 3, out_covs m x 9 column-major, out_index m; returns m. Brute-force neighbour search.
+ * _ex: *indefinite (optional) receives the number of kept points with a column k where U.col(k) . V.col(k) < 0
+ * (a negative eigenvalue: the returned matrix is indefinite). */
 size_t oracle_preprocess(size_t n, const double* points, double voxel_size, int knn,
                          double* out_points, double* out_covs, uint64_t* out_index);
+size_t oracle_preprocess_ex(size_t n, const double* points, double voxel_size, int knn,
+                            double* out_points, double* out_covs, uint64_t* out_index, uint64_t* indefinite);
+/* Test hooks. oracle_jacobi_svd3: the JacobiSVD restatement on ANY real 3x3 (column-major in and out):
+ * A = U diag(sv) V^T, sv descending; returns the number of columns with U.col(k) . V.col(k) < 0 (negative
+ * eigenvalues of a symmetric A), -1 for a non-finite input.
+ * oracle_regularize: U diag(1, 1, 1e-2) V^T of a 3x3, same return value. */
+int oracle_jacobi_svd3(const double A[9], double U[9], double V[9], double sv[3]);
+int oracle_regularize(const double cov[9], double out[9]);
 
 /* CloudPreprocessor::deskew (src/CloudPreprocessor.cpp:25-74) with Utils::interpolateSE3 and
  * Utils::transformPoints (src/Utils.cpp:13-20,65-75): every point taken before an IMU state's timestamp is

@@ -68,7 +68,24 @@ def main():
     np.savez(os.path.join(HERE, "frame_small.npz"), points=raw, point_time=t, states=st, deskewed=desk,
              moved=np.int64(moved), kept_points=kp, kept_covs=kc, kept_index=ki, voxel_size=np.float64(0.3),
              knn=np.int32(30))
-    for f in ("c1_uniform.npz", "c1_structured.npz", "tiny.npz", "frame_small.npz"):
+    # neighbourhoods whose cumulant covariance has rounding-level eigenvalues (exact tilted plane, collinear and
+    # repeated points, far from the origin): the reference's U F V^T then returns INDEFINITE matrices
+    # (src/CloudPreprocessor.cpp:119-123); inputs stored, with the count of affected points
+    rng = np.random.default_rng(3)
+    nrm = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    b1 = np.cross(nrm, [1.0, 0.0, 0.0])
+    b1 /= np.linalg.norm(b1)
+    b2 = np.cross(nrm, b1)
+    uv = rng.uniform(-1.5, 1.5, (600, 2))
+    plane = np.array([50.0, -70.0, 40.0]) + uv[:, :1] * b1 + uv[:, 1:] * b2
+    line = np.array([-30.0, 20.0, 60.0]) + rng.uniform(-2.0, 2.0, (200, 1)) * np.array([2.0, -1.0, 0.5]) / np.sqrt(5.25)
+    same = np.repeat(np.array([[80.3, -41.7, 12.9]]), 40, axis=0)
+    exact = np.repeat(np.array([[80.25, -41.5, 12.75]]), 40, axis=0)
+    deg = np.concatenate([plane, line, same, exact])
+    dp, dc, di, bad = oracle.preprocess_ex(deg, 0.3, 30)
+    np.savez(os.path.join(HERE, "prep_degenerate.npz"), points=deg, kept_points=dp, kept_covs=dc, kept_index=di,
+             indefinite=np.int64(bad), plane_normal=nrm, voxel_size=np.float64(0.3), knn=np.int32(30))
+    for f in ("c1_uniform.npz", "c1_structured.npz", "tiny.npz", "frame_small.npz", "prep_degenerate.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -998,8 +998,10 @@ def _assert_preprocess_parity(got, ref, pts, exact=True):
         assert np.array_equal(G, R), np.abs(G - R).max()
     else:
         assert np.abs(G - R).max() < 1e-9
-    ev = np.linalg.eigvalsh(G)
-    assert np.allclose(ev, [1e-2, 1.0, 1.0], atol=1e-11)
+    # U F V^T with orthogonal U, V: singular values (1, 1, 1e-2) always; eigenvalues (1e-2, 1, 1) unless the
+    # neighbourhood is degenerate (repeated / coplanar / collinear points: rounding-level eigenvalues of either sign,
+    # test_preprocess_degenerate_neighbourhoods_are_the_references_class)
+    assert np.allclose(np.linalg.svd(G, compute_uv=False), [1.0, 1.0, 1e-2], atol=1e-9)
 
 
 @pytest.mark.parametrize("n,knn", [(3_000, 30), (20_000, 30), (20_000, 7)])
@@ -1068,6 +1070,30 @@ def test_preprocess_ties_duplicates_and_crowded_cells(gpu_ctx, oracle):
     mixed = mixed[rng.permutation(len(mixed))]
     for h in (0.3, 0.8):
         _assert_preprocess_parity(gpu_ctx.preprocess(mixed, h, 30), oracle.preprocess(mixed, h, 30), mixed)
+
+
+def test_preprocess_degenerate_neighbourhoods_are_the_references_class(gpu_ctx, oracle):
+    """tests/golden/prep_degenerate.npz: an exact tilted plane, collinear and repeated points far from the origin. The
+    cumulant covariance then has rounding-level eigenvalues of either sign and the reference's svd.matrixU() * F *
+    svd.matrixV()^T (src/CloudPreprocessor.cpp:119-123) returns INDEFINITE matrices; the device returns the oracle's bits
+    for them too and reports how many kept points were affected (VGICP_COUNTER_PREP_INDEFINITE)."""
+    g = np.load(os.path.join(GOLDEN, "prep_degenerate.npz"))
+    pts = g["points"]
+    gp, gc, gi = gpu_ctx.preprocess(pts, float(g["voxel_size"]), int(g["knn"]))
+    assert np.array_equal(gi, g["kept_index"]) and np.array_equal(gp, g["kept_points"])
+    assert np.array_equal(gc, g["kept_covs"])
+    assert gpu_ctx.counter(4) == int(g["indefinite"]) > 0
+    rp, rc, ri, bad = oracle.preprocess_ex(pts, float(g["voxel_size"]), int(g["knn"]))
+    assert np.array_equal(gc, rc) and bad == int(g["indefinite"])
+    # whatever the signs, the singular values of every result are (1, 1, 1e-2): U and V are orthogonal
+    sv = np.linalg.svd(_cov_mats(gc), compute_uv=False)
+    assert np.allclose(sv, [1.0, 1.0, 1e-2], atol=1e-9)
+    # the fused chain reports the same count, and an ordinary scan reports none
+    kept, _ = gpu_ctx.scan_prepare(pts, None, None, None, float(g["voxel_size"]), int(g["knn"]))
+    assert kept == len(gi) and gpu_ctx.counter(4) == int(g["indefinite"])
+    from eskf_lio_amd import synth
+    gpu_ctx.preprocess(synth.make_lidar_scan(3_000, seed=2), 0.3, 30)
+    assert gpu_ctx.counter(4) == 0
 
 
 def test_preprocess_feeds_the_registration(gpu_ctx, oracle):

@@ -362,7 +362,7 @@ def _cov_mats(c9):
 
 def test_preprocess_oracle_matches_numpy(oracle):
     """First point per voxel, 30 nearest neighbours, cumulant covariance, U diag(1,1,1e-2) V^T
-    (CloudPreprocessor.cpp:76-127): Jacobi eigenvectors in the oracle, LAPACK's SVD in numpy."""
+    (CloudPreprocessor.cpp:76-127): Eigen's JacobiSVD restated in the oracle, LAPACK's SVD in numpy."""
     pts = synth.make_lidar_scan(3_000)
     op, oc, ix = oracle.preprocess(pts, 0.3, 30)
     npts, ncov, nix = npo.preprocess(pts, 0.3, 30)
@@ -391,6 +391,112 @@ def test_preprocess_known_answers(oracle):
     assert len(ix) == 2 and np.allclose(_cov_mats(oc), np.diag([1.0, 1.0, 1e-2]), atol=1e-15)
     # empty scan
     assert len(oracle.preprocess(np.zeros((0, 3)), 0.3, 30)[2]) == 0
+
+
+def test_jacobi_svd_restatement_against_lapack(oracle):
+    """The oracle's Eigen::JacobiSVD<Matrix3d> restatement (published operation order) on ANY real 3x3 -- general,
+    symmetric, rank-deficient, scaled over ten decades -- against LAPACK: reconstruction, orthogonality, singular
+    values, descending order.  This is the independent pin of the regulariser's arithmetic
+    (src/CloudPreprocessor.cpp:119-123)."""
+    rng = np.random.default_rng(11)
+    for k in range(3000):
+        A = rng.standard_normal((3, 3)) * 10.0 ** rng.uniform(-5, 5)
+        if k % 3 == 0:
+            A = A + A.T
+        if k % 7 == 0:
+            A[:, 2] = 2.0 * A[:, 0]
+        U, sv, V, _ = oracle.jacobi_svd3(A)
+        scale = np.abs(A).max()
+        assert np.abs(U @ np.diag(sv) @ V.T - A).max() <= 2e-14 * scale
+        assert np.abs(U.T @ U - np.eye(3)).max() <= 2e-14 and np.abs(V.T @ V - np.eye(3)).max() <= 2e-14
+        assert sv[0] >= sv[1] >= sv[2] >= 0.0
+        assert np.abs(sv - np.linalg.svd(A, compute_uv=False)).max() <= 2e-14 * scale
+    # exact cases: the zero matrix and the identity need no rotation: U = V = I, F comes out as it is
+    for A in (np.zeros((3, 3)), np.eye(3), np.diag([3.0, 2.0, 1.0])):
+        R, neg = oracle.regularize(A)
+        assert neg == 0 and np.array_equal(R, np.diag([1.0, 1.0, 1e-2]))
+    # values in ascending order on the diagonal: the sort moves the columns, the small factor follows the small value
+    R, _ = oracle.regularize(np.diag([1.0, 2.0, 3.0]))
+    assert np.array_equal(R, np.diag([1e-2, 1.0, 1.0]))
+    assert oracle.jacobi_svd3(np.full((3, 3), np.nan))[3] == -1
+
+
+def test_regulariser_carries_the_sign_of_a_negative_eigenvalue(oracle):
+    """U F V^T of a symmetric matrix is sum_k f_k sign(lambda_k) q_k q_k^T ordered by |lambda| (an SVD has S >= 0,
+    so the sign of a negative eigenvalue sits in U against V): what the reference's JacobiSVD line does, checked
+    against LAPACK's SVD and against the closed form."""
+    rng = np.random.default_rng(5)
+    F = np.diag([1.0, 1.0, 1e-2])
+    for _ in range(2000):
+        Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        lam = rng.standard_normal(3) * 10.0 ** rng.uniform(-3, 3, 3)
+        a = np.sort(np.abs(lam))
+        if a[1] < 1.01 * a[0] or a[2] < 1.01 * a[1]:
+            continue                                   # (near-)equal |lambda|: which direction gets 1e-2 is not defined
+        A = Q @ np.diag(lam) @ Q.T
+        A = 0.5 * (A + A.T)
+        R, neg = oracle.regularize(A)
+        assert neg == int((lam < 0).sum())
+        order = np.argsort(-np.abs(lam))
+        want = sum(f * np.sign(lam[k]) * np.outer(Q[:, k], Q[:, k]) for f, k in zip((1.0, 1.0, 1e-2), order))
+        tol = 1e-12 * a[2] / min(a[1] - a[0], a[2] - a[1])           # directions are as good as the gaps allow
+        assert np.abs(R - want).max() < tol
+        Us, _, Vt = np.linalg.svd(A)
+        assert np.abs(R - Us @ F @ Vt).max() < tol
+
+
+def _degenerate_scans():
+    """Neighbourhoods whose cumulant covariance E[xx^T] - E[x]E[x]^T has rounding-level eigenvalues far from the
+    origin: an exact tilted plane, collinear points, repeated points."""
+    rng = np.random.default_rng(3)
+    n = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    b1 = np.cross(n, [1.0, 0.0, 0.0])
+    b1 /= np.linalg.norm(b1)
+    b2 = np.cross(n, b1)
+    uv = rng.uniform(-1.5, 1.5, (600, 2))
+    plane = np.array([50.0, -70.0, 40.0]) + uv[:, :1] * b1 + uv[:, 1:] * b2
+    line = np.array([-30.0, 20.0, 60.0]) + rng.uniform(-2.0, 2.0, (200, 1)) * np.array([2.0, -1.0, 0.5]) / np.sqrt(5.25)
+    same = np.repeat(np.array([[80.3, -41.7, 12.9]]), 40, axis=0)
+    return plane, n, line, same
+
+
+def test_preprocess_degenerate_neighbourhoods(oracle):
+    """KATs for the behaviour class VERDICT r2 reproduced: the reference can emit an INDEFINITE covariance. Exact plane:
+    eigenvalues (+-1e-2, 1, 1), the +-1e-2 direction is the plane's normal, the count of indefinite points is
+    reported; numpy (LAPACK SVD) agrees up to the sign of the rounding-level term, which no restatement can pin."""
+    plane, normal, line, same = _degenerate_scans()
+    op, oc, ix, bad = oracle.preprocess_ex(plane, 0.3, 30)
+    C = _cov_mats(oc)
+    ev, evec = np.linalg.eigh(C)
+    small = np.argmin(np.abs(ev), axis=1)
+    assert np.allclose(np.sort(np.abs(ev), axis=1), [1e-2, 1.0, 1.0], atol=1e-9)
+    nrm = evec[np.arange(len(C)), :, small]
+    assert np.all(np.abs(np.abs(nrm @ normal) - 1.0) < 1e-6)
+    negative = int((ev[np.arange(len(C)), small] < 0).sum())
+    assert bad == negative                                            # the count the caller can see
+    assert 0 < negative < len(C)                                      # this input does reach the indefinite class
+    _, ncov, nix = npo.preprocess(plane, 0.3, 30)
+    assert np.array_equal(ix, nix.astype(np.uint64))
+    flip = 0.02 * nrm[:, :, None] * nrm[:, None, :]                   # the +-1e-2 n n^T term, either sign
+    d = np.abs(C - ncov).reshape(len(C), -1).max(axis=1)
+    d_flipped = np.minimum(np.abs(C + flip - ncov).reshape(len(C), -1).max(axis=1),
+                           np.abs(C - flip - ncov).reshape(len(C), -1).max(axis=1))
+    assert np.all(np.minimum(d, d_flipped) < 1e-6)
+    # collinear points: one direction carries the variance, the other two eigenvalues are BOTH noise (either sign, nearly
+    # equal in size, so U and V may even disagree inside that plane and the result need not be symmetric): what is
+    # defined is that the singular values of U F V^T are (1, 1, 1e-2) and that the line's direction keeps the factor 1
+    _, oc, _, _ = oracle.preprocess_ex(line, 0.3, 30)
+    C = _cov_mats(oc)
+    assert np.allclose(np.linalg.svd(C, compute_uv=False), [1.0, 1.0, 1e-2], atol=1e-9)
+    along = np.array([2.0, -1.0, 0.5]) / np.sqrt(5.25)
+    assert np.allclose(np.einsum("i,nij,j->n", along, C, along), 1.0, atol=1e-6)
+    # K identical points: every eigenvalue is noise (sum of 30 equal terms / 30 is not the term): singular values only
+    _, oc, ix, _ = oracle.preprocess_ex(same, 0.3, 30)
+    assert len(ix) == 1 and np.allclose(np.linalg.svd(_cov_mats(oc)[0], compute_uv=False), [1.0, 1.0, 1e-2], atol=1e-9)
+    # ... unless the cumulants are exact (dyadic coordinates): covariance exactly zero -> no rotation, U = V = I, F itself
+    exact = np.repeat(np.array([[80.25, -41.5, 12.75]]), 40, axis=0)
+    _, oc, ix, bad = oracle.preprocess_ex(exact, 0.3, 30)
+    assert len(ix) == 1 and bad == 0 and np.array_equal(_cov_mats(oc)[0], np.diag([1.0, 1.0, 1e-2]))
 
 
 # ---- deskew (SURVEY.md 8(f) N4): oracle vs the numpy restatement ------------------------------------
@@ -446,7 +552,13 @@ def test_golden_frame_fixture_is_hermetic(oracle):
     assert moved == int(g["moved"]) and np.array_equal(desk, g["deskewed"])
     kp, kc, ki = oracle.preprocess(desk, float(g["voxel_size"]), int(g["knn"]))
     assert np.array_equal(ki, g["kept_index"]) and np.array_equal(kp, g["kept_points"])
-    assert np.abs(kc - g["kept_covs"]).max() < 1e-12
+    assert np.array_equal(kc, g["kept_covs"])
     npts, ncov, nidx = npo.preprocess(g["deskewed"], float(g["voxel_size"]), int(g["knn"]))
     assert np.array_equal(nidx, g["kept_index"].astype(np.int64))
     assert np.abs(ncov - g["kept_covs"].reshape(-1, 3, 3).transpose(0, 2, 1)).max() < 1e-10
+
+
+def test_oracle_reproduces_the_degenerate_fixture(oracle):
+    g = np.load(os.path.join(GOLDEN, "prep_degenerate.npz"))
+    kp, kc, ki, bad = oracle.preprocess_ex(g["points"], float(g["voxel_size"]), int(g["knn"]))
+    assert np.array_equal(ki, g["kept_index"]) and np.array_equal(kc, g["kept_covs"]) and bad == int(g["indefinite"]) > 0
