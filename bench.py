@@ -16,7 +16,15 @@ iteration ends in the exchange of the 28-double normal-equation row; all ranks r
 `value` = N_points · 20 · steps / wall of that sharded align ("scaling": "strong": the total work is fixed).
 N independent scans, one per rank (no communication), are measured too and reported as
 `replicas_aggregate` — a throughput figure, not the metric.  `multi_gpu_parity` compares the sharded result
-with the whole scan on one GPU.
+with the whole scan on one GPU.  `config.sharding.transport` names what carried the per-iteration exchange in the
+timed region ("mailbox": the kernels' own stores into peer-mapped mailboxes; "rccl": one launch + one ncclAllReduce
+per iteration) and `exchange_us_per_round` what it cost (sharded round minus the same shard registered alone).
+BENCH_SHARE_DEVICE=1 is the dress rehearsal of that line on a box with ONE GPU: N ranks as N processes on device 0,
+rendezvous over gloo, the mailboxes wired by hand (vgicp_peer_export / _connect), 256 / N workgroups per rank.
+
+The upload is measured honestly: the reference deep-copies a FRESH cloud every frame (src/Registration.cpp:11), so
+the timed loop rotates over freshly allocated host buffers the HIP runtime has never seen (total far above the host's
+last-level cache); `upload` reports the first pass (never-seen pages), later passes and the old same-buffer figure.
 
 `roofline` is measured live over the timed region: every align brackets its iteration launch(es) with a HIP
 event pair on the module's own stream (stats.device_seconds); `achieved` = ALGORITHMIC bytes per launch
@@ -48,7 +56,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from eskf_lio_amd import capi, synth  # noqa: E402
-from eskf_lio_amd.distributed import shard_bounds, share_unique_id  # noqa: E402
+from eskf_lio_amd.distributed import gather_bytes, shard_bounds, share_unique_id  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s achievable)
 ITERATIONS = 20
@@ -145,15 +153,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
     # BENCH_FORCE_COMM=1 runs the multi-GPU code path (process group, unique-id hand-off, per-iteration
     # exchange) with however many ranks there are — on one GPU a way to exercise it
     force_comm = os.environ.get("BENCH_FORCE_COMM", "0") == "1"
+    # BENCH_SHARE_DEVICE=1: every rank is a process on device 0 (a box with one GPU): gloo for the host side, the
+    # mailboxes of the device-initiated exchange wired by hand, the CUs divided between the ranks
+    share_device = os.environ.get("BENCH_SHARE_DEVICE", "0") == "1" and world > 1
     use_dist = world > 1 or force_comm
+    if share_device:
+        local_rank = 0
+        os.environ.setdefault("VGICP_PERSIST_GRID", str(max(1, 256 // world)))
+    torch.cuda.set_device(local_rank)
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if os.environ.get("VGICP_LIB_PATH") and rank == 0:
+        print(f"[bench] VGICP_LIB_PATH override active: measuring {capi.LIB_PATH}", file=sys.stderr)
 
     n_points, n_voxels = synth.CONFIGS[args.config]
     vmap = synth.make_map(n_voxels)
@@ -161,12 +180,23 @@ def main():
     guess = synth.default_guess()
     lo, hi = shard_bounds(n_points, world, rank)
     my_pts, my_covs = np.ascontiguousarray(pts[lo:hi]), np.ascontiguousarray(covs[lo:hi])
+    n_local = hi - lo
 
     ctx = capi.Context(local_rank)
     ctx.map_reset(vmap.voxel_size, n_voxels)
     ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
-    if use_dist:
+    if share_device:
+        ctx.peer_connect(world, rank, gather_bytes(ctx.peer_export(), world))
+        dist.barrier()                                             # every mailbox initialised before any kernel writes
+    elif use_dist:
         ctx.comm_init(world, rank, share_unique_id(ctx, rank))     # every rank or none: a failure ends the run
+
+    def host_max(x: float) -> float:
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if share_device else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def fence():
         torch.cuda.synchronize()
@@ -174,57 +204,102 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step_host(flags=0):
+    def align_host(p, c, flags=0):
         """ICP::align as the reference calls it: scan (this rank's shard) in host buffers."""
-        return ctx.align(my_pts, my_covs, guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
+        return ctx.align(p, c, guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
 
     def step_resident(flags=0):
         return ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
 
     def timed(step, steps):
+        """steps calls of step(k) between two fences; -> (max-over-ranks wall, summed device spans, last result,
+        per-step host seconds of this rank)."""
         import gc
+        per_step = np.zeros(steps)
         fence()
         gc.collect()
         gc.disable()                  # no collector pauses of the host language inside the timed region
         t0 = time.perf_counter()
-        dev_s, res = 0.0, None
-        for _ in range(steps):
-            res = step()
+        dev_s, res, t_prev = 0.0, None, t0
+        for k in range(steps):
+            res = step(k)
             dev_s += res.device_seconds
+            t_now = time.perf_counter()
+            per_step[k] = t_now - t_prev
+            t_prev = t_now
         fence()
         elapsed = time.perf_counter() - t0
         gc.enable()
-        if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed, dev_s, res
+        return host_max(elapsed), dev_s, res, per_step
 
-    headline = step_resident if args.resident else step_host
+    # ---- the upload, honestly: every timed step takes its scan from a host buffer the HIP runtime has never seen ----
+    # (the reference deep-copies a FRESH cloud per frame, src/Registration.cpp:11). As many distinct buffers as steps,
+    # up to 6 GB of host memory (500 steps x 9.6 MB = 4.8 GB at C2); beyond that the rotation wraps and later passes are
+    # cache-cold but not first-touch.
+    scan_bytes = 96 * n_local
+    n_cold = int(max(1, min(args.steps, 6e9 // max(1, scan_bytes))))
+    if args.resident:
+        n_cold = 0
+    cold = [(my_pts.copy(), my_covs.copy()) for _ in range(n_cold)]   # written once (by the copy), never read since
+
+    def step_cold(k):
+        p, c = cold[k % n_cold]
+        return align_host(p, c)
+
     if args.resident:
         ctx.scan_upload(my_pts, my_covs)
-    for _ in range(args.warmup):
-        res = headline()
-    elapsed, dev_s, res = timed(headline, args.steps)              # ---- the timed region ----
-    assert res.iterations == ITERATIONS, res.iterations
-
-    # secondary: the same loop over the scan already resident (kernel + launch + copy-back only)
-    if args.resident:
+        for _ in range(args.warmup):
+            res = step_resident()
+        elapsed, dev_s, res, _ = timed(lambda k: step_resident(), args.steps)
+        upload_report = None
         elapsed_res = elapsed
     else:
+        for _ in range(args.warmup):                               # warm-up on a buffer of its own
+            res = align_host(my_pts, my_covs)
+        ns0 = ctx.counter(3)
+        elapsed, dev_s, res, per_step = timed(step_cold, args.steps)   # ---- the timed region ----
+        ns_cold = ctx.counter(3) - ns0
+        first = per_step[:n_cold]
+        # the same buffers a second time (the runtime has seen the pages; the CPU caches have long lost them)
+        again = min(n_cold, 100)
+        ns0 = ctx.counter(3)
+        el_again, _, _, _ = timed(step_cold, again)
+        ns_again = ctx.counter(3) - ns0
+        # one buffer over and over (what rounds 1-2 timed)
+        reused = min(args.steps, 100)
+        ns0 = ctx.counter(3)
+        el_reused, _, _, _ = timed(lambda k: align_host(my_pts, my_covs), reused)
+        ns_reused = ctx.counter(3) - ns0
+        upload_report = {
+            "bytes_per_step": scan_bytes,
+            "buffers": n_cold,
+            "buffers_used_by_the_timed_steps": "every timed step read a freshly allocated, never-uploaded pageable host "
+                                               f"buffer ({n_cold} distinct buffers, {n_cold * scan_bytes / 1e6:.0f} MB in all"
+                                               + (")" if n_cold >= args.steps else f"; the rotation wrapped after {n_cold} steps)"),
+            "ms_per_step_cold": elapsed / args.steps * 1e3,
+            "ms_per_step_first_touch": float(first.mean() * 1e3),
+            "ms_per_step_second_pass": el_again / again * 1e3,
+            "ms_per_step_reused": el_reused / reused * 1e3,
+            "upload_ms_cold": ns_cold / 1e6 / args.steps,
+            "upload_ms_second_pass": ns_again / 1e6 / again,
+            "upload_ms_reused": ns_reused / 1e6 / reused,
+            "what": "host side of the two hipMemcpyAsync from the caller's pageable buffers + the enqueue of the pack "
+                    "kernel, in front of the persistent launch; `value` is the cold figure",
+        }
+        del cold
         for _ in range(2):
             step_resident()
-        elapsed_res, _, _ = timed(step_resident, args.steps)
-    upload_ns, upload_bytes = ctx.counter(3), ctx.counter(2)
+        elapsed_res, _, _, _ = timed(lambda k: step_resident(), args.steps)
+    assert res.iterations == ITERATIONS, res.iterations
 
     # per-launch variant: every iteration launch bracketed by HIP events on the module's stream
+    # (not with BENCH_SHARE_DEVICE: that rehearsal has no RCCL communicator for the launch-per-round loop to use)
     kernel_ms = []
-    for _ in range(max(3, min(args.steps, 20))):
+    for _ in range(0 if share_device else max(3, min(args.steps, 20))):
         r = step_resident(capi.FLAG_PROFILE)
         kernel_ms.append(r.kernel_ms[:ITERATIONS])
     kernel_ms = np.array(kernel_ms)
-    bracketed_s = float(kernel_ms.mean()) * 1e-3
-    n_local = hi - lo
+    bracketed_s = float(kernel_ms.mean()) * 1e-3 if kernel_ms.size else None
     matches = float(res.corr_count.mean()) / world                 # corr_count is summed over the communicator
     bytes_per_round = algorithmic_bytes(n_local, matches)
     persistent = res.launches == 1                                 # single GPU: the whole align is ONE launch
@@ -238,23 +313,45 @@ def main():
     # N > 1, secondary: N independent scans, one per rank, no communication (throughput, not the metric)
     replicas = None
     solo = None
+    exchange = None
     if use_dist:
         solo = capi.Context(local_rank)
         solo.map_reset(vmap.voxel_size, n_voxels)
         solo.map_upsert(vmap.keys, vmap.means, vmap.covs)
         own_pts, own_covs = synth.make_uniform_scan(n_points, vmap, seed=synth.SCAN_SEED + rank)
 
-        def step_replica():
+        def step_replica(k):
             return solo.align(own_pts, own_covs, guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
         for _ in range(3):
-            step_replica()
+            step_replica(0)
         steps_r = max(3, args.steps // 2)
-        el, _, _ = timed(step_replica, steps_r)
+        el, _, _, _ = timed(step_replica, steps_r)
         replicas = {"value": world * n_points * ITERATIONS * steps_r / el, "unit": "points/s",
                     "ms_per_step": el / steps_r * 1e3,
                     "what": f"{world} independent {n_points}-point scans, one per rank, host buffers, replicated map, "
                             f"no communication — aggregate throughput, NOT the BASELINE metric"}
+        # what the exchange between the ranks costs per round: the sharded round (scan resident) minus the SAME shard
+        # registered alone on the same grid (no exchange between ranks); all ranks measure at the same time
+        steps_x = max(3, min(args.steps, 50))
+        for _ in range(2):
+            step_resident()
+        _, dev_sh, r_sh, _ = timed(lambda k: step_resident(), steps_x)
+        solo.scan_upload(my_pts, my_covs)
 
+        def step_alone(k):
+            return solo.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS)
+        for _ in range(2):
+            step_alone(0)
+        _, dev_al, r_al, _ = timed(step_alone, steps_x)
+        us_sharded = host_max(dev_sh / steps_x / ITERATIONS * 1e6)
+        us_alone = host_max(dev_al / steps_x / ITERATIONS * 1e6)
+        exchange = {"exchange_us_per_round": us_sharded - us_alone, "sharded_us_per_round": us_sharded,
+                    "shard_alone_us_per_round": us_alone, "aligns": steps_x,
+                    "what": "device span per round of the sharded align (scan resident) minus the same shard registered "
+                            "alone on the same workgroups, no exchange between ranks; slowest rank of each"}
+
+    # which transport carried the exchange of the TIMED aligns: one launch with several ranks = the mailboxes
+    transport = "mailbox" if (persistent and res.world_size > 1) else "rccl"
     out = None
     if rank == 0:
         kernel = "vgicp::persistent_kernel" if persistent else "vgicp::iterate_kernel"
@@ -288,15 +385,23 @@ def main():
             "config": {
                 "workload": workload,
                 "points": n_points, "voxels": n_voxels, "iterations": ITERATIONS,
-                "sharding": "single GPU" if world == 1 and not use_dist else
-                            f"contiguous point shards over {world} rank(s), replicated map, RCCL all-reduce of 28 "
-                            f"doubles per iteration",
+                "sharding": "single GPU" if not use_dist else {
+                    "layout": f"contiguous point shards over {world} rank(s), replicated map",
+                    "transport": transport,
+                    "transport_detail": {
+                        "mailbox": "device-initiated: the ONE persistent launch of every rank stores its 28-double row "
+                                   "of each iteration into all ranks' peer-mapped mailboxes and adds what it receives",
+                        "rccl": "one iterate launch + one ncclAllReduce of 32 doubles per iteration"}[transport],
+                    "wiring": "BENCH_SHARE_DEVICE=1: all ranks are processes on ONE device (dress rehearsal), gloo "
+                              "rendezvous, vgicp_peer_export/_connect by hand, "
+                              f"VGICP_PERSIST_GRID={os.environ.get('VGICP_PERSIST_GRID')}" if share_device else
+                              "one rank per GPU, torch.distributed (nccl = RCCL) rendezvous, vgicp_comm_init",
+                    **(exchange or {}),
+                },
                 "matches_per_iteration": float(res.corr_count.mean()),
-                "upload": {"bytes_per_step": 96 * n_local,
-                           "host_side_ms_per_upload": (upload_ns / 1e6) / max(1, upload_bytes // max(1, 96 * n_local)),
-                           "what": "two hipMemcpyAsync from the caller's pageable buffers (pinned on the fly by the runtime, DMA in "
-                                   "place) + pack kernel, enqueued in front of the persistent launch"},
+                "upload": upload_report,
                 "persistent_fallbacks": fallbacks,
+                "library": capi.LIB_PATH if os.environ.get("VGICP_LIB_PATH") else "eskf_lio_amd/lib/libvgicp_hip.so",
             },
             "roofline": {
                 "bound": "hbm",
@@ -318,7 +423,7 @@ def main():
                 "us_per_round": span_s / rounds_per_launch * 1e6,
                 "launch_us_source": "HIP event pair on the module's stream around the launch(es) of every "
                                     f"timed align, {launches} launches",
-                "per_launch_variant_us_per_round": bracketed_s * 1e6,
+                "per_launch_variant_us_per_round": bracketed_s * 1e6 if bracketed_s is not None else None,
                 "per_launch_variant_source": "iterate_kernel (one launch per round, the multi-GPU path), HIP event "
                                              f"pair around each of {kernel_ms.size} launches, ~2 us event overhead each",
             },
@@ -351,6 +456,7 @@ def main():
     # regime that sharding is for.  Any failure is reported in the field, never raised.
     c5 = None
     if args.config == "C2" and not args.no_c5:
+        r5 = None
         try:
             n5, v5 = synth.CONFIGS["C5"]
             map5 = synth.make_map(v5)
@@ -360,23 +466,37 @@ def main():
             ctx.map_upsert(map5.keys, map5.means, map5.covs)
             ctx.scan_upload(np.ascontiguousarray(pts5[lo5:hi5]), np.ascontiguousarray(covs5[lo5:hi5]))
             del map5, pts5, covs5
-            for _ in range(3):
-                r5 = step_resident()
-            steps5 = 10
-            el5, dev5, r5 = timed(step_resident, steps5)
-            per_rank_bytes = algorithmic_bytes(hi5 - lo5, float(r5.corr_count.mean()) / world) * ITERATIONS
-            launches5 = r5.launches
-            c5 = {"value": n5 * ITERATIONS * steps5 / el5, "unit": "points/s", "ms_per_step": el5 / steps5 * 1e3,
-                  "us_per_round": dev5 / steps5 / ITERATIONS * 1e6,
-                  "achieved_GBs_per_gpu": per_rank_bytes / (dev5 / steps5) / 1e9,
-                  "frac_of_8TBs_per_gpu": per_rank_bytes / (dev5 / steps5) / 1e9 / HBM_PEAK_GBS,
-                  "single_launch": launches5 == 1, "matches_per_iteration": float(r5.corr_count.mean()),
-                  "workload": f"C5: {n5}-pt scan vs {v5}-voxel map, {ITERATIONS} rounds per align, scan resident, "
-                              f"point-sharded over {world} rank(s); algorithmic bytes of a rank / its event span"}
+            ready, why = 1.0, ""
         except Exception as e:  # noqa: BLE001 - reported in the JSON line
-            c5 = {"error": f"{type(e).__name__}: {e}"}
+            ready, why = 0.0, f"{type(e).__name__}: {e}"
+        # the aligns below are collective under --gpus N: every rank runs them or none does (a rank that failed to
+        # set up would leave its peers waiting in the exchange)
+        all_ready = -host_max(-ready) > 0.5
+        if not all_ready:
+            c5 = {"error": why or "another rank could not set up the C5 map / scan; leg skipped on every rank"}
+        else:
+            try:
+                for _ in range(3):
+                    r5 = step_resident()
+                steps5 = 10
+                el5, dev5, r5, _ = timed(lambda k: step_resident(), steps5)
+                per_rank_bytes = algorithmic_bytes(hi5 - lo5, float(r5.corr_count.mean()) / world) * ITERATIONS
+                c5 = {"value": n5 * ITERATIONS * steps5 / el5, "unit": "points/s", "ms_per_step": el5 / steps5 * 1e3,
+                      "us_per_round": dev5 / steps5 / ITERATIONS * 1e6,
+                      "achieved_GBs_per_gpu": per_rank_bytes / (dev5 / steps5) / 1e9,
+                      "frac_of_8TBs_per_gpu": per_rank_bytes / (dev5 / steps5) / 1e9 / HBM_PEAK_GBS,
+                      "single_launch": r5.launches == 1, "matches_per_iteration": float(r5.corr_count.mean()),
+                      "workload": f"C5: {n5}-pt scan vs {v5}-voxel map, {ITERATIONS} rounds per align, scan resident, "
+                                  f"point-sharded over {world} rank(s); algorithmic bytes of a rank / its event span"}
+            except Exception as e:  # noqa: BLE001 - a failing collective align is fatal for the run: say so and stop
+                if use_dist:
+                    raise
+                c5 = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0 and out is not None:
             out["c5_resident"] = c5
+    if share_device:
+        dist.barrier()                 # nobody unmaps a mailbox a peer's kernel may still be writing into
+        ctx.peer_disconnect()
     ctx.close()
     if use_dist:
         dist.barrier()

@@ -130,6 +130,7 @@ struct vgicp_ctx {
   bool peers_connected = false;
   bool peer_enabled = true;            // cleared for good when a launch gave up waiting for a peer
   uint32_t mail_round0 = 0;            // rounds executed through the mailboxes so far (same on every rank)
+  uint32_t mail_seq = 0;               // aligns attempted through the mailboxes so far (same on every rank)
 
   // RCCL
   RcclApi rccl;
@@ -391,32 +392,50 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.rank = multi ? (uint32_t)ctx->peer_rank : 0u;
   a.mail = ctx->d_mail_table;
   a.mail_round0 = ctx->mail_round0;
+  a.mail_seq = multi ? ++ctx->mail_seq : 0u;
+  // the launch reports into the header row of the pinned log: who gave up (any workgroup) and workgroup 0's verdict
+  AlignState* header = reinterpret_cast<AlignState*>(ctx->h_log - kSlots);
+  header->abort_seq = 0;
+  header->outcome = kOutcomeNone;
   // one launch, one synchronisation
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
   VG_HIP(ctx, launch_persistent(ctx->stream, a, grid));
   VG_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   VG_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_begin, ctx->ev_end));
-  std::memcpy(result, ctx->h_log - kSlots, sizeof(AlignState));
+  std::memcpy(result, header, sizeof(AlignState));
   ++ctx->persistent_launches;
-  if (result->seq != a.seq) {
-    // an in-kernel wait timed out (a workgroup was not resident: something else holds CUs of this device).
-    // Put the exchange back into its initial state, use the per-launch loop for this align and the next
-    // few, then try the single launch again.
+  const bool committed = result->seq == a.seq && result->outcome == kOutcomeCommitted;
+  const bool someone_gave_up = result->abort_seq == a.seq;
+  if (!committed || someone_gave_up) {
+    // An in-kernel wait timed out (a workgroup was not resident: something else holds CUs of this device; or a
+    // peer GPU did not deliver).  `someone_gave_up` with `committed`: workgroup 0 arrived late, found every row in
+    // place and finished while another workgroup had already stopped waiting — its rows of the later rounds are
+    // missing, the result must not be used.  Put the exchange back into its initial state, use the per-launch
+    // loop for this align and the next few, then try the single launch again.
     ++ctx->persistent_fallbacks;
     ctx->persistent_cooldown = kPersistentCooldownAligns;
-    if (multi) {
-      // a peer did not deliver: its kernel may still be writing into this mailbox, so the mailboxes are not
-      // touched again — this communicator stays on the host-enqueued collective from here on
-      ctx->peer_enabled = false;
-      std::fprintf(stderr, "[vgicp] rank %d: the in-kernel exchange between GPUs gave up waiting for a peer; this "
-                   "communicator continues with one launch + one RCCL all-reduce per iteration\n", ctx->peer_rank);
-    }
     if (ctx->persistent_fallbacks == 1 || std::getenv("VGICP_VERBOSE"))
-      std::fprintf(stderr, "[vgicp] persistent align launch gave up waiting for a workgroup (fallback #%llu): using one "
-                   "launch per iteration for the next %d aligns\n", (unsigned long long)ctx->persistent_fallbacks,
-                   kPersistentCooldownAligns);
-    return reset_persistent_exchange(ctx);
+      std::fprintf(stderr, "[vgicp] persistent align launch gave up waiting for a workgroup%s (fallback #%llu): using one "
+                   "launch per iteration for the next %d aligns\n", multi ? " or a peer GPU" : "",
+                   (unsigned long long)ctx->persistent_fallbacks, kPersistentCooldownAligns);
+    int rc = reset_persistent_exchange(ctx);
+    if (multi) {
+      // Between GPUs the outcome is collective (the verdict words at the end of the launch): every rank leaves the
+      // mailboxes for good in the SAME align and re-runs it through the host collective, so the all-reduces pair up.
+      // A peer's kernel may still be writing into a mailbox, so they are not touched again.
+      ctx->peer_enabled = false;
+      const bool agreed = result->outcome == kOutcomeAgreedAbort || (result->outcome == kOutcomeNone && !committed);
+      std::fprintf(stderr, "[vgicp] rank %d: the in-kernel exchange between GPUs gave up (%s); this communicator "
+                   "continues with one launch + one RCCL all-reduce per iteration\n", ctx->peer_rank,
+                   result->outcome == kOutcomeAgreedAbort ? "a peer reported it" :
+                   result->outcome == kOutcomeNoAgreement ? "a peer's verdict never arrived" :
+                   committed ? "a workgroup of this rank, after the verdict was sent" : "this rank timed out");
+      if (rc == VGICP_OK && !agreed)
+        return fail(ctx, VGICP_ERR_RCCL, "the ranks could not agree on the outcome of this align (a peer's verdict is missing "
+                    "or this rank's verdict was sent before one of its workgroups gave up): not re-running it alone");
+    }
+    return rc;
   }
   ctx->persist_round0 = (ctx->persist_round0 + (uint32_t)result->iteration) % 3u;
   if (multi) ctx->mail_round0 += (uint32_t)result->iteration;
@@ -562,8 +581,6 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
 }  // namespace
 
 namespace {
-constexpr size_t kMailWords = 3 * (size_t)kMaxRanks * kSlots;
-
 int ensure_mailbox(vgicp_ctx* ctx) {
   if (ctx->d_mail) return VGICP_OK;
   // fine-grained: stores of another GPU's kernel become visible to this GPU's running kernel
@@ -640,11 +657,16 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   if (const char* pm = std::getenv("VGICP_PREFETCH_MARGIN")) ctx->prefetch_margin = std::atof(pm);
   if (const char* sl = std::getenv("VGICP_SPIN_LIMIT")) ctx->persist_spin_limit = (uint32_t)std::strtoul(sl, nullptr, 10);
   {
-    // the in-kernel exchange needs every workgroup resident: one 512-thread workgroup with the full dynamic LDS
-    // must fit a CU (checked once here instead of found out by a timeout)
+    // the in-kernel exchange needs every workgroup resident: one 512-thread workgroup with the LARGEST dynamic LDS
+    // a launch plan asks for (memo + parked points of a scan bigger than the grid: 150 KB) must fit a CU — checked
+    // once here instead of found out by a timeout on every align
     uint32_t resident = 0;
-    VG_CREATE(persistent_max_resident(persistent_dyn_lds_bytes(0, 0), ctx->cu_count, &resident));
-    if (resident < ctx->persist_grid) ctx->persistent_enabled = false;
+    VG_CREATE(persistent_max_resident(persistent_max_dyn_lds_bytes(), ctx->cu_count, &resident));
+    if (resident < ctx->persist_grid) {
+      ctx->persistent_enabled = false;
+      std::fprintf(stderr, "[vgicp] a persistent workgroup with %u bytes of LDS does not fit a compute unit of this device: "
+                   "aligns use one launch per iteration\n", persistent_max_dyn_lds_bytes());
+    }
   }
   if (const char* blk = std::getenv("VGICP_ITER_BLOCK")) {
     const int b = std::atoi(blk);
@@ -1532,6 +1554,7 @@ int vgicp_peer_connect(vgicp_ctx* ctx, int world_size, int rank, const void* han
   ctx->world_size = world_size;
   ctx->rank = rank;
   ctx->mail_round0 = 0;
+  ctx->mail_seq = 0;
   ctx->peer_enabled = true;
   ctx->peers_connected = true;
   return VGICP_OK;

@@ -50,7 +50,15 @@ struct AlignState {
   int32_t converged;
   uint32_t seq;       // persistent launch: echo of PersistArgs::seq, written last (0 from the per-launch loop)
   uint32_t pad;
+  // persistent launch only (the host zeroes both before the launch)
+  uint32_t abort_seq; // = PersistArgs::seq when ANY workgroup gave up waiting (whatever workgroup 0 concluded)
+  uint32_t outcome;   // workgroup 0's verdict: kOutcome*
 };
+// AlignState::outcome of a persistent launch
+constexpr uint32_t kOutcomeNone = 0;         // workgroup 0 gave up inside a round (or never ran)
+constexpr uint32_t kOutcomeCommitted = 1;    // the loop ran to its end (several GPUs: on every rank)
+constexpr uint32_t kOutcomeAgreedAbort = 2;  // several GPUs: some rank gave up, every rank knows it
+constexpr uint32_t kOutcomeNoAgreement = 3;  // several GPUs: a peer's verdict never arrived
 
 struct IterArgs {
   const double* scan;  // SoA planes
@@ -85,6 +93,8 @@ constexpr int kMaxRanks = 16;                               // mailbox rows; = k
 constexpr int kFolders = 16;                                // = 512 / kSlots, the groups of iterate_kernel<512>'s fold
 constexpr unsigned long long kRowUnset = ~0ull;             // a NaN pattern no fp64 operation produces
 constexpr unsigned long long kRowNaN = 0x7FF8000000000000ull;  // what a computed NaN is published as
+constexpr size_t kMailRowWords = 3 * (size_t)kMaxRanks * kSlots;  // the rows of a mailbox
+constexpr size_t kMailWords = kMailRowWords + kSlots;          // + the verdict words (kMaxRanks used)
 struct PersistArgs {
   const double* scan;  // SoA planes
   uint64_t stride;
@@ -112,10 +122,14 @@ struct PersistArgs {
   // kernels themselves over xGMI (no host-enqueued collective between launches)
   uint32_t world, rank;
   uint32_t mail_round0;    // rounds all ranks have executed on this communicator before this launch
-  uint32_t pad_;
+  uint32_t mail_seq;       // aligns attempted through the mailboxes on this communicator, this one included (same on
+                           // every rank, >= 1): the verdict words at the end of a launch carry it
   double* const* mail;     // device array of kMaxRanks pointers; mail[r]: rank r's mailbox as mapped into THIS
                            // process, [3][kMaxRanks][kSlots] words: by round % 3, row = sender rank (rows >=
-                           // world hold +0.0 for good)
+                           // world hold +0.0 for good), then kMaxRanks VERDICT words (index = sender rank):
+                           // mail_seq << 1 | 1 "my loop ran to its end", mail_seq << 1 "I gave up" — written by
+                           // workgroup 0 of the sender at the end of its launch, so that all ranks commit an align
+                           // or none does
   double prefetch_margin;  // > 0 (only with memo_points == stash_points == 0): a point closer than this many
                            // voxel sizes to a face of its voxel has the neighbour behind that face looked up
                            // into LDS while the workers wait for the exchange
@@ -136,6 +150,7 @@ void persistent_exchange_image(uint32_t grid, unsigned long long* rows_words, un
 // current device: *max_grid = cu_count then, else 0 (the in-kernel exchange needs every workgroup resident).
 hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_t* max_grid);
 uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_points);
+uint32_t persistent_max_dyn_lds_bytes();  // the most a launch plan ever asks for
 // One VGICP round over the resident scan: prologue folds args.prev and advances the pose, body
 // accumulates this round's rows. block = 256 / 512 / 1024 threads per workgroup.
 hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, int block);

@@ -1026,22 +1026,50 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
     if (STAMPS) { const uint64_t n = wall_clock64(); acc_solve += n - t_mark; t_mark = n; }
     if (stop) break;
   }
-  if (gave_up) return;  // the host sees state->seq != seq, resets the exchange buffers and uses launches
+  if (gave_up) {
+    // The host sees state->seq != seq (workgroup 0) or state->abort_seq == seq (any other workgroup: it may have
+    // timed out although workgroup 0 found everything in place), resets the exchange buffers and uses launches.
+    if (tid == 0) a.state->abort_seq = a.seq;
+    if (MULTI && blk == 0 && tid < a.world)   // the peers learn it from the verdict word, at the latest at their end
+      store_system_bits(a.mail[tid] + kMailRowWords + a.rank, (unsigned long long)a.mail_seq << 1);
+    return;
+  }
 
-  if (wave == 0) {
-    if (blk == 0 && lane == 0) {
+  if (wave == 0 && blk == 0) {
+    uint32_t outcome = kOutcomeCommitted;
+    if (MULTI) {
+      // All ranks commit this align or none does: every rank's workgroup 0 tells every rank how its loop ended and
+      // waits for everybody's word.  (A rank that gave up alone would otherwise re-run the align through the host
+      // collective while a late peer, finding that rank's last row already in its mailbox, returns success.)
+      const unsigned long long mine = ((unsigned long long)a.mail_seq << 1) | 1ull;
+      if (lane < a.world) store_system_bits(a.mail[lane] + kMailRowWords + a.rank, mine);
+      const double* src = a.mail[a.rank] + kMailRowWords + (lane < a.world ? lane : 0u);
+      unsigned long long w = lane < a.world ? load_system_bits(src) : mine;
+      bool late = false;
+      for (uint32_t spins = 0; __any((w >> 1) < a.mail_seq); ++spins) {
+        if (spins >= a.spin_limit) { late = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+        if ((w >> 1) < a.mail_seq) w = load_system_bits(src);
+      }
+      if (late) outcome = kOutcomeNoAgreement;
+      else if (__any(w != mine)) outcome = kOutcomeAgreedAbort;
+    }
+    if (lane == 0) {
       AlignState* out = a.state;
+      out->outcome = outcome;
+      if (outcome == kOutcomeCommitted) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) out->pose[k] = total.R[k];
+        for (int k = 0; k < 9; ++k) out->pose[k] = total.R[k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) out->pose[9 + k] = total.t[k];
-      out->cosine_threshold = cos_thr;
-      out->translation_sq_threshold = tsq_thr;
-      out->max_iteration = max_it;
-      out->iteration = it;
-      out->done = 1;
-      out->pad = 0;
-      out->seq = a.seq;
+        for (int k = 0; k < 3; ++k) out->pose[9 + k] = total.t[k];
+        out->cosine_threshold = cos_thr;
+        out->translation_sq_threshold = tsq_thr;
+        out->max_iteration = max_it;
+        out->iteration = it;
+        out->done = 1;
+        out->pad = 0;
+        out->seq = a.seq;
+      }
     }
   }
   if (STAMPS && tid == 0) atomicAdd((unsigned long long*)&a.stamps[32 + blk], (unsigned long long)acc_body);
@@ -1308,6 +1336,7 @@ void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint3
 uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_points) {
   return memo_points * kMemoBytesPerPoint + stash_points * kStashBytesPerPoint;
 }
+uint32_t persistent_max_dyn_lds_bytes() { return kPersistDynLds; }
 
 size_t persistent_rows_words() { return 3 * (size_t)kExchangeRows * kSlots; }
 size_t persistent_parts_words() { return 3 * (size_t)kFolders * kSlots; }
@@ -1374,8 +1403,11 @@ hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t gr
 // resident at once on the current device (the in-kernel exchange requires it).
 hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_t* max_grid) {
   int per_cu = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-      &per_cu, reinterpret_cast<const void*>(&persistent_kernel<512, true, false, true>), 512, dyn_lds_bytes);
+  const void* fn = reinterpret_cast<const void*>(&persistent_kernel<512, true, false, true>);
+  // more than the default 64 KB of LDS per workgroup has to be asked for before the occupancy query can say yes
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistDynLds);
+  if (e != hipSuccess) return e;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, dyn_lds_bytes);
   if (e != hipSuccess) return e;
   *max_grid = per_cu > 0 ? (uint32_t)cu_count : 0u;  // one workgroup per CU is what the design uses
   return hipSuccess;

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Child process of test_peer_exchange_two_processes_one_device: one rank of a device-initiated exchange.
 
-usage: peer_worker.py <rank> <world> <dir> <points> <rounds>
+usage: peer_worker.py <rank> <world> <dir> <points> <rounds> [giveup]
+"giveup": rank 0 runs with a tiny spin limit, the other ranks start their (one-round) align half a second late: rank 0
+gives up waiting, the late ranks find its row already in their mailboxes — and must NOT return success on their own:
+the outcome of an align is collective (verdict words at the end of the launch). There is no RCCL communicator in this
+set-up, so every rank has to fail with VGICP_ERR_RCCL; exit code 0 = it did.
 Every rank is its own process with its own vgicp context on device 0 (the 1-GPU box has one device; on a
 multi-GPU node the ranks would sit on different GPUs and the mailbox stores would cross xGMI).  The mailbox
 handles travel through files in <dir>.  Exit code 0 = the sharded aligns completed through the mailboxes and
@@ -27,8 +31,44 @@ def wait_for(paths, seconds=60.0):
         time.sleep(0.01)
 
 
+def giveup_case(rank, world, d, n):
+    if rank == 0:
+        os.environ["VGICP_SPIN_LIMIT"] = "100"       # x20 between ranks: a few milliseconds
+    vmap = synth.make_map(50_000)
+    pts, covs = synth.make_uniform_scan(n, vmap, seed=4242)
+    g = synth.default_guess()
+    lo, hi = shard_bounds(n, world, rank)
+    with capi.Context(0) as ctx:
+        ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+        ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+        with open(os.path.join(d, f"handle{rank}.tmp"), "wb") as f:
+            f.write(ctx.peer_export())
+        os.rename(os.path.join(d, f"handle{rank}.tmp"), os.path.join(d, f"handle{rank}"))
+        wait_for([os.path.join(d, f"handle{r}") for r in range(world)])
+        ctx.peer_connect(world, rank, b"".join(open(os.path.join(d, f"handle{r}"), "rb").read() for r in range(world)))
+        open(os.path.join(d, f"connected{rank}"), "w").close()
+        wait_for([os.path.join(d, f"connected{r}") for r in range(world)])
+        if rank != 0:
+            time.sleep(0.5)
+        code = capi.OK
+        try:
+            ctx.align(pts[lo:hi], covs[lo:hi], g, 1, 1e-6, 2.0)      # ONE round: the round the align ends in
+        except capi.VgicpError as e:
+            code = e.code
+        with open(os.path.join(d, f"code{rank}"), "w") as f:
+            f.write(str(code))
+        open(os.path.join(d, f"done{rank}"), "w").close()
+        wait_for([os.path.join(d, f"done{r}") for r in range(world)])
+        ctx.peer_disconnect()
+    if code != capi.ERR_RCCL:
+        raise SystemExit(f"rank {rank}: status {code}, expected {capi.ERR_RCCL} on every rank")
+    print(f"rank {rank}: gave up together with its peers")
+
+
 def main():
     rank, world, d, n, rounds = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+    if len(sys.argv) > 6 and sys.argv[6] == "giveup":
+        return giveup_case(rank, world, d, n)
     vmap = synth.make_map(50_000)
     pts, covs = synth.make_uniform_scan(n, vmap, seed=4242)
     g = synth.default_guess()

@@ -803,6 +803,61 @@ def test_bench_line_keeps_its_contract():
     assert d["config"]["persistent_fallbacks"] == 0
 
 
+    up = d["config"]["upload"]
+    assert up["buffers"] == 5 and up["ms_per_step_cold"] > 0 and up["ms_per_step_reused"] > 0
+    assert d["config"]["sharding"] == "single GPU"
+
+
+def _run_bench(extra_args, env_extra, launcher=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable] + (launcher or []) + [os.path.join(root, "bench.py")] + extra_args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_through_the_rccl_loop_world_one():
+    """BENCH_FORCE_COMM=1: the N > 1 branch of bench.py with one rank — process group, unique-id hand-off,
+    vgicp_comm_init, one launch + one ncclAllReduce per iteration — and a line that says so."""
+    d = _run_bench(["--steps", "4", "--warmup", "1", "--no-c5", "--no-cpu-baseline"],
+                   {"BENCH_FORCE_COMM": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541", "RANK": "0",
+                    "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    sh = d["config"]["sharding"]
+    assert sh["transport"] == "rccl" and d["n_gpus"] == 1 and d["roofline"]["rounds_per_launch"] == 1
+    assert d["multi_gpu_parity"]["identical_counts"] is True and d["multi_gpu_parity"]["pose_delta"] < 1e-11
+    assert "replicas_aggregate" in d and "exchange_us_per_round" in sh
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_line_with_real_ranks_sharing_the_device(world):
+    """Dress rehearsal of `bench.py --gpus N` (BASELINE config C3) before any multi-GPU hardware sees it: N real
+    ranks launched by torch.distributed.run as N processes on THE ONE device of this box (BENCH_SHARE_DEVICE=1: gloo
+    rendezvous, mailboxes wired through vgicp_peer_export / _connect, 256 / N workgroups each). The merge across
+    ranks is the cross-device form of reference src/Registration.cpp:71-75; here the mailbox stores stay on one
+    device instead of crossing xGMI, everything else is the code the driver's scaling run executes."""
+    import sys
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                "--master-port", str(29550 + world)]
+    d = _run_bench(["--gpus", str(world), "--steps", "6", "--warmup", "2", "--no-c5"],
+                   {"BENCH_SHARE_DEVICE": "1", "VGICP_SPIN_LIMIT": "400000"}, launcher=launcher, timeout=1200)
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["steps"] == 6
+    assert d["value"] > 1e8 and abs(d["value"] - 100_000 * 20 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    sh = d["config"]["sharding"]
+    assert sh["transport"] == "mailbox" and "BENCH_SHARE_DEVICE" in sh["wiring"]
+    assert sh["sharded_us_per_round"] > 0 and sh["shard_alone_us_per_round"] > 0
+    assert abs(sh["exchange_us_per_round"] - (sh["sharded_us_per_round"] - sh["shard_alone_us_per_round"])) < 1e-9
+    assert d["multi_gpu_parity"]["identical_counts"] is True and d["multi_gpu_parity"]["pose_delta"] < 1e-11
+    assert d["replicas_aggregate"]["value"] > 0
+    assert d["roofline"]["rounds_per_launch"] == 20 and d["config"]["persistent_fallbacks"] == 0
+    assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
+
+
 # ---- multi-GPU code path on one device: RCCL communicator of size 1 ---------------------------
 def test_rccl_path_world_size_one(c1_gpu, c1_inputs):
     from eskf_lio_amd import synth
@@ -877,6 +932,35 @@ def test_peer_exchange_two_processes_one_device(tmp_path, world, grid):
         assert np.array_equal(results[0]["pose"], other["pose"])
         assert np.array_equal(results[0]["normal_eq"], other["normal_eq"])
         assert np.array_equal(results[0]["half_pose"], other["half_pose"])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_exchange_give_up_is_collective(tmp_path, world):
+    """A rank that gives up waiting for a late peer in the round an align ENDS in must not leave that peer returning
+    success on its own (it finds the row of the rank that gave up already in its mailbox): the ranks exchange verdict
+    words at the end of the launch and commit the align together or not at all. Here rank 0 has a spin limit of a few
+    milliseconds and the others start a one-round align 0.5 s late; there is no RCCL communicator to fall back to, so
+    EVERY rank has to report VGICP_ERR_RCCL (tests/peer_worker.py, mode "giveup")."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VGICP_PERSIST_GRID=str(200 // world))
+    worker = os.path.join(os.path.dirname(__file__), "peer_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path), "20000", "1", "giveup"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    from eskf_lio_amd import capi
+    codes = [int(open(os.path.join(tmp_path, f"code{r}")).read()) for r in range(world)]
+    assert codes == [capi.ERR_RCCL] * world, codes
 
 
 # ---- BASELINE's full size (C2): size-independent properties ------------------------------------
