@@ -204,12 +204,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # a communicator of ONE rank has nothing to exchange and would take the single launch: BENCH_FORCE_COMM at world 1
+    # asks for the launch-per-round loop with its (one-rank) ncclAllReduce, which is what it is there to exercise
+    base_flags = capi.FLAG_NO_PERSISTENT if (force_comm and world == 1) else 0
+
     def align_host(p, c, flags=0):
         """ICP::align as the reference calls it: scan (this rank's shard) in host buffers."""
-        return ctx.align(p, c, guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
+        return ctx.align(p, c, guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags | base_flags)
 
     def step_resident(flags=0):
-        return ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags)
+        return ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0, chunk_iterations=ITERATIONS, flags=flags | base_flags)
 
     def timed(step, steps):
         """steps calls of step(k) between two fences; -> (max-over-ranks wall, summed device spans, last result,

@@ -847,7 +847,8 @@ def test_bench_line_with_real_ranks_sharing_the_device(world):
     d = _run_bench(["--gpus", str(world), "--steps", "6", "--warmup", "2", "--no-c5"],
                    {"BENCH_SHARE_DEVICE": "1", "VGICP_SPIN_LIMIT": "400000"}, launcher=launcher, timeout=1200)
     assert d["n_gpus"] == world and d["scaling"] == "strong" and d["steps"] == 6
-    assert d["value"] > 1e8 and abs(d["value"] - 100_000 * 20 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # (no speed expectation: N processes share one device's CUs, caches and its one PCIe link here)
+    assert d["value"] > 1e6 and abs(d["value"] - 100_000 * 20 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     sh = d["config"]["sharding"]
     assert sh["transport"] == "mailbox" and "BENCH_SHARE_DEVICE" in sh["wiring"]
     assert sh["sharded_us_per_round"] > 0 and sh["shard_alone_us_per_round"] > 0
