@@ -129,6 +129,144 @@ def cpu_baseline(vmap, pts, covs, guess, budget_s: float):
     }, ref
 
 
+def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, cpu: bool = True):
+    """Secondary record (never `value`): the frame sequence of reference src/Odometry.cpp:73-87 — raw sweep in host
+    memory -> extrinsic + deskew -> down-sampling + 30-NN covariances (CloudPreprocessor::process) -> ICP::align ->
+    LocalMap::updateLocalMap — through the no-round-trip entry points (vgicp_scan_prepare_async, vgicp_align_resident,
+    vgicp_map_insert_resident_async).  A lidar-like world is seen from a slowly moving sensor; IMU states of a sensor
+    at rest drive the deskew (its arithmetic runs in full, the points stay where they are).  Pass 1: host wall per
+    frame, kernel launches / copies / host synchronisations per frame.  Pass 2 (fresh context, stage events on):
+    device spans per stage, and the parity of every frame's prepared scan, pose and of the final map against the CPU
+    oracle chain.  The oracle's time per stage on the last frame stands beside it (`cpu`)."""
+    from oracle import binding as oracle
+    cap, knn, h = 20, 30, 0.3
+    world = synth.make_lidar_scan(sweep_points, seed=0x46524D, extent=25.0)
+    st = synth.make_imu_states(48, seed=5)
+    st[:, 1:4] = 0.0
+    st[:, 4:8] = [0.0, 0.0, 0.0, 1.0]                                # at rest: the deskew moves nothing
+    tt = synth.make_point_times(sweep_points, st[1, 0] + 1e-4, st[-3, 0] + 0.4 / 400.0, seed=5)
+    ext = synth.se3_to_SE3([0.01, -0.02, 0.03, 0.002, -0.001, 0.003])
+    ext_inv = synth.invert_pose(ext)
+    truth = [synth.se3_to_SE3([0.05 * f, 0.02 * f, 0.0, 0.0, 0.0, 0.004 * f]) for f in range(frames + 1)]
+    rng = np.random.default_rng(12)
+
+    def sweep(f):
+        # what the sensor at truth[f] sees, in the LiDAR frame (the extrinsic brings it to the IMU frame)
+        Tinv = ext_inv @ synth.invert_pose(truth[f])
+        pts = world + rng.normal(scale=0.005, size=world.shape)
+        return np.ascontiguousarray(pts @ Tinv[:3, :3].T + Tinv[:3, 3])
+    sweeps = [sweep(f) for f in range(frames + 1)]
+
+    def run(ctx, record=None):
+        ctx.map_reset(h, 400_000)
+        ctx.scan_prepare_async(sweeps[0], tt, st, ext, h, knn)
+        if record is not None:
+            record(0, ctx, np.eye(4), None)
+        ctx.map_insert_resident_async(np.eye(4), cap)
+        ctx.map_size()
+        pose, results = np.eye(4), []
+        ctx.frame_stats(reset=True)
+        t0 = time.perf_counter()
+        for f in range(1, frames + 1):
+            ctx.scan_prepare_async(sweeps[f], tt, st, ext, h, knn)
+            r = ctx.align_resident(pose, 30, 1e-6, 0.9999)
+            pose = r.pose
+            if record is not None:
+                record(f, ctx, pose, r)
+            ctx.map_insert_resident_async(pose, cap)
+            results.append(r)
+        wall = time.perf_counter() - t0
+        fs = ctx.frame_stats()
+        ctx.map_size()
+        return wall, fs, results, pose
+
+    out = {"what": f"{frames} frames of a {sweep_points}-point raw sweep (host memory) -> extrinsic + deskew (48 IMU states) "
+                   f"-> down-sampling + {knn}-NN covariances -> ICP::align (thresholds of hilti_config.yaml) -> map insertion "
+                   f"(cap {cap}); reference src/Odometry.cpp:73-87; vgicp_scan_prepare_async / vgicp_align_resident / "
+                   f"vgicp_map_insert_resident_async"}
+    with capi.Context(device) as ctx:
+        run(ctx)                                                       # warm-up (allocations, code objects)
+        wall, fs, results, _ = run(ctx)
+        out.update({
+            "ms_per_frame": wall / frames * 1e3,
+            "kernel_launches_per_frame": fs.kernel_launches / frames,
+            "copies_per_frame": fs.copies / frames,
+            "host_syncs_per_frame": fs.host_syncs / frames,
+            "align_rounds_per_frame": float(np.mean([r.iterations for r in results])),
+        })
+    # pass 2: stage events + parity, on a fresh context
+    stage = {"prepare_head": [], "prepare": [], "align": [], "insert": []}
+    kept_points, mismatches, pose_delta = [], [], 0.0
+    omap = oracle.OracleMap(h, cap)
+    cpu_times = {}
+
+    def record(f, ctx, pose, r):
+        nonlocal pose_delta
+        gp, gc = ctx.scan_download()
+        moved, _ = oracle.transform(sweeps[f], np.tile(np.eye(3).reshape(9), (sweep_points, 1)), ext)
+        last = f == frames
+        t0 = time.perf_counter()
+        desk, _ = oracle.deskew(moved, tt, st)
+        t1 = time.perf_counter()
+        if last or f <= 1:                                             # the brute-force oracle search is seconds per frame
+            rp, rc, _ = oracle.preprocess(desk, h, knn)
+            t2 = time.perf_counter()
+            if not (np.array_equal(gp, rp) and np.array_equal(gc, rc)):
+                mismatches.append(f)
+            if last:
+                cpu_times["deskew_ms"] = (t1 - t0) * 1e3
+                cpu_times["downsample_knn_cov_ms"] = (t2 - t1) * 1e3
+        if r is not None:
+            ref = omap.align(gp, gc, prev_pose[0], 30, 1e-6, 0.9999)
+            if last:
+                t0 = time.perf_counter()
+                omap.align(gp, gc, prev_pose[0], 30, 1e-6, 0.9999, mode=oracle.FAITHFUL)
+                cpu_times["align_ms"] = (time.perf_counter() - t0) * 1e3
+            if ref.iterations != r.iterations or not np.array_equal(ref.corr_count, r.corr_count):
+                mismatches.append(-f)
+            pose_delta = max(pose_delta, float(np.abs(ref.pose - r.pose).max()))
+            fsn = ctx.frame_stats()
+            stage["prepare_head"].append(fsn.prepare_head_us)
+            stage["prepare"].append(fsn.prepare_us)
+            stage["align"].append(fsn.align_us)
+        t0 = time.perf_counter()
+        wp, wc = oracle.transform(gp, gc, pose)
+        omap.insert(wp, wc)
+        if last:
+            cpu_times["insert_ms"] = (time.perf_counter() - t0) * 1e3
+        kept_points.append(len(gp))
+        prev_pose[0] = pose
+    prev_pose = [np.eye(4)]
+    with capi.Context(device) as ctx:
+        ctx.set_option(capi.OPTION_STAGE_EVENTS, 1)
+        _, _, results2, _ = run(ctx, record)
+        fsn = ctx.frame_stats()
+        stage["insert"].append(fsn.insert_us)
+        gk, gm, gcv, gn = ctx.map_export()
+    k, m, c, cnt = omap.export()
+    o = np.lexsort(k.T)
+    map_equal = bool(np.array_equal(gk, k[o]) and np.array_equal(gn, cnt[o]) and
+                     np.abs(gm - m[o]).max() < 1e-9 and np.abs(gcv - c[o]).max() < 1e-9)
+    head = float(np.mean(stage["prepare_head"]))
+    out.update({
+        "kept_points_per_frame": float(np.mean(kept_points)),
+        "stage_us": {"upload_extrinsic_deskew": head, "downsample_knn_cov": float(np.mean(stage["prepare"])) - head,
+                     "align": float(np.mean(stage["align"])), "map_insert": float(np.mean(stage["insert"])),
+                     "source": "HIP events on the module's stream (VGICP_OPTION_STAGE_EVENTS), mean over the frames of a "
+                               "second run; map_insert: the last frame's"},
+        "parity": {"prepared_scans_bit_equal_to_oracle": not [f for f in mismatches if f >= 0],
+                   "align_rounds_and_counts_equal_to_oracle": not [f for f in mismatches if f < 0],
+                   "pose_delta_max": pose_delta, "final_map_equal": map_equal,
+                   "frames_checked": "prepared scan: frames 0, 1 and the last; align + map: every frame"},
+    })
+    if cpu:
+        cpu_times["what"] = ("the oracle's stages on the last frame, OpenMP on all host cores: deskew (serial, as the "
+                             "reference), down-sampling + BRUTE-FORCE 30-NN + covariances (the reference uses a KD-tree; "
+                             "this is the checker's search, not a baseline for it), faithful-mode align, serial insertion")
+        out["cpu_oracle_last_frame"] = cpu_times
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +276,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary C5 (1M points / 10M voxels) leg")
+    ap.add_argument("--no-frame-chain", action="store_true", help="skip the secondary frame-chain record")
+    ap.add_argument("--frames", type=int, default=30, help="frames of the frame-chain record")
     ap.add_argument("--resident", action="store_true",
                     help="time vgicp_align_resident (scan already in HBM) as the step: profiling aid, the JSON "
                          "line then says so in config.workload")
@@ -442,6 +582,11 @@ def main():
             same_counts = bool((ref.corr_count == res.corr_count).all())
             dt = float(np.linalg.norm(ref.pose[:3, 3] - res.pose[:3, 3]))
             out["parity"] = {"identical_counts": same_counts, "pose_delta_m": dt}
+        if world == 1 and not use_dist and not args.no_frame_chain:
+            try:
+                out["frame_chain"] = frame_chain_leg(local_rank, frames=args.frames)
+            except Exception as e:  # noqa: BLE001 - a secondary record: reported, never raised
+                out["frame_chain"] = {"error": f"{type(e).__name__}: {e}"}
         if use_dist:
             # evidence that the sharded, exchanged loop computes what one GPU computes
             one = solo.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0)

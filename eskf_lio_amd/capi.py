@@ -33,6 +33,8 @@ EXPORTS = (
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
     "vgicp_accumulate", "vgicp_solve_step", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_scan_prepare", "vgicp_scan_download",
+    "vgicp_scan_prepare_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
+    "vgicp_set_option",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
     "vgicp_peer_export", "vgicp_peer_connect", "vgicp_peer_disconnect",
 )
@@ -48,6 +50,15 @@ class Params(C.Structure):
     _fields_ = [("max_iteration", C.c_int32), ("chunk_iterations", C.c_int32),
                 ("translation_sq_threshold", C.c_double), ("cosine_threshold", C.c_double),
                 ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("kernel_launches", C.c_uint64), ("copies", C.c_uint64), ("host_syncs", C.c_uint64),
+                ("prepare_us", C.c_double), ("align_us", C.c_double), ("insert_us", C.c_double),
+                ("prepare_head_us", C.c_double)]
+
+
+OPTION_STAGE_EVENTS = 1
 
 
 class Stats(C.Structure):
@@ -98,6 +109,11 @@ def load_library() -> C.CDLL:
     lib.vgicp_scan_prepare.argtypes = [vp, sz, dp, dp, sz, dp, dp, C.c_double, C.c_int, C.POINTER(sz),
                                        C.POINTER(C.c_int64)]
     lib.vgicp_scan_download.argtypes = [vp, sz, dp, dp, C.POINTER(sz)]
+    lib.vgicp_scan_prepare_async.argtypes = [vp, sz, dp, dp, sz, dp, dp, C.c_double, C.c_int]
+    lib.vgicp_scan_info.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+    lib.vgicp_map_insert_resident_async.argtypes = [vp, dp, sz]
+    lib.vgicp_get_frame_stats.argtypes = [vp, C.POINTER(FrameStats), C.c_int]
+    lib.vgicp_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.vgicp_deskew.argtypes = [vp, sz, dp, dp, sz, dp, C.POINTER(C.c_int64)]
     lib.vgicp_preprocess.argtypes = [vp, sz, dp, C.c_double, C.c_int, sz, dp, dp, C.POINTER(C.c_uint64),
                                      C.POINTER(sz)]
@@ -433,6 +449,38 @@ class Context:
                                                  _dp(st) if st.size else None, _dp(ext) if ext is not None else None,
                                                  float(voxel_size), int(knn), C.byref(kept), C.byref(moved)))
         return kept.value, int(moved.value)
+
+    def scan_prepare_async(self, points, point_time=None, states=None, extrinsic=None, voxel_size: float = 0.3,
+                           knn: int = 30):
+        """vgicp_scan_prepare_async: the same, only enqueued (nothing waited for, nothing returned)."""
+        pts = _f64(points, 3)
+        n = pts.shape[0]
+        st = _f64(states, 8) if states is not None and len(states) else np.zeros((0, 8))
+        t = np.ascontiguousarray(point_time, dtype=np.float64).reshape(-1) if point_time is not None else np.zeros(0)
+        if st.shape[0] and t.shape[0] != n:
+            raise ValueError("one capture time per point")
+        ext = pose_to_abi(extrinsic) if extrinsic is not None else None
+        self._check(self._lib.vgicp_scan_prepare_async(self._h, n, _dp(pts), _dp(t) if t.size else None, st.shape[0],
+                                                       _dp(st) if st.size else None, _dp(ext) if ext is not None else None,
+                                                       float(voxel_size), int(knn)))
+
+    def scan_info(self):
+        """(kept points, what the deskew reports, indefinite covariances) of the last preparation."""
+        kept, moved, bad = C.c_size_t(0), C.c_int64(0), C.c_uint64(0)
+        self._check(self._lib.vgicp_scan_info(self._h, C.byref(kept), C.byref(moved), C.byref(bad)))
+        return kept.value, int(moved.value), int(bad.value)
+
+    def map_insert_resident_async(self, transform, max_points_per_voxel: int):
+        T = pose_to_abi(transform)
+        self._check(self._lib.vgicp_map_insert_resident_async(self._h, _dp(T), int(max_points_per_voxel)))
+
+    def frame_stats(self, reset: bool = False) -> FrameStats:
+        st = FrameStats()
+        self._check(self._lib.vgicp_get_frame_stats(self._h, C.byref(st), 1 if reset else 0))
+        return st
+
+    def set_option(self, option: int, value: int):
+        self._check(self._lib.vgicp_set_option(self._h, int(option), int(value)))
 
     def scan_download(self):
         """The resident scan -> (points n x 3, covs n x 9)."""

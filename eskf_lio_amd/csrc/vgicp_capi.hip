@@ -23,6 +23,13 @@
 
 using namespace vgicp;
 
+// what a frame costs the host besides kernels: copies / memsets enqueued and synchronisations (vgicp_get_frame_stats)
+namespace { thread_local uint64_t g_copy_ops = 0, g_sync_ops = 0; }
+#define hipMemcpyAsync(...) (++g_copy_ops, hipMemcpyAsync(__VA_ARGS__))
+#define hipMemsetAsync(...) (++g_copy_ops, hipMemsetAsync(__VA_ARGS__))
+#define hipStreamSynchronize(...) (++g_sync_ops, hipStreamSynchronize(__VA_ARGS__))
+#define hipEventSynchronize(...) (++g_sync_ops, hipEventSynchronize(__VA_ARGS__))
+
 namespace {
 
 // ---- the few RCCL entry points used, bound at run time so the library loads without RCCL ----
@@ -112,6 +119,25 @@ struct vgicp_ctx {
   uint64_t upload_bytes = 0;
   double upload_seconds = 0.0;
   uint64_t prep_indefinite = 0;      // kept points of the last scan preparation with an indefinite covariance
+  // scan preparation without host round trips
+  void* d_tiles = nullptr;           // tile slots of the two device-wide scans
+  uint32_t* h_prep = nullptr;        // pinned: the counter block as a preparation left it (kCounterWords)
+  uint32_t prep_epoch = 0;
+  bool scan_pending = false;         // a prepared scan is resident but the host has not read its size / verdict yet
+  uint32_t n_upper = 0;              // raw points of the pending scan (>= its kept points)
+  int64_t prep_deskewed = 0;
+  bool prep_with_deskew = false;
+  // deferred map insertion (vgicp_map_insert_resident_async): running totals on the device, read at the next sync
+  uint32_t* d_ins_counters = nullptr;
+  uint32_t* h_ins_counters = nullptr;  // pinned
+  uint32_t ins_seen[2] = {0, 0};
+  bool insert_pending = false;
+  uint64_t insert_pending_upper = 0;
+  // frame statistics
+  uint64_t stat_launches0 = 0, stat_copies0 = 0, stat_syncs0 = 0;
+  bool stage_events = false;
+  hipEvent_t ev_stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [6]: behind the prologue
+  bool ev_stage_set[7] = {false, false, false, false, false, false, false};
   int iter_block = 512;           // threads per workgroup of the iteration kernel (measured best at C2)
   double* d_log = nullptr;
   double* h_log = nullptr;  // pinned
@@ -140,6 +166,10 @@ struct vgicp_ctx {
 };
 
 namespace {
+
+int settle(vgicp_ctx* ctx);         // defined with the scan preparation below
+int settle_scan(vgicp_ctx* ctx);
+int settle_insert(vgicp_ctx* ctx);
 
 int fail(const vgicp_ctx* ctx, int code, const std::string& text) {
   if (ctx) ctx->err = text; else g_create_error = text;
@@ -179,7 +209,7 @@ int alloc_table(vgicp_ctx* ctx, uint64_t slots, VoxelRecord** out) {
 
 // Keep load (FULL + TOMB + incoming) <= 1/2 at all times; size new tables for load <= 1/4.
 int ensure_table(vgicp_ctx* ctx, uint64_t incoming) {
-  const uint64_t used = ctx->voxels + ctx->tombstones + incoming;
+  const uint64_t used = ctx->voxels + ctx->tombstones + incoming + ctx->insert_pending_upper;
   if (ctx->table && used * 2 <= ctx->slots) return VGICP_OK;
   const uint64_t slots = next_pow2(std::max<uint64_t>(kMinSlots, (ctx->voxels + incoming) * 4));
   VoxelRecord* fresh = nullptr;
@@ -363,7 +393,8 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   std::memset(&a, 0, sizeof a);
   a.scan = ctx->d_scan;
   a.stride = ctx->stride;
-  a.n = ctx->n;
+  a.n = ctx->n;                                        // a pending scan: the raw count, an upper bound ...
+  a.n_dev = ctx->scan_pending ? ctx->d_counters : nullptr;  // ... and the kept count is read from the device
   a.mask = (uint32_t)(ctx->slots - 1);
   a.table = ctx->table;
   a.voxel_size = ctx->voxel_size;
@@ -401,10 +432,27 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
   VG_HIP(ctx, launch_persistent(ctx->stream, a, grid));
   VG_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+  if (ctx->stage_events) VG_HIP(ctx, hipEventRecord(ctx->ev_stage[3], ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   VG_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_begin, ctx->ev_end));
   std::memcpy(result, header, sizeof(AlignState));
   ++ctx->persistent_launches;
+  {
+    // the frame's ONE synchronisation has happened: what was deferred is known now (a pending scan's size and
+    // verdict, the counts of the previous frame's map insertion)
+    const int rc_scan = settle_scan(ctx);
+    const int rc_ins = settle_insert(ctx);
+    if (rc_scan != VGICP_OK || rc_ins != VGICP_OK) {
+      // the launch itself may well have completed: keep the exchange buffers' rotation in step before reporting
+      if (result->seq == a.seq && result->outcome == kOutcomeCommitted && result->abort_seq != a.seq) {
+        ctx->persist_round0 = (ctx->persist_round0 + (uint32_t)result->iteration) % 3u;
+        if (multi) ctx->mail_round0 += (uint32_t)result->iteration;
+      } else {
+        (void)reset_persistent_exchange(ctx);
+      }
+      return rc_scan != VGICP_OK ? rc_scan : rc_ins;
+    }
+  }
   const bool committed = result->seq == a.seq && result->outcome == kOutcomeCommitted;
   const bool someone_gave_up = result->abort_seq == a.seq;
   if (!committed || someone_gave_up) {
@@ -459,15 +507,25 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
 
   const bool peer_path = ctx->peers_connected && ctx->peer_enabled && ctx->peer_world > 1;
   const bool alone = ctx->world_size == 1;  // also a communicator of one rank: nothing to exchange
+  const bool single_launch = !(ctx->persistent_cooldown > 0 && !peer_path) && ctx->persistent_enabled &&
+                             (alone || peer_path) && !profile && max_it > 0 &&
+                             (params->flags & VGICP_FLAG_NO_PERSISTENT) == 0;
+  if (!single_launch) {
+    // the launch-per-round loop sizes its grid from the scan: a pending scan has to be settled first
+    rc = settle(ctx);
+    if (rc != VGICP_OK) return rc;
+    if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident");
+  }
   if (ctx->persistent_cooldown > 0 && !peer_path) --ctx->persistent_cooldown;
-  else if (ctx->persistent_enabled && (alone || peer_path) && !profile && max_it > 0 &&
-           (params->flags & VGICP_FLAG_NO_PERSISTENT) == 0) {
+  else if (single_launch) {
     bool ran = false;
     float ms = 0.f;
     AlignState* hf = &ctx->h_state[0];
+    if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[2], ctx->stream)); ctx->ev_stage_set[2] = true; }
     rc = run_align_persistent(ctx, guess, params, &ctx->h_state[1], &ran, &ms);
     if (rc != VGICP_OK) return rc;
     if (ran) {
+      if (ctx->stage_events) ctx->ev_stage_set[3] = true;
       *hf = ctx->h_state[1];
       state_to_pose(hf->pose, out_pose);
       if (stats) {
@@ -639,6 +697,21 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   VG_CREATE(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), kCounterWords * sizeof(uint32_t)));
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), kCounterWords * sizeof(uint32_t), 0));
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_prep), kCounterWords * sizeof(uint32_t), 0));
+  VG_CREATE(hipMalloc(&ctx->d_tiles, preprocess_tile_bytes()));
+  VG_CREATE(hipMemset(ctx->d_tiles, 0, preprocess_tile_bytes()));
+  VG_CREATE(hipMemset(ctx->d_counters, 0, kCounterWords * sizeof(uint32_t)));
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_ins_counters), 4 * sizeof(uint32_t)));
+  VG_CREATE(hipMemset(ctx->d_ins_counters, 0, 4 * sizeof(uint32_t)));
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_ins_counters), 4 * sizeof(uint32_t), 0));
+  ctx->h_ins_counters[0] = ctx->h_ins_counters[1] = 0;
+  if (const char* se = std::getenv("VGICP_STAGE_EVENTS"); se && se[0] == '1') {
+    for (auto& e : ctx->ev_stage) VG_CREATE(hipEventCreate(&e));
+    ctx->stage_events = true;
+  }
+  ctx->stat_launches0 = g_kernel_launches;
+  ctx->stat_copies0 = g_copy_ops;
+  ctx->stat_syncs0 = g_sync_ops;
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_state), 2 * sizeof(AlignState)));
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state),
                           (1 + kMaxChunksInFlight) * sizeof(AlignState), 0));
@@ -738,6 +811,11 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipFree(ctx->table);
   (void)hipFree(ctx->d_counters);
   (void)hipHostFree(ctx->h_counters);
+  (void)hipHostFree(ctx->h_prep);
+  (void)hipFree(ctx->d_tiles);
+  (void)hipFree(ctx->d_ins_counters);
+  (void)hipHostFree(ctx->h_ins_counters);
+  for (auto& e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
   (void)hipFree(ctx->d_stage);
   (void)hipFree(ctx->d_cells);
   (void)hipFree(ctx->d_scan);
@@ -792,6 +870,7 @@ int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
 
 int vgicp_map_reset(vgicp_ctx* ctx, double voxel_size, size_t capacity_hint) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!(voxel_size > 0.0) || !std::isfinite(voxel_size))
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "voxel_size must be positive and finite");
   VG_HIP(ctx, hipSetDevice(ctx->device));
@@ -811,6 +890,7 @@ int vgicp_map_reset(vgicp_ctx* ctx, double voxel_size, size_t capacity_hint) {
 int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double* means,
                      const double* covs) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (n == 0) return VGICP_OK;
   if (!keys || !means || !covs) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL batch pointer");
@@ -841,6 +921,7 @@ int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double
 
 int vgicp_map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (n == 0) return VGICP_OK;
   if (!keys) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL batch pointer");
@@ -863,6 +944,7 @@ int vgicp_map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys) {
 
 int vgicp_map_size(const vgicp_ctx* ctx, size_t* voxels, size_t* table_slots) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  { const int rc_settle = settle(const_cast<vgicp_ctx*>(ctx)); if (rc_settle != VGICP_OK) return rc_settle; }  // a deferred insertion
   if (voxels) *voxels = ctx->voxels;
   if (table_slots) *table_slots = ctx->slots;
   return VGICP_OK;
@@ -872,6 +954,7 @@ int vgicp_map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const 
                           const double transform[16], size_t max_points_per_voxel, size_t* new_voxels) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (new_voxels) *new_voxels = 0;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (n == 0) return VGICP_OK;
   if (!points || !covs || !transform) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
@@ -907,6 +990,7 @@ int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t
                               size_t* new_voxels) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (new_voxels) *new_voxels = 0;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload first");
   if (!transform) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
@@ -934,9 +1018,84 @@ int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t
   return VGICP_OK;
 }
 
+int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload first");
+  if (!transform) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
+  if (max_points_per_voxel == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "max_points_per_voxel must be >= 1");
+  if (ctx->comm || ctx->peers_connected) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "resident scan is a shard: use vgicp_map_insert_scan with the whole scan");
+  // the scan's size has to be known (the align that registered it has settled it); an insertion still pending
+  // from an earlier frame is settled by the same synchronisation
+  int rc = (ctx->scan_pending || ctx->insert_pending) ? settle(ctx) : VGICP_OK;
+  if (rc != VGICP_OK) return rc;
+  const size_t n = ctx->n;
+  if (n == 0) return VGICP_OK;
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  rc = ensure_table(ctx, n);  // every point may open a voxel (grows / rehashes with a synchronisation when it has to)
+  if (rc != VGICP_OK) return rc;
+  const size_t sb = map_insert_scratch_bytes((uint32_t)n);
+  rc = ensure_stage(ctx, sb);
+  if (rc != VGICP_OK) return rc;
+  double pose12[12];
+  pose_to_state(transform, pose12);
+  if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[4], ctx->stream)); ctx->ev_stage_set[4] = true; }
+  VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size,
+                                ctx->d_scan_aos, ctx->d_scan_aos + 3 * ctx->scan_capacity, (uint32_t)n, pose12,
+                                (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_ins_counters));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_ins_counters, ctx->d_ins_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[5], ctx->stream)); ctx->ev_stage_set[5] = true; }
+  ctx->insert_pending = true;
+  ctx->insert_pending_upper = n;
+  return VGICP_OK;
+}
+
+int vgicp_get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset) {
+  if (!ctx || !out) return VGICP_ERR_BAD_ARGUMENT;
+  std::memset(out, 0, sizeof *out);
+  out->kernel_launches = g_kernel_launches - ctx->stat_launches0;
+  out->copies = g_copy_ops - ctx->stat_copies0;
+  out->host_syncs = g_sync_ops - ctx->stat_syncs0;
+  out->prepare_us = out->align_us = out->insert_us = out->prepare_head_us = -1.0;
+  if (ctx->stage_events) {
+    VG_HIP(ctx, hipSetDevice(ctx->device));
+    float ms = 0.f;
+    if (ctx->ev_stage_set[0] && ctx->ev_stage_set[1] && hipEventElapsedTime(&ms, ctx->ev_stage[0], ctx->ev_stage[1]) == hipSuccess)
+      out->prepare_us = ms * 1e3;
+    if (ctx->ev_stage_set[0] && ctx->ev_stage_set[6] && hipEventElapsedTime(&ms, ctx->ev_stage[0], ctx->ev_stage[6]) == hipSuccess)
+      out->prepare_head_us = ms * 1e3;
+    if (ctx->ev_stage_set[2] && ctx->ev_stage_set[3] && hipEventElapsedTime(&ms, ctx->ev_stage[2], ctx->ev_stage[3]) == hipSuccess)
+      out->align_us = ms * 1e3;
+    if (ctx->ev_stage_set[4] && ctx->ev_stage_set[5] && hipEventElapsedTime(&ms, ctx->ev_stage[4], ctx->ev_stage[5]) == hipSuccess)
+      out->insert_us = ms * 1e3;
+  }
+  if (reset) {
+    ctx->stat_launches0 = g_kernel_launches;
+    ctx->stat_copies0 = g_copy_ops;
+    ctx->stat_syncs0 = g_sync_ops;
+  }
+  return VGICP_OK;
+}
+
+int vgicp_set_option(vgicp_ctx* ctx, int option, int value) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  switch (option) {
+    case VGICP_OPTION_STAGE_EVENTS:
+      VG_HIP(ctx, hipSetDevice(ctx->device));
+      if (value && !ctx->ev_stage[0])
+        for (auto& e : ctx->ev_stage) VG_HIP(ctx, hipEventCreate(&e));
+      ctx->stage_events = value != 0;
+      for (bool& b : ctx->ev_stage_set) b = false;
+      return VGICP_OK;
+    default:
+      return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown option");
+  }
+}
+
 int vgicp_map_evict(vgicp_ctx* ctx, const double position[3], double distance_threshold, size_t* removed) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (removed) *removed = 0;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (!position) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
   VG_HIP(ctx, hipSetDevice(ctx->device));
@@ -956,6 +1115,7 @@ int vgicp_map_export(vgicp_ctx* ctx, size_t capacity, int32_t* keys, double* mea
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (!written) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "written is NULL");
   *written = 0;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (capacity == 0 || ctx->voxels == 0) return VGICP_OK;
   if (!keys || !means || !covs || !counts) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL array pointer");
@@ -1014,6 +1174,7 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
 
 int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const double* covs) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   const double t0 = now_seconds();
   int rc = scan_upload_enqueue(ctx, n, points, covs);
   if (rc != VGICP_OK) return rc;
@@ -1035,6 +1196,7 @@ int vgicp_align(vgicp_ctx* ctx, size_t n, const double* points, const double* co
                 const double guess[16], const vgicp_params* params, double out_pose[16],
                 vgicp_stats* stats) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   const double t0 = now_seconds();
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   // the upload is only enqueued: the pack kernel and the align's first launch follow it in stream order
@@ -1117,6 +1279,7 @@ int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* co
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (!matched) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "matched is NULL");
   *matched = 0;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (n == 0) return VGICP_OK;
   if (!points || !covs || !src_points || !src_covs || !map_points || !map_covs)
@@ -1163,6 +1326,7 @@ int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* co
 
 int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* keys) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (n == 0) return VGICP_OK;
   if (!points || !keys) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL array pointer");
   if (!(ctx->voxel_size > 0.0)) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel size: call vgicp_map_reset first");
@@ -1191,43 +1355,124 @@ int ensure_cells(vgicp_ctx* ctx, size_t need) {
   return VGICP_OK;
 }
 
-// The scan preparation on points that are already on the device; outputs stay on the device. One host
-// synchronisation in the middle (number of kept points and of octree cells). capacity bounds *kept.
-int preprocess_on_device(vgicp_ctx* ctx, const double* d_pts, size_t n, double voxel_size, int knn, void* scratch,
-                         size_t capacity, double* d_out_pts, double* d_out_covs, unsigned long long* d_out_idx,
-                         uint32_t* kept) {
-  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, kCounterWords * sizeof(uint32_t), ctx->stream));
-  VG_HIP(ctx, launch_preprocess_sort(ctx->stream, d_pts, (uint32_t)n, voxel_size, scratch, ctx->d_counters));
-  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint32_t m = ctx->h_counters[0], cells = ctx->h_counters[1];
-  if (ctx->h_counters[3] != 0) {
-    *kept = 0;
-    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "a point lies beyond the search grid (more than 2^17 voxel sizes from the origin)");
-  }
-  *kept = m;
-  if (m > capacity) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "output capacity smaller than the number of occupied voxels");
-  const uint64_t entries = preprocess_cell_entries(cells);
+// The scan preparation on points that are already on the device, ENQUEUED as one sequence without a host round
+// trip: tables and grids are sized from n, the kept count stays on the device (counter word 0) and a copy of the
+// counter block travels to pinned host memory behind the last kernel. resolve_prepare() reads it after a
+// synchronisation of the stream.
+struct DeskewOnDevice {
+  const double* point_time = nullptr;
+  const double* state_time = nullptr;
+  const double* poses = nullptr;
+  uint32_t states = 0;
+  bool ordered = false;
+  uint32_t* ends = nullptr;
+};
+int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, int knn, const double* extrinsic16,
+                    const DeskewOnDevice& dk, void* scratch, double* d_out_pts, double* d_out_covs,
+                    unsigned long long* d_out_idx, double* soa, uint64_t soa_stride) {
+  const uint64_t entries = preprocess_cell_entries_for((uint32_t)n);
   int rc = ensure_cells(ctx, preprocess_cell_bytes(entries));
   if (rc != VGICP_OK) return rc;
   const int debug = std::getenv("VGICP_DEBUG_PREP") ? std::atoi(std::getenv("VGICP_DEBUG_PREP")) : 0;
-  VG_HIP(ctx, launch_preprocess_finish(ctx->stream, d_pts, (uint32_t)n, voxel_size, knn, m, scratch, ctx->d_cells,
-                                       entries, d_out_pts, d_out_covs, d_out_idx, ctx->d_counters, debug));
-  if (debug) {
-    VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 72 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (debug) VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 72 * sizeof(uint32_t), ctx->stream));
+  if (++ctx->prep_epoch == 0) ++ctx->prep_epoch;
+  PrepareArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.pts = d_pts;
+  a.n = (uint32_t)n;
+  a.voxel_size = voxel_size;
+  a.knn = knn;
+  a.extrinsic16 = extrinsic16;
+  a.point_time = dk.point_time;
+  a.state_time = dk.state_time;
+  a.poses = dk.poses;
+  a.states = dk.states;
+  a.ordered_states = dk.ordered;
+  a.ends = dk.ends;
+  a.scratch = scratch;
+  a.cell_table = ctx->d_cells;
+  a.table_entries = entries;
+  a.out_pts = d_out_pts;
+  a.out_covs = d_out_covs;
+  a.out_idx = d_out_idx;
+  a.soa = soa;
+  a.soa_stride = soa_stride;
+  a.counters = ctx->d_counters;
+  a.tiles = ctx->d_tiles;
+  a.epoch = ctx->prep_epoch;
+  a.debug = debug;
+  a.ev_after_prologue = ctx->stage_events ? ctx->ev_stage[6] : nullptr;
+  if (ctx->stage_events) ctx->ev_stage_set[6] = true;
+  VG_HIP(ctx, launch_prepare(ctx->stream, a));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_prep, ctx->d_counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  return VGICP_OK;
+}
+
+// After the stream has been synchronised: what the preparation found. *kept is set even on refusal.
+int resolve_prepare(vgicp_ctx* ctx, uint32_t* kept) {
+  const uint32_t* h = ctx->h_prep;
+  *kept = 0;
+  if (h[kScanTimeout] == ctx->prep_epoch)
+    return fail(ctx, VGICP_ERR_HIP, "a device-wide scan of the scan preparation gave up waiting for a tile");
+  if (h[kBeyondGrid] == ctx->prep_epoch)
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "a point lies beyond the search grid (more than 2^17 voxel sizes from the origin)");
+  *kept = h[0];
+  ctx->prep_indefinite = h[kIndefiniteCounter];
+  ctx->prep_deskewed = (int64_t)h[kDeskewedCounter];
+  if (std::getenv("VGICP_DEBUG_PREP")) {
+    const int debug = std::atoi(std::getenv("VGICP_DEBUG_PREP"));
     if (debug >= 2) {
       std::fprintf(stderr, "[vgicp prep] queries by cells taken (buckets of 8):");
-      for (int i = 0; i < 32; ++i) std::fprintf(stderr, " %u", ctx->h_counters[8 + i]);
+      for (int i = 0; i < 32; ++i) std::fprintf(stderr, " %u", h[8 + i]);
       std::fprintf(stderr, "\n[vgicp prep] queries by time in the search (buckets of 8 us):");
-      for (int i = 0; i < 32; ++i) std::fprintf(stderr, " %u", ctx->h_counters[40 + i]);
+      for (int i = 0; i < 32; ++i) std::fprintf(stderr, " %u", h[40 + i]);
       std::fprintf(stderr, "\n");
     }
-    std::fprintf(stderr, "[vgicp prep] kept %u cells %u queries that spilled %u | point batches total %u (%.1f/query) max %u | cells taken total %u (%.1f/query) max %u | queries starting above the voxel level: %u\n",
-                 m, cells, ctx->h_counters[2], ctx->h_counters[3], ctx->h_counters[3] / (double)(m ? m : 1), ctx->h_counters[4],
-                 ctx->h_counters[5], ctx->h_counters[5] / (double)(m ? m : 1), ctx->h_counters[6], ctx->h_counters[7]);
+    const uint32_t m = h[0];
+    if (debug) std::fprintf(stderr, "[vgicp prep] kept %u cells %u queries that spilled %u | point batches total %u (%.1f/query) max %u | cells taken total %u (%.1f/query) max %u | queries starting above the voxel level: %u\n",
+                            m, h[1], h[2], h[3], h[3] / (double)(m ? m : 1), h[4], h[5], h[5] / (double)(m ? m : 1), h[6], h[7]);
   }
   return VGICP_OK;
+}
+
+// The deferred map insertion's counts (running totals), once the stream has been synchronised.
+int settle_insert(vgicp_ctx* ctx) {
+  if (!ctx->insert_pending) return VGICP_OK;
+  ctx->insert_pending = false;
+  ctx->insert_pending_upper = 0;
+  const uint32_t created = ctx->h_ins_counters[0] - ctx->ins_seen[0];
+  const uint32_t failed = ctx->h_ins_counters[1] - ctx->ins_seen[1];
+  ctx->ins_seen[0] = ctx->h_ins_counters[0];
+  ctx->ins_seen[1] = ctx->h_ins_counters[1];
+  ctx->voxels += created;
+  if (failed) return fail(ctx, VGICP_ERR_TABLE_FULL, "voxel table probe sequence exhausted (deferred map insertion)");
+  return VGICP_OK;
+}
+
+// A pending scan's size and verdict, once the stream has been synchronised.
+int settle_scan(vgicp_ctx* ctx) {
+  if (!ctx->scan_pending) return VGICP_OK;
+  ctx->scan_pending = false;
+  uint32_t m = 0;
+  const int rc = resolve_prepare(ctx, &m);
+  if (rc != VGICP_OK) {
+    ctx->scan_ready = false;
+    ctx->n = 0;
+    return rc;
+  }
+  ctx->n = m;
+  return VGICP_OK;
+}
+
+// Everything deferred is brought up to date (one synchronisation if anything is pending): entry points that read
+// or change what a pending operation still owns call this first.
+int settle(vgicp_ctx* ctx) {
+  if (!ctx->scan_pending && !ctx->insert_pending) return VGICP_OK;
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int rc_scan = settle_scan(ctx);
+  const int rc_ins = settle_insert(ctx);
+  return rc_scan != VGICP_OK ? rc_scan : rc_ins;
 }
 
 int check_preprocess_args(vgicp_ctx* ctx, size_t n, double voxel_size, int knn) {
@@ -1245,6 +1490,7 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
   *kept = 0;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   int rc = check_preprocess_args(ctx, n, voxel_size, knn);
   if (rc != VGICP_OK) return rc;
   if (n == 0) return VGICP_OK;
@@ -1262,19 +1508,21 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
   double* d_out_covs = reinterpret_cast<double*>(base + 2 * pb);
   unsigned long long* d_out_idx = reinterpret_cast<unsigned long long*>(base + 2 * pb + cb);
   VG_HIP(ctx, hipMemcpyAsync(base, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  rc = enqueue_prepare(ctx, reinterpret_cast<double*>(base), n, voxel_size, knn, nullptr, DeskewOnDevice(),
+                       base + 2 * pb + cb + ib, d_out_pts, d_out_covs, d_out_idx, nullptr, 0);
+  if (rc != VGICP_OK) return rc;
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   uint32_t m = 0;
-  rc = preprocess_on_device(ctx, reinterpret_cast<const double*>(base), n, voxel_size, knn, base + 2 * pb + cb + ib,
-                            out_points && out_covs ? capacity : 0, d_out_pts, d_out_covs, d_out_idx, &m);
+  rc = resolve_prepare(ctx, &m);
   *kept = m;
   if (rc != VGICP_OK) return rc;
+  if (m > (out_points && out_covs ? capacity : 0))
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "output capacity smaller than the number of occupied voxels");
   VG_HIP(ctx, hipMemcpyAsync(out_points, d_out_pts, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipMemcpyAsync(out_covs, d_out_covs, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (out_index)
     VG_HIP(ctx, hipMemcpyAsync(out_index, d_out_idx, (size_t)m * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters + kIndefiniteCounter, ctx->d_counters + kIndefiniteCounter, sizeof(uint32_t),
-                             hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->prep_indefinite = ctx->h_counters[kIndefiniteCounter];
   return VGICP_OK;
 }
 
@@ -1386,6 +1634,7 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (!transformed) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "transformed is NULL");
   *transformed = 0;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (n == 0 || num_states == 0) return VGICP_OK;
   if (!points || !point_time || !states) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
   if (n > 0x7FFFFFFFull || num_states > 0x7FFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan or state queue too large");
@@ -1419,13 +1668,12 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
   return VGICP_OK;
 }
 
-int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
-                       size_t num_states, const double* states, const double extrinsic[16],
-                       double voxel_size, int knn, size_t* kept, int64_t* deskewed) {
-  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
-  if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
-  *kept = 0;
-  if (deskewed) *deskewed = 0;
+namespace {
+// CloudPreprocessor::process enqueued on the context's stream with the prepared scan left resident: upload of the
+// raw sweep, then launch_prepare writing the AoS scan AND the SoA planes the registration reads. Nothing is waited
+// for: the scan is `pending` (its size is on the device, ctx->n_upper bounds it).
+int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, size_t num_states,
+                         const double* states, const double extrinsic[16], double voxel_size, int knn) {
   int rc = check_preprocess_args(ctx, n, voxel_size, knn);
   if (rc != VGICP_OK) return rc;
   if (ctx->comm || ctx->peers_connected) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the prepared scan is whole: not available on a communicator (shards)");
@@ -1437,8 +1685,13 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
   rc = ensure_scan(ctx, n);
   if (rc != VGICP_OK) return rc;
   ctx->scan_ready = false;
+  ctx->scan_pending = false;
   ctx->n = 0;
+  ctx->n_upper = 0;
   ctx->stride = ctx->scan_capacity;
+  ctx->prep_with_deskew = with_deskew;
+  ctx->prep_deskewed = 0;
+  ctx->prep_indefinite = 0;
   if (n == 0) {
     ctx->scan_ready = true;
     return VGICP_OK;
@@ -1447,10 +1700,10 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
   size_t used = 0;
   bool ordered = false;
   if (with_deskew && !deskew_table(n, point_time, num_states, states, host, used, ordered)) {
-    if (deskewed) *deskewed = -1;
+    ctx->prep_deskewed = -1;
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the IMU states do not bracket the end of the sweep");
   }
-  // stage: [points 3n][times n][state table][segment ends][kept index n][scratch]
+  // stage: [points 3n][times n][state table][segment ends + first hits][kept index n][scratch]
   const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
   const size_t tb = (n * sizeof(double) + 255) & ~size_t(255);
   const size_t sb = (used * 13 * sizeof(double) + 255) & ~size_t(255);
@@ -1462,31 +1715,74 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
   double* d_pts = reinterpret_cast<double*>(base);
   double* d_time = reinterpret_cast<double*>(base + pb);
   double* d_states = reinterpret_cast<double*>(base + pb + tb);
-  uint32_t* d_ends = reinterpret_cast<uint32_t*>(base + pb + tb + sb);
   unsigned long long* d_idx = reinterpret_cast<unsigned long long*>(base + pb + tb + sb + eb);
   void* scratch = base + pb + tb + sb + eb + ib;
+  if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[0], ctx->stream)); ctx->ev_stage_set[0] = true; }
   VG_HIP(ctx, hipMemcpyAsync(d_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (extrinsic) VG_HIP(ctx, launch_transform_points(ctx->stream, d_pts, (uint32_t)n, extrinsic));
+  DeskewOnDevice dk;
   if (with_deskew) {
     VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     VG_HIP(ctx, hipMemcpyAsync(d_states, host.data(), used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    VG_HIP(ctx, launch_deskew(ctx->stream, d_pts, (uint32_t)n, d_time, d_states, (uint32_t)used, d_states + used, d_ends, ordered));
-    VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters + 4, d_ends + (used - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    dk.point_time = d_time;
+    dk.state_time = d_states;
+    dk.poses = d_states + used;
+    dk.states = (uint32_t)used;
+    dk.ordered = ordered;
+    dk.ends = reinterpret_cast<uint32_t*>(base + pb + tb + sb);
   }
-  double* aos_pts = ctx->d_scan_aos;
-  double* aos_cov = ctx->d_scan_aos + 3 * ctx->scan_capacity;
-  uint32_t m = 0;
-  rc = preprocess_on_device(ctx, d_pts, n, voxel_size, knn, scratch, n, aos_pts, aos_cov, d_idx, &m);  // syncs
+  rc = enqueue_prepare(ctx, d_pts, n, voxel_size, knn, extrinsic, dk, scratch, ctx->d_scan_aos,
+                       ctx->d_scan_aos + 3 * ctx->scan_capacity, d_idx, ctx->d_scan, ctx->stride);
   if (rc != VGICP_OK) return rc;
-  if (with_deskew && deskewed) *deskewed = (int64_t)ctx->h_counters[4];
-  if (m > 0) VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, m, ctx->d_scan, ctx->stride));
-  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters + kIndefiniteCounter, ctx->d_counters + kIndefiniteCounter, sizeof(uint32_t),
-                             hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->prep_indefinite = ctx->h_counters[kIndefiniteCounter];
-  ctx->n = m;
+  if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[1], ctx->stream)); ctx->ev_stage_set[1] = true; }
+  ctx->n_upper = (uint32_t)n;
+  ctx->n = (uint32_t)n;          // an upper bound until the pending scan is settled
+  ctx->scan_pending = true;
   ctx->scan_ready = true;
-  *kept = m;
+  return VGICP_OK;
+}
+}  // namespace
+
+int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
+                             size_t num_states, const double* states, const double extrinsic[16],
+                             double voxel_size, int knn) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  // nothing is settled here: a map insertion still pending from the previous frame has counters of its own and is
+  // read at this frame's one synchronisation (the align); a scan that was prepared but never used is simply replaced
+  return scan_prepare_enqueue(ctx, n, points, point_time, num_states, states, extrinsic, voxel_size, knn);
+}
+
+int vgicp_scan_info(vgicp_ctx* ctx, size_t* kept, int64_t* deskewed, uint64_t* indefinite) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (kept) *kept = 0;
+  if (deskewed) *deskewed = 0;
+  if (indefinite) *indefinite = 0;
+  int rc = settle(ctx);
+  if (rc != VGICP_OK) return rc;
+  if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident");
+  if (kept) *kept = ctx->n;
+  if (deskewed) *deskewed = ctx->prep_with_deskew ? ctx->prep_deskewed : 0;
+  if (indefinite) *indefinite = ctx->prep_indefinite;
+  return VGICP_OK;
+}
+
+int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
+                       size_t num_states, const double* states, const double extrinsic[16],
+                       double voxel_size, int knn, size_t* kept, int64_t* deskewed) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
+  *kept = 0;
+  if (deskewed) *deskewed = 0;
+  int rc = settle(ctx);
+  if (rc != VGICP_OK) return rc;
+  rc = scan_prepare_enqueue(ctx, n, points, point_time, num_states, states, extrinsic, voxel_size, knn);
+  if (rc != VGICP_OK) {
+    if (deskewed && ctx->prep_deskewed < 0) *deskewed = -1;
+    return rc;
+  }
+  rc = settle(ctx);  // one synchronisation
+  if (rc != VGICP_OK) return rc;
+  *kept = ctx->n;
+  if (deskewed && ctx->prep_with_deskew) *deskewed = ctx->prep_deskewed;
   return VGICP_OK;
 }
 
@@ -1494,6 +1790,7 @@ int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double*
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (!n) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "n is NULL");
   *n = 0;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload or vgicp_scan_prepare first");
   *n = ctx->n;
   if (ctx->n == 0 || (!points && !covs)) return VGICP_OK;  // both NULL: size query
@@ -1521,6 +1818,7 @@ int vgicp_peer_export(vgicp_ctx* ctx, void* handle64) {
 
 int vgicp_peer_connect(vgicp_ctx* ctx, int world_size, int rank, const void* handles) {
   if (!ctx || !handles) return VGICP_ERR_BAD_ARGUMENT;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (world_size < 1 || world_size > kMaxRanks || rank < 0 || rank >= world_size)
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "bad world_size / rank (at most 16 ranks)");
   if (ctx->peers_connected) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "peers already connected");
@@ -1585,6 +1883,7 @@ int vgicp_comm_unique_id(vgicp_ctx* ctx, void* id128) {
 
 int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128) {
   if (!ctx || !id128) return VGICP_ERR_BAD_ARGUMENT;
+  { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (world_size < 1 || rank < 0 || rank >= world_size)
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "bad world_size / rank");
   if (ctx->comm) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "communicator already initialised");

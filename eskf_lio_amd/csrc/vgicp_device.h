@@ -98,7 +98,7 @@ constexpr size_t kMailWords = kMailRowWords + kSlots;          // + the verdict 
 struct PersistArgs {
   const double* scan;  // SoA planes
   uint64_t stride;
-  uint32_t n;
+  uint32_t n;          // points of the scan — an UPPER BOUND when n_dev is set (the launch plan is made from it)
   uint32_t mask;
   const VoxelRecord* table;
   double voxel_size;
@@ -130,6 +130,8 @@ struct PersistArgs {
                            // mail_seq << 1 | 1 "my loop ran to its end", mail_seq << 1 "I gave up" — written by
                            // workgroup 0 of the sender at the end of its launch, so that all ranks commit an align
                            // or none does
+  const uint32_t* n_dev;   // nullptr, or where the device holds the scan's size (a scan prepared on the device whose
+                           // kept count the host has not read yet: no host round trip between preparation and align)
   double prefetch_margin;  // > 0 (only with memo_points == stash_points == 0): a point closer than this many
                            // voxel sizes to a face of its voxel has the neighbour behind that face looked up
                            // into LDS while the workers wait for the exchange
@@ -188,20 +190,62 @@ uint32_t match_blocks(uint32_t n);
 size_t map_insert_scratch_bytes(uint32_t n);
 
 // vgicp_preprocess.hip — voxel down-sampling + k-NN covariances (CloudPreprocessor.cpp:76-127)
-// words of the context's counter block: [0] kept points, [1] octree cells, [2..7] developer counts, [3] also the
-// "point beyond the search grid" flag of stage A, [8..71] developer histograms, [72] kept points whose regularised
-// covariance is indefinite (a negative eigenvalue of the cumulant covariance, src/CloudPreprocessor.cpp:119-123)
-constexpr int kCounterWords = 80;
+// Words of the context's counter block (device; a copy travels to pinned host memory after a preparation):
+//   [0] kept points  [1] octree cells over all levels  [2..7] developer counts  [8..71] developer histograms
+//   [72] kept points whose regularised covariance is indefinite (src/CloudPreprocessor.cpp:119-123)
+//   [73] = the call's epoch when a point lies beyond the search grid (the scan is refused)
+//   [74] what the deskew reports (leading points moved)   [75] = epoch when a device-wide scan gave up waiting
+//   [76], [77] tile tickets of the two single-launch scans
+constexpr int kCounterWords = 96;
 constexpr int kIndefiniteCounter = 72;
+constexpr int kBeyondGrid = 73;
+constexpr int kDeskewedCounter = 74;
+constexpr int kScanTimeout = 75;
+constexpr int kTicketA = 76;
+constexpr int kTicketB = 77;
+constexpr uint32_t kMaxScanTiles = 4096;  // x 2 048 points: scans up to 8 M points
 size_t preprocess_scratch_bytes(uint32_t n);
 int preprocess_max_knn();
 uint64_t preprocess_cell_entries(uint32_t cells);
 size_t preprocess_cell_bytes(uint64_t entries);
-hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, double h, void* scratch,
-                                  uint32_t* counters);
-hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n, double h, int knn, uint32_t m,
-                                    void* scratch, void* cell_table, uint64_t table_entries, double* out_pts,
-                                    double* out_covs, unsigned long long* out_idx, uint32_t* counters, int debug);
+size_t preprocess_tile_bytes();  // the tile slots of the two device-wide scans (allocated once per context, zeroed)
+// CloudPreprocessor::process after the upload, enqueued as ONE sequence with no host round trip in it:
+// [deskew bounds] -> extrinsic + deskew + Morton codes (+ clears) -> sort -> runs / kept points / query list ->
+// output slots -> octree cells -> exact k-NN -> covariances.  Everything the host does not know yet (kept points,
+// cells) stays on the device: tables and grids are sized from n.  pts: n x 3 on the device, moved in place by the
+// extrinsic and the deskew.  Outputs: AoS points / covariances / indices (capacity n) and, when soa != nullptr, the
+// 12 SoA planes the registration reads.  counters: the context's counter block (layout above); epoch: a number
+// that differs from call to call (never 0).
+struct PrepareArgs {
+  double* pts;
+  uint32_t n;
+  double voxel_size;
+  int knn;
+  const double* extrinsic16;     // host, column-major 4x4, or nullptr
+  const double* point_time;      // device, n (deskew) or nullptr
+  const double* state_time;      // device, `states` timestamps
+  const double* poses;           // device, 12 doubles per state
+  uint32_t states;               // 0 = no deskew
+  bool ordered_states;
+  uint32_t* ends;                // device scratch, deskew_scratch_words(states)
+  void* scratch;                 // preprocess_scratch_bytes(n)
+  void* cell_table;              // preprocess_cell_bytes(preprocess_cell_entries_for(n))
+  uint64_t table_entries;
+  double* out_pts;
+  double* out_covs;
+  unsigned long long* out_idx;
+  double* soa;                   // optional
+  uint64_t soa_stride;
+  uint32_t* counters;
+  void* tiles;                   // preprocess_tile_bytes()
+  uint32_t epoch;
+  int debug;
+  hipEvent_t ev_after_prologue;  // optional: recorded behind the prologue (extrinsic + deskew + codes)
+};
+hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a);
+uint64_t preprocess_cell_entries_for(uint32_t n);  // from the number of points alone (no host round trip)
+// kernels enqueued by the launchers of this module since the counter was last reset (per host thread)
+extern thread_local uint64_t g_kernel_launches;
 hipError_t launch_transform_points(hipStream_t s, double* pts, uint32_t n, const double T16[16]);
 // CloudPreprocessor::deskew: ends = scratch of deskew_scratch_words(states) words (the first `states` are the
 // segment ends); poses = 12 doubles per state (R column-major, t); ordered_states: the host has checked that the

@@ -755,9 +755,10 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool worker = wave != 0;
+  const uint32_t n_pts = a.n_dev ? *a.n_dev : a.n;  // uniform
   const uint32_t grid = gridDim.x, blk = blockIdx.x;
   const uint32_t stride_pts = grid * kWorkers;
-  const uint32_t first = worker ? blk * kWorkers + (tid - 64) : a.n;
+  const uint32_t first = worker ? blk * kWorkers + (tid - 64) : n_pts;
   const bool folder = blk < (uint32_t)kFolders;  // folder g adds the rows of workgroups g, g + 16, g + 32 ...
   // row of workgroup b inside a buffer: the 16 rows of a folder are consecutive
   const uint32_t my_row = (blk % kFolders) * kFolders + blk / kFolders;
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   double q0[kScanPlanes];
 #pragma unroll
   for (int k = 0; k < kScanPlanes; ++k) q0[k] = 0.0;
-  const bool have = first < a.n;
+  const bool have = first < n_pts;
   if (have) load_point(a.scan, a.stride, first, q0);
 
   // what the first point used last round: key, hit flag, voxel payload (raw)
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
         // a.stash_points are parked in LDS after round 0, the rest is re-read from HBM every round
         if (have) one_point(q0, 0u, Flag<true>{});
         uint32_t e = 1;
-        for (uint32_t i = first + stride_pts; i < a.n; i += stride_pts, ++e) {
+        for (uint32_t i = first + stride_pts; i < n_pts; i += stride_pts, ++e) {
           double q[kScanPlanes];
           if (e <= a.stash_points) {
             double* slot = stash + (size_t)(e - 1) * kScanPlanes * kWorkers + (tid - 64);
@@ -1302,9 +1303,9 @@ inline uint32_t blocks_for(uint64_t work, uint32_t block) { return (uint32_t)((w
 
 hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, int block) {
   switch (block) {
-    case 256: hipLaunchKernelGGL(iterate_kernel<256>, dim3(grid), dim3(256), 0, s, args); break;
-    case 512: hipLaunchKernelGGL(iterate_kernel<512>, dim3(grid), dim3(512), 0, s, args); break;
-    case 1024: hipLaunchKernelGGL(iterate_kernel<1024>, dim3(grid), dim3(1024), 0, s, args); break;
+    case 256: ++g_kernel_launches; hipLaunchKernelGGL(iterate_kernel<256>, dim3(grid), dim3(256), 0, s, args); break;
+    case 512: ++g_kernel_launches; hipLaunchKernelGGL(iterate_kernel<512>, dim3(grid), dim3(512), 0, s, args); break;
+    case 1024: ++g_kernel_launches; hipLaunchKernelGGL(iterate_kernel<1024>, dim3(grid), dim3(1024), 0, s, args); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1369,7 +1370,7 @@ hipError_t launch_persistent_as(hipStream_t s, const PersistArgs& args, uint32_t
     if (e != hipSuccess) return e;
     raised[device] = true;
   }
-  hipLaunchKernelGGL((persistent_kernel<512, MULTI, STAMPS, MANY>), dim3(grid), dim3(512), dyn, s, args);
+  ++g_kernel_launches; hipLaunchKernelGGL((persistent_kernel<512, MULTI, STAMPS, MANY>), dim3(grid), dim3(512), dyn, s, args);
   return hipGetLastError();
 }
 }  // namespace
@@ -1417,9 +1418,9 @@ hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_
 // its sums are added in the same order as every other round's (and as the persistent launch adds them).
 hipError_t launch_close(hipStream_t s, const IterArgs& args, int block) {
   switch (block) {
-    case 256: hipLaunchKernelGGL(close_kernel<256>, dim3(1), dim3(256), 0, s, args); break;
-    case 512: hipLaunchKernelGGL(close_kernel<512>, dim3(1), dim3(512), 0, s, args); break;
-    case 1024: hipLaunchKernelGGL(close_kernel<1024>, dim3(1), dim3(1024), 0, s, args); break;
+    case 256: ++g_kernel_launches; hipLaunchKernelGGL(close_kernel<256>, dim3(1), dim3(256), 0, s, args); break;
+    case 512: ++g_kernel_launches; hipLaunchKernelGGL(close_kernel<512>, dim3(1), dim3(512), 0, s, args); break;
+    case 1024: ++g_kernel_launches; hipLaunchKernelGGL(close_kernel<1024>, dim3(1), dim3(1024), 0, s, args); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1427,27 +1428,27 @@ hipError_t launch_close(hipStream_t s, const IterArgs& args, int block) {
 
 hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosine_threshold,
                              double translation_sq_threshold, int force_pivoted, double* out20) {
-  hipLaunchKernelGGL(solve_step_kernel, dim3(1), dim3(64), 0, s, packed27, cosine_threshold,
+  ++g_kernel_launches; hipLaunchKernelGGL(solve_step_kernel, dim3(1), dim3(64), 0, s, packed27, cosine_threshold,
                      translation_sq_threshold, force_pivoted, out20);
   return hipGetLastError();
 }
 
 hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, const AlignState* state,
                             double* sums) {
-  hipLaunchKernelGGL(fold_rows_kernel, dim3(1), dim3(1024), 0, s, rows, nrows, state, sums);
+  ++g_kernel_launches; hipLaunchKernelGGL(fold_rows_kernel, dim3(1), dim3(1024), 0, s, rows, nrows, state, sums);
   return hipGetLastError();
 }
 
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
                             uint32_t n, double* soa, uint64_t stride) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_scan_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, points_aos,
+  ++g_kernel_launches; hipLaunchKernelGGL(pack_scan_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, points_aos,
                      covs_aos, n, soa, stride);
   return hipGetLastError();
 }
 
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots) {
-  hipLaunchKernelGGL(table_clear_kernel, dim3(blocks_for(slots * 8, 256)), dim3(256), 0, s, table,
+  ++g_kernel_launches; hipLaunchKernelGGL(table_clear_kernel, dim3(blocks_for(slots * 8, 256)), dim3(256), 0, s, table,
                      slots);
   return hipGetLastError();
 }
@@ -1456,7 +1457,7 @@ hipError_t launch_upsert(hipStream_t s, VoxelRecord* table, uint32_t mask, uint3
                          const int32_t* keys, const double* means, const double* covs,
                          uint32_t* counters) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(upsert_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask, n, keys,
+  ++g_kernel_launches; hipLaunchKernelGGL(upsert_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask, n, keys,
                      means, covs, counters);
   return hipGetLastError();
 }
@@ -1464,14 +1465,14 @@ hipError_t launch_upsert(hipStream_t s, VoxelRecord* table, uint32_t mask, uint3
 hipError_t launch_erase(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
                         const int32_t* keys, uint32_t* counters) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(erase_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask, n, keys,
+  ++g_kernel_launches; hipLaunchKernelGGL(erase_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask, n, keys,
                      counters);
   return hipGetLastError();
 }
 
 hipError_t launch_rehash(hipStream_t s, const VoxelRecord* old_table, uint64_t old_slots,
                          VoxelRecord* table, uint32_t mask, uint32_t* counters) {
-  hipLaunchKernelGGL(rehash_kernel, dim3(blocks_for(old_slots, 256)), dim3(256), 0, s, old_table,
+  ++g_kernel_launches; hipLaunchKernelGGL(rehash_kernel, dim3(blocks_for(old_slots, 256)), dim3(256), 0, s, old_table,
                      old_slots, table, mask, counters);
   return hipGetLastError();
 }
@@ -1479,7 +1480,7 @@ hipError_t launch_rehash(hipStream_t s, const VoxelRecord* old_table, uint64_t o
 hipError_t launch_voxel_index(hipStream_t s, const double* points_aos, uint32_t n, double voxel_size,
                               int32_t* keys) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(voxel_index_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, points_aos, n,
+  ++g_kernel_launches; hipLaunchKernelGGL(voxel_index_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, points_aos, n,
                      voxel_size, keys);
   return hipGetLastError();
 }
@@ -1491,10 +1492,10 @@ hipError_t launch_match(hipStream_t s, const double* points_aos, const double* c
                         uint32_t* block_counts, uint32_t* total, double* src_points,
                         double* src_covs, double* map_points, double* map_covs, uint64_t* src_index) {
   const uint32_t nb = match_blocks(n);
-  hipLaunchKernelGGL(match_count_kernel, dim3(nb), dim3(kMatchBlock), 0, s, points_aos, n, table,
+  ++g_kernel_launches; hipLaunchKernelGGL(match_count_kernel, dim3(nb), dim3(kMatchBlock), 0, s, points_aos, n, table,
                      mask, voxel_size, block_counts);
-  hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nb, total);
-  hipLaunchKernelGGL(match_write_kernel, dim3(nb), dim3(kMatchBlock), 0, s, points_aos, covs_aos, n,
+  ++g_kernel_launches; hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nb, total);
+  ++g_kernel_launches; hipLaunchKernelGGL(match_write_kernel, dim3(nb), dim3(kMatchBlock), 0, s, points_aos, covs_aos, n,
                      table, mask, voxel_size, block_counts, src_points, src_covs, map_points,
                      map_covs, src_index);
   return hipGetLastError();

@@ -266,7 +266,7 @@ hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, d
   InsertScratch w = carve(scratch, n, cub_bytes);
   Pose12 pose;
   for (int k = 0; k < 12; ++k) pose.v[k] = pose12[k];
-  hipLaunchKernelGGL(insert_prepare_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask,
+  ++g_kernel_launches; hipLaunchKernelGGL(insert_prepare_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask,
                      voxel_size, points_aos, covs_aos, n, pose, w.wpts, w.wcovs, w.slot_in, w.idx_in,
                      counters);
   hipError_t e = hipGetLastError();
@@ -274,14 +274,18 @@ hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, d
   // stable: equal slots keep ascending point index = scan order
   e = sort_slots(w.cub, cub_bytes, w.slot_in, w.slot_out, w.idx_in, w.idx_out, n, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(insert_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, w.slot_out,
+  for (uint64_t run = 2048; ; run <<= 1) {  // rocPRIM's merge sort: one block sort + one merge launch per doubling
+    ++g_kernel_launches;
+    if (run >= n) break;
+  }
+  ++g_kernel_launches; hipLaunchKernelGGL(insert_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, w.slot_out,
                      w.idx_out, n, w.wpts, w.wcovs, max_points);
   return hipGetLastError();
 }
 
 hipError_t launch_map_evict(hipStream_t s, VoxelRecord* table, uint64_t slots, double voxel_size,
                             const double position[3], double distance, uint32_t* counters) {
-  hipLaunchKernelGGL(evict_kernel, dim3(blocks_for(slots, 256)), dim3(256), 0, s, table, slots,
+  ++g_kernel_launches; hipLaunchKernelGGL(evict_kernel, dim3(blocks_for(slots, 256)), dim3(256), 0, s, table, slots,
                      voxel_size, position[0], position[1], position[2], distance, counters);
   return hipGetLastError();
 }
@@ -289,7 +293,7 @@ hipError_t launch_map_evict(hipStream_t s, VoxelRecord* table, uint64_t slots, d
 hipError_t launch_map_export(hipStream_t s, const VoxelRecord* table, uint64_t slots, uint32_t capacity,
                              int32_t* keys, double* means, double* covs, uint64_t* counts,
                              uint32_t* counters) {
-  hipLaunchKernelGGL(export_kernel, dim3(blocks_for(slots, 256)), dim3(256), 0, s, table, slots,
+  ++g_kernel_launches; hipLaunchKernelGGL(export_kernel, dim3(blocks_for(slots, 256)), dim3(256), 0, s, table, slots,
                      capacity, keys, means, covs, counts, counters);
   return hipGetLastError();
 }

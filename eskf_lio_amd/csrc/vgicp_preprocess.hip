@@ -32,7 +32,9 @@
 // Output order is ascending original index (the reference's is unordered_map iteration order).
 // This file is compiled without FMA contraction and keeps the oracle's operation order: the
 // distances, sums and rotations round as they do on the CPU.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <string.h>
+
 #include <rocprim/rocprim.hpp>
 
 #include "vgicp_device.h"
@@ -104,17 +106,118 @@ __device__ __forceinline__ bool beyond_grid(double v, double fine) {
   return c < -(double)kCoordOffset || c > (double)(kCoordMax - kCoordOffset);  // false for NaN / infinity
 }
 
-__global__ void morton_kernel(const double* __restrict__ pts, uint32_t n, double fine,
-                              unsigned long long* __restrict__ codes, uint32_t* __restrict__ idx,
-                              uint32_t* __restrict__ keep_by_index, uint32_t* __restrict__ counters) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  keep_by_index[i] = 0u;
-  const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
-  codes[i] = morton3(cell_coord(x, fine), cell_coord(y, fine), cell_coord(z, fine));
-  idx[i] = i;
+// First kernel of a preparation, one thread per raw point (CloudPreprocessor::process, src/CloudPreprocessor.cpp:8-23,
+// up to the point where the neighbour search starts):
+//   extrinsic   Open3D PointCloud::Transform on points: p <- (T [p;1]).xyz / w              (:14)
+//   deskew      p <- T_s p for the IMU state s whose segment holds the point (:25-74); the segment ends are the
+//               minimum over the blocks of deskew_first_hit_kernel, taken here by every workgroup for itself
+//               (a few thousand words) instead of by a launch of its own
+//   Morton code of the point's finest cell, identity index, kept flag cleared
+// and, on the side, what later kernels of the sequence need cleared: the octree's cell table (grid-stride over the
+// entries), the tile tickets of the scans and the indefinite-covariance count (workgroup 0).
+struct Mat16 { double m[16]; };
+struct PrologueArgs {
+  double* pts;
+  uint32_t n;
+  int has_T;
+  Mat16 T;
+  uint32_t states;          // 0: no deskew
+  uint32_t parts;           // blocks of deskew_first_hit_kernel; 0: `ends` already hold the segment ends
+  const uint32_t* part;     // [parts][states] first hits
+  uint32_t* ends;           // [states] segment ends (written by workgroup 0 when parts != 0)
+  const double* poses;      // 12 doubles per state
+  double fine;
+  unsigned long long* codes;
+  uint32_t* idx;
+  uint32_t* keep_by_index;
+  uint32_t* counters;
+  uint32_t epoch;
+  unsigned long long* table;  // CellEntry[entries] as 16-byte pairs
+  unsigned long long entries;
+};
+__global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char prologue_lds[];
+  uint32_t* ends_sh = reinterpret_cast<uint32_t*>(prologue_lds);
+  __shared__ uint32_t last_found;
+  const uint32_t tid = threadIdx.x;
+  if (a.states) {
+    if (a.parts) {
+      if (tid == 0) last_found = 0u;
+      for (uint32_t s = tid; s < a.states; s += blockDim.x) ends_sh[s] = 0xFFFFFFFFu;
+      __syncthreads();
+      for (uint32_t k = tid; k < a.parts * a.states; k += blockDim.x) {
+        const uint32_t v = a.part[k];
+        if (v != 0xFFFFFFFFu) atomicMin(&ends_sh[k % a.states], v);
+      }
+      __syncthreads();
+      // first hits are non-decreasing in s and the states without one form a tail: they keep the last bound found
+      for (uint32_t s = tid; s < a.states; s += blockDim.x)
+        if (ends_sh[s] != 0xFFFFFFFFu) atomicMax(&last_found, ends_sh[s]);
+      __syncthreads();
+      const uint32_t keep = last_found;
+      for (uint32_t s = tid; s < a.states; s += blockDim.x)
+        if (ends_sh[s] == 0xFFFFFFFFu) ends_sh[s] = keep;
+      __syncthreads();
+      if (blockIdx.x == 0)
+        for (uint32_t s = tid; s < a.states; s += blockDim.x) a.ends[s] = ends_sh[s];
+    } else {
+      for (uint32_t s = tid; s < a.states; s += blockDim.x) ends_sh[s] = a.ends[s];
+      __syncthreads();
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    a.counters[kTicketA] = 0u;
+    a.counters[kTicketB] = 0u;
+    a.counters[kIndefiniteCounter] = 0u;
+    a.counters[kDeskewedCounter] = a.states ? ends_sh[a.states - 1] : 0u;
+  }
+  // the cell table: key = empty, bounds 0 (16-byte entries, two 8-byte words each)
+  {
+    const unsigned long long total = (unsigned long long)gridDim.x * blockDim.x;
+    ulonglong2* t2 = reinterpret_cast<ulonglong2*>(a.table);
+    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + tid; e < a.entries; e += total)
+      t2[e] = make_ulonglong2(kEmptyCell, 0ull);
+  }
+  const uint32_t i = blockIdx.x * blockDim.x + tid;
+  if (i >= a.n) return;
+  double x = a.pts[3 * (size_t)i], y = a.pts[3 * (size_t)i + 1], z = a.pts[3 * (size_t)i + 2];
+  bool moved = false;
+  if (a.has_T) {
+    double q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[r] = a.T.m[r] * x + a.T.m[r + 4] * y + a.T.m[r + 8] * z + a.T.m[r + 12];
+    x = q[0] / q[3];
+    y = q[1] / q[3];
+    z = q[2] / q[3];
+    moved = true;
+  }
+  if (a.states) {
+    uint32_t lo = 0, hi = a.states;  // first s with i < ends[s]
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (i < ends_sh[mid]) hi = mid; else lo = mid + 1;
+    }
+    if (lo < a.states) {  // (after the last segment: left as it is)
+      const double* T = a.poses + 12 * (size_t)lo;
+      const double rx = T[0] * x + T[3] * y + T[6] * z;
+      const double ry = T[1] * x + T[4] * y + T[7] * z;
+      const double rz = T[2] * x + T[5] * y + T[8] * z;
+      x = rx + T[9];
+      y = ry + T[10];
+      z = rz + T[11];
+      moved = true;
+    }
+  }
+  if (moved) {
+    a.pts[3 * (size_t)i] = x;
+    a.pts[3 * (size_t)i + 1] = y;
+    a.pts[3 * (size_t)i + 2] = z;
+  }
+  a.keep_by_index[i] = 0u;
+  a.codes[i] = morton3(cell_coord(x, a.fine), cell_coord(y, a.fine), cell_coord(z, a.fine));
+  a.idx[i] = i;
   const bool is_finite = x - x == 0.0 && y - y == 0.0 && z - z == 0.0;
-  if (is_finite && (beyond_grid(x, fine) || beyond_grid(y, fine) || beyond_grid(z, fine))) counters[3] = 1u;
+  if (is_finite && (beyond_grid(x, a.fine) || beyond_grid(y, a.fine) || beyond_grid(z, a.fine))) a.counters[kBeyondGrid] = a.epoch;
 }
 
 // Element and operator of the segmented scan over the sorted order: count = voxel runs started so far, packed =
@@ -136,50 +239,250 @@ struct RunMinOp {
   }
 };
 
-// One pass over the sorted codes: the points are copied into sorted order (32-byte records), voxel-level run starts
-// become the scan's input, and the number of runs over all levels sizes the cell table.
-__global__ void run_count_kernel(const double* __restrict__ pts, const unsigned long long* __restrict__ codes,
-                                 const uint32_t* __restrict__ idx, uint32_t n, double* __restrict__ sorted_pts,
-                                 RunMin* __restrict__ run_in) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) {
-    const unsigned long long c = codes[j];
-    const unsigned long long prev = j ? codes[j - 1] : 0ull;
-    const uint32_t i = idx[j];
-    // 32-byte records {x, y, z, original index}: the search fetches a candidate with two aligned 16-byte loads
-    double2* rec = reinterpret_cast<double2*>(sorted_pts + 4 * (size_t)j);
-    rec[0] = make_double2(pts[3 * (size_t)i], pts[3 * (size_t)i + 1]);
-    rec[1] = make_double2(pts[3 * (size_t)i + 2], __longlong_as_double((long long)i));
-    uint32_t runs = 0;
+// ---- device-wide scans in ONE launch each ---------------------------------------------------------------------
+// A scan is 10^4 .. 10^6 points: 5 .. 500 tiles of 2 048.  Every tile publishes its aggregate and folds the aggregates
+// of ALL tiles before it (they are few, the fold is integer arithmetic in tile order): no second pass, no prefix
+// status.  Tile numbers are drawn from a ticket, so a tile only ever waits for tiles that started before it (never a
+// cycle, whatever the dispatch order or residency); waits are bounded all the same and a timeout is reported through
+// the counter block instead of hanging the device.  Hand-off per MI355X_MICROARCH.md ("who signals ... ONE lane"):
+// write-through stores of the aggregate, s_waitcnt vmcnt(0), write-through store of the flag (= the call's epoch, so
+// the slots need no clearing between calls); the consumer polls the flag and then reads the aggregate write-through.
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr uint32_t kScanTile = kScanThreads * kScanItems;
+constexpr uint32_t kScanSpinLimit = 1u << 22;
+
+struct TileSlot {  // 32 bytes
+  unsigned long long packed;
+  uint32_t count, runs;
+  uint32_t flag;
+  uint32_t pad[3];
+};
+static_assert(sizeof(TileSlot) == 32, "tile slot layout");
+
+typedef __attribute__((address_space(1))) unsigned long long pg64;
+typedef __attribute__((address_space(1))) unsigned int pg32;
+__device__ __forceinline__ void st_through64(void* p, unsigned long long v) {
+  __hip_atomic_store((pg64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_through32(void* p, uint32_t v) {
+  __hip_atomic_store((pg32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_through64(const void* p) {
+  return __hip_atomic_load((pg64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_through32(const void* p) {
+  return __hip_atomic_load((pg32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ RunMin runmin_identity() {
+  RunMin r;
+  r.packed = ~0ull;
+  r.count = 0;
+  r.runs = 0;
+  return r;
+}
+__device__ __forceinline__ RunMin runmin_up(const RunMin& v, int d) {
+  RunMin r;
+  const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v.packed >> 32), d, 64);
+  const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v.packed, d, 64);
+  r.packed = ((unsigned long long)hi << 32) | lo;
+  r.count = (uint32_t)__shfl_up((int)v.count, d, 64);
+  r.runs = (uint32_t)__shfl_up((int)v.runs, d, 64);
+  return r;
+}
+__device__ __forceinline__ RunMin runmin_lane(const RunMin& v, int src) {
+  RunMin r;
+  const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v.packed >> 32), src, 64);
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v.packed, src, 64);
+  r.packed = ((unsigned long long)hi << 32) | lo;
+  r.count = (uint32_t)__shfl((int)v.count, src, 64);
+  r.runs = (uint32_t)__shfl((int)v.runs, src, 64);
+  return r;
+}
+// inclusive scan over the 64 lanes of a wave, in lane order
+__device__ __forceinline__ RunMin runmin_wave_scan(RunMin v, uint32_t lane) {
+  const RunMinOp op;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const RunMin o = runmin_up(v, d);
+    if ((int)lane >= d) v = op(o, v);
+  }
+  return v;
+}
+
+// The pass over the sorted codes, fused: the points are copied into sorted order (32-byte records {x, y, z, index}),
+// voxel-level run starts feed the segmented scan, and the last point of every voxel's run -- which then knows the
+// voxel's rank, its kept point (lowest original index of the run) and that point's sorted position -- writes the
+// query list (Morton order of the voxels) and the kept flag.  The scan's total is the number of kept points and of
+// octree cells over all levels (counters[0], [1]); no atomics on shared words ("a note on atomics").
+__global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
+    const double* __restrict__ pts, const unsigned long long* __restrict__ codes, const uint32_t* __restrict__ idx,
+    uint32_t n, double* __restrict__ sorted_pts, uint32_t* __restrict__ queries, uint32_t* __restrict__ keep_by_index,
+    uint32_t* counters, TileSlot* tiles, uint32_t epoch) {
+  __shared__ uint32_t tile_sh;
+  __shared__ RunMin wave_tot[kScanThreads / 64];
+  __shared__ RunMin prefix_sh;
+  const RunMinOp op;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) tile_sh = atomicAdd(&counters[kTicketA], 1u);
+  __syncthreads();
+  const uint32_t tile = tile_sh;
+  const uint32_t j0 = tile * kScanTile + tid * kScanItems;  // this thread's kScanItems consecutive sorted positions
+  unsigned long long c[kScanItems + 2];                     // codes j0 - 1 .. j0 + kScanItems
+#pragma unroll
+  for (int k = 0; k < kScanItems + 2; ++k) {
+    const long long j = (long long)j0 + k - 1;
+    c[k] = (j >= 0 && j < (long long)n) ? codes[j] : 0ull;
+  }
+  RunMin e[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const uint32_t j = j0 + (uint32_t)k;
+    e[k] = runmin_identity();
+    if (j < n) {
+      const unsigned long long cur = c[k + 1], prev = c[k];
+      const uint32_t i = idx[j];
+      double2* rec = reinterpret_cast<double2*>(sorted_pts + 4 * (size_t)j);
+      rec[0] = make_double2(pts[3 * (size_t)i], pts[3 * (size_t)i + 1]);
+      rec[1] = make_double2(pts[3 * (size_t)i + 2], __longlong_as_double((long long)i));
+      uint32_t runs = 0;
 #pragma unroll 1
-    for (int l = 0; l < kLevels; ++l) {
-      if (j != 0 && (c >> (3 * l)) == (prev >> (3 * l))) break;
-      ++runs;
+      for (int l = 0; l < kLevels; ++l) {
+        if (j != 0 && (cur >> (3 * l)) == (prev >> (3 * l))) break;
+        ++runs;
+      }
+      e[k].packed = ((unsigned long long)i << 32) | j;
+      e[k].count = (j == 0 || (cur >> (3 * kFineShift)) != (prev >> (3 * kFineShift))) ? 1u : 0u;
+      e[k].runs = runs;
     }
-    const uint32_t first = (j == 0 || (c >> (3 * kFineShift)) != (prev >> (3 * kFineShift))) ? 1u : 0u;
-    RunMin e;
-    e.packed = ((unsigned long long)i << 32) | j;
-    e.count = first;
-    e.runs = runs;
-    run_in[j] = e;
+  }
+#pragma unroll
+  for (int k = 1; k < kScanItems; ++k) e[k] = op(e[k - 1], e[k]);
+  const RunMin incl = runmin_wave_scan(e[kScanItems - 1], lane);
+  if (lane == 63u) wave_tot[wave] = incl;
+  RunMin excl = runmin_up(incl, 1);
+  if (lane == 0u) excl = runmin_identity();
+  __syncthreads();
+  if (wave == 0) {
+    // publish this tile's aggregate, then fold the aggregates of all tiles before it, in tile order
+    RunMin agg = wave_tot[0];
+#pragma unroll
+    for (int w = 1; w < kScanThreads / 64; ++w) agg = op(agg, wave_tot[w]);
+    if (lane == 0u) {
+      TileSlot* mine = tiles + tile;
+      st_through64(&mine->packed, agg.packed);
+      st_through64(&mine->count, ((unsigned long long)agg.runs << 32) | agg.count);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      st_through32(&mine->flag, epoch);
+    }
+    RunMin pre = runmin_identity();
+    bool late = false;
+    for (uint32_t base = 0; base < tile; base += 64u) {
+      const uint32_t t = base + lane;
+      RunMin v = runmin_identity();
+      if (t < tile) {
+        const TileSlot* src = tiles + t;
+        uint32_t spins = 0;
+        while (ld_through32(&src->flag) != epoch) {
+          if (++spins > kScanSpinLimit) { late = true; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("" ::: "memory");
+        v.packed = ld_through64(&src->packed);
+        const unsigned long long cr = ld_through64(&src->count);
+        v.count = (uint32_t)cr;
+        v.runs = (uint32_t)(cr >> 32);
+      }
+      const RunMin sc = runmin_wave_scan(v, lane);
+      pre = op(pre, runmin_lane(sc, 63));
+    }
+    if (__any(late) && lane == 0u) counters[kScanTimeout] = epoch;
+    if (lane == 0u) prefix_sh = pre;
+  }
+  __syncthreads();
+  RunMin base_prefix = prefix_sh;
+  for (uint32_t w = 0; w < wave; ++w) base_prefix = op(base_prefix, wave_tot[w]);
+  base_prefix = op(base_prefix, excl);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const uint32_t j = j0 + (uint32_t)k;
+    if (j >= n) break;
+    // the last point of a voxel's run reads the scan
+    if (j + 1 < n && (c[k + 2] >> (3 * kFineShift)) == (c[k + 1] >> (3 * kFineShift))) continue;
+    const RunMin v = op(base_prefix, e[k]);
+    if (j + 1 == n) {
+      counters[0] = v.count;
+      counters[1] = v.runs;
+    }
+    queries[v.count - 1u] = (uint32_t)v.packed;
+    keep_by_index[(uint32_t)(v.packed >> 32)] = 1u;
   }
 }
 
-// query list in Morton order of the voxels (sorted positions of the kept points) and the kept flags: the last
-// point of every voxel run reads the scan
-__global__ void query_list_kernel(const unsigned long long* __restrict__ codes, const RunMin* __restrict__ run_out,
-                                  uint32_t n, uint32_t* __restrict__ queries, uint32_t* __restrict__ keep_by_index,
-                                  uint32_t* __restrict__ counters) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  if (j + 1 < n && (codes[j + 1] >> (3 * kFineShift)) == (codes[j] >> (3 * kFineShift))) return;
-  const RunMin e = run_out[j];
-  if (j + 1 == n) {  // the scan's total: kept points and cells (no atomics: device-scope atomics on one word
-    counters[0] = e.count;  // from 1 500 waves cost this pipeline 35 us)
-    counters[1] = e.runs;
+// Exclusive prefix sum of the kept flags over SCAN order: every kept point's output slot (ascending original
+// index). Same single-launch scheme; a tile's aggregate travels as one 8-byte granule {epoch, sum}: the data is
+// the signal.
+__global__ __launch_bounds__(kScanThreads) void keep_scan_kernel(const uint32_t* __restrict__ keep_by_index, uint32_t n,
+                                                                 uint32_t* __restrict__ rank_of_index, uint32_t* counters,
+                                                                 unsigned long long* tiles, uint32_t epoch) {
+  __shared__ uint32_t tile_sh;
+  __shared__ uint32_t wave_tot[kScanThreads / 64];
+  __shared__ uint32_t prefix_sh;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) tile_sh = atomicAdd(&counters[kTicketB], 1u);
+  __syncthreads();
+  const uint32_t tile = tile_sh;
+  const uint32_t i0 = tile * kScanTile + tid * kScanItems;
+  uint32_t f[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) f[k] = (i0 + (uint32_t)k < n) ? keep_by_index[i0 + (uint32_t)k] : 0u;
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) sum += f[k];
+  uint32_t incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+    if ((int)lane >= d) incl += o;
   }
-  queries[e.count - 1u] = (uint32_t)e.packed;
-  keep_by_index[(uint32_t)(e.packed >> 32)] = 1u;
+  if (lane == 63u) wave_tot[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t agg = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) agg += wave_tot[w];
+    if (lane == 0u) st_through64(tiles + tile, ((unsigned long long)epoch << 32) | agg);
+    uint32_t pre = 0;
+    bool late = false;
+    for (uint32_t base = 0; base < tile; base += 64u) {
+      const uint32_t t = base + lane;
+      uint32_t v = 0;
+      if (t < tile) {
+        uint32_t spins = 0;
+        unsigned long long w = ld_through64(tiles + t);
+        while ((uint32_t)(w >> 32) != epoch) {
+          if (++spins > kScanSpinLimit) { late = true; break; }
+          __builtin_amdgcn_s_sleep(2);
+          w = ld_through64(tiles + t);
+        }
+        v = (uint32_t)w;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+      pre += v;
+    }
+    if (__any(late) && lane == 0u) counters[kScanTimeout] = epoch;
+    if (lane == 0u) prefix_sh = pre;
+  }
+  __syncthreads();
+  uint32_t run = prefix_sh + (incl - sum);
+  for (uint32_t w = 0; w < wave; ++w) run += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (i0 + (uint32_t)k < n) rank_of_index[i0 + (uint32_t)k] = run;
+    run += f[k];
+  }
 }
 
 // Runs of every level in one pass: point j opens the cells whose run starts at j (its code differs from its
@@ -241,8 +544,9 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     const double* __restrict__ spts, const uint32_t* __restrict__ sorted_idx, uint32_t n, double h, int knn,
     const CellEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ queries,
-    const uint32_t* __restrict__ slot_of_index, uint32_t m, uint32_t* __restrict__ nbr,
-    double* __restrict__ out_pts, unsigned long long* __restrict__ out_idx, uint32_t* counters, int debug) {
+    const uint32_t* __restrict__ slot_of_index, uint32_t epoch, uint32_t* __restrict__ nbr,
+    double* __restrict__ out_pts, unsigned long long* __restrict__ out_idx, double* __restrict__ soa, uint64_t soa_stride,
+    uint32_t* counters, int debug) {
   __shared__ float pool_d[kSearchBlock / 64][kPool];   // cell distances rounded DOWN: ordering and pruning stay safe
   __shared__ unsigned long long pool_key[kSearchBlock / 64][kPool];
   __shared__ uint32_t pool_start[kSearchBlock / 64][kPool];
@@ -252,6 +556,10 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous
   // eighth of the Morton-ordered queries, so that neighbouring queries (same cells, same points) share an L2.
   constexpr uint32_t kXcds = 8;
+  // the number of kept points is still on the device (the grid was sized from the raw scan): surplus waves leave;
+  // so does everyone when the scan was refused (a point beyond the search grid) or a device-wide scan timed out
+  const uint32_t m = uniform_u32(counters[0]);
+  if (uniform_u32(counters[kBeyondGrid]) == epoch || uniform_u32(counters[kScanTimeout]) == epoch) return;
   const uint32_t per_xcd = (m + kXcds - 1) / kXcds;
   const uint32_t slot_in_xcd = (blockIdx.x / kXcds) * (kSearchBlock / 64) + wave;
   const uint32_t qrank = (blockIdx.x % kXcds) * per_xcd + slot_in_xcd;
@@ -621,6 +929,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   if (lane < kMaxKnn) nbr[(size_t)o * kMaxKnn + lane] = li;  // original indices: the list carries nothing else
   if (lane == 0) {
     out_pts[3 * (size_t)o] = qx; out_pts[3 * (size_t)o + 1] = qy; out_pts[3 * (size_t)o + 2] = qz;
+    if (soa) { soa[o] = qx; soa[soa_stride + o] = qy; soa[2 * soa_stride + o] = qz; }  // the planes the registration reads
     out_idx[o] = qi;
 #ifdef VGICP_PREP_TRACE  // developer build only (tools/ab_build.sh trace -DVGICP_PREP_TRACE): the index output carries a trace record
     {
@@ -776,10 +1085,12 @@ __device__ __forceinline__ bool jacobi_svd3(const double (&A)[3][3], double (&U)
 
 // Covariance of the neighbours + regularisation, one thread per kept point.
 __global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict__ pts,
-                                                        const uint32_t* __restrict__ nbr, uint32_t m, int found,
-                                                        double* __restrict__ out_covs, uint32_t* __restrict__ indefinite) {
+                                                        const uint32_t* __restrict__ nbr, int found,
+                                                        double* __restrict__ out_covs, double* __restrict__ soa,
+                                                        uint64_t soa_stride, uint32_t* __restrict__ counters, uint32_t epoch) {
   const uint32_t o = blockIdx.x * kCovBlock + threadIdx.x;
-  if (o >= m) return;
+  if (o >= counters[0] || counters[kBeyondGrid] == epoch || counters[kScanTimeout] == epoch) return;
+  uint32_t* indefinite = counters + kIndefiniteCounter;
   double cov[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   if (found >= 3) {
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -826,18 +1137,12 @@ __global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-      out_covs[9 * (size_t)o + r + 3 * cc] =
-          ok ? U[r][0] * V[cc][0] + U[r][1] * V[cc][1] + (U[r][2] * 1e-2) * V[cc][2] : __builtin_nan("");
+    for (int r = 0; r < 3; ++r) {
+      const double v = ok ? U[r][0] * V[cc][0] + U[r][1] * V[cc][1] + (U[r][2] * 1e-2) * V[cc][2] : __builtin_nan("");
+      out_covs[9 * (size_t)o + r + 3 * cc] = v;
+      if (soa) soa[(size_t)(3 + r + 3 * cc) * soa_stride + o] = v;  // plane order x y z c00 c10 c20 c01 ...
+    }
   if (opposed > 0) atomicAdd(indefinite, 1u);   // rare: a negative eigenvalue, the matrix written is indefinite
-}
-
-__global__ void cell_clear_kernel(CellEntry* table, uint64_t entries) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= entries) return;
-  table[i].key = kEmptyCell;
-  table[i].start = 0;
-  table[i].end = 0;
 }
 
 // ---- CloudPreprocessor::deskew (src/CloudPreprocessor.cpp:25-74) -----------------------------------
@@ -879,6 +1184,7 @@ __global__ __launch_bounds__(kBoundsBlock) void deskew_bounds_kernel(const doubl
 // the first-hit of the states in between to j (LDS atomicMin); blocks cover contiguous parts of the scan and a
 // second small kernel takes the minimum over the blocks. 163 us -> two launches of a few us per 60k-point sweep.
 constexpr uint32_t kDeskewParts = 512;      // at most this many blocks share the scan (one load per thread: the loop is a chain)
+constexpr uint32_t kProloguePartsMax = 64;  // ... and this many when every workgroup of the prologue merges them for itself
 constexpr uint32_t kDeskewMaxStates = 4096; // LDS: 12 bytes per state; longer queues take the walk
 __global__ __launch_bounds__(256) void deskew_first_hit_kernel(const double* __restrict__ point_time, uint32_t n,
                                                                const double* __restrict__ state_time, uint32_t states,
@@ -959,21 +1265,6 @@ __global__ void deskew_apply_kernel(double* __restrict__ pts, uint32_t n, const 
   pts[3 * (size_t)i + 2] = rz + T[11];
 }
 
-// Open3D PointCloud::Transform on points only: p <- (T [p;1]).xyz / w (what cloud->Transform(T_il) does
-// at src/CloudPreprocessor.cpp:14 before any covariance exists). T: column-major 4x4 in the dispatch packet.
-struct Mat16 { double m[16]; };
-__global__ void transform_points_kernel(double* __restrict__ pts, uint32_t n, Mat16 T) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
-  double q[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) q[r] = T.m[r] * x + T.m[r + 4] * y + T.m[r + 8] * z + T.m[r + 12];
-  pts[3 * (size_t)i] = q[0] / q[3];
-  pts[3 * (size_t)i + 1] = q[1] / q[3];
-  pts[3 * (size_t)i + 2] = q[2] / q[3];
-}
-
 inline uint32_t blocks_for(uint64_t work, uint32_t block) { return (uint32_t)((work + block - 1) / block); }
 __host__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 __host__ inline uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
@@ -991,19 +1282,15 @@ inline hipError_t sort_codes(void* temp, size_t& temp_bytes, const unsigned long
 }
 
 struct Layout {
-  size_t codes_in, codes_out, idx_in, idx_out, spts, keep_i, rank_i, queries, run_in, run_out, nbr, cub, total;
+  size_t codes_in, codes_out, idx_in, idx_out, spts, keep_i, rank_i, queries, nbr, cub, total;
   size_t cub_bytes;
 };
 
 __host__ inline Layout layout_for(uint32_t n) {
   Layout L;
-  size_t sort_pairs = 0, scan = 0;
+  size_t sort_pairs = 0;
   (void)sort_codes(nullptr, sort_pairs, nullptr, nullptr, nullptr, nullptr, n, nullptr);
-  size_t run_scan = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-  (void)hipcub::DeviceScan::InclusiveScan(nullptr, run_scan, (const RunMin*)nullptr, (RunMin*)nullptr, RunMinOp(), (int)n);
-  L.cub_bytes = sort_pairs > scan ? sort_pairs : scan;
-  if (run_scan > L.cub_bytes) L.cub_bytes = run_scan;
+  L.cub_bytes = sort_pairs;
   size_t off = 0;
   L.codes_in = off; off += align256((size_t)n * 8);
   L.codes_out = off; off += align256((size_t)n * 8);
@@ -1013,8 +1300,6 @@ __host__ inline Layout layout_for(uint32_t n) {
   L.keep_i = off; off += align256((size_t)n * 4);
   L.rank_i = off; off += align256((size_t)n * 4);
   L.queries = off; off += align256((size_t)n * 4);
-  L.run_in = off; off += align256((size_t)n * sizeof(RunMin));
-  L.run_out = off; off += align256((size_t)n * sizeof(RunMin));
   L.nbr = off; off += align256((size_t)n * kMaxKnn * 4);
   L.cub = off; off += align256(L.cub_bytes);
   L.total = off + 256;
@@ -1023,20 +1308,38 @@ __host__ inline Layout layout_for(uint32_t n) {
 
 }  // namespace
 
+thread_local uint64_t g_kernel_launches = 0;
+
 size_t preprocess_scratch_bytes(uint32_t n) { return layout_for(n ? n : 1).total; }
 int preprocess_max_knn() { return kMaxKnn; }
 // Load factor 1/8 .. 1/16: most of the search's lookups are for children that do not exist and end at the first
 // empty slot; with a fuller table the longest probe sequence among 64 lanes sets the pace (x2: 411 us, x4: 350,
 // x8: 337 for the search alone, and the kernels that build the table gain as well).
 uint64_t preprocess_cell_entries(uint32_t cells) { return pow2_at_least((uint64_t)cells * 8 + 64); }
+// Sized from the number of POINTS, so that no host round trip is needed for the cell count: a point opens at most
+// kLevels = 12 cells, a real sweep 2.5 - 3 per point (260 654 cells for 100 000 points), so 32 entries per point
+// keep the load at 1/10 - 1/13 there (the same table sizes the measured cell count gave) and below 3/8 whatever
+// the scan looks like.
+uint64_t preprocess_cell_entries_for(uint32_t n) { return pow2_at_least((uint64_t)(n ? n : 1) * 32 + 64); }
 size_t preprocess_cell_bytes(uint64_t entries) { return entries * sizeof(CellEntry); }
+size_t preprocess_tile_bytes() { return (size_t)kMaxScanTiles * (sizeof(TileSlot) + sizeof(unsigned long long)); }
 
-// Stage A: Morton codes, the sort, the points in sorted order, the kept flags with their two prefix sums,
-// the query list; counters[0] = kept points, counters[1] = cells over all levels.
-hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, double h, void* scratch,
-                                  uint32_t* counters) {
+namespace {
+// launches of rocPRIM's merge sort (merge_sort_config<512, 512, 4>: 2 048-item blocks): one block sort and one
+// merge launch per doubling of the sorted run length
+uint32_t merge_sort_launches(uint32_t n) {
+  uint32_t launches = 1;
+  for (uint64_t run = 2048; run < n; run <<= 1) ++launches;
+  return launches;
+}
+}  // namespace
+
+hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a) {
+  const uint32_t n = a.n;
+  if (n == 0) return hipSuccess;
+  if ((uint64_t)blocks_for(n, kScanTile) > kMaxScanTiles) return hipErrorInvalidValue;
   const Layout L = layout_for(n);
-  char* b = static_cast<char*>(scratch);
+  char* b = static_cast<char*>(a.scratch);
   auto* codes_in = reinterpret_cast<unsigned long long*>(b + L.codes_in);
   auto* codes_out = reinterpret_cast<unsigned long long*>(b + L.codes_out);
   auto* idx_in = reinterpret_cast<uint32_t*>(b + L.idx_in);
@@ -1045,60 +1348,77 @@ hipError_t launch_preprocess_sort(hipStream_t s, const double* pts, uint32_t n, 
   auto* keep_i = reinterpret_cast<uint32_t*>(b + L.keep_i);
   auto* rank_i = reinterpret_cast<uint32_t*>(b + L.rank_i);
   auto* queries = reinterpret_cast<uint32_t*>(b + L.queries);
-  auto* run_in = reinterpret_cast<RunMin*>(b + L.run_in);
-  auto* run_out = reinterpret_cast<RunMin*>(b + L.run_out);
-  const double fine = h / (double)(1 << kFineShift);
-  hipLaunchKernelGGL(morton_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, fine, codes_in, idx_in, keep_i,
-                     counters);
+  auto* nbr = reinterpret_cast<uint32_t*>(b + L.nbr);
+  auto* table = static_cast<CellEntry*>(a.cell_table);
+  const uint32_t mask = (uint32_t)(a.table_entries - 1);
+  auto* tiles_a = static_cast<TileSlot*>(a.tiles);
+  auto* tiles_b = reinterpret_cast<unsigned long long*>(static_cast<char*>(a.tiles) + (size_t)kMaxScanTiles * sizeof(TileSlot));
+
+  // ---- deskew bounds (times only), then the prologue: extrinsic + deskew + codes + clears ----
+  PrologueArgs pa;
+  std::memset(&pa, 0, sizeof pa);
+  pa.pts = a.pts;
+  pa.n = n;
+  pa.has_T = a.extrinsic16 != nullptr;
+  if (a.extrinsic16) for (int k = 0; k < 16; ++k) pa.T.m[k] = a.extrinsic16[k];
+  pa.states = a.states;
+  pa.ends = a.ends;
+  pa.poses = a.poses;
+  if (a.states) {
+    if (a.ordered_states && a.states <= kDeskewMaxStates) {
+      // few blocks: every workgroup of the prologue merges their first hits for itself
+      uint32_t parts = blocks_for(n, 1024);
+      if (parts > kProloguePartsMax) parts = kProloguePartsMax;
+      const uint32_t per_block = blocks_for(n, parts);
+      uint32_t* part = a.ends + a.states;
+      hipLaunchKernelGGL(deskew_first_hit_kernel, dim3(parts), dim3(256), (size_t)a.states * 12, s, a.point_time, n,
+                         a.state_time, a.states, per_block, part);
+      ++g_kernel_launches;
+      pa.parts = parts;
+      pa.part = part;
+    } else {
+      hipLaunchKernelGGL(deskew_bounds_kernel, dim3(1), dim3(kBoundsBlock), 0, s, a.point_time, n, a.state_time, a.states,
+                         a.ends);
+      ++g_kernel_launches;
+      pa.parts = 0;
+    }
+  }
+  pa.fine = a.voxel_size / (double)(1 << kFineShift);
+  pa.codes = codes_in;
+  pa.idx = idx_in;
+  pa.keep_by_index = keep_i;
+  pa.counters = a.counters;
+  pa.epoch = a.epoch;
+  pa.table = reinterpret_cast<unsigned long long*>(table);
+  pa.entries = a.table_entries;
+  hipLaunchKernelGGL(sweep_prologue_kernel, dim3(blocks_for(n, 256)), dim3(256), (size_t)a.states * sizeof(uint32_t), s, pa);
+  ++g_kernel_launches;
+  if (a.ev_after_prologue) {
+    const hipError_t ee = hipEventRecord(a.ev_after_prologue, s);
+    if (ee != hipSuccess) return ee;
+  }
+
+  // ---- the one sort ----
   size_t cub_bytes = L.cub_bytes;
   hipError_t e = sort_codes(b + L.cub, cub_bytes, codes_in, codes_out, idx_in, idx_out, n, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(run_count_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, codes_out, idx_out, n, spts,
-                     run_in);
-  cub_bytes = L.cub_bytes;
-  e = hipcub::DeviceScan::InclusiveScan(b + L.cub, cub_bytes, run_in, run_out, RunMinOp(), (int)n, s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(query_list_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, codes_out, run_out, n, queries,
-                     keep_i, counters);
-  cub_bytes = L.cub_bytes;
-  e = hipcub::DeviceScan::ExclusiveSum(b + L.cub, cub_bytes, keep_i, rank_i, (int)n, s);
-  if (e != hipSuccess) return e;
-  return hipGetLastError();
-}
+  g_kernel_launches += merge_sort_launches(n);
 
-// Stage B: the cell table (entries = preprocess_cell_entries(counters[1])), the neighbour search (one wave
-// per kept point), the covariances (one thread per kept point).
-hipError_t launch_preprocess_finish(hipStream_t s, const double* pts, uint32_t n, double h, int knn, uint32_t m,
-                                    void* scratch, void* cell_table, uint64_t table_entries, double* out_pts,
-                                    double* out_covs, unsigned long long* out_idx, uint32_t* counters, int debug) {
-  if (m == 0) return hipSuccess;
-  const Layout L = layout_for(n);
-  char* b = static_cast<char*>(scratch);
-  auto* codes_out = reinterpret_cast<unsigned long long*>(b + L.codes_out);
-  auto* idx_out = reinterpret_cast<uint32_t*>(b + L.idx_out);
-  auto* spts = reinterpret_cast<double*>(b + L.spts);
-  auto* rank_i = reinterpret_cast<uint32_t*>(b + L.rank_i);
-  auto* queries = reinterpret_cast<uint32_t*>(b + L.queries);
-  auto* nbr = reinterpret_cast<uint32_t*>(b + L.nbr);
-  auto* table = static_cast<CellEntry*>(cell_table);
-  const uint32_t mask = (uint32_t)(table_entries - 1);
-  hipLaunchKernelGGL(cell_clear_kernel, dim3(blocks_for(table_entries, 256)), dim3(256), 0, s, table,
-                     table_entries);
+  // ---- runs, kept points, query list (one launch); output slots in scan order (one launch) ----
+  hipLaunchKernelGGL(run_scan_kernel, dim3(blocks_for(n, kScanTile)), dim3(kScanThreads), 0, s, a.pts, codes_out, idx_out, n,
+                     spts, queries, keep_i, a.counters, tiles_a, a.epoch);
+  hipLaunchKernelGGL(keep_scan_kernel, dim3(blocks_for(n, kScanTile)), dim3(kScanThreads), 0, s, keep_i, n, rank_i,
+                     a.counters, tiles_b, a.epoch);
+  // ---- octree cells of all levels, the exact search (one wave per kept point; the grid covers every raw point,
+  //      the waves beyond the kept count leave at once), covariances ----
   hipLaunchKernelGGL(cell_build_kernel, dim3(blocks_for(n, 256), kLevels), dim3(256), 0, s, codes_out, n, table, mask);
-  // 8 XCDs x ceil(m / 8) queries each (see the kernel's query mapping)
-  hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((m + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts, idx_out,
-                     n, h, knn, table, mask, queries, rank_i, m, nbr, out_pts, out_idx, counters, debug);
-  const int found = knn < (int)n ? knn : (int)n;
-  hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(m, kCovBlock)), dim3(kCovBlock), 0, s, pts, nbr, m, found, out_covs,
-                     counters + kIndefiniteCounter);
-  return hipGetLastError();
-}
-
-hipError_t launch_transform_points(hipStream_t s, double* pts, uint32_t n, const double T16[16]) {
-  if (n == 0) return hipSuccess;
-  Mat16 T;
-  for (int k = 0; k < 16; ++k) T.m[k] = T16[k];
-  hipLaunchKernelGGL(transform_points_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, T);
+  hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((n + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts,
+                     idx_out, n, a.voxel_size, a.knn, table, mask, queries, rank_i, a.epoch, nbr, a.out_pts, a.out_idx, a.soa,
+                     a.soa_stride, a.counters, a.debug);
+  const int found = a.knn < (int)n ? a.knn : (int)n;
+  hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(n, kCovBlock)), dim3(kCovBlock), 0, s, a.pts, nbr, found, a.out_covs, a.soa,
+                     a.soa_stride, a.counters, a.epoch);
+  g_kernel_launches += 5;
   return hipGetLastError();
 }
 
@@ -1115,10 +1435,13 @@ hipError_t launch_deskew(hipStream_t s, double* pts, uint32_t n, const double* p
     hipLaunchKernelGGL(deskew_first_hit_kernel, dim3(parts), dim3(256), (size_t)states * 12, s, point_time, n,
                        state_time, states, per_block, part);
     hipLaunchKernelGGL(deskew_merge_kernel, dim3(1), dim3(1024), (size_t)states * 4, s, part, parts, states, ends);
+    g_kernel_launches += 2;
   } else {
     hipLaunchKernelGGL(deskew_bounds_kernel, dim3(1), dim3(kBoundsBlock), 0, s, point_time, n, state_time, states, ends);
+    ++g_kernel_launches;
   }
   hipLaunchKernelGGL(deskew_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pts, n, ends, states, poses);
+  ++g_kernel_launches;
   return hipGetLastError();
 }
 

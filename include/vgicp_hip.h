@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGICP_ABI_VERSION 2
+#define VGICP_ABI_VERSION 3
 
 typedef struct vgicp_ctx vgicp_ctx;
 
@@ -237,6 +237,45 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
 int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
                        size_t num_states, const double* states, const double extrinsic[16],
                        double voxel_size, int knn, size_t* kept, int64_t* deskewed);
+/* The frame sequence of src/Odometry.cpp:73-87 with ONE host synchronisation per frame:
+ *   vgicp_scan_prepare_async      CloudPreprocessor::process (:73-75): as vgicp_scan_prepare, but only ENQUEUED — the
+ *                                 tables and grids of the preparation are sized from n, the number of kept points
+ *                                 stays on the device, nothing is waited for and nothing is returned;
+ *   vgicp_align_resident          ICP::align (:79, through ErrorStateKF::update): the single launch reads the scan's
+ *                                 size from the device; its synchronisation is the frame's only one and also
+ *                                 brings back what the preparation found (a refused scan fails this call) and
+ *                                 the counts of the previous frame's map insertion;
+ *   vgicp_map_insert_resident_async   LocalMap::updateLocalMap (:86): enqueued, counts read at the next
+ *                                 synchronisation (a failure of the insertion is reported by the next call that
+ *                                 synchronises: vgicp_align_resident, vgicp_map_size, ...).
+ * vgicp_scan_info returns what the last preparation found (it synchronises if that is still pending). Any other
+ * entry point first brings a pending preparation / insertion up to date. */
+int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
+                             size_t num_states, const double* states, const double extrinsic[16],
+                             double voxel_size, int knn);
+int vgicp_scan_info(vgicp_ctx* ctx, size_t* kept, int64_t* deskewed, uint64_t* indefinite);
+int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel);
+
+/* What the calls of THIS HOST THREAD into the module (whatever the context) have cost the host since this context's
+ * counters were last reset (reset != 0 resets them):
+ * kernels launched (library sorts counted by their launch formula), copies / memsets enqueued, host
+ * synchronisations; and, with VGICP_OPTION_STAGE_EVENTS on (or VGICP_STAGE_EVENTS=1 in the environment), the device
+ * spans (HIP events on the module's stream, microseconds; -1 when not recorded) of the LAST preparation (upload of
+ * the raw sweep included), the last single-launch align and the last deferred map insertion — the three stage
+ * timers of src/Odometry.cpp:73-87. */
+typedef struct vgicp_frame_stats {
+  uint64_t kernel_launches;
+  uint64_t copies;
+  uint64_t host_syncs;
+  double prepare_us;       /* upload of the raw sweep + extrinsic + deskew + down-sampling + 30-NN + covariances */
+  double align_us;
+  double insert_us;
+  double prepare_head_us;  /* the first part of prepare_us: upload + extrinsic + deskew (+ Morton codes) */
+} vgicp_frame_stats;
+int vgicp_get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset);
+#define VGICP_OPTION_STAGE_EVENTS 1
+int vgicp_set_option(vgicp_ctx* ctx, int option, int value);
+
 /* Copies the resident scan (vgicp_scan_upload / vgicp_scan_prepare) to the host: points n x 3, covs n x 9
  * column-major, e.g. for a host-side map or for saving. capacity in points; with both pointers NULL only
  * *n is written (size query). */

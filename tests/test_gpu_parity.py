@@ -751,6 +751,73 @@ def test_frame_stream_trajectory_matches_the_cpu_loop(gpu_ctx, oracle):
     assert np.abs(gm - m[o]).max() < 1e-9 and np.abs(gc - c[o]).max() < 1e-9   # poses agree to 1e-9, so do the maps
 
 
+def test_async_frame_chain_has_one_sync_per_frame_and_the_same_bits(oracle):
+    """The frame sequence of src/Odometry.cpp:73-87 without host round trips — vgicp_scan_prepare_async (tables sized
+    from the raw count, kept count left on the device) -> vgicp_align_resident (reads the size from the device; its
+    synchronisation is the frame's only one) -> vgicp_map_insert_resident_async (counts read at the next frame's
+    synchronisation) — against the same frames through the synchronous calls on a second context: identical poses,
+    counts, prepared scans and maps, bit for bit; ONE host synchronisation per frame (vgicp_get_frame_stats)."""
+    from eskf_lio_amd import capi, synth
+    frames, n, cap = 6, 9_000, 20
+    st = synth.make_imu_states(48, seed=21)
+    t = synth.make_point_times(n, st[1, 0] + 1e-4, st[-3, 0] + 0.4 / 400.0, seed=21, jitter=1e-3)
+    ext = synth.se3_to_SE3([0.02, -0.01, 0.03, 0.01, -0.02, 0.005])
+    with capi.Context(0) as a, capi.Context(0) as b:
+        for c in (a, b):
+            c.map_reset(0.3, 400_000)                              # no table growth (a rehash synchronises) in the loop
+        pose = np.eye(4)
+        a.frame_stats(reset=True)
+        syncs = []
+        for f in range(frames):
+            raw = synth.make_lidar_scan(n, seed=500 + f, extent=25.0)
+            kept_b, moved_b = b.scan_prepare(raw, t, st, ext, 0.3, 30)
+            if f == 0:
+                a.scan_prepare_async(raw, t, st, ext, 0.3, 30)
+                pa, ca = a.scan_download()                         # (settles the pending scan)
+                pb, cb = b.scan_download()
+                assert np.array_equal(pa, pb) and np.array_equal(ca, cb)
+                moved, _ = oracle.transform(raw, np.tile(np.eye(3).reshape(9), (n, 1)), ext)   # Open3D Transform
+                rp, rc, _ = oracle.preprocess(oracle.deskew(moved, t, st)[0], 0.3, 30)
+                assert np.array_equal(pa, rp) and np.array_equal(ca, rc)
+                a.map_insert_resident_async(pose, cap)
+                b.map_insert_resident(pose, cap)
+                a.frame_stats(reset=True)
+                continue
+            guess = pose @ synth.se3_to_SE3([0.01, 0.0, 0.0, 0.0, 0.0, 0.002])
+            rb = b.align_resident(guess, 12, 1e-6, 0.9999)
+            b.map_insert_resident(rb.pose, cap)
+            # context a's frame on its own (the statistics count what this host thread does, whatever the context)
+            a.frame_stats(reset=True)
+            a.scan_prepare_async(raw, t, st, ext, 0.3, 30)
+            ra = a.align_resident(guess, 12, 1e-6, 0.9999)
+            a.map_insert_resident_async(ra.pose, cap)
+            fs = a.frame_stats()
+            syncs.append(fs.host_syncs)
+            assert fs.kernel_launches > 0
+            assert ra.launches == 1 and ra.iterations == rb.iterations
+            assert np.array_equal(ra.pose, rb.pose) and np.array_equal(ra.normal_eq, rb.normal_eq)
+            assert a.scan_info() == (kept_b, moved_b, b.counter(4))
+            pose = ra.pose
+        assert syncs == [1] * (frames - 1), syncs
+        assert a.map_size() == b.map_size()
+        for x, y in zip(a.map_export(), b.map_export()):
+            assert np.array_equal(x, y)
+    # a refused scan (a point beyond the search grid) fails the align that would have used it, not the enqueue
+    with capi.Context(0) as c:
+        c.map_reset(0.3, 1000)
+        bad = synth.make_lidar_scan(2_000, seed=3)
+        bad[7, 0] = 0.3 * (2 ** 17) + 5.0
+        c.scan_prepare_async(bad, None, None, None, 0.3, 30)
+        with pytest.raises(capi.VgicpError) as e:
+            c.align_resident(np.eye(4), 5, 1e-6, 0.9999)
+        assert e.value.code == capi.ERR_BAD_ARGUMENT and "search grid" in str(e.value)
+        with pytest.raises(capi.VgicpError):
+            c.align_resident(np.eye(4), 5, 1e-6, 0.9999)           # no scan resident any more
+        good = synth.make_lidar_scan(2_000, seed=3)
+        c.scan_prepare_async(good, None, None, None, 0.3, 30)
+        assert c.scan_info()[0] == len(oracle.preprocess(good, 0.3, 30)[2])
+
+
 def test_cpp_example_tracks_a_moving_sensor():
     """examples/register_frames.cpp: the reference's frame loop written in C++ against the shim."""
     import subprocess
