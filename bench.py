@@ -414,6 +414,14 @@ def main():
         ns0 = ctx.counter(3)
         el_reused, _, _, _ = timed(lambda k: align_host(my_pts, my_covs), reused)
         ns_reused = ctx.counter(3) - ns0
+        # ... and the same buffer page-locked once by the caller (vgicp_host_register: a pool of clouds)
+        ctx.host_register(my_pts)
+        ctx.host_register(my_covs)
+        for _ in range(3):
+            align_host(my_pts, my_covs)
+        el_reg, _, _, _ = timed(lambda k: align_host(my_pts, my_covs), reused)
+        ctx.host_unregister(my_pts)
+        ctx.host_unregister(my_covs)
         upload_report = {
             "bytes_per_step": scan_bytes,
             "buffers": n_cold,
@@ -424,6 +432,9 @@ def main():
             "ms_per_step_first_touch": float(first.mean() * 1e3),
             "ms_per_step_second_pass": el_again / again * 1e3,
             "ms_per_step_reused": el_reused / reused * 1e3,
+            "ms_per_step_registered": el_reg / reused * 1e3,
+            "host_threads": "2 (points on a helper thread and stream, covariances on the caller's)"
+                            if os.environ.get("VGICP_UPLOAD_THREADS", "2") != "1" else "1",
             "upload_ms_cold": ns_cold / 1e6 / args.steps,
             "upload_ms_second_pass": ns_again / 1e6 / again,
             "upload_ms_reused": ns_reused / 1e6 / reused,

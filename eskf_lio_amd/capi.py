@@ -34,7 +34,7 @@ EXPORTS = (
     "vgicp_accumulate", "vgicp_solve_step", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_scan_prepare", "vgicp_scan_download",
     "vgicp_scan_prepare_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
-    "vgicp_set_option",
+    "vgicp_set_option", "vgicp_host_register", "vgicp_host_unregister",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
     "vgicp_peer_export", "vgicp_peer_connect", "vgicp_peer_disconnect",
 )
@@ -114,6 +114,8 @@ def load_library() -> C.CDLL:
     lib.vgicp_map_insert_resident_async.argtypes = [vp, dp, sz]
     lib.vgicp_get_frame_stats.argtypes = [vp, C.POINTER(FrameStats), C.c_int]
     lib.vgicp_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.vgicp_host_register.argtypes = [vp, vp, sz]
+    lib.vgicp_host_unregister.argtypes = [vp, vp]
     lib.vgicp_deskew.argtypes = [vp, sz, dp, dp, sz, dp, C.POINTER(C.c_int64)]
     lib.vgicp_preprocess.argtypes = [vp, sz, dp, C.c_double, C.c_int, sz, dp, dp, C.POINTER(C.c_uint64),
                                      C.POINTER(sz)]
@@ -481,6 +483,12 @@ class Context:
 
     def set_option(self, option: int, value: int):
         self._check(self._lib.vgicp_set_option(self._h, int(option), int(value)))
+
+    def host_register(self, array: np.ndarray):
+        self._check(self._lib.vgicp_host_register(self._h, array.ctypes.data, array.nbytes))
+
+    def host_unregister(self, array: np.ndarray):
+        self._check(self._lib.vgicp_host_unregister(self._h, array.ctypes.data))
 
     def scan_download(self):
         """The resident scan -> (points n x 3, covs n x 9)."""

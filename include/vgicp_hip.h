@@ -161,6 +161,15 @@ int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const doub
 int vgicp_align_resident(vgicp_ctx* ctx, const double guess[16], const vgicp_params* params,
                          double out_pose[16], vgicp_stats* stats);
 
+/* Optional, for callers that keep their clouds in buffers which live across frames (a pool): page-lock such a buffer
+ * once and every upload out of it runs at the link's rate from the first time on (9.6 MB in 0.19 ms; a pageable
+ * buffer the runtime has never seen takes 0.27 - 0.56 ms, tools/micro/h2d_cold_probe.hip).  The reference allocates
+ * a fresh cloud per frame (src/Registration.cpp:11), for which there is nothing to register: that case is what the
+ * two-thread upload inside vgicp_align is for, and the resident chain (vgicp_scan_prepare*) avoids the upload of the
+ * covariances altogether.  Unregister before the buffer is freed. */
+int vgicp_host_register(vgicp_ctx* ctx, const void* buffer, size_t bytes);
+int vgicp_host_unregister(vgicp_ctx* ctx, const void* buffer);
+
 /* ---- single-step hooks (API parity + tests) -------------------------------------------------
  * One iteration's normal equations at a given total pose, no solve: what the accumulation loop of
  * ICP::computeTransform (src/Registration.cpp:60-76) leaves in JTJ / JTr, plus the match count.

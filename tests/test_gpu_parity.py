@@ -346,6 +346,36 @@ def test_persistent_launch_that_gives_up_falls_back_and_recovers(c1_inputs, monk
         assert ctx.counter(0) == 2 and ctx.counter(1) == 2
 
 
+def test_upload_paths_return_the_same_bits(c1_inputs, monkeypatch):
+    """vgicp_align's upload: the points on a helper thread and stream with the covariances on the caller's (scans of
+    512 KB of points and more), everything on the caller's thread (VGICP_UPLOAD_THREADS=1), and buffers page-locked by
+    the caller (vgicp_host_register) — three ways to the same resident scan, hence the same bits."""
+    from eskf_lio_amd import capi, synth
+    vmap, _, _ = c1_inputs
+    pts, covs = synth.make_uniform_scan(40_000, vmap, seed=99)          # 960 KB of points: the helper thread takes them
+    g = synth.default_guess()
+    results = []
+    for threads in ("2", "1"):
+        monkeypatch.setenv("VGICP_UPLOAD_THREADS", threads)
+        with capi.Context(0) as ctx:
+            ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+            ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+            for k in range(4):
+                p, c = pts.copy(), covs.copy()                            # fresh host buffers every time
+                results.append(ctx.align(p, c, g, 6, 1e-6, 2.0))
+            if threads == "2":
+                p, c = pts.copy(), covs.copy()
+                ctx.host_register(p)
+                ctx.host_register(c)
+                results.append(ctx.align(p, c, g, 6, 1e-6, 2.0))
+                ctx.host_unregister(p)
+                ctx.host_unregister(c)
+                dp, dc = ctx.scan_download()
+                assert np.array_equal(dp, pts) and np.array_equal(dc, covs)
+    for r in results[1:]:
+        assert np.array_equal(r.pose, results[0].pose) and np.array_equal(r.normal_eq, results[0].normal_eq)
+
+
 def test_resident_scan_is_not_modified_by_align(c1_gpu, c1_inputs):
     from eskf_lio_amd import synth
     _, pts, covs = c1_inputs

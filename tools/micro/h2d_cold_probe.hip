@@ -96,6 +96,30 @@ int main() {
     hipHostRegister(p.a, a_bytes, 0); hipHostRegister(p.b, b_bytes, 0);
     hipMemcpyAsync(da, p.a, a_bytes, hipMemcpyHostToDevice, s1); hipMemcpyAsync(db, p.b, b_bytes, hipMemcpyHostToDevice, s1);
     hipStreamSynchronize(s1); hipHostUnregister(p.a); hipHostUnregister(p.b); });
+  {
+    // where the time of the register path goes (cold buffers)
+    std::vector<Pair> bufs;
+    for (int i = 0; i < reps; ++i) bufs.push_back(fresh(false));
+    double tr = 0, tc = 0, tu = 0;
+    for (int i = 0; i < reps; ++i) {
+      const Pair& p = bufs[i];
+      double t0 = now();
+      hipHostRegister(p.a, a_bytes, 0); hipHostRegister(p.b, b_bytes, 0);
+      double t1 = now();
+      hipMemcpyAsync(da, p.a, a_bytes, hipMemcpyHostToDevice, s1); hipMemcpyAsync(db, p.b, b_bytes, hipMemcpyHostToDevice, s1);
+      hipStreamSynchronize(s1);
+      double t2 = now();
+      hipHostUnregister(p.a); hipHostUnregister(p.b);
+      double t3 = now();
+      tr += t1 - t0; tc += t2 - t1; tu += t3 - t2;
+    }
+    printf("register path, cold, mean: register %.3f ms, copies + sync %.3f ms, unregister %.3f ms\n", tr / reps * 1e3, tc / reps * 1e3, tu / reps * 1e3);
+    for (auto& p : bufs) { free(p.a); free(p.b); }
+  }
+  run("register in 2 threads (one per array), copy, unregister in 2 threads", false, [&](const Pair& p) {
+    std::thread t([&] { hipHostRegister(p.a, a_bytes, 0); hipMemcpyAsync(da, p.a, a_bytes, hipMemcpyHostToDevice, s2); hipStreamSynchronize(s2); hipHostUnregister(p.a); });
+    hipHostRegister(p.b, b_bytes, 0); hipMemcpyAsync(db, p.b, b_bytes, hipMemcpyHostToDevice, s1); hipStreamSynchronize(s1); hipHostUnregister(p.b);
+    t.join(); });
   run("transparent huge pages (madvise), two hipMemcpyAsync", true, [&](const Pair& p) { chunked(p, 1 << 30); });
   run("transparent huge pages, chunks of 1 MB", true, [&](const Pair& p) { chunked(p, 1 << 20); });
   return 0;
