@@ -183,6 +183,8 @@ struct vgicp_ctx {
   uint32_t prep_epoch = 0;
   bool scan_pending = false;         // a prepared scan is resident but the host has not read its size / verdict yet
   uint32_t n_upper = 0;              // raw points of the pending scan (>= its kept points)
+  uint32_t scan_seq = 0;             // uploads so far; pack_scan_kernel marks an asymmetric covariance with it
+  bool scan_sym_known = false;       // the resident scan went through pack_scan_kernel (not a scan prepared on the device)
   int64_t prep_deskewed = 0;
   bool prep_with_deskew = false;
   // deferred map insertion (vgicp_map_insert_resident_async): running totals on the device, read at the next sync
@@ -453,6 +455,9 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.stride = ctx->stride;
   a.n = ctx->n;                                        // a pending scan: the raw count, an upper bound ...
   a.n_dev = ctx->scan_pending ? ctx->d_counters : nullptr;  // ... and the kept count is read from the device
+  a.asym_dev = ctx->scan_sym_known ? ctx->d_ins_counters + 2 : nullptr;  // word 2 of that block: the symmetry verdict
+  a.scan_seq = ctx->scan_seq;
+  if (std::getenv("VGICP_NO_SYM")) a.asym_dev = nullptr;  // developer A/B: always read all twelve planes
   a.mask = (uint32_t)(ctx->slots - 1);
   a.table = ctx->table;
   a.voxel_size = ctx->voxel_size;
@@ -1269,7 +1274,10 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
     VG_HIP(ctx, hipMemcpyAsync(aos_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     VG_HIP(ctx, hipMemcpyAsync(aos_cov, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   }
-  VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, (uint32_t)n, ctx->d_scan, ctx->stride));
+  if (++ctx->scan_seq == 0) ++ctx->scan_seq;
+  ctx->scan_sym_known = true;
+  VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, (uint32_t)n, ctx->d_scan, ctx->stride,
+                               ctx->d_ins_counters + 2, ctx->scan_seq));
   ctx->upload_bytes += n * kScanPlanes * sizeof(double);
   ctx->upload_seconds += now_seconds() - t0;  // host side of the two copies + the enqueue of the pack kernel
   return VGICP_OK;
@@ -1856,6 +1864,7 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   if (rc != VGICP_OK) return rc;
   if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[1], ctx->stream)); ctx->ev_stage_set[1] = true; }
   ctx->n_upper = (uint32_t)n;
+  ctx->scan_sym_known = false;   // covariances made on the device: all twelve planes are read
   ctx->n = (uint32_t)n;          // an upper bound until the pending scan is settled
   ctx->scan_pending = true;
   ctx->scan_ready = true;

@@ -130,6 +130,9 @@ struct PersistArgs {
                            // mail_seq << 1 | 1 "my loop ran to its end", mail_seq << 1 "I gave up" — written by
                            // workgroup 0 of the sender at the end of its launch, so that all ranks commit an align
                            // or none does
+  const uint32_t* asym_dev;  // nullptr, or the word pack_scan_kernel sets to scan_seq when some covariance of the scan is
+  uint32_t scan_seq;         // NOT bitwise symmetric; while it differs, the planes above the diagonal are not read
+  uint32_t pad_sym_;
   const uint32_t* n_dev;   // nullptr, or where the device holds the scan's size (a scan prepared on the device whose
                            // kept count the host has not read yet: no host round trip between preparation and align)
   double prefetch_margin;  // > 0 (only with memo_points == stash_points == 0): a point closer than this many
@@ -164,8 +167,9 @@ hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, c
 // Test hook: solve + exponential + convergence test of one round on given normal equations (one wave).
 hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosine_threshold,
                              double translation_sq_threshold, int force_pivoted, double* out20);
+// asym: one device word that receives seq when a covariance is not bitwise symmetric (PersistArgs::asym_dev)
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
-                            uint32_t n, double* soa, uint64_t stride);
+                            uint32_t n, double* soa, uint64_t stride, uint32_t* asym, uint32_t seq);
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots);
 hipError_t launch_upsert(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
                          const int32_t* keys, const double* means, const double* covs,

@@ -375,6 +375,22 @@ __device__ __forceinline__ void load_point(const double* scan, uint64_t stride, 
   for (int k = 0; k < kScanPlanes; ++k) q[k] = s[k * stride];
 }
 
+// The same for a scan whose covariances are ALL bitwise symmetric (pack_scan_kernel found no exception): the three
+// planes above the diagonal are copies of the three below it and are not read — 72 instead of 96 bytes per point.
+__device__ __forceinline__ void load_point_sym(const double* scan, uint64_t stride, uint32_t i,
+                                               double (&q)[kScanPlanes], bool symmetric) {
+  if (!symmetric) {
+    load_point(scan, stride, i, q);
+    return;
+  }
+  const double* s = scan + i;
+  // planes: x y z c00 c10 c20 c01 c11 c21 c02 c12 c22
+  q[0] = s[0]; q[1] = s[stride]; q[2] = s[2 * stride];
+  q[3] = s[3 * stride]; q[4] = s[4 * stride]; q[5] = s[5 * stride];
+  q[7] = s[7 * stride]; q[8] = s[8 * stride]; q[11] = s[11 * stride];
+  q[6] = q[4]; q[9] = q[5]; q[10] = q[8];
+}
+
 // One correspondence: p (already in the map frame), scan covariance C, voxel mean / covariance.
 // ICP::computeJTJAndJTr in structured form (J = [I | -[p]x]); S holds C_voxel on entry.
 template <bool B>
@@ -756,6 +772,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool worker = wave != 0;
   const uint32_t n_pts = a.n_dev ? *a.n_dev : a.n;  // uniform
+  const bool cov_sym = MANY && a.asym_dev != nullptr && *a.asym_dev != a.scan_seq;  // uniform
   const uint32_t grid = gridDim.x, blk = blockIdx.x;
   const uint32_t stride_pts = grid * kWorkers;
   const uint32_t first = worker ? blk * kWorkers + (tid - 64) : n_pts;
@@ -871,7 +888,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
           if (e <= a.stash_points) {
             double* slot = stash + (size_t)(e - 1) * kScanPlanes * kWorkers + (tid - 64);
             if (it == 0) {
-              load_point(a.scan, a.stride, i, q);
+              load_point_sym(a.scan, a.stride, i, q, cov_sym);
 #pragma unroll
               for (int k = 0; k < kScanPlanes; ++k) slot[k * kWorkers] = q[k];
             } else {
@@ -879,7 +896,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
               for (int k = 0; k < kScanPlanes; ++k) q[k] = slot[k * kWorkers];
             }
           } else {
-            load_point(a.scan, a.stride, i, q);
+            load_point_sym(a.scan, a.stride, i, q, cov_sym);
           }
           one_point(q, e, Flag<false>{});
         }
@@ -1106,13 +1123,22 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(const double* __restric
 
 // AoS (the caller's Eigen memory) -> 12 SoA planes.
 __global__ void pack_scan_kernel(const double* __restrict__ pts, const double* __restrict__ covs,
-                                 uint32_t n, double* __restrict__ soa, uint64_t stride) {
+                                 uint32_t n, double* __restrict__ soa, uint64_t stride, uint32_t* asym, uint32_t seq) {
+  // *asym = seq as soon as one covariance is not bitwise symmetric (the word needs no clearing: seq differs per upload)
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
 #pragma unroll
   for (int k = 0; k < 3; ++k) soa[k * stride + i] = pts[3 * (size_t)i + k];
+  double c[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) soa[(3 + k) * stride + i] = covs[9 * (size_t)i + k];
+  for (int k = 0; k < 9; ++k) {
+    c[k] = covs[9 * (size_t)i + k];
+    soa[(3 + k) * stride + i] = c[k];
+  }
+  const bool same = __double_as_longlong(c[1]) == __double_as_longlong(c[3]) &&
+                    __double_as_longlong(c[2]) == __double_as_longlong(c[6]) &&
+                    __double_as_longlong(c[5]) == __double_as_longlong(c[7]);
+  if (!same) *asym = seq;
 }
 
 __global__ void table_clear_kernel(VoxelRecord* table, uint64_t slots) {
@@ -1440,10 +1466,10 @@ hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, c
 }
 
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
-                            uint32_t n, double* soa, uint64_t stride) {
+                            uint32_t n, double* soa, uint64_t stride, uint32_t* asym, uint32_t seq) {
   if (n == 0) return hipSuccess;
   ++g_kernel_launches; hipLaunchKernelGGL(pack_scan_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, points_aos,
-                     covs_aos, n, soa, stride);
+                     covs_aos, n, soa, stride, asym, seq);
   return hipGetLastError();
 }
 

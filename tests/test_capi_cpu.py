@@ -160,3 +160,21 @@ def test_module_fallback_solve_is_the_oracles_ldlt_bit_for_bit(oracle):
     for xi in ([0.1, -0.2, 0.3, 0.0, 0.0, 0.0], [0.1, -0.2, 0.3, 6e-8, 0.0, 8e-8], [0, 0, 0, 0, 0, np.pi / 2],
                [1.0, 2.0, 3.0, 0.3, -0.4, 1.2]):
         assert np.allclose(host.math_se3_exp(xi), oracle.se3_to_SE3(np.array(xi, dtype=np.float64)), rtol=0, atol=1e-15)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/include/ESKF_LIO"),
+                    reason="build-container check: needs the reference's own Types.hpp on the include path")
+def test_shim_native_types_branch_meets_a_compiler(tmp_path):
+    """include/eskf_lio_shim/*.hpp have two branches: dependency-free stand-in types (compiled and tested everywhere
+    in this repository) and the reference's REAL types — Eigen, Open3D, yaml-cpp — which this image does not have.
+    tests/compile_native/ gives that second branch compiler contact: minimal stand-in headers that declare only the
+    members the branch and the reference's call sites use (src/ErrorStateKF.cpp:126-130, src/Odometry.cpp:11-16,61,74,
+    86, reproduced in call_sites.cpp), plus the reference's own include/ESKF_LIO/Types.hpp read where it lies.
+    It pins NOTHING numerically (the stand-ins compute nothing); it retires "never compiled"."""
+    out = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-c", "-o", str(tmp_path / "call_sites.o"),
+                          "-I" + os.path.join(ROOT, "tests", "compile_native", "stubs"), "-I" + os.path.join(ROOT, "include"),
+                          "-I/root/reference/include", os.path.join(ROOT, "tests", "compile_native", "call_sites.cpp")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-4000:]
+    syms = subprocess.run(["nm", "-C", str(tmp_path / "call_sites.o")], capture_output=True, text=True, check=True).stdout
+    assert "ESKF_LIO::ICP::align" in syms and "vgicp_align" in syms and "vgicp_map_upsert" in syms

@@ -1433,6 +1433,24 @@ def test_scans_larger_than_the_grid_park_points_in_lds(gpu_ctx, c1_inputs, monke
     # a different partition of the points into workgroups: same sums up to the order of addition
     assert np.allclose(loop.normal_eq, parked.normal_eq, rtol=1e-11, atol=1e-9)
     assert np.abs(loop.pose - parked.pose).max() < 1e-12
+    # The scan above has bitwise symmetric covariances, so the launch read 9 of its 12 planes (the upload's pack kernel
+    # found no exception); reading all twelve gives the same bits ...
+    monkeypatch.setenv("VGICP_NO_SYM", "1")
+    full = gpu_ctx.align_resident(g, 12, 1e-6, 2.0, chunk_iterations=12)
+    monkeypatch.delenv("VGICP_NO_SYM")
+    assert np.array_equal(full.pose, parked.pose) and np.array_equal(full.normal_eq, parked.normal_eq)
+    # ... and ONE covariance that differs in its last bit above the diagonal switches the shortcut off for the scan:
+    # the result is then the twelve-plane one for the new data (the loop of launches always reads everything)
+    skew = covs.copy()
+    skew[123_456, 3] = np.nextafter(skew[123_456, 3], np.inf)        # c01 != c10 now
+    gpu_ctx.scan_upload(pts, skew)
+    a = gpu_ctx.align_resident(g, 6, 1e-6, 2.0, chunk_iterations=6)
+    monkeypatch.setenv("VGICP_NO_SYM", "1")
+    b = gpu_ctx.align_resident(g, 6, 1e-6, 2.0, chunk_iterations=6)
+    monkeypatch.delenv("VGICP_NO_SYM")
+    assert a.launches == 1 and np.array_equal(a.pose, b.pose) and np.array_equal(a.normal_eq, b.normal_eq)
+    sym_again = gpu_ctx.align(pts, covs, g, 6, 1e-6, 2.0)             # a later symmetric upload takes the shortcut again
+    assert np.array_equal(sym_again.normal_eq, parked.normal_eq[:6])
 
 
 @pytest.mark.parametrize("seed", range(6))
