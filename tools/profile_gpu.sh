@@ -12,8 +12,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="--steps 30 --warmup 3 --no-cpu-baseline --no-c5 --no-frame-chain $*"
 python3 bench.py $ARGS > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
-# the trace pass also runs the frame chain (10 frames): its kernels appear in the same per-kernel statistics
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-c5 --frames 10 $* > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err"
 find "$OUT" -name "*.csv" | head -20
