@@ -1608,7 +1608,7 @@ int check_preprocess_args(vgicp_ctx* ctx, size_t n, double voxel_size, int knn) 
   if (!(voxel_size > 0.0)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "voxel_size must be positive");
   if (knn < 1 || knn > preprocess_max_knn())
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "knn must be in [1, " + std::to_string(preprocess_max_knn()) + "]");
-  if (n > 0x7FFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
+  if (n > (size_t)kMaxScanTiles * 2048u) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large (more than 8 M points)");
   return VGICP_OK;
 }
 }  // namespace
