@@ -134,14 +134,21 @@ int main(int argc, char ** argv)
       for (int a = 0; a < 3; ++a) {packed[8 * s + 1 + a] = states[s].position(a);}
       for (int a = 0; a < 4; ++a) {packed[8 * s + 4 + a] = states[s].attitude.c[a];}
     }
+    // chain C: the same again through the calls that do not wait (one host synchronisation per frame)
+    vgicp_ctx * ctxC = nullptr;
+    shim::check(nullptr, vgicp_create(0, &ctxC), "vgicp_create");
+    shim::check(ctxC, vgicp_map_reset(ctxC, voxel, 400000), "vgicp_map_reset");
     vgicp_params params{};
     params.max_iteration = 100; params.translation_sq_threshold = 1e-6; params.cosine_threshold = 0.9999;
 
     Isometry3d estimateA = Isometry3d::Identity();
     double estimateB[16];
     std::memcpy(estimateB, shim::poseData(estimateA), sizeof estimateB);
+    double estimateC[16];
+    std::memcpy(estimateC, shim::poseData(estimateA), sizeof estimateC);
     int bad = 0, residentFrames = 0;
-    double residentMs = 0.0;
+    double residentMs = 0.0, asyncMs = 0.0;
+    unsigned long long asyncSyncs = 0, asyncLaunches = 0;
     for (int f = 0; f < frames; ++f) {
       const double end = 0.1 * f;
       LidarMeasurementPtr meas = sweep(t0, end, n, 77 + f, f > 0);
@@ -174,6 +181,22 @@ int main(int argc, char ** argv)
       const double frameMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
       if (f > 0) {residentMs += frameMs; ++residentFrames;}
 
+      // ---- C: vgicp_scan_prepare_async -> vgicp_align_resident -> vgicp_map_insert_resident_async ----
+      vgicp_frame_stats fs{};
+      shim::check(ctxC, vgicp_get_frame_stats(ctxC, &fs, 1), "vgicp_get_frame_stats");
+      const auto c0 = std::chrono::steady_clock::now();
+      shim::check(ctxC, vgicp_scan_prepare_async(ctxC, raw.size(), raw[0].data(), times.data(), f == 0 ? 0 : states.size(),
+                                               packed.data(), nullptr, voxel, 30), "vgicp_scan_prepare_async");
+      if (f > 0) {
+        const Isometry3d guess = toIsometry(motion(end - 0.1));
+        shim::check(ctxC, vgicp_align_resident(ctxC, shim::poseData(guess), &params, estimateC, nullptr), "vgicp_align_resident");
+      }
+      shim::check(ctxC, vgicp_map_insert_resident_async(ctxC, estimateC, 20), "vgicp_map_insert_resident_async");
+      const double asyncFrameMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+      shim::check(ctxC, vgicp_get_frame_stats(ctxC, &fs, 0), "vgicp_get_frame_stats");
+      if (f > 0) {asyncMs += asyncFrameMs; asyncSyncs += fs.host_syncs; asyncLaunches += fs.kernel_launches;}
+      for (int k = 0; k < 16; ++k) {if (estimateC[k] != estimateB[k]) {++bad;}}   // the same bits as chain B
+
       const double errA = positionError(shim::poseData(estimateA), truth), errB = positionError(estimateB, truth);
       double gap = 0.0;
       for (int k = 0; k < 16; ++k) {gap = std::fmax(gap, std::fabs(shim::poseData(estimateA)[k] - estimateB[k]));}
@@ -185,7 +208,17 @@ int main(int argc, char ** argv)
       std::printf("resident chain (raw sweep in, pose out, map updated): %.3f ms per %zu-point frame on average over %d frames\n",
         residentMs / residentFrames, n, residentFrames);
     }
+    if (residentFrames) {
+      std::printf("the same without waiting (prepare_async / align / insert_async): %.3f ms per frame, %.1f kernel launches and "
+        "%.1f host synchronisations per frame, poses bit-equal to the resident chain\n", asyncMs / residentFrames,
+        (double)asyncLaunches / residentFrames, (double)asyncSyncs / residentFrames);
+    }
+    size_t voxelsB = 0, voxelsC = 0;
+    shim::check(ctx, vgicp_map_size(ctx, &voxelsB, nullptr), "vgicp_map_size");
+    shim::check(ctxC, vgicp_map_size(ctxC, &voxelsC, nullptr), "vgicp_map_size");
+    if (voxelsB != voxelsC) {++bad;}
     vgicp_destroy(ctx);
+    vgicp_destroy(ctxC);
     return bad == 0 ? 0 : 2;
   } catch (const std::exception & e) {
     std::fprintf(stderr, "frame_chain: %s\n", e.what());

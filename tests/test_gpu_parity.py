@@ -871,6 +871,10 @@ def test_cpp_frame_chain_classes_and_resident_abi_agree():
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("frame")]
     assert len(lines) == 6 and "deskewed" in lines[1]
+    # the third chain of the example: the calls that do not wait — same bits (the example's exit code), one host
+    # synchronisation per frame
+    tail = [ln for ln in out.stdout.splitlines() if ln.startswith("the same without waiting")]
+    assert len(tail) == 1 and "1.0 host synchronisations per frame" in tail[0], out.stdout
 
 
 def test_bench_line_keeps_its_contract():
