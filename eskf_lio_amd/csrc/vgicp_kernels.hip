@@ -943,6 +943,11 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
     }
 
     if (wave == 0) {
+      // Addresses that depend on the lane are re-made here every round: hoisted out of the loop they would sit in
+      // registers through the whole accumulate phase (the MANY instantiations spilled them to scratch).
+      uint32_t lane_here = tid & 63;
+      asm volatile("" : "+v"(lane_here));
+      const uint32_t lane = lane_here;
       // the buffers rotate with a round number that runs on from launch to launch (a.round0: rounds executed on
       // this context before): nothing has to be tidied up when a launch ends
       const uint32_t buf = (a.round0 + (uint32_t)it) % 3u, rearm = (a.round0 + (uint32_t)it + 2u) % 3u;

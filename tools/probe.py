@@ -13,6 +13,15 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eskf_lio_amd import capi, synth  # noqa: E402
 
+
+
+def digest(r):
+    """pose bits + correspondence counts + normal equations of the last align, to compare builds in an A/B"""
+    import hashlib
+    h = hashlib.sha1(r.pose.tobytes() + r.corr_count.tobytes())
+    return h.hexdigest()[:12]
+
+
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 n, v = synth.CONFIGS[cfg]
@@ -38,7 +47,7 @@ with capi.Context(0) as ctx:
         spans.append(r.device_seconds)
         walls.append(r.seconds)
     print(f"[probe] eager: device span/iter {np.mean(spans) / IT * 1e6:.2f} us (min {np.min(spans) / IT * 1e6:.2f}), "
-          f"host wall/align {np.mean(walls) * 1e3:.3f} ms", flush=True)
+          f"host wall/align {np.mean(walls) * 1e3:.3f} ms; result digest {digest(r)}", flush=True)
     kms = []
     for _ in range(reps):
         r = ctx.align_resident(guess, IT, 1e-6, 2.0, flags=capi.FLAG_PROFILE)
