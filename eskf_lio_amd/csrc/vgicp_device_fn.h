@@ -65,6 +65,17 @@ __device__ __forceinline__ int32_t voxel_coord_fast(double x, double h, double i
   return voxel_coord_fast(x, h, inv_h, &r);
 }
 
+// "Is floor(fl(x / h)) still k?" without computing the key: voxel_coord_fast's acceptance test applied to a GIVEN
+// candidate (the key of the round before).  r = x - k h by one FMA has the exact sign; 0 <= r and h - r > margin put
+// the exact quotient into [k, k + 1 - margin / h), and a margin of 2^-20 h exceeds voxel_coord_fast's
+// (|k| + 4) 2^-52 h for every int32 k, so the correctly rounded division cannot round up to k + 1 either.  True
+// therefore IMPLIES an unchanged key; false (a changed key, a point within a millionth of a voxel of its upper face,
+// NaN) sends the caller to the full computation.  Five instructions per coordinate, no branch.
+__device__ __forceinline__ bool same_voxel_coord(double x, int32_t k, double h, double margin) {
+  const double r = fma(-(double)k, h, x);
+  return ((int)(r >= 0.0) & (int)((h - r) > margin)) != 0;  // no short circuit: no branch
+}
+
 // q = R p + t evaluated as Open3D's homogeneous product does (left to right, no FMA contraction),
 // so the first round reproduces the CPU path's voxel keys bit for bit.
 __device__ __forceinline__ void transform_point(const double* R, const double* t, double x, double y,

@@ -788,6 +788,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   const double cos_thr = a.cosine_threshold, tsq_thr = a.translation_sq_threshold;
   const int max_it = a.max_iteration;
   const double inv_voxel = 1.0 / a.voxel_size;
+  const double same_margin = 0x1p-20 * a.voxel_size;  // same_voxel_coord
 
   double q0[kScanPlanes];
 #pragma unroll
@@ -854,23 +855,35 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
         auto one_point = [&](const double (&q)[kScanPlanes], uint32_t e, auto first_of_round) {
           double p[3], C[9], m2[3], S[9];
           transform_point(R, t, q[0], q[1], q[2], p);
-          const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
-          const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
-          const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
           bool got;
           if (e < a.memo_points) {
             int4* mslot = memo + (size_t)e * kWorkers + (tid - 64);
             const int4 m = *mslot;
-            if (it != 0 && m.x == kx && m.y == ky && m.z == kz) {
+            // still inside last round's voxel?  (true implies an unchanged key; the key itself is made only otherwise)
+            const bool stayed = ((int)(it != 0) & (int)same_voxel_coord(p[0], m.x, a.voxel_size, same_margin) &
+                                 (int)same_voxel_coord(p[1], m.y, a.voxel_size, same_margin) &
+                                 (int)same_voxel_coord(p[2], m.z, a.voxel_size, same_margin)) != 0;
+            if (stayed) {
               got = (uint32_t)m.w != kMemoMiss;
               if (got) load_payload(a.table + (uint32_t)m.w, m2, S);
             } else {
-              const VoxelRecord* rec = find_voxel(a.table, a.mask, kx, ky, kz);
-              got = rec != nullptr;
-              *mslot = make_int4(kx, ky, kz, got ? (int32_t)(uint32_t)(rec - a.table) : (int32_t)kMemoMiss);
-              if (got) load_payload(rec, m2, S);
+              const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
+              const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
+              const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
+              if (it != 0 && m.x == kx && m.y == ky && m.z == kz) {  // a point right below a face: key unchanged after all
+                got = (uint32_t)m.w != kMemoMiss;
+                if (got) load_payload(a.table + (uint32_t)m.w, m2, S);
+              } else {
+                const VoxelRecord* rec = find_voxel(a.table, a.mask, kx, ky, kz);
+                got = rec != nullptr;
+                *mslot = make_int4(kx, ky, kz, got ? (int32_t)(uint32_t)(rec - a.table) : (int32_t)kMemoMiss);
+                if (got) load_payload(rec, m2, S);
+              }
             }
           } else {
+            const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
+            const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
+            const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
             got = find_and_load(a.table, a.mask, kx, ky, kz, m2, S);
           }
           if (got) {
@@ -1244,9 +1257,23 @@ __global__ void voxel_index_kernel(const double* __restrict__ pts, uint32_t n, d
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // the division-free form the loop kernels use (exact, see voxel_coord_fast): this hook is how tests pin it
+  // ... and the persistent launch's shortcut "still in last round's voxel?" (same_voxel_coord): it may say no for
+  // the true key (the caller then makes the key), but a yes for any OTHER key would be a wrong correspondence — the
+  // hook poisons the key it returns in that case, so the same tests pin both functions.
   const double inv_voxel = 1.0 / voxel_size;
+  const double same_margin = 0x1p-20 * voxel_size;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) keys[3 * (size_t)i + k] = voxel_coord_fast(pts[3 * (size_t)i + k], voxel_size, inv_voxel);
+  for (int k = 0; k < 3; ++k) {
+    const double x = pts[3 * (size_t)i + k];
+    int32_t key = voxel_coord_fast(x, voxel_size, inv_voxel);
+    bool wrong_yes = false;
+#pragma unroll
+    for (int d = 1; d <= 2; ++d) {
+      if (key <= INT32_MAX - d) wrong_yes = wrong_yes || same_voxel_coord(x, key + d, voxel_size, same_margin);
+      if (key >= INT32_MIN + d) wrong_yes = wrong_yes || same_voxel_coord(x, key - d, voxel_size, same_margin);
+    }
+    keys[3 * (size_t)i + k] = wrong_yes ? INT32_MIN : key;
+  }
 }
 
 // ---- correspondence materialisation: count per block, scan block counts, compact ----

@@ -178,3 +178,39 @@ def test_shim_native_types_branch_meets_a_compiler(tmp_path):
     assert out.returncode == 0, out.stderr[-4000:]
     syms = subprocess.run(["nm", "-C", str(tmp_path / "call_sites.o")], capture_output=True, text=True, check=True).stdout
     assert "ESKF_LIO::ICP::align" in syms and "vgicp_align" in syms and "vgicp_map_upsert" in syms
+
+
+def test_same_voxel_shortcut_implies_an_unchanged_key():
+    """The persistent launch asks "is the point still inside last round's voxel?" before it makes a key
+    (`same_voxel_coord`, eskf_lio_amd/csrc/vgicp_device_fn.h): r = fma(-k, h, x); yes iff 0 <= r and h - r > 2^-20 h.
+    Restated here with exact rational arithmetic for the FMA (one rounding, like the instruction): on coordinates
+    within a few ulps of cell faces, for several voxel sizes and keys up to 2^29, a yes must IMPLY
+    floor(fl(x / h)) == k (reference: LocalMap::getVoxelIndex, src/LocalMap.cpp:114-118); a no is always allowed.
+    The device function itself is pinned by the hook behind `vgicp_voxel_index` (-m gpu)."""
+    from fractions import Fraction
+
+    def same(x, k, h):
+        r = float(Fraction(x) - Fraction(int(k)) * Fraction(h))  # fma(-k, h, x): exact, then ONE rounding
+        return r >= 0.0 and (h - r) > 2.0 ** -20 * h
+
+    rng = np.random.default_rng(11)
+    yes = total = 0
+    for h in (0.3, 0.1, 0.7, 1.0, 0.05, 2.5, 1.0 / 3.0):
+        ks = np.concatenate([np.arange(-40, 40), rng.integers(-2**29, 2**29, size=150),
+                             rng.integers(-70_000, 70_000, size=150)])
+        for k in ks:
+            base = float(k) * h
+            xs = [base, base + 0.5 * h, base + h * (1 - 2.0 ** -19), base + h * (1 - 2.0 ** -22)]
+            for ulps in (1, 2, 5, 17):
+                up, dn = base, base
+                for _ in range(ulps):
+                    up, dn = np.nextafter(up, np.inf), np.nextafter(dn, -np.inf)
+                xs += [float(up), float(dn)]
+            for x in xs:
+                true_key = int(np.floor(np.float64(x) / np.float64(h)))
+                for cand in (true_key - 1, true_key, true_key + 1, int(k)):
+                    total += 1
+                    if same(x, cand, h):
+                        yes += 1
+                        assert cand == true_key, (x, h, cand, true_key)
+    assert yes > total // 10  # the shortcut does say yes for ordinary points
