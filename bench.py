@@ -47,9 +47,14 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# the exchange between GPUs maps peer memory through dmabuf IPC handles; the pool's hosts only support that mode.
+# The driver's shell exports this already; a bare shell would otherwise fail in hipIpcGetMemHandle (must be set
+# before anything initialises the GPU)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -476,8 +476,8 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.cosine_threshold = params->cosine_threshold;
   a.translation_sq_threshold = params->translation_sq_threshold;
   a.max_iteration = max_it;
-  persistent_lds_plan(ctx->n, grid, &a.memo_points, &a.stash_points);
-  if (std::getenv("VGICP_NO_STASH")) a.stash_points = 0;
+  persistent_lds_plan(ctx->n, grid, &a.memo_points, &a.stash_points, &a.stash_bytes);
+  if (std::getenv("VGICP_NO_STASH")) a.stash_points = a.stash_bytes = 0;
   if (std::getenv("VGICP_NO_MEMO")) a.memo_points = 0;
   a.prefetch_margin = (a.memo_points == 0 && a.stash_points == 0 && ctx->n <= grid * 448u) ? ctx->prefetch_margin : 0.0;
   a.stamps = ctx->d_stamps;

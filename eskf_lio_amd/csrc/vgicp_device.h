@@ -114,7 +114,8 @@ struct PersistArgs {
   double cosine_threshold;
   double translation_sq_threshold;
   int32_t max_iteration;
-  uint32_t stash_points;   // extra points per thread kept in LDS across rounds (scans larger than the grid)
+  uint32_t stash_points;   // at most this many extra points per thread are kept in LDS across rounds (scans larger
+                           // than the grid); the kernel parks as many of them as fit stash_bytes
   uint32_t memo_points;    // extra points per thread whose last key + table slot are remembered in LDS
   uint32_t round0;         // rounds executed on this context before this launch (mod 3 matters): the exchange
                            // buffers rotate with round0 + it, so a launch leaves nothing to tidy up
@@ -132,7 +133,8 @@ struct PersistArgs {
                            // or none does
   const uint32_t* asym_dev;  // nullptr, or the word pack_scan_kernel sets to scan_seq when some covariance of the scan is
   uint32_t scan_seq;         // NOT bitwise symmetric; while it differs, the planes above the diagonal are not read
-  uint32_t pad_sym_;
+  uint32_t stash_bytes;      // LDS behind the memos that may hold parked points; how many fit depends on the planes
+                             // a parked point needs (9 or 12) and on the point-carrying threads (448 or 512)
   const uint32_t* n_dev;   // nullptr, or where the device holds the scan's size (a scan prepared on the device whose
                            // kept count the host has not read yet: no host round trip between preparation and align)
   double prefetch_margin;  // > 0 (only with memo_points == stash_points == 0): a point closer than this many
@@ -146,7 +148,7 @@ struct PersistArgs {
 hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid);
 // How launch_persistent splits the CU's LDS for a scan of n points on `grid` workgroups: points per
 // thread beyond the first that get a memo (last key + slot, 16 B) and that are parked whole (96 B).
-void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points);
+void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points, uint32_t* stash_bytes);
 // Sizes (8-byte words) of the rows / parts exchange buffers, and their content between launches.
 size_t persistent_rows_words();
 size_t persistent_parts_words();
@@ -154,7 +156,7 @@ void persistent_exchange_image(uint32_t grid, unsigned long long* rows_words, un
 // Whether one 512-thread workgroup of the persistent kernel with this much dynamic LDS fits a CU of the
 // current device: *max_grid = cu_count then, else 0 (the in-kernel exchange needs every workgroup resident).
 hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_t* max_grid);
-uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_points);
+uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_bytes);
 uint32_t persistent_max_dyn_lds_bytes();  // the most a launch plan ever asks for
 // One VGICP round over the resident scan: prologue folds args.prev and advances the pose, body
 // accumulates this round's rows. block = 256 / 512 / 1024 threads per workgroup.

@@ -759,8 +759,6 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   // others, the first a.memo_points have a 16-byte memo {key, slot} and the first a.stash_points are
   // parked whole after round 0 (plane-major per point: conflict-free), so only the rest is re-read.
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  int4* memo = reinterpret_cast<int4*>(dyn_lds);
-  double* stash = reinterpret_cast<double*>(dyn_lds + (size_t)a.memo_points * kWorkers * sizeof(int4));
   // Scans that fit the grid (one point per thread, no memo / stash): the same LDS holds, per thread, the voxel
   // BEHIND THE NEAREST FACE of the point's voxel, looked up while the workers wait for the exchange: key + slot
   // (int4) and the 96-byte payload (6 planes of double2).  A point that changes voxel next round usually
@@ -770,12 +768,23 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   const bool prefetch = !MANY && a.prefetch_margin > 0.0;  // uniform
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool worker = wave != 0;
   const uint32_t n_pts = a.n_dev ? *a.n_dev : a.n;  // uniform
   const bool cov_sym = MANY && a.asym_dev != nullptr && *a.asym_dev != a.scan_seq;  // uniform
   const uint32_t grid = gridDim.x, blk = blockIdx.x;
-  const uint32_t stride_pts = grid * kWorkers;
-  const uint32_t first = worker ? blk * kWorkers + (tid - 64) : n_pts;
+  // MANY (the scan, or the upper bound the launch plan was made from, has more points than grid x 448): a thread owns
+  // several points anyway, so wave 0 owns points as well and turns solver after the accumulate phase — 512 points
+  // per workgroup pass instead of 448, two point-carrying waves on every SIMD instead of 2/2/2/1.
+  constexpr uint32_t W = MANY ? (uint32_t)BLOCK : (uint32_t)kWorkers;  // point-carrying threads of a workgroup
+  const bool worker = MANY || wave != 0;
+  const uint32_t wt = MANY ? tid : tid - 64u;  // index among them (workers only)
+  const uint32_t stride_pts = grid * W;
+  const uint32_t first = worker ? blk * W + wt : n_pts;
+  int4* memo = reinterpret_cast<int4*>(dyn_lds);
+  double* stash = reinterpret_cast<double*>(dyn_lds + (size_t)a.memo_points * W * sizeof(int4));
+  // parked points hold the planes that are read: 9 of a scan whose covariances are all bitwise symmetric, else 12
+  const uint32_t park_planes = cov_sym ? 9u : (uint32_t)kScanPlanes;
+  const uint32_t fit = a.stash_bytes / (park_planes * W * (uint32_t)sizeof(double));
+  const uint32_t parked = MANY ? (fit < a.stash_points ? fit : a.stash_points) : 0u;  // uniform
   const bool folder = blk < (uint32_t)kFolders;  // folder g adds the rows of workgroups g, g + 16, g + 32 ...
   // row of workgroup b inside a buffer: the 16 rows of a folder are consecutive
   const uint32_t my_row = (blk % kFolders) * kFolders + blk / kFolders;
@@ -857,7 +866,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
           transform_point(R, t, q[0], q[1], q[2], p);
           bool got;
           if (e < a.memo_points) {
-            int4* mslot = memo + (size_t)e * kWorkers + (tid - 64);
+            int4* mslot = memo + (size_t)e * W + wt;
             const int4 m = *mslot;
             // still inside last round's voxel?  (true implies an unchanged key; the key itself is made only otherwise)
             const bool stayed = ((int)(it != 0) & (int)same_voxel_coord(p[0], m.x, a.voxel_size, same_margin) &
@@ -898,15 +907,26 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
         uint32_t e = 1;
         for (uint32_t i = first + stride_pts; i < n_pts; i += stride_pts, ++e) {
           double q[kScanPlanes];
-          if (e <= a.stash_points) {
-            double* slot = stash + (size_t)(e - 1) * kScanPlanes * kWorkers + (tid - 64);
+          if (e <= parked) {
+            double* slot = stash + (size_t)(e - 1) * park_planes * W + wt;
             if (it == 0) {
               load_point_sym(a.scan, a.stride, i, q, cov_sym);
+              if (cov_sym) {
+                constexpr int kUsed[9] = {0, 1, 2, 3, 4, 5, 7, 8, 11};
 #pragma unroll
-              for (int k = 0; k < kScanPlanes; ++k) slot[k * kWorkers] = q[k];
+                for (int j = 0; j < 9; ++j) slot[j * W] = q[kUsed[j]];
+              } else {
+#pragma unroll
+                for (int k = 0; k < kScanPlanes; ++k) slot[k * W] = q[k];
+              }
+            } else if (cov_sym) {
+              constexpr int kUsed[9] = {0, 1, 2, 3, 4, 5, 7, 8, 11};
+#pragma unroll
+              for (int j = 0; j < 9; ++j) q[kUsed[j]] = slot[j * W];
+              q[6] = q[4]; q[9] = q[5]; q[10] = q[8];
             } else {
 #pragma unroll
-              for (int k = 0; k < kScanPlanes; ++k) q[k] = slot[k * kWorkers];
+              for (int k = 0; k < kScanPlanes; ++k) q[k] = slot[k * W];
             }
           } else {
             load_point_sym(a.scan, a.stride, i, q, cov_sym);
@@ -969,10 +989,12 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
       // ---- level 1: publish this workgroup's row (every re-arming store of mine has completed) ----
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane <= (uint32_t)kCountSlot) {
-        double w_sum[kWaves - 1];
+        double w_sum[kWaves];
 #pragma unroll
-        for (int w = 1; w < kWaves; ++w) w_sum[w - 1] = red[w][lane];
-        store_through_bits(rows + (size_t)my_row * kSlots + lane, publishable(tree_sum<kWaves - 1>(w_sum)));
+        for (int w = 0; w < kWaves; ++w) w_sum[w] = red[w][lane];
+        // all eight waves when wave 0 carries points too, else waves 1..7 (iterate_kernel<512>'s order)
+        const double row_sum = MANY ? tree_sum<kWaves>(w_sum) : tree_sum<kWaves - 1>(w_sum + 1);
+        store_through_bits(rows + (size_t)my_row * kSlots + lane, publishable(row_sum));
       }
       bool ok = true;
       if (folder) {  // uniform
@@ -1371,29 +1393,30 @@ hipError_t launch_iterate(hipStream_t s, const IterArgs& args, uint32_t grid, in
 
 namespace {
 constexpr uint32_t kPersistWorkers = 512 - 64;
-constexpr uint32_t kStashBytesPerPoint = kScanPlanes * kPersistWorkers * sizeof(double);  // 43 008
-constexpr uint32_t kMemoBytesPerPoint = kPersistWorkers * sizeof(int4);                   //  7 168
+constexpr uint32_t kPersistWide = 512;  // point-carrying threads when a thread owns several points (wave 0 included)
+constexpr uint32_t kMemoBytesPerPoint = kPersistWide * sizeof(int4);  // 8 192
 // dynamic LDS of the persistent launch: the CU's 160 KB minus the kernel's static use and a margin
 constexpr uint32_t kPersistDynLds = 150 * 1024;
 constexpr uint32_t kMaxMemoPoints = 12;  // beyond that a thread's points are looked up every round
 constexpr uint32_t kPrefetchBytes = kPersistWorkers * (sizeof(int4) + 6 * sizeof(double2));  // 50 176
 }  // namespace
 
-void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points) {
-  *memo_points = *stash_points = 0;
-  const uint64_t per_round = (uint64_t)grid * kPersistWorkers;
-  if (n <= per_round) return;  // one point per thread: registers (and the neighbour prefetch area)
+// The plan is made from n, which may be an upper bound of the scan's size (a scan prepared on the device): it is
+// sized for 512 point-carrying threads; a launch that finds fewer points than grid x 448 uses 448 and less of it.
+void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points, uint32_t* stash_bytes) {
+  *memo_points = *stash_points = *stash_bytes = 0;
+  if ((uint64_t)n <= (uint64_t)grid * kPersistWorkers) return;  // one point per thread: registers (and the neighbour prefetch area)
+  const uint64_t per_round = (uint64_t)grid * kPersistWide;
   const uint32_t per_thread = (uint32_t)((n + per_round - 1) / per_round);  // points per thread (upper bound)
   // the memo first (it saves the table access, the larger term), the rest of the LDS parks whole points
   const uint32_t memo = per_thread < kMaxMemoPoints ? per_thread : kMaxMemoPoints;
-  const uint32_t left = kPersistDynLds - memo * kMemoBytesPerPoint;
-  const uint32_t stash = left / kStashBytesPerPoint;
   *memo_points = memo;
-  *stash_points = stash < per_thread - 1 ? stash : per_thread - 1;  // the first point of a thread lives in registers
+  *stash_points = per_thread - 1;  // the first point of a thread lives in registers
+  *stash_bytes = *stash_points ? kPersistDynLds - memo * kMemoBytesPerPoint : 0u;
 }
 
-uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_points) {
-  return memo_points * kMemoBytesPerPoint + stash_points * kStashBytesPerPoint;
+uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_bytes) {
+  return memo_points * kMemoBytesPerPoint + stash_bytes;
 }
 uint32_t persistent_max_dyn_lds_bytes() { return kPersistDynLds; }
 
@@ -1438,7 +1461,7 @@ hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t gr
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
   if (device < 0 || device >= 64) return hipErrorInvalidDevice;
-  size_t dyn = (size_t)args.memo_points * kMemoBytesPerPoint + (size_t)args.stash_points * kStashBytesPerPoint;
+  size_t dyn = (size_t)args.memo_points * kMemoBytesPerPoint + (size_t)args.stash_bytes;
   if (args.prefetch_margin > 0.0) {
     if (dyn != 0) return hipErrorInvalidValue;  // the prefetch area shares the LDS of memo / stash
     dyn = kPrefetchBytes;
