@@ -811,7 +811,7 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   }
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_sums), kSlots * sizeof(double)));
   VG_CREATE(hipMemset(ctx->d_state, 0, 2 * sizeof(AlignState)));
-  if (const char* dbg = std::getenv("VGICP_DEBUG_STAMPS"); dbg && dbg[0] == '1') {
+  if (const char* dbg = std::getenv("VGICP_DEBUG_STAMPS"); dbg && (dbg[0] == '1' || dbg[0] == '2')) {
     VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_stamps), (32 + kExchangeRows) * sizeof(uint64_t)));
     VG_CREATE(hipMemset(ctx->d_stamps, 0, (32 + kExchangeRows) * sizeof(uint64_t)));
   }
@@ -881,6 +881,10 @@ int vgicp_destroy(vgicp_ctx* ctx) {
       }
       std::fprintf(stderr, "[vgicp stamps] persistent, time to the first barrier per workgroup (mean over rounds): min %.2f us, "
                    "mean %.2f us, max %.2f us (workgroup %d)\n", lo, sum / g, hi, hi_at);
+      if (const char* all = std::getenv("VGICP_DEBUG_STAMPS"); all && all[0] == '2') {  // every workgroup's figure
+        for (int b = 0; b < g; ++b) std::fprintf(stderr, "%s%.2f", b % 16 ? " " : "\n[vgicp stamps wg] ", wg[b] * k);
+        std::fprintf(stderr, "\n");
+      }
     }
     (void)hipFree(ctx->d_stamps);
   }

@@ -777,8 +777,20 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   constexpr uint32_t W = MANY ? (uint32_t)BLOCK : (uint32_t)kWorkers;  // point-carrying threads of a workgroup
   const bool worker = MANY || wave != 0;
   const uint32_t wt = MANY ? tid : tid - 64u;  // index among them (workers only)
-  const uint32_t stride_pts = grid * W;
-  const uint32_t first = worker ? blk * W + wt : n_pts;
+  // Which points a thread owns.  One point per thread (!MANY): point blk x 448 + its index among the workers.  MANY: the
+  // scan is dealt out in UNITS of 64 consecutive points (one wave's worth), every workgroup a contiguous run of
+  // floor(U / grid) units and the first U mod grid workgroups one more, taken eight units (512 points) per pass —
+  // so all workgroups hold the same number of points to within one unit.  (Dealing whole passes of grid x 512
+  // points out instead left the last, partial pass to the first workgroups only: at C5 161 workgroups of 8 points
+  // per thread and 95 of 7, 23 against 20 us to the barrier, and the round waits for the slowest.)
+  uint32_t stride_pts = grid * W, first = worker ? blk * W + wt : n_pts, end_pts = n_pts;
+  if constexpr (MANY) {
+    const uint32_t units = (n_pts + 63u) / 64u, share = units / grid, extra = units % grid;  // uniform
+    const uint32_t u0 = blk * share + (blk < extra ? blk : extra), u1 = u0 + share + (blk < extra ? 1u : 0u);
+    stride_pts = W;
+    first = u0 * 64u + wt;
+    end_pts = u1 * 64u < n_pts ? u1 * 64u : n_pts;
+  }
   int4* memo = reinterpret_cast<int4*>(dyn_lds);
   double* stash = reinterpret_cast<double*>(dyn_lds + (size_t)a.memo_points * W * sizeof(int4));
   // parked points hold the planes that are read: 9 of a scan whose covariances are all bitwise symmetric, else 12
@@ -802,7 +814,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   double q0[kScanPlanes];
 #pragma unroll
   for (int k = 0; k < kScanPlanes; ++k) q0[k] = 0.0;
-  const bool have = first < n_pts;
+  const bool have = first < end_pts;
   if (have) load_point(a.scan, a.stride, first, q0);
 
   // what the first point used last round: key, hit flag, voxel payload (raw)
@@ -905,7 +917,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
         // a.stash_points are parked in LDS after round 0, the rest is re-read from HBM every round
         if (have) one_point(q0, 0u, Flag<true>{});
         uint32_t e = 1;
-        for (uint32_t i = first + stride_pts; i < n_pts; i += stride_pts, ++e) {
+        for (uint32_t i = first + stride_pts; i < end_pts; i += stride_pts, ++e) {
           double q[kScanPlanes];
           if (e <= parked) {
             double* slot = stash + (size_t)(e - 1) * park_planes * W + wt;
@@ -1406,8 +1418,9 @@ constexpr uint32_t kPrefetchBytes = kPersistWorkers * (sizeof(int4) + 6 * sizeof
 void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points, uint32_t* stash_bytes) {
   *memo_points = *stash_points = *stash_bytes = 0;
   if ((uint64_t)n <= (uint64_t)grid * kPersistWorkers) return;  // one point per thread: registers (and the neighbour prefetch area)
-  const uint64_t per_round = (uint64_t)grid * kPersistWide;
-  const uint32_t per_thread = (uint32_t)((n + per_round - 1) / per_round);  // points per thread (upper bound)
+  // units of 64 points, dealt out evenly: a workgroup holds at most ceil(units / grid), taken 8 units per pass
+  const uint32_t units = (n + 63u) / 64u, most = (units + grid - 1) / grid;
+  const uint32_t per_thread = (most + kPersistWide / 64 - 1) / (kPersistWide / 64);  // points per thread (upper bound)
   // the memo first (it saves the table access, the larger term), the rest of the LDS parks whole points
   const uint32_t memo = per_thread < kMaxMemoPoints ? per_thread : kMaxMemoPoints;
   *memo_points = memo;
