@@ -319,6 +319,40 @@ def test_persistent_launch_on_fewer_workgroups(c1_inputs, monkeypatch, grid):
         assert ctx.counter(1) == 0
 
 
+@pytest.mark.parametrize("grid,n", [(1, 9_000), (3, 20_000), (16, 131_072), (255, 131_073)])
+def test_persistent_launch_with_many_points_per_thread(c1_inputs, monkeypatch, grid, n):
+    """Scans much larger than the launch's grid: more points per thread than memos (12), a last pass that is partial
+    in some workgroups and missing in others (the scan is dealt out in units of 64 points), one point per thread in
+    the eight-wave mapping, and covariances that are NOT bitwise symmetric (parked points then hold twelve planes).
+    Same counts as the per-launch loop, sums equal to rounding, the same bits run to run and with nothing parked."""
+    from eskf_lio_amd import capi, synth
+    vmap = c1_inputs[0]
+    pts, covs = synth.make_uniform_scan(n, vmap, seed=grid)
+    g = synth.default_guess()
+    monkeypatch.setenv("VGICP_PERSIST_GRID", str(grid))
+    with capi.Context(0) as ctx:
+        monkeypatch.delenv("VGICP_PERSIST_GRID")
+        ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+        ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+        for skewed in (False, True):
+            c = covs.copy()
+            if skewed:
+                c[n // 3, 3] = np.nextafter(c[n // 3, 3], np.inf)      # c01 != c10 for one point: twelve planes are read
+            ctx.scan_upload(pts, c)
+            a = ctx.align_resident(g, 5, 1e-6, 2.0)
+            b = ctx.align_resident(g, 5, 1e-6, 2.0, flags=capi.FLAG_NO_PERSISTENT)
+            again = ctx.align_resident(g, 5, 1e-6, 2.0)
+            monkeypatch.setenv("VGICP_NO_STASH", "1")
+            bare = ctx.align_resident(g, 5, 1e-6, 2.0)
+            monkeypatch.delenv("VGICP_NO_STASH")
+            assert a.launches == 1 and b.launches > 1 and a.iterations == b.iterations == 5
+            assert np.array_equal(a.corr_count, b.corr_count)
+            assert np.allclose(a.normal_eq, b.normal_eq, rtol=1e-11, atol=1e-8)
+            assert np.array_equal(a.normal_eq, again.normal_eq) and np.array_equal(a.pose, again.pose)
+            assert np.array_equal(a.normal_eq, bare.normal_eq) and np.array_equal(a.pose, bare.pose)
+        assert ctx.counter(1) == 0
+
+
 def test_persistent_launch_that_gives_up_falls_back_and_recovers(c1_inputs, monkeypatch):
     """A persistent launch whose in-kernel wait runs out (forced here with a poll budget of zero; in the field:
     another process holds compute units) must leave no trace: the align is re-run with one launch per
