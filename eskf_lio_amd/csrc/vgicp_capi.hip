@@ -187,6 +187,7 @@ struct vgicp_ctx {
   bool scan_sym_known = false;       // the resident scan went through pack_scan_kernel (not a scan prepared on the device)
   int64_t prep_deskewed = 0;
   bool prep_with_deskew = false;
+  double prep_voxel = 0.0;           // > 0: the resident scan was down-sampled on the device to one point per voxel of this size
   // deferred map insertion (vgicp_map_insert_resident_async): running totals on the device, read at the next sync
   uint32_t* d_ins_counters = nullptr;
   uint32_t* h_ins_counters = nullptr;  // pinned
@@ -1066,6 +1067,17 @@ int vgicp_map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const 
   return VGICP_OK;
 }
 
+namespace {
+// A scan the device down-sampled itself holds one point per voxel of ITS grid: a voxel of the map then receives at
+// most (map voxel / scan voxel + 1)^3 of them, and when that is a handful the insertion goes without its sort
+// (launch_map_insert, short_lists).  Any other resident scan (uploaded as it came) keeps the sort.
+bool insertion_lists_stay_short(const vgicp_ctx* ctx) {
+  if (!(ctx->prep_voxel > 0.0) || std::getenv("VGICP_INSERT_SORT")) return false;
+  const double per_axis = std::ceil(ctx->voxel_size / ctx->prep_voxel) + 1.0;
+  return per_axis * per_axis * per_axis <= 64.0;
+}
+}  // namespace
+
 int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel,
                               size_t* new_voxels) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
@@ -1089,7 +1101,8 @@ int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
   VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size,
                                 ctx->d_scan_aos, ctx->d_scan_aos + 3 * ctx->scan_capacity, (uint32_t)n, pose12,
-                                (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_counters));
+                                (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_counters,
+                                insertion_lists_stay_short(ctx)));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->voxels += ctx->h_counters[0];
@@ -1122,7 +1135,8 @@ int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], 
   if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[4], ctx->stream)); ctx->ev_stage_set[4] = true; }
   VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size,
                                 ctx->d_scan_aos, ctx->d_scan_aos + 3 * ctx->scan_capacity, (uint32_t)n, pose12,
-                                (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_ins_counters));
+                                (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_ins_counters,
+                                insertion_lists_stay_short(ctx)));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_ins_counters, ctx->d_ins_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[5], ctx->stream)); ctx->ev_stage_set[5] = true; }
   ctx->insert_pending = true;
@@ -1237,6 +1251,7 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
   int rc = ensure_scan(ctx, n);
   if (rc != VGICP_OK) return rc;
   ctx->scan_ready = false;
+  ctx->prep_voxel = 0.0;
   ctx->n = (uint32_t)n;
   ctx->stride = ctx->scan_capacity;
   if (n == 0) return VGICP_OK;
@@ -1823,6 +1838,7 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   ctx->n_upper = 0;
   ctx->stride = ctx->scan_capacity;
   ctx->prep_with_deskew = with_deskew;
+  ctx->prep_voxel = voxel_size;
   ctx->prep_deskewed = 0;
   ctx->prep_indefinite = 0;
   if (n == 0) {

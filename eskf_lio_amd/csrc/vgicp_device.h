@@ -262,7 +262,10 @@ hipError_t launch_deskew(hipStream_t s, double* pts, uint32_t n, const double* p
 hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, double voxel_size,
                              const double* points_aos, const double* covs_aos, uint32_t n,
                              const double pose12[12], uint64_t max_points, void* scratch,
-                             size_t scratch_bytes, uint32_t* counters);
+                             size_t scratch_bytes, uint32_t* counters, bool short_lists = false);
+// short_lists: no sort — every voxel's points hang on a list (the record's spare word) that the voxel's first point
+// walks in scan order.  For scans that put a handful of points into a voxel at most (a scan the device down-sampled
+// itself); correct for any scan, quadratic in the points of one voxel beyond eight.
 // Erase every voxel whose centre is farther than `distance` from `position`; counters[0] += erased.
 hipError_t launch_map_evict(hipStream_t s, VoxelRecord* table, uint64_t slots, double voxel_size,
                             const double position[3], double distance, uint32_t* counters);

@@ -14,6 +14,16 @@
 //   3. apply     the thread at the head of a segment walks it and applies the constructor / addPoint
 //                arithmetic of the reference sequentially, in registers, one record write at the end
 // Arithmetic is bit-exact with the CPU path (tests compare means, covariances and counts with `==`).
+//
+// A scan that the device has down-sampled itself (vgicp_scan_prepare: one point per voxel of its grid) puts only a
+// handful of points into any voxel of the map, and for those the sort is most of the insertion's time (five launches
+// for 27 000 pairs).  launch_map_insert(..., short_lists = true) keeps the order without it:
+//   1. prepare   as above, and every point pushes itself onto its voxel's list (the record's spare word is the head:
+//                atomic exchange, the old head becomes the point's `next`); the point that found the list empty is the
+//                voxel's LEADER
+//   2. apply     the leader walks the list, takes the points in ascending index = scan order (a register buffer of
+//                kListChunk indices per walk; longer lists take several walks: correct for any length, quadratic
+//                beyond the buffer, which is why arbitrary scans keep the sort), applies them, empties the list.
 #include <hipcub/hipcub.hpp>
 #include <rocprim/rocprim.hpp>
 
@@ -142,6 +152,9 @@ __device__ __forceinline__ uint32_t prepare_point(VoxelRecord* table, uint32_t m
   return found;
 }
 
+// LISTS: idx_of receives the point's `next` on its voxel's list (index + 1 of the point that headed the list before;
+// 0: this point found the list empty and is the voxel's leader) instead of the point's own index for the sort.
+template <bool LISTS>
 __global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double voxel_size,
                                       const double* __restrict__ pts, const double* __restrict__ covs,
                                       uint32_t n, Pose12 pose, double* __restrict__ wpts,
@@ -153,7 +166,13 @@ __global__ void insert_prepare_kernel(VoxelRecord* table, uint32_t mask, double 
     const uint32_t found = prepare_point(table, mask, voxel_size, pts, covs, i, pose, wpts, wcovs, fresh);
     lost = found == kNoSlot;
     slot_of[i] = found;
-    idx_of[i] = i;
+    if constexpr (LISTS) {
+      uint32_t next = 0xFFFFFFFFu;  // on no list
+      if (!lost) next = atomicExch(reinterpret_cast<uint32_t*>(&table[found].reserved), i + 1u);
+      idx_of[i] = next;
+    } else {
+      idx_of[i] = i;
+    }
   }
   // one atomic per workgroup and counter (every wave of a scan that opens new ground creates some voxel: one
   // atomic per wave on the same word was half of this kernel's time)
@@ -205,6 +224,75 @@ __global__ void insert_apply_kernel(VoxelRecord* table, const uint32_t* __restri
 #pragma unroll
   for (int k = 0; k < 9; ++k) rec->cov[k] = cov[k];
   rec->count = count;
+}
+
+// The same for a voxel whose points hang on its list (short_lists): run by the voxel's leader.
+constexpr int kListChunk = 8;
+__global__ void insert_apply_list_kernel(VoxelRecord* table, const uint32_t* __restrict__ slot_of,
+                                         const uint32_t* __restrict__ next_of, uint32_t n,
+                                         const double* __restrict__ wpts, const double* __restrict__ wcovs,
+                                         uint64_t max_points) {
+  const uint32_t me = blockIdx.x * blockDim.x + threadIdx.x;
+  if (me >= n || next_of[me] != 0u) return;  // on no list (table full), or not the leader
+  VoxelRecord* rec = table + slot_of[me];
+  const uint32_t head = (uint32_t)rec->reserved;  // index + 1 of the point that pushed itself last
+  uint64_t count = rec->count;
+  double mean[3], cov[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) mean[k] = rec->mean[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) cov[k] = rec->cov[k];
+  auto apply = [&](uint32_t i) {
+    if (count == 0) {  // constructor
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mean[k] = wpts[3 * (size_t)i + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cov[k] = wcovs[9 * (size_t)i + k];
+      count = 1;
+    } else if (count < max_points) {  // addPoint
+#pragma clang fp contract(off)
+      const double nn = (double)count, n1 = (double)(count + 1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mean[k] = (nn * mean[k] + wpts[3 * (size_t)i + k]) / n1;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cov[k] = (nn * cov[k] + wcovs[9 * (size_t)i + k]) / n1;
+      ++count;
+    }
+  };
+  if (head == me + 1u) {
+    apply(me);  // the usual case: the voxel received this one point
+  } else {
+    // ascending index, kListChunk at a time: every walk keeps the smallest indices above the last one applied
+    long long done = -1;  // the largest index applied so far
+    for (;;) {
+      uint32_t buf[kListChunk];
+#pragma unroll
+      for (int k = 0; k < kListChunk; ++k) buf[k] = 0xFFFFFFFFu;
+      int held = 0;
+      for (uint32_t cur = head; cur != 0u; cur = next_of[cur - 1u]) {
+        uint32_t x = cur - 1u;
+        if ((long long)x <= done) continue;
+        // insert x into the ascending buffer, dropping the largest when it is full (static indices: registers)
+#pragma unroll
+        for (int k = 0; k < kListChunk; ++k) {
+          const uint32_t lo = x < buf[k] ? x : buf[k], hi = x < buf[k] ? buf[k] : x;
+          buf[k] = lo;
+          x = hi;
+        }
+        if (held < kListChunk) ++held;
+      }
+#pragma unroll
+      for (int k = 0; k < kListChunk; ++k)
+        if (k < held) { apply(buf[k]); done = (long long)buf[k]; }
+      if (held < kListChunk) break;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) rec->mean[k] = mean[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) rec->cov[k] = cov[k];
+  rec->count = count;
+  rec->reserved = 0;  // the list is empty again
 }
 
 // LocalMap::needsPointRemoval (src/LocalMap.cpp:149-154): |(index + 0.5) * voxelSize - position| > d
@@ -259,14 +347,23 @@ size_t map_insert_scratch_bytes(uint32_t n) {
 hipError_t launch_map_insert(hipStream_t s, VoxelRecord* table, uint32_t mask, double voxel_size,
                              const double* points_aos, const double* covs_aos, uint32_t n,
                              const double pose12[12], uint64_t max_points, void* scratch,
-                             size_t scratch_bytes, uint32_t* counters) {
+                             size_t scratch_bytes, uint32_t* counters, bool short_lists) {
   if (n == 0) return hipSuccess;
   if (scratch_bytes < map_insert_scratch_bytes(n)) return hipErrorInvalidValue;
   size_t cub_bytes = sort_temp_bytes(n);
   InsertScratch w = carve(scratch, n, cub_bytes);
   Pose12 pose;
   for (int k = 0; k < 12; ++k) pose.v[k] = pose12[k];
-  ++g_kernel_launches; hipLaunchKernelGGL(insert_prepare_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask,
+  if (short_lists) {
+    ++g_kernel_launches; hipLaunchKernelGGL(insert_prepare_kernel<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, table,
+                       mask, voxel_size, points_aos, covs_aos, n, pose, w.wpts, w.wcovs, w.slot_in, w.idx_in, counters);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    ++g_kernel_launches; hipLaunchKernelGGL(insert_apply_list_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table,
+                       w.slot_in, w.idx_in, n, w.wpts, w.wcovs, max_points);
+    return hipGetLastError();
+  }
+  ++g_kernel_launches; hipLaunchKernelGGL(insert_prepare_kernel<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask,
                      voxel_size, points_aos, covs_aos, n, pose, w.wpts, w.wcovs, w.slot_in, w.idx_in,
                      counters);
   hipError_t e = hipGetLastError();

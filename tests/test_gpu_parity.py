@@ -1340,6 +1340,43 @@ def test_preprocess_feeds_the_registration(gpu_ctx, oracle):
     assert et < 0.05 and er < 0.01                                 # and it recovers the motion
 
 
+@pytest.mark.parametrize("map_voxel,scan_voxel,cap", [(0.3, 0.3, 20), (0.3, 0.1, 5), (0.3, 0.1, 100), (1.0, 0.1, 100)])
+def test_resident_insertion_without_the_sort_is_bit_exact(oracle, monkeypatch, map_voxel, scan_voxel, cap):
+    """LocalMap::updateLocalMap (src/LocalMap.cpp:44-72) on a scan the device down-sampled itself: a map voxel receives
+    a handful of its points at most, and the insertion then keeps scan order through per-voxel lists instead of a sort
+    (launch_map_insert, short_lists).  Maps three times coarser than the scan's grid give lists longer than the
+    leader's register buffer (several walks); ten times coarser falls back to the sort.  Every variant must leave the
+    map the serial reference loop leaves: keys, means, covariances and counts compared with ==, over three frames
+    with different poses (existing voxels take addPoint, the cap freezes them)."""
+    from eskf_lio_amd import capi, synth
+    om = oracle.OracleMap(map_voxel, cap)
+    maps = {}
+    for variant in ("lists", "sort"):
+        if variant == "sort":
+            monkeypatch.setenv("VGICP_INSERT_SORT", "1")
+        with capi.Context(0) as ctx:
+            ctx.map_reset(map_voxel, 0)
+            for f in range(3):
+                raw = synth.make_lidar_scan(20_000, seed=40 + f)
+                T = synth.se3_to_SE3(np.array([0.3 * f, -0.2 * f, 0.05 * f, 0.01 * f, -0.02 * f, 0.03 * f]))
+                kept, _ = ctx.scan_prepare(raw, None, None, None, scan_voxel, 30)
+                if variant == "lists":
+                    gp, gc = ctx.scan_download()
+                    assert kept == len(gp)
+                    om.insert(*oracle.transform(gp, gc, T))
+                if f == 1:
+                    ctx.map_insert_resident_async(T, cap)              # the call that does not wait
+                else:
+                    ctx.map_insert_resident(T, cap)
+            maps[variant] = ctx.map_export()
+        monkeypatch.delenv("VGICP_INSERT_SORT", raising=False)
+    ref = _sorted_oracle_export(om)
+    for variant, got in maps.items():
+        assert len(got[0]) == len(om), variant
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), variant
+
+
 def test_host_mirror_cloud_preprocessor(oracle):
     """ESKF_LIO::CloudPreprocessor::voxelDownsampleAndEstimateCovariances through the C++ mirror
     (include/eskf_lio_shim/CloudPreprocessor.hpp): the cloud comes back as the oracle leaves it."""
