@@ -195,6 +195,9 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
         out.update({
             "ms_per_frame": wall / frames * 1e3,
             "kernel_launches_per_frame": fs.kernel_launches / frames,
+            "kernel_launches_note": "counted by the library; rocPRIM's merge sort (the scan preparation's one sort) is counted "
+                                    "as one block sort + one launch per doubling of the run length, rocprofv3 sees two more "
+                                    "at this size (profiles/*_frame_kernel_stats.csv)",
             "copies_per_frame": fs.copies / frames,
             "host_syncs_per_frame": fs.host_syncs / frames,
             "align_rounds_per_frame": float(np.mean([r.iterations for r in results])),
