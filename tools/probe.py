@@ -31,7 +31,7 @@ pts, covs = synth.make_uniform_scan(n, vmap)
 guess = synth.default_guess()
 print(f"[probe] {cfg}: inputs in {time.time() - t0:.1f}s", flush=True)
 with capi.Context(0) as ctx:
-    ctx.map_reset(vmap.voxel_size, v)
+    ctx.map_reset(vmap.voxel_size, int(os.environ.get("PROBE_MAP_HINT", v)))   # PROBE_MAP_HINT: size the table for fewer voxels (a fuller, smaller table)
     t0 = time.time()
     ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
     print(f"[probe] map upsert {time.time() - t0:.3f}s size {ctx.map_size()}", flush=True)
