@@ -742,8 +742,9 @@ __device__ __forceinline__ void load_payload(const VoxelRecord* rec, double (&mu
 
 // MULTI: several GPUs (the rank totals cross xGMI through mailboxes); STAMPS: in-kernel phase clocks
 // (VGICP_DEBUG_STAMPS=1).  Separate instantiations: the single-GPU production kernel carries neither.
-// MANY: a thread owns several points (scan larger than grid x 448); all of them go through the memo / stash in LDS
-// and nothing point-specific stays in registers.  !MANY: one point per thread, kept in registers together with the
+// MANY: a thread owns several points (scan larger than grid x 448), wave 0 included; every point has a memo in LDS, the
+// thread's first point stays in registers (its voxel record does not), some more are parked in LDS.  !MANY: one point
+// per thread (waves 1..7), kept in registers together with the
 // voxel record it used, plus the neighbour prefetch.  Separate instantiations keep both within 256 VGPRs.
 template <int BLOCK, bool MULTI, bool STAMPS, bool MANY>
 __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
