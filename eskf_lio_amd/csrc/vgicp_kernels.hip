@@ -747,7 +747,7 @@ __device__ __forceinline__ void load_payload(const VoxelRecord* rec, double (&mu
 // per thread (waves 1..7), kept in registers together with the
 // voxel record it used, plus the neighbour prefetch.  Separate instantiations keep both within 256 VGPRs.
 template <int BLOCK, bool MULTI, bool STAMPS, bool MANY>
-__global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
+__device__ __forceinline__ void persistent_body(const PersistArgs& a) {
   static_assert(BLOCK / kSlots == kFolders, "the exchange reproduces the fold order of iterate_kernel<512>");
   constexpr int kWaves = BLOCK / 64;
   constexpr int kWorkers = BLOCK - 64;
@@ -1152,6 +1152,23 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
     atomicAdd((unsigned long long*)&a.stamps[o + 3], (unsigned long long)acc_solve);
     atomicAdd((unsigned long long*)&a.stamps[o + 5], (unsigned long long)it);
   }
+}
+
+// The launch.  A MANY launch is planned from a.n, which is an UPPER BOUND for a scan whose size is still on the device
+// (a scan prepared there and aligned without waiting for its count): when the real size turns out to fit the grid
+// after all, the workgroups run the one-point-per-thread body — the mapping, the sums and hence the bits of the launch
+// that a settled scan of that size gets (without the neighbour prefetch, which changes no result) — so the chain that
+// does not wait returns the bits of the one that does, whatever the sweep's raw size.
+template <int BLOCK, bool MULTI, bool STAMPS, bool MANY>
+__global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
+  if constexpr (MANY) {
+    const uint32_t n_pts = a.n_dev ? *a.n_dev : a.n;  // uniform
+    if (n_pts <= gridDim.x * (uint32_t)(BLOCK - 64)) {
+      persistent_body<BLOCK, MULTI, STAMPS, false>(a);
+      return;
+    }
+  }
+  persistent_body<BLOCK, MULTI, STAMPS, MANY>(a);
 }
 
 // Multi-GPU only: fold this rank's rows into one row (fixed order) so the all-reduce moves 256 B.
