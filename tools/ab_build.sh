@@ -9,7 +9,9 @@ OUT=$ROOT/eskf_lio_amd/lib_ab/$NAME
 mkdir -p "$OUT" /tmp/ab_$NAME
 cd "$ROOT/eskf_lio_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-unused-parameter $*"
-/opt/rocm/bin/hipcc $FLAGS -c -o /tmp/ab_$NAME/k.o vgicp_kernels.hip &
+# the kernels file with the Makefile's scheduler strategy (KERNEL_SCHED="" tools/ab_build.sh ... builds without it)
+KS=${KERNEL_SCHED--mllvm -amdgpu-sched-strategy=max-memory-clause}
+/opt/rocm/bin/hipcc $FLAGS $KS -c -o /tmp/ab_$NAME/k.o vgicp_kernels.hip &
 /opt/rocm/bin/hipcc $FLAGS -Wno-unused-function -c -o /tmp/ab_$NAME/m.o vgicp_mapupdate.hip &
 /opt/rocm/bin/hipcc $FLAGS -ffp-contract=off -Wno-unused-function -c -o /tmp/ab_$NAME/p.o vgicp_preprocess.hip &
 /opt/rocm/bin/hipcc $FLAGS -c -o /tmp/ab_$NAME/c.o vgicp_capi.hip &
