@@ -188,6 +188,12 @@ struct vgicp_ctx {
   int64_t prep_deskewed = 0;
   bool prep_with_deskew = false;
   double prep_voxel = 0.0;           // > 0: the resident scan was down-sampled on the device to one point per voxel of this size
+  // the deskew's state table on its way to the device: pinned, two slots in turn (an enqueue-only preparation returns
+  // before the copy has run, so the table cannot live on the caller's stack)
+  double* h_state_table[2] = {nullptr, nullptr};
+  size_t state_table_cap[2] = {0, 0};
+  hipEvent_t ev_state_table[2] = {nullptr, nullptr};
+  uint32_t state_table_next = 0;
   // deferred map insertion (vgicp_map_insert_resident_async): running totals on the device, read at the next sync
   uint32_t* d_ins_counters = nullptr;
   uint32_t* h_ins_counters = nullptr;  // pinned
@@ -896,6 +902,10 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipFree(ctx->d_tiles);
   (void)hipFree(ctx->d_ins_counters);
   (void)hipHostFree(ctx->h_ins_counters);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->h_state_table[k]) (void)hipHostFree(ctx->h_state_table[k]);
+    if (ctx->ev_state_table[k]) (void)hipEventDestroy(ctx->ev_state_table[k]);
+  }
   for (auto& e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
   (void)hipFree(ctx->d_stage);
   (void)hipFree(ctx->d_cells);
@@ -943,7 +953,13 @@ int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
     case VGICP_COUNTER_PERSISTENT_FALLBACKS: *value = ctx->persistent_fallbacks; break;
     case VGICP_COUNTER_UPLOAD_BYTES: *value = ctx->upload_bytes; break;
     case VGICP_COUNTER_UPLOAD_NANOSECONDS: *value = (uint64_t)(ctx->upload_seconds * 1e9); break;
-    case VGICP_COUNTER_PREP_INDEFINITE: *value = ctx->prep_indefinite; break;
+    case VGICP_COUNTER_PREP_INDEFINITE: {
+      // a preparation that was only enqueued has not reported yet: bring it up to date like every other reader
+      const int rc_settle = settle(const_cast<vgicp_ctx*>(ctx));
+      if (rc_settle != VGICP_OK) return rc_settle;
+      *value = ctx->prep_indefinite;
+      break;
+    }
     default: return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown counter");
   }
   return VGICP_OK;
@@ -1252,6 +1268,9 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
   if (rc != VGICP_OK) return rc;
   ctx->scan_ready = false;
   ctx->prep_voxel = 0.0;
+  ctx->prep_with_deskew = false;   // what vgicp_scan_info reports belongs to a PREPARED scan, not to this one
+  ctx->prep_deskewed = 0;
+  ctx->prep_indefinite = 0;
   ctx->n = (uint32_t)n;
   ctx->stride = ctx->scan_capacity;
   if (n == 0) return VGICP_OK;
@@ -1852,6 +1871,9 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     ctx->prep_deskewed = -1;
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the IMU states do not bracket the end of the sweep");
   }
+  // the fused prologue keeps the segment ends of the states that can own points in LDS (4 bytes each, 64 KB by default)
+  if (used > kPrepareMaxStates)
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "more than 16000 IMU states inside one sweep: use vgicp_deskew + vgicp_preprocess");
   // stage: [points 3n][times n][state table][segment ends + first hits][kept index n][scratch]
   const size_t pb = (n * 3 * sizeof(double) + 255) & ~size_t(255);
   const size_t tb = (n * sizeof(double) + 255) & ~size_t(255);
@@ -1871,7 +1893,20 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   DeskewOnDevice dk;
   if (with_deskew) {
     VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    VG_HIP(ctx, hipMemcpyAsync(d_states, host.data(), used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t slot = ctx->state_table_next++ & 1u;
+    if (ctx->ev_state_table[slot]) VG_HIP(ctx, hipEventSynchronize(ctx->ev_state_table[slot]));  // long complete, normally
+    else VG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_state_table[slot], hipEventDisableTiming));
+    if (ctx->state_table_cap[slot] < used * 13) {
+      if (ctx->h_state_table[slot]) VG_HIP(ctx, hipHostFree(ctx->h_state_table[slot]));
+      ctx->h_state_table[slot] = nullptr;
+      ctx->state_table_cap[slot] = 0;
+      const size_t cap = std::max<size_t>(used * 13 * 2, 13 * 256);
+      VG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state_table[slot]), cap * sizeof(double), 0));
+      ctx->state_table_cap[slot] = cap;
+    }
+    std::memcpy(ctx->h_state_table[slot], host.data(), used * 13 * sizeof(double));
+    VG_HIP(ctx, hipMemcpyAsync(d_states, ctx->h_state_table[slot], used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VG_HIP(ctx, hipEventRecord(ctx->ev_state_table[slot], ctx->stream));
     dk.point_time = d_time;
     dk.state_time = d_states;
     dk.poses = d_states + used;

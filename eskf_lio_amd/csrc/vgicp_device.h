@@ -209,6 +209,7 @@ constexpr int kDeskewedCounter = 74;
 constexpr int kScanTimeout = 75;
 constexpr int kTicketA = 76;
 constexpr int kTicketB = 77;
+constexpr uint32_t kPrepareMaxStates = 16000;  // IMU states that can own points of ONE sweep in the fused preparation (LDS)
 constexpr uint32_t kMaxScanTiles = 4096;  // x 2 048 points: scans up to 8 M points
 size_t preprocess_scratch_bytes(uint32_t n);
 int preprocess_max_knn();

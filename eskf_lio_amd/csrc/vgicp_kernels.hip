@@ -769,7 +769,8 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
   const bool prefetch = !MANY && a.prefetch_margin > 0.0;  // uniform
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t n_pts = a.n_dev ? *a.n_dev : a.n;  // uniform
+  // a.n bounds the count the device holds (a scan preparation that gave up must not send this launch out of range)
+  const uint32_t n_pts = a.n_dev ? (*a.n_dev < a.n ? *a.n_dev : a.n) : a.n;  // uniform
   const bool cov_sym = MANY && a.asym_dev != nullptr && *a.asym_dev != a.scan_seq;  // uniform
   const uint32_t grid = gridDim.x, blk = blockIdx.x;
   // MANY (the scan, or the upper bound the launch plan was made from, has more points than grid x 448): a thread owns
@@ -1162,7 +1163,7 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
 template <int BLOCK, bool MULTI, bool STAMPS, bool MANY>
 __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a) {
   if constexpr (MANY) {
-    const uint32_t n_pts = a.n_dev ? *a.n_dev : a.n;  // uniform
+    const uint32_t n_pts = a.n_dev ? (*a.n_dev < a.n ? *a.n_dev : a.n) : a.n;  // uniform
     if (n_pts <= gridDim.x * (uint32_t)(BLOCK - 64)) {
       persistent_body<BLOCK, MULTI, STAMPS, false>(a);
       return;

@@ -26,9 +26,10 @@
 //      the k-th distance: the result is the EXACT k nearest neighbours, ties broken by index, for
 //      work proportional to what lies inside that ball (DESIGN.md §9 has the measurements behind
 //      every choice in this kernel)
-//   5. one THREAD per kept point: cumulants in ascending-distance order, covariance, cyclic-Jacobi
-//      eigen-decomposition (for a symmetric positive semi-definite matrix U = V = eigenvectors),
-//      U diag(1,1,1e-2) U^T.
+//   5. one THREAD per kept point: cumulants in ascending-distance order, Open3D's cumulant covariance, then
+//      svd.matrixU() diag(1,1,1e-2) svd.matrixV()^T with Eigen 3.4's two-sided JacobiSVD restated in its
+//      published operation order (U != V where an eigenvalue of the — in floating point possibly indefinite —
+//      covariance is negative: the reference then emits an indefinite matrix, and so does this kernel).
 // Output order is ascending original index (the reference's is unordered_map iteration order).
 // This file is compiled without FMA contraction and keeps the oracle's operation order: the
 // distances, sums and rotations round as they do on the CPU.
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
   __shared__ uint32_t tile_sh;
   __shared__ RunMin wave_tot[kScanThreads / 64];
   __shared__ RunMin prefix_sh;
+  __shared__ uint32_t abort_sh;
   const RunMinOp op;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) tile_sh = atomicAdd(&counters[kTicketA], 1u);
@@ -397,10 +399,22 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
       const RunMin sc = runmin_wave_scan(v, lane);
       pre = op(pre, runmin_lane(sc, 63));
     }
-    if (__any(late) && lane == 0u) counters[kScanTimeout] = epoch;
-    if (lane == 0u) prefix_sh = pre;
+    const bool gave_up = __any(late);
+    if (gave_up && lane == 0u) counters[kScanTimeout] = epoch;
+    if (lane == 0u) {
+      prefix_sh = pre;
+      abort_sh = gave_up ? 1u : 0u;
+    }
   }
   __syncthreads();
+  if (abort_sh != 0u) {
+    // The prefix was folded from slots that were never published (stale values of an older call, possibly of a larger
+    // scan): nothing this tile would store is trustworthy, and the indices it would store THROUGH are not even in
+    // range.  No store at all; the tile that owns the scan's total leaves an empty scan behind, so that a kernel
+    // enqueued behind the preparation (the align that does not wait for the host) finds nothing to read.
+    if (tid == 0 && (size_t)(tile + 1) * kScanTile >= n) counters[0] = counters[1] = 0u;
+    return;
+  }
   RunMin base_prefix = prefix_sh;
   for (uint32_t w = 0; w < wave; ++w) base_prefix = op(base_prefix, wave_tot[w]);
   base_prefix = op(base_prefix, excl);
@@ -429,6 +443,7 @@ __global__ __launch_bounds__(kScanThreads) void keep_scan_kernel(const uint32_t*
   __shared__ uint32_t tile_sh;
   __shared__ uint32_t wave_tot[kScanThreads / 64];
   __shared__ uint32_t prefix_sh;
+  __shared__ uint32_t abort_sh;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) tile_sh = atomicAdd(&counters[kTicketB], 1u);
   __syncthreads();
@@ -472,10 +487,15 @@ __global__ __launch_bounds__(kScanThreads) void keep_scan_kernel(const uint32_t*
       for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
       pre += v;
     }
-    if (__any(late) && lane == 0u) counters[kScanTimeout] = epoch;
-    if (lane == 0u) prefix_sh = pre;
+    const bool gave_up = __any(late);
+    if (gave_up && lane == 0u) counters[kScanTimeout] = epoch;
+    if (lane == 0u) {
+      prefix_sh = pre;
+      abort_sh = gave_up ? 1u : 0u;
+    }
   }
   __syncthreads();
+  if (abort_sh != 0u) return;  // a prefix made of stale slots: no output slot is written (every reader checks the timeout word)
   uint32_t run = prefix_sh + (incl - sum);
   for (uint32_t w = 0; w < wave; ++w) run += wave_tot[w];
 #pragma unroll

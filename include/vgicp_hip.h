@@ -258,7 +258,12 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
  *                                 synchronisation (a failure of the insertion is reported by the next call that
  *                                 synchronises: vgicp_align_resident, vgicp_map_size, ...).
  * vgicp_scan_info returns what the last preparation found (it synchronises if that is still pending). Any other
- * entry point first brings a pending preparation / insertion up to date. */
+ * entry point first brings a pending preparation / insertion up to date.
+ * Lifetime of the caller's buffers: `points` and `point_time` of vgicp_scan_prepare_async must stay valid and unchanged
+ * until the next call that synchronises (vgicp_align_resident, vgicp_scan_info, ...).  From pageable memory the copy
+ * has in fact been made when the call returns, but a buffer registered with vgicp_host_register is read by the DMA
+ * engine later, in stream order.  `states` and `extrinsic` are copied before the call returns.  At most 16 000 IMU
+ * states may fall inside one sweep (VGICP_ERR_BAD_ARGUMENT beyond; vgicp_deskew has no such limit). */
 int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
                              size_t num_states, const double* states, const double extrinsic[16],
                              double voxel_size, int knn);
