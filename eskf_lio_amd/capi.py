@@ -26,7 +26,7 @@ PEER_HANDLE_BYTES = 64
 
 # every symbol include/vgicp_hip.h declares
 EXPORTS = (
-    "vgicp_abi_version", "vgicp_create", "vgicp_destroy", "vgicp_last_error", "vgicp_device_info",
+    "vgicp_abi_version", "vgicp_create", "vgicp_create_multi", "vgicp_destroy", "vgicp_last_error", "vgicp_device_info",
     "vgicp_get_counter",
     "vgicp_map_reset", "vgicp_map_upsert", "vgicp_map_erase", "vgicp_map_size",
     "vgicp_map_insert_scan", "vgicp_map_insert_resident", "vgicp_map_evict", "vgicp_map_export",
@@ -86,6 +86,7 @@ def load_library() -> C.CDLL:
     sz = C.c_size_t
     lib.vgicp_abi_version.restype = C.c_int
     lib.vgicp_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.vgicp_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     lib.vgicp_destroy.argtypes = [vp]
     lib.vgicp_last_error.argtypes = [vp]
     lib.vgicp_last_error.restype = C.c_char_p
@@ -199,12 +200,18 @@ def expand_normal_eq(rows: np.ndarray):
 
 
 class Context:
-    """One vgicp_ctx bound to one HIP device (one process per GPU)."""
+    """One vgicp_ctx: bound to one HIP device, or (a list of ordinals) driving several from this one thread."""
 
-    def __init__(self, device_id: int = 0):
+    def __init__(self, device_id=0):
+        """device_id: one ordinal, or a sequence of ordinals for an in-process multi-device context
+        (vgicp_create_multi; an ordinal may repeat: those sub-contexts share the device's compute units)."""
         self._lib = load_library()
         self._h = C.c_void_p()
-        rc = self._lib.vgicp_create(int(device_id), C.byref(self._h))
+        if isinstance(device_id, (list, tuple)):
+            ids = (C.c_int * len(device_id))(*[int(d) for d in device_id])
+            rc = self._lib.vgicp_create_multi(ids, len(device_id), C.byref(self._h))
+        else:
+            rc = self._lib.vgicp_create(int(device_id), C.byref(self._h))
         if rc != OK:
             msg = self._lib.vgicp_last_error(None).decode()
             self._h = C.c_void_p()

@@ -6,251 +6,18 @@
 // the thread merge at reference src/Registration.cpp:71-75).
 // No PyTorch, no oracle, no CPU fallback: without a gfx950 device every compute entry point fails
 // with VGICP_ERR_NO_DEVICE / VGICP_ERR_HIP.
-#include <dlfcn.h>
-#include <hip/hip_runtime.h>
+#include "vgicp_context.h"
 
-#include <chrono>
-#include <condition_variable>
-#include <limits>
-#include <mutex>
-#include <thread>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "../../include/vgicp_hip.h"
-#include "vgicp_device.h"
-
-using namespace vgicp;
-
-// what a frame costs the host besides kernels: copies / memsets enqueued and synchronisations (vgicp_get_frame_stats)
-namespace { thread_local uint64_t g_copy_ops = 0, g_sync_ops = 0; }
-#define hipMemcpyAsync(...) (++g_copy_ops, hipMemcpyAsync(__VA_ARGS__))
-#define hipMemsetAsync(...) (++g_copy_ops, hipMemsetAsync(__VA_ARGS__))
-#define hipStreamSynchronize(...) (++g_sync_ops, hipStreamSynchronize(__VA_ARGS__))
-#define hipEventSynchronize(...) (++g_sync_ops, hipEventSynchronize(__VA_ARGS__))
-
-namespace {
-
-// ---- the few RCCL entry points used, bound at run time so the library loads without RCCL ----
-typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[VGICP_UNIQUE_ID_BYTES]; } ncclUniqueId;
-struct RcclApi {
-  void* lib = nullptr;
-  int (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  int (*CommDestroy)(ncclComm_t) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-};
-constexpr int kNcclDouble = 8;  // ncclFloat64, rccl.h
-constexpr int kNcclSum = 0;
-constexpr int kNcclChar = 0;   // ncclInt8
-
+namespace vgicp {
+thread_local uint64_t g_copy_ops = 0, g_sync_ops = 0;
 thread_local std::string g_create_error;
-
-double now_seconds() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-uint64_t next_pow2(uint64_t v) {
-  uint64_t p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
-
-constexpr uint64_t kMinSlots = 1024;
-constexpr int kDefaultChunk = 4;
-constexpr int kMaxChunksInFlight = 2;
-constexpr int kPersistentCooldownAligns = 8;  // aligns on the per-launch loop after the single launch gave up
-
-}  // namespace
-
-// A second host thread for the scan upload. hipMemcpyAsync from pageable memory the runtime has never seen spends
-// as long again preparing the pages as the DMA then takes (tools/micro/h2d_cold_probe.hip: 9.6 MB cold 0.35 - 0.56 ms
-// on one thread, 0.27 - 0.28 ms with the two arrays on two threads and two streams; buffers seen before: 0.19 / 0.20
-// ms).  The helper copies the points while the caller's thread copies the covariances; the context's stream waits
-// for the helper's event before the pack kernel.
-struct UploadHelper {
-  std::thread th;
-  std::mutex m;
-  std::condition_variable cv;
-  bool has_job = false, done = true, quit = false;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev = nullptr;
-  void* dst = nullptr;
-  const void* src = nullptr;
-  size_t bytes = 0;
-  hipError_t result = hipSuccess;
-
-  void run() {
-    (void)hipSetDevice(device);
-    std::unique_lock<std::mutex> lk(m);
-    for (;;) {
-      cv.wait(lk, [&] { return has_job || quit; });
-      if (quit) return;
-      has_job = false;
-      lk.unlock();
-      hipError_t e = (hipMemcpyAsync)(dst, src, bytes, hipMemcpyHostToDevice, stream);
-      if (e == hipSuccess) e = hipEventRecord(ev, stream);
-      lk.lock();
-      result = e;
-      done = true;
-      cv.notify_all();
-    }
-  }
-  void post(void* d, const void* s, size_t n) {
-    std::lock_guard<std::mutex> lk(m);
-    dst = d; src = s; bytes = n;
-    done = false;
-    has_job = true;
-    cv.notify_all();
-  }
-  hipError_t wait() {
-    std::unique_lock<std::mutex> lk(m);
-    cv.wait(lk, [&] { return done; });
-    return result;
-  }
-};
-
-struct vgicp_ctx {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  mutable std::string err;
-  int cu_count = 0;
-  uint64_t hbm_bytes = 0;
-  std::string arch;
-
-  // voxel table
-  double voxel_size = 0.0;
-  VoxelRecord* table = nullptr;
-  uint64_t slots = 0;
-  uint64_t voxels = 0;      // FULL records
-  uint64_t tombstones = 0;
-  uint32_t* d_counters = nullptr;  // 8 words + 64 of developer histograms (VGICP_DEBUG_PREP=2)
-  uint32_t* h_counters = nullptr;  // pinned
-
-  // batch staging (upsert / erase / hooks)
-  void* d_stage = nullptr;
-  size_t stage_bytes = 0;
-  void* d_cells = nullptr;  // cell table of the scan preparation (vgicp_preprocess)
-  size_t cells_bytes = 0;
-
-  // resident scan
-  double* d_scan_aos = nullptr;  // points (3n) then covs (9n)
-  double* d_scan = nullptr;      // SoA planes
-  size_t scan_capacity = 0;      // points
-  uint32_t n = 0;
-  uint64_t stride = 0;
-  bool scan_ready = false;
-
-  // align state
-  AlignState* d_state = nullptr;  // two, ping-pong: launch j reads [j&1], writes [(j+1)&1]
-  AlignState* h_state = nullptr;  // pinned, kMaxChunksInFlight + 1 slots
-  double* d_rows[2] = {nullptr, nullptr};  // partial rows, ping-pong like the state
-  double* d_sums = nullptr;       // one row: the all-reduce message (multi-GPU)
-  // persistent single-launch align (single GPU)
-  uint32_t persist_round0 = 0;       // rounds the persistent launches of this context have executed, mod 3
-  uint32_t persist_seq = 0;
-  uint32_t persist_grid = 0;         // workgroups of every persistent launch: min(CUs, kExchangeRows), all resident
-  double* d_rows_persist = nullptr;  // [3][kExchangeRows][kSlots] (vgicp_device.h, PersistArgs)
-  double* d_parts_persist = nullptr; // [3][kFolders][kSlots]
-  void* h_exchange_image = nullptr;  // pinned: what the two buffers hold between launches
-  bool persistent_enabled = true;    // cleared by VGICP_PERSISTENT=0 or when a workgroup does not fit a CU
-  double prefetch_margin = 0.03;     // see PersistArgs::prefetch_margin; VGICP_PREFETCH_MARGIN overrides (0 = off)
-  uint32_t persist_spin_limit = 50000;  // polls (>= ~1 us each) before an in-kernel wait gives up
-  int persistent_cooldown = 0;       // aligns left on the per-launch loop after an in-kernel wait timed out
-  uint64_t persistent_launches = 0;  // diagnostics (vgicp_get_counter)
-  uint64_t persistent_fallbacks = 0;
-  uint64_t upload_bytes = 0;
-  double upload_seconds = 0.0;
-  uint64_t prep_indefinite = 0;      // kept points of the last scan preparation with an indefinite covariance
-  UploadHelper* uploader = nullptr;  // created with the first large upload (VGICP_UPLOAD_THREADS=1 keeps one thread)
-  bool uploader_enabled = true;
-  // host buffers uploaded recently (address of the covariances, ring of 1 024): a buffer the runtime has seen before
-  // goes up fastest from ONE thread (9.6 MB: 0.19 ms against 0.33 ms with two), a new one from TWO (0.32 against 0.44)
-  const void* seen_ptr[1024] = {nullptr};
-  size_t seen_bytes[1024] = {0};
-  uint32_t seen_next = 0;
-  // scan preparation without host round trips
-  void* d_tiles = nullptr;           // tile slots of the two device-wide scans
-  uint32_t* h_prep = nullptr;        // pinned: the counter block as a preparation left it (kCounterWords)
-  uint32_t prep_epoch = 0;
-  bool scan_pending = false;         // a prepared scan is resident but the host has not read its size / verdict yet
-  uint32_t n_upper = 0;              // raw points of the pending scan (>= its kept points)
-  uint32_t scan_seq = 0;             // uploads so far; pack_scan_kernel marks an asymmetric covariance with it
-  bool scan_sym_known = false;       // the resident scan went through pack_scan_kernel (not a scan prepared on the device)
-  int64_t prep_deskewed = 0;
-  bool prep_with_deskew = false;
-  double prep_voxel = 0.0;           // > 0: the resident scan was down-sampled on the device to one point per voxel of this size
-  // the deskew's state table on its way to the device: pinned, two slots in turn (an enqueue-only preparation returns
-  // before the copy has run, so the table cannot live on the caller's stack)
-  double* h_state_table[2] = {nullptr, nullptr};
-  size_t state_table_cap[2] = {0, 0};
-  hipEvent_t ev_state_table[2] = {nullptr, nullptr};
-  uint32_t state_table_next = 0;
-  // deferred map insertion (vgicp_map_insert_resident_async): running totals on the device, read at the next sync
-  uint32_t* d_ins_counters = nullptr;
-  uint32_t* h_ins_counters = nullptr;  // pinned
-  uint32_t ins_seen[2] = {0, 0};
-  bool insert_pending = false;
-  uint64_t insert_pending_upper = 0;
-  // frame statistics
-  uint64_t stat_launches0 = 0, stat_copies0 = 0, stat_syncs0 = 0;
-  bool stage_events = false;
-  hipEvent_t ev_stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [6]: behind the prologue
-  bool ev_stage_set[7] = {false, false, false, false, false, false, false};
-  int iter_block = 512;           // threads per workgroup of the iteration kernel (measured best at C2)
-  double* d_log = nullptr;
-  double* h_log = nullptr;  // pinned
-  double* h_log_dev = nullptr;  // the same memory as the device addresses it (the persistent launch writes state + log there)
-  int log_capacity = 0;     // iterations
-  uint64_t* d_stamps = nullptr;  // only with VGICP_DEBUG_STAMPS=1
-  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-  hipEvent_t ev_chunk[kMaxChunksInFlight] = {nullptr, nullptr};
-  std::vector<hipEvent_t> ev_prof;
-
-  // device-initiated exchange between GPUs: peer-mapped mailboxes (vgicp_peer_*)
-  double* d_mail = nullptr;            // this rank's mailbox, fine-grained device memory, [3][kMaxRanks][kSlots]
-  double* peer_mail[kMaxRanks] = {nullptr};  // every rank's mailbox as mapped here ([peer_rank] = d_mail)
-  double** d_mail_table = nullptr;     // device copy of peer_mail
-  int peer_world = 1, peer_rank = 0;
-  bool peers_connected = false;
-  bool peer_enabled = true;            // cleared for good when a launch gave up waiting for a peer
-  uint32_t mail_round0 = 0;            // rounds executed through the mailboxes so far (same on every rank)
-  uint32_t mail_seq = 0;               // aligns attempted through the mailboxes so far (same on every rank)
-
-  // RCCL
-  RcclApi rccl;
-  ncclComm_t comm = nullptr;
-  int world_size = 1;
-  int rank = 0;
-};
+}  // namespace vgicp
 
 namespace {
 
 int settle(vgicp_ctx* ctx);         // defined with the scan preparation below
 int settle_scan(vgicp_ctx* ctx);
 int settle_insert(vgicp_ctx* ctx);
-
-int fail(const vgicp_ctx* ctx, int code, const std::string& text) {
-  if (ctx) ctx->err = text; else g_create_error = text;
-  return code;
-}
-int fail_hip(const vgicp_ctx* ctx, hipError_t e, const char* what) {
-  return fail(ctx, VGICP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-
-#define VG_HIP(ctx, call)                                              \
-  do {                                                                 \
-    hipError_t e__ = (call);                                           \
-    if (e__ != hipSuccess) return fail_hip((ctx), e__, #call);         \
-  } while (0)
 
 int ensure_stage(vgicp_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->stage_bytes) return VGICP_OK;
@@ -532,6 +299,12 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
     // missing, the result must not be used.  Put the exchange back into its initial state, use the per-launch
     // loop for this align and the next few, then try the single launch again.
     ++ctx->persistent_fallbacks;
+    if (ctx->owner && multi) {
+      // a sub-context of an in-process multi-device context: every sub-context's launch has ended when its thread
+      // returns, so the group itself re-arms all mailboxes and runs this align with the rows added on the host
+      const int rc_reset = reset_persistent_exchange(ctx);
+      return rc_reset != VGICP_OK ? rc_reset : vgicp_internal::kNeedGroupLoop;
+    }
     ctx->persistent_cooldown = kPersistentCooldownAligns;
     if (ctx->persistent_fallbacks == 1 || std::getenv("VGICP_VERBOSE"))
       std::fprintf(stderr, "[vgicp] persistent align launch gave up waiting for a workgroup%s (fallback #%llu): using one "
@@ -580,6 +353,7 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
   const bool single_launch = !(ctx->persistent_cooldown > 0 && !peer_path) && ctx->persistent_enabled &&
                              (alone || peer_path) && !profile && max_it > 0 &&
                              (params->flags & VGICP_FLAG_NO_PERSISTENT) == 0;
+  if (ctx->owner && ctx->peer_world > 1 && !single_launch) return vgicp_internal::kNeedGroupLoop;  // the group's host-summed loop
   if (!single_launch) {
     // the launch-per-round loop sizes its grid from the scan: a pending scan has to be settled first
     rc = settle(ctx);
@@ -719,7 +493,7 @@ int ensure_mailbox(vgicp_ctx* ctx) {
 
 void close_peers(vgicp_ctx* ctx) {
   for (int r = 0; r < kMaxRanks; ++r) {
-    if (ctx->peer_mail[r] && ctx->peer_mail[r] != ctx->d_mail) (void)hipIpcCloseMemHandle(ctx->peer_mail[r]);
+    if (ctx->peer_mail_is_ipc && ctx->peer_mail[r] && ctx->peer_mail[r] != ctx->d_mail) (void)hipIpcCloseMemHandle(ctx->peer_mail[r]);
     ctx->peer_mail[r] = nullptr;
   }
   ctx->peers_connected = false;
@@ -732,7 +506,11 @@ extern "C" {
 
 int vgicp_abi_version(void) { return VGICP_ABI_VERSION; }
 
-int vgicp_create(int device_id, vgicp_ctx** out) {
+int vgicp_create(int device_id, vgicp_ctx** out) { return vgicp_internal::create_context(device_id, 0, out); }
+
+}  // extern "C"
+
+int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgicp_ctx** out) {
   if (!out) return fail(nullptr, VGICP_ERR_BAD_ARGUMENT, "out is NULL");
   *out = nullptr;
   int count = 0;
@@ -792,6 +570,7 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_parts_persist), persistent_parts_words() * 8));
   VG_CREATE(hipHostMalloc(&ctx->h_exchange_image, (persistent_rows_words() + persistent_parts_words()) * 8, 0));
   ctx->persist_grid = (uint32_t)std::min<int>(ctx->cu_count, kExchangeRows);
+  if (max_persist_grid >= 1 && max_persist_grid < ctx->persist_grid) ctx->persist_grid = max_persist_grid;
   if (const char* pg = std::getenv("VGICP_PERSIST_GRID")) {  // fewer workgroups: several contexts sharing one device
     const long v = std::atol(pg);
     if (v >= 1 && v <= (long)ctx->persist_grid) ctx->persist_grid = (uint32_t)v;
@@ -836,8 +615,11 @@ int vgicp_create(int device_id, vgicp_ctx** out) {
   return VGICP_OK;
 }
 
+extern "C" {
+
 int vgicp_destroy(vgicp_ctx* ctx) {
   if (!ctx) return VGICP_OK;
+  if (ctx->multi) return vgicp_multi_api::destroy(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->uploader) {
@@ -937,6 +719,7 @@ const char* vgicp_last_error(const vgicp_ctx* ctx) {
 int vgicp_device_info(const vgicp_ctx* ctx, char* name, size_t name_len, int32_t* cu_count,
                       uint64_t* hbm_bytes) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::device_info(ctx, name, name_len, cu_count, hbm_bytes);
   if (name && name_len) {
     std::strncpy(name, ctx->arch.c_str(), name_len - 1);
     name[name_len - 1] = '\0';
@@ -948,6 +731,7 @@ int vgicp_device_info(const vgicp_ctx* ctx, char* name, size_t name_len, int32_t
 
 int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
   if (!ctx || !value) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::get_counter(ctx, which, value);
   switch (which) {
     case VGICP_COUNTER_PERSISTENT_LAUNCHES: *value = ctx->persistent_launches; break;
     case VGICP_COUNTER_PERSISTENT_FALLBACKS: *value = ctx->persistent_fallbacks; break;
@@ -967,6 +751,7 @@ int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
 
 int vgicp_map_reset(vgicp_ctx* ctx, double voxel_size, size_t capacity_hint) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::map_reset(ctx, voxel_size, capacity_hint);
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!(voxel_size > 0.0) || !std::isfinite(voxel_size))
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "voxel_size must be positive and finite");
@@ -987,6 +772,7 @@ int vgicp_map_reset(vgicp_ctx* ctx, double voxel_size, size_t capacity_hint) {
 int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double* means,
                      const double* covs) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::map_upsert(ctx, n, keys, means, covs);
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (n == 0) return VGICP_OK;
@@ -1018,6 +804,7 @@ int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double
 
 int vgicp_map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::map_erase(ctx, n, keys);
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (n == 0) return VGICP_OK;
@@ -1041,6 +828,7 @@ int vgicp_map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys) {
 
 int vgicp_map_size(const vgicp_ctx* ctx, size_t* voxels, size_t* table_slots) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::map_size(ctx, voxels, table_slots);
   { const int rc_settle = settle(const_cast<vgicp_ctx*>(ctx)); if (rc_settle != VGICP_OK) return rc_settle; }  // a deferred insertion
   if (voxels) *voxels = ctx->voxels;
   if (table_slots) *table_slots = ctx->slots;
@@ -1050,6 +838,7 @@ int vgicp_map_size(const vgicp_ctx* ctx, size_t* voxels, size_t* table_slots) {
 int vgicp_map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
                           const double transform[16], size_t max_points_per_voxel, size_t* new_voxels) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::map_insert_scan(ctx, n, points, covs, transform, max_points_per_voxel, new_voxels);
   if (new_voxels) *new_voxels = 0;
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
@@ -1097,13 +886,14 @@ bool insertion_lists_stay_short(const vgicp_ctx* ctx) {
 int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel,
                               size_t* new_voxels) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::map_insert_resident(ctx, transform, max_points_per_voxel, new_voxels, false);
   if (new_voxels) *new_voxels = 0;
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload first");
   if (!transform) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
   if (max_points_per_voxel == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "max_points_per_voxel must be >= 1");
-  if (ctx->comm || ctx->peers_connected) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "resident scan is a shard: use vgicp_map_insert_scan with the whole scan");
+  if ((ctx->comm || ctx->peers_connected) && !ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "resident scan is a shard: use vgicp_map_insert_scan with the whole scan");
   const size_t n = ctx->n;
   if (n == 0) return VGICP_OK;
   VG_HIP(ctx, hipSetDevice(ctx->device));
@@ -1129,11 +919,12 @@ int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t
 
 int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::map_insert_resident(ctx, transform, max_points_per_voxel, nullptr, true);
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload first");
   if (!transform) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
   if (max_points_per_voxel == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "max_points_per_voxel must be >= 1");
-  if (ctx->comm || ctx->peers_connected) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "resident scan is a shard: use vgicp_map_insert_scan with the whole scan");
+  if ((ctx->comm || ctx->peers_connected) && !ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "resident scan is a shard: use vgicp_map_insert_scan with the whole scan");
   // the scan's size has to be known (the align that registered it has settled it); an insertion still pending
   // from an earlier frame is settled by the same synchronisation
   int rc = (ctx->scan_pending || ctx->insert_pending) ? settle(ctx) : VGICP_OK;
@@ -1162,6 +953,7 @@ int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], 
 
 int vgicp_get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset) {
   if (!ctx || !out) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::get_frame_stats(ctx, out, reset);
   std::memset(out, 0, sizeof *out);
   out->kernel_launches = g_kernel_launches - ctx->stat_launches0;
   out->copies = g_copy_ops - ctx->stat_copies0;
@@ -1189,6 +981,7 @@ int vgicp_get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset) {
 
 int vgicp_set_option(vgicp_ctx* ctx, int option, int value) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::set_option(ctx, option, value);
   switch (option) {
     case VGICP_OPTION_STAGE_EVENTS:
       VG_HIP(ctx, hipSetDevice(ctx->device));
@@ -1204,6 +997,7 @@ int vgicp_set_option(vgicp_ctx* ctx, int option, int value) {
 
 int vgicp_map_evict(vgicp_ctx* ctx, const double position[3], double distance_threshold, size_t* removed) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::map_evict(ctx, position, distance_threshold, removed);
   if (removed) *removed = 0;
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
@@ -1223,6 +1017,7 @@ int vgicp_map_evict(vgicp_ctx* ctx, const double position[3], double distance_th
 int vgicp_map_export(vgicp_ctx* ctx, size_t capacity, int32_t* keys, double* means, double* covs,
                      uint64_t* counts, size_t* written) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::map_export(ctx, capacity, keys, means, covs, counts, written);
   if (!written) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "written is NULL");
   *written = 0;
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
@@ -1324,6 +1119,7 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
 
 int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const double* covs) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::scan_upload(ctx, n, points, covs);
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   const double t0 = now_seconds();
   int rc = scan_upload_enqueue(ctx, n, points, covs);
@@ -1336,6 +1132,11 @@ int vgicp_scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const doub
 
 int vgicp_host_register(vgicp_ctx* ctx, const void* buffer, size_t bytes) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {  // page-locked once, for every device (portable)
+    if (!buffer || bytes == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL / empty buffer");
+    VG_HIP(ctx, hipHostRegister(const_cast<void*>(buffer), bytes, hipHostRegisterPortable));
+    return VGICP_OK;
+  }
   if (!buffer || bytes == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL / empty buffer");
   VG_HIP(ctx, hipSetDevice(ctx->device));
   VG_HIP(ctx, hipHostRegister(const_cast<void*>(buffer), bytes, hipHostRegisterDefault));
@@ -1344,6 +1145,14 @@ int vgicp_host_register(vgicp_ctx* ctx, const void* buffer, size_t bytes) {
 
 int vgicp_host_unregister(vgicp_ctx* ctx, const void* buffer) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {
+    if (!buffer) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL buffer");
+    size_t unused = 0;
+    const int rc_sync = vgicp_multi_api::map_size(ctx, &unused, nullptr);  // settles every sub-context: no copy in flight
+    if (rc_sync != VGICP_OK) return rc_sync;
+    VG_HIP(ctx, hipHostUnregister(const_cast<void*>(buffer)));
+    return VGICP_OK;
+  }
   if (!buffer) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL buffer");
   VG_HIP(ctx, hipSetDevice(ctx->device));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // no copy out of the buffer may still be in flight
@@ -1355,6 +1164,7 @@ int vgicp_align_resident(vgicp_ctx* ctx, const double guess[16], const vgicp_par
                          double out_pose[16], vgicp_stats* stats) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (!guess || !out_pose) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pose pointer");
+  if (ctx->multi) return vgicp_multi_api::align_resident(ctx, guess, params, out_pose, stats);
   VG_HIP(ctx, hipSetDevice(ctx->device));
   return run_align(ctx, guess, params, out_pose, stats);
 }
@@ -1363,6 +1173,10 @@ int vgicp_align(vgicp_ctx* ctx, size_t n, const double* points, const double* co
                 const double guess[16], const vgicp_params* params, double out_pose[16],
                 vgicp_stats* stats) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {
+    if (!guess || !out_pose) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pose pointer");
+    return vgicp_multi_api::align(ctx, n, points, covs, guess, params, out_pose, stats);
+  }
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   const double t0 = now_seconds();
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
@@ -1378,6 +1192,12 @@ int vgicp_align(vgicp_ctx* ctx, size_t n, const double* points, const double* co
 int vgicp_accumulate(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
                      const double pose[16], double JTJ[36], double JTr[6], uint64_t* count) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {  // a hook that works on one device ("local rank only"): the whole scan on sub-context 0
+    vgicp_ctx* first = vgicp_multi_api::first(ctx);
+    const int rc = vgicp_accumulate(first, n, points, covs, pose, JTJ, JTr, count);
+    if (rc != VGICP_OK) ctx->err = first->err;
+    return rc;
+  }
   if (!pose || !JTJ || !JTr) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL output pointer");
   if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
   int rc = vgicp_scan_upload(ctx, n, points, covs);
@@ -1414,6 +1234,12 @@ int vgicp_solve_step(vgicp_ctx* ctx, const double JTJ[36], const double JTr[6], 
                      double translation_sq_threshold, uint32_t flags, double se3[6], double step[16],
                      int32_t* used_pivoted, int32_t* converged) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {
+    vgicp_ctx* first = vgicp_multi_api::first(ctx);
+    const int rc = vgicp_solve_step(first, JTJ, JTr, cosine_threshold, translation_sq_threshold, flags, se3, step, used_pivoted, converged);
+    if (rc != VGICP_OK) ctx->err = first->err;
+    return rc;
+  }
   if (!JTJ || !JTr || !se3 || !step) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
   VG_HIP(ctx, hipSetDevice(ctx->device));
   int rc = ensure_stage(ctx, 64 * sizeof(double));
@@ -1444,6 +1270,12 @@ int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* co
                 double* src_points, double* src_covs, double* map_points, double* map_covs,
                 uint64_t* src_index, size_t* matched) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {  // the map is replicated: any replica answers
+    vgicp_ctx* first = vgicp_multi_api::first(ctx);
+    const int rc = vgicp_match(first, n, points, covs, src_points, src_covs, map_points, map_covs, src_index, matched);
+    if (rc != VGICP_OK) ctx->err = first->err;
+    return rc;
+  }
   if (!matched) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "matched is NULL");
   *matched = 0;
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
@@ -1493,6 +1325,12 @@ int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* co
 
 int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* keys) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {
+    vgicp_ctx* first = vgicp_multi_api::first(ctx);
+    const int rc = vgicp_voxel_index(first, n, points, keys);
+    if (rc != VGICP_OK) ctx->err = first->err;
+    return rc;
+  }
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (n == 0) return VGICP_OK;
   if (!points || !keys) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL array pointer");
@@ -1655,6 +1493,12 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
                      size_t capacity, double* out_points, double* out_covs, uint64_t* out_index,
                      size_t* kept) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {  // scan preparation with the result returned to the host: one device's work
+    vgicp_ctx* first = vgicp_multi_api::first(ctx);
+    const int rc = vgicp_preprocess(first, n, points, voxel_size, knn, capacity, out_points, out_covs, out_index, kept);
+    if (rc != VGICP_OK) ctx->err = first->err;
+    return rc;
+  }
   if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
   *kept = 0;
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
@@ -1799,6 +1643,12 @@ bool deskew_table(size_t n, const double* point_time, size_t num_states, const d
 int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_time, size_t num_states,
                  const double* states, int64_t* transformed) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {
+    vgicp_ctx* first = vgicp_multi_api::first(ctx);
+    const int rc = vgicp_deskew(first, n, points, point_time, num_states, states, transformed);
+    if (rc != VGICP_OK) ctx->err = first->err;
+    return rc;
+  }
   if (!transformed) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "transformed is NULL");
   *transformed = 0;
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
@@ -1843,7 +1693,7 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
                          const double* states, const double extrinsic[16], double voxel_size, int knn) {
   int rc = check_preprocess_args(ctx, n, voxel_size, knn);
   if (rc != VGICP_OK) return rc;
-  if (ctx->comm || ctx->peers_connected) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the prepared scan is whole: not available on a communicator (shards)");
+  if ((ctx->comm || ctx->peers_connected) && !ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the prepared scan is whole: not available on a communicator (shards)");
   if (n > 0 && !points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
   const bool with_deskew = n > 0 && num_states > 0;
   if (with_deskew && (!point_time || !states)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
@@ -1894,7 +1744,10 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   if (with_deskew) {
     VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const uint32_t slot = ctx->state_table_next++ & 1u;
-    if (ctx->ev_state_table[slot]) VG_HIP(ctx, hipEventSynchronize(ctx->ev_state_table[slot]));  // long complete, normally
+    if (ctx->ev_state_table[slot]) {
+      // the copy out of this slot two preparations ago: long complete, normally (no host wait then)
+      if (hipEventQuery(ctx->ev_state_table[slot]) != hipSuccess) VG_HIP(ctx, hipEventSynchronize(ctx->ev_state_table[slot]));
+    }
     else VG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_state_table[slot], hipEventDisableTiming));
     if (ctx->state_table_cap[slot] < used * 13) {
       if (ctx->h_state_table[slot]) VG_HIP(ctx, hipHostFree(ctx->h_state_table[slot]));
@@ -1931,6 +1784,7 @@ int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, con
                              size_t num_states, const double* states, const double extrinsic[16],
                              double voxel_size, int knn) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::scan_prepare(ctx, n, points, point_time, num_states, states, extrinsic, voxel_size, knn, nullptr, nullptr, true);
   // nothing is settled here: a map insertion still pending from the previous frame has counters of its own and is
   // read at this frame's one synchronisation (the align); a scan that was prepared but never used is simply replaced
   return scan_prepare_enqueue(ctx, n, points, point_time, num_states, states, extrinsic, voxel_size, knn);
@@ -1938,6 +1792,7 @@ int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, con
 
 int vgicp_scan_info(vgicp_ctx* ctx, size_t* kept, int64_t* deskewed, uint64_t* indefinite) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::scan_info(ctx, kept, deskewed, indefinite);
   if (kept) *kept = 0;
   if (deskewed) *deskewed = 0;
   if (indefinite) *indefinite = 0;
@@ -1954,6 +1809,10 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
                        size_t num_states, const double* states, const double extrinsic[16],
                        double voxel_size, int knn, size_t* kept, int64_t* deskewed) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {
+    if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
+    return vgicp_multi_api::scan_prepare(ctx, n, points, point_time, num_states, states, extrinsic, voxel_size, knn, kept, deskewed, false);
+  }
   if (!kept) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "kept is NULL");
   *kept = 0;
   if (deskewed) *deskewed = 0;
@@ -1973,6 +1832,7 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
 
 int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double* covs, size_t* n) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::scan_download(ctx, capacity, points, covs, n);
   if (!n) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "n is NULL");
   *n = 0;
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
@@ -1991,6 +1851,7 @@ int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double*
 
 int vgicp_peer_export(vgicp_ctx* ctx, void* handle64) {
   if (!ctx || !handle64) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi || ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "a multi-device context has its exchange built in: communicators and hand-wired peers are for one-process-per-GPU hosts");
   static_assert(sizeof(hipIpcMemHandle_t) == VGICP_PEER_HANDLE_BYTES, "handle size");
   VG_HIP(ctx, hipSetDevice(ctx->device));
   int rc = ensure_mailbox(ctx);
@@ -2003,6 +1864,7 @@ int vgicp_peer_export(vgicp_ctx* ctx, void* handle64) {
 
 int vgicp_peer_connect(vgicp_ctx* ctx, int world_size, int rank, const void* handles) {
   if (!ctx || !handles) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi || ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "a multi-device context has its exchange built in: communicators and hand-wired peers are for one-process-per-GPU hosts");
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (world_size < 1 || world_size > kMaxRanks || rank < 0 || rank >= world_size)
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "bad world_size / rank (at most 16 ranks)");
@@ -2045,6 +1907,7 @@ int vgicp_peer_connect(vgicp_ctx* ctx, int world_size, int rank, const void* han
 
 int vgicp_peer_disconnect(vgicp_ctx* ctx) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi || ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "a multi-device context has its exchange built in: communicators and hand-wired peers are for one-process-per-GPU hosts");
   VG_HIP(ctx, hipSetDevice(ctx->device));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   close_peers(ctx);
@@ -2057,6 +1920,7 @@ int vgicp_peer_disconnect(vgicp_ctx* ctx) {
 
 int vgicp_comm_unique_id(vgicp_ctx* ctx, void* id128) {
   if (!ctx || !id128) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi || ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "a multi-device context has its exchange built in: communicators and hand-wired peers are for one-process-per-GPU hosts");
   int rc = load_rccl(ctx);
   if (rc != VGICP_OK) return rc;
   ncclUniqueId id;
@@ -2068,6 +1932,7 @@ int vgicp_comm_unique_id(vgicp_ctx* ctx, void* id128) {
 
 int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128) {
   if (!ctx || !id128) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi || ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "a multi-device context has its exchange built in: communicators and hand-wired peers are for one-process-per-GPU hosts");
   { const int rc_settle = settle(ctx); if (rc_settle != VGICP_OK) return rc_settle; }
   if (world_size < 1 || rank < 0 || rank >= world_size)
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "bad world_size / rank");
@@ -2146,6 +2011,7 @@ int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128)
 
 int vgicp_comm_destroy(vgicp_ctx* ctx) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi || ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "a multi-device context has its exchange built in: communicators and hand-wired peers are for one-process-per-GPU hosts");
   if (ctx->peers_connected) {
     VG_HIP(ctx, hipSetDevice(ctx->device));
     VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2163,3 +2029,261 @@ int vgicp_comm_destroy(vgicp_ctx* ctx) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// What the in-process multi-device context (vgicp_multi.hip) needs from this file besides the entry points above.
+// ---------------------------------------------------------------------------------------------------------------
+namespace vgicp_internal {
+
+int settle_context(vgicp_ctx* ctx) { return settle(ctx); }
+
+bool insertion_lists_stay_short_for(const vgicp_ctx* ctx, double prep_voxel) {
+  if (!(prep_voxel > 0.0) || std::getenv("VGICP_INSERT_SORT")) return false;
+  const double per_axis = std::ceil(ctx->voxel_size / prep_voxel) + 1.0;
+  return per_axis * per_axis * per_axis <= 64.0;
+}
+
+int wire_mailboxes(vgicp_ctx* const* subs, int n) {
+  if (n < 1 || n > kMaxRanks) return fail(subs[0], VGICP_ERR_BAD_ARGUMENT, "at most 16 devices");
+  // every device must be able to store into every other device's mailbox (xGMI / PCIe peer access)
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b) {
+      if (subs[a]->device == subs[b]->device) continue;
+      int can = 0;
+      VG_HIP(subs[a], hipDeviceCanAccessPeer(&can, subs[a]->device, subs[b]->device));
+      if (!can) return fail(subs[a], VGICP_ERR_HIP, "device " + std::to_string(subs[a]->device) + " cannot access device " +
+                            std::to_string(subs[b]->device) + " as a peer");
+      VG_HIP(subs[a], hipSetDevice(subs[a]->device));
+      const hipError_t e = hipDeviceEnablePeerAccess(subs[b]->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail_hip(subs[a], e, "hipDeviceEnablePeerAccess");
+      (void)hipGetLastError();
+    }
+  for (int r = 0; r < n; ++r) {
+    vgicp_ctx* ctx = subs[r];
+    VG_HIP(ctx, hipSetDevice(ctx->device));
+    const int rc = ensure_mailbox(ctx);
+    if (rc != VGICP_OK) return rc;
+    // this rank's mailbox: the rows the ranks write are unset, the others +0.0 for good; verdict words 0
+    std::vector<unsigned long long> img(kMailWords, 0ull);
+    for (int buf = 0; buf < 3; ++buf)
+      for (int q = 0; q < n; ++q)
+        for (int sl = 0; sl <= kCountSlot; ++sl) img[((size_t)buf * kMaxRanks + q) * kSlots + sl] = kRowUnset;
+    VG_HIP(ctx, hipMemcpy(ctx->d_mail, img.data(), kMailWords * 8, hipMemcpyHostToDevice));
+  }
+  for (int r = 0; r < n; ++r) {
+    vgicp_ctx* ctx = subs[r];
+    VG_HIP(ctx, hipSetDevice(ctx->device));
+    for (int q = 0; q < kMaxRanks; ++q) ctx->peer_mail[q] = q < n ? subs[q]->d_mail : nullptr;
+    VG_HIP(ctx, hipMemcpy(ctx->d_mail_table, ctx->peer_mail, kMaxRanks * sizeof(double*), hipMemcpyHostToDevice));
+    ctx->peer_mail_is_ipc = false;
+    ctx->peer_world = n;
+    ctx->peer_rank = r;
+    ctx->world_size = n;
+    ctx->rank = r;
+    ctx->mail_round0 = 0;
+    ctx->mail_seq = 0;
+    ctx->peer_enabled = true;
+    ctx->peers_connected = true;
+  }
+  return VGICP_OK;
+}
+
+namespace {
+// tree_sum<16> of vgicp_kernels.hip on the host: the order in which poll_and_sum<true> adds the ranks' rows
+double tree_sum_host(const double* v, int count) {
+  if (count == 1) return v[0];
+  return tree_sum_host(v, count / 2) + tree_sum_host(v + count / 2, count - count / 2);
+}
+}  // namespace
+
+int align_host_summed(vgicp_ctx* const* subs, int n, const double guess[16], const vgicp_params* params,
+                      double out_pose[16], vgicp_stats* stats) {
+  const double t0 = now_seconds();
+  vgicp_ctx* lead = subs[0];
+  int rc = check_params(lead, params);
+  if (rc != VGICP_OK) return rc;
+  const int max_it = params->max_iteration;
+  const bool profile = (params->flags & VGICP_FLAG_PROFILE) != 0;
+  std::vector<uint32_t> grid((size_t)n);
+  for (int r = 0; r < n; ++r) {
+    vgicp_ctx* ctx = subs[r];
+    VG_HIP(ctx, hipSetDevice(ctx->device));
+    rc = settle(ctx);
+    if (rc != VGICP_OK) return rc;
+    if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+    if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident: call vgicp_scan_upload first");
+    rc = ensure_log(ctx, max_it);
+    if (rc != VGICP_OK) return rc;
+    AlignState* h0 = &ctx->h_state[0];
+    std::memset(h0, 0, sizeof(AlignState));
+    pose_to_state(guess, h0->pose);
+    h0->cosine_threshold = params->cosine_threshold;
+    h0->translation_sq_threshold = params->translation_sq_threshold;
+    h0->max_iteration = max_it;
+    h0->done = (max_it == 0) ? 1 : 0;
+    VG_HIP(ctx, hipMemcpyAsync(ctx->d_state, h0, sizeof(AlignState), hipMemcpyHostToDevice, ctx->stream));
+    grid[(size_t)r] = iterate_grid(ctx);
+  }
+  const int total_launches = max_it > 0 ? max_it + 1 : 0;  // max_it bodies + the closing prologue
+  VG_HIP(lead, hipSetDevice(lead->device));
+  if (profile && (int)lead->ev_prof.size() < 2 * total_launches) {
+    const size_t old = lead->ev_prof.size();
+    lead->ev_prof.resize(2 * (size_t)total_launches, nullptr);
+    for (size_t k = old; k < lead->ev_prof.size(); ++k) VG_HIP(lead, hipEventCreate(&lead->ev_prof[k]));
+  }
+  VG_HIP(lead, hipEventRecord(lead->ev_begin, lead->stream));
+  int launched = 0;
+  for (int j = 0; j < total_launches; ++j) {
+    const bool closing = j == max_it;
+    for (int r = 0; r < n; ++r) {
+      vgicp_ctx* ctx = subs[r];
+      VG_HIP(ctx, hipSetDevice(ctx->device));
+      IterArgs a = base_args(ctx);
+      a.state_in = ctx->d_state + (j & 1);
+      a.state_out = ctx->d_state + ((j + 1) & 1);
+      a.rows = ctx->d_rows[j & 1];
+      a.prev = ctx->d_sums;           // the row the host summed over the ranks
+      a.prev_rows = j > 0 ? 1u : 0u;
+      if (profile && r == 0) VG_HIP(ctx, hipEventRecord(ctx->ev_prof[2 * j], ctx->stream));
+      if (closing) VG_HIP(ctx, launch_close(ctx->stream, a, ctx->iter_block));
+      else {
+        VG_HIP(ctx, launch_iterate(ctx->stream, a, grid[(size_t)r], ctx->iter_block));
+        VG_HIP(ctx, launch_fold_rows(ctx->stream, a.rows, grid[(size_t)r], a.state_out, ctx->d_sums));
+        // the rank's row goes to pinned memory (the header row of the pinned log: unused outside a persistent launch)
+        VG_HIP(ctx, hipMemcpyAsync(ctx->h_log - kSlots, ctx->d_sums, kSlots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      }
+      if (profile && r == 0) VG_HIP(ctx, hipEventRecord(ctx->ev_prof[2 * j + 1], ctx->stream));
+      VG_HIP(ctx, hipMemcpyAsync(&ctx->h_state[1], a.state_out, sizeof(AlignState), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ++launched;
+    for (int r = 0; r < n; ++r) {
+      VG_HIP(subs[r], hipSetDevice(subs[r]->device));
+      VG_HIP(subs[r], hipStreamSynchronize(subs[r]->stream));
+    }
+    if (closing || lead->h_state[1].done) break;
+    // the ranks' rows, added in the order the mailbox path adds them (identical bits on every device)
+    double total[kSlots];
+    for (int sl = 0; sl < kSlots; ++sl) {
+      double x[kMaxRanks];
+      for (int q = 0; q < kMaxRanks; ++q) x[q] = (q < n && sl <= kCountSlot) ? (subs[q]->h_log - kSlots)[sl] : 0.0;
+      total[sl] = tree_sum_host(x, kMaxRanks);
+    }
+    for (int r = 0; r < n; ++r) {
+      vgicp_ctx* ctx = subs[r];
+      VG_HIP(ctx, hipSetDevice(ctx->device));
+      std::memcpy(ctx->h_log - kSlots, total, sizeof total);
+      VG_HIP(ctx, hipMemcpyAsync(ctx->d_sums, ctx->h_log - kSlots, kSlots * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
+  VG_HIP(lead, hipSetDevice(lead->device));
+  VG_HIP(lead, hipEventRecord(lead->ev_end, lead->stream));
+  AlignState* hf = &lead->h_state[0];
+  VG_HIP(lead, hipMemcpyAsync(hf, lead->d_state + (launched & 1), sizeof(AlignState), hipMemcpyDeviceToHost, lead->stream));
+  const bool want_log = stats && (stats->corr_count || stats->normal_eq);
+  if (want_log && max_it > 0)
+    VG_HIP(lead, hipMemcpyAsync(lead->h_log, lead->d_log, (size_t)max_it * kSlots * sizeof(double), hipMemcpyDeviceToHost, lead->stream));
+  VG_HIP(lead, hipStreamSynchronize(lead->stream));
+  state_to_pose(hf->pose, out_pose);
+  if (stats) {
+    stats->iterations = hf->iteration;
+    stats->converged = hf->converged;
+    stats->world_size = n;
+    stats->launches = launched;
+    float ms = 0.f;
+    VG_HIP(lead, hipEventElapsedTime(&ms, lead->ev_begin, lead->ev_end));
+    stats->device_seconds = ms * 1e-3;
+    for (int it = 0; it < hf->iteration; ++it) {
+      const double* row = lead->h_log + (size_t)it * kSlots;
+      if (stats->corr_count) stats->corr_count[it] = (uint64_t)row[kCountSlot];
+      if (stats->normal_eq) std::memcpy(stats->normal_eq + (size_t)it * kNormalEq, row, kNormalEq * sizeof(double));
+    }
+    if (profile && stats->kernel_ms) {
+      for (int it = 0; it < std::min(launched, max_it); ++it) {
+        float k = 0.f;
+        VG_HIP(lead, hipEventElapsedTime(&k, lead->ev_prof[2 * it], lead->ev_prof[2 * it + 1]));
+        stats->kernel_ms[it] = k;
+      }
+    }
+    stats->seconds = now_seconds() - t0;
+  }
+  if (!finite16(out_pose)) return fail(lead, VGICP_ERR_DEGENERATE, "solved pose is not finite (singular normal equations)");
+  return VGICP_OK;
+}
+
+int adopt_device_scan(vgicp_ctx* ctx, int src_device, const double* d_points, const double* d_covs, size_t n,
+                      double prep_voxel, hipEvent_t ready) {
+  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = settle(ctx);
+  if (rc != VGICP_OK) return rc;
+  rc = ensure_scan(ctx, n);
+  if (rc != VGICP_OK) return rc;
+  ctx->scan_ready = false;
+  ctx->prep_voxel = prep_voxel;
+  ctx->prep_with_deskew = false;
+  ctx->prep_deskewed = 0;
+  ctx->prep_indefinite = 0;
+  ctx->n = (uint32_t)n;
+  ctx->stride = ctx->scan_capacity;
+  if (ready) VG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ready, 0));
+  if (n > 0) {
+    double* aos_pts = ctx->d_scan_aos;
+    double* aos_cov = ctx->d_scan_aos + 3 * ctx->scan_capacity;
+    if (src_device != ctx->device) {
+      VG_HIP(ctx, hipMemcpyPeerAsync(aos_pts, ctx->device, d_points, src_device, n * 3 * sizeof(double), ctx->stream));
+      VG_HIP(ctx, hipMemcpyPeerAsync(aos_cov, ctx->device, d_covs, src_device, n * 9 * sizeof(double), ctx->stream));
+      g_copy_ops += 2;
+    } else {
+      VG_HIP(ctx, hipMemcpyAsync(aos_pts, d_points, n * 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      VG_HIP(ctx, hipMemcpyAsync(aos_cov, d_covs, n * 9 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (++ctx->scan_seq == 0) ++ctx->scan_seq;
+    ctx->scan_sym_known = true;
+    VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, (uint32_t)n, ctx->d_scan, ctx->stride,
+                                 ctx->d_ins_counters + 2, ctx->scan_seq));
+  }
+  ctx->scan_ready = true;
+  return VGICP_OK;
+}
+
+int map_insert_device(vgicp_ctx* ctx, const double* d_points, const double* d_covs, size_t n, const double transform[16],
+                      size_t max_points_per_voxel, bool short_lists, bool deferred, size_t* new_voxels) {
+  if (new_voxels) *new_voxels = 0;
+  if (!ctx->table) return fail(ctx, VGICP_ERR_NOT_READY, "no voxel map: call vgicp_map_reset first");
+  if (!transform) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
+  if (max_points_per_voxel == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "max_points_per_voxel must be >= 1");
+  if (n > 0x7FFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = (ctx->scan_pending || ctx->insert_pending) ? settle(ctx) : VGICP_OK;
+  if (rc != VGICP_OK) return rc;
+  if (n == 0) return VGICP_OK;
+  rc = ensure_table(ctx, n);
+  if (rc != VGICP_OK) return rc;
+  const size_t sb = map_insert_scratch_bytes((uint32_t)n);
+  rc = ensure_stage(ctx, sb);
+  if (rc != VGICP_OK) return rc;
+  double pose12[12];
+  pose_to_state(transform, pose12);
+  if (deferred) {
+    if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[4], ctx->stream)); ctx->ev_stage_set[4] = true; }
+    VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size, d_points, d_covs,
+                                  (uint32_t)n, pose12, (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_ins_counters,
+                                  short_lists));
+    VG_HIP(ctx, hipMemcpyAsync(ctx->h_ins_counters, ctx->d_ins_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[5], ctx->stream)); ctx->ev_stage_set[5] = true; }
+    ctx->insert_pending = true;
+    ctx->insert_pending_upper = n;
+    return VGICP_OK;
+  }
+  VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size, d_points, d_covs,
+                                (uint32_t)n, pose12, (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_counters, short_lists));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->voxels += ctx->h_counters[0];
+  if (new_voxels) *new_voxels = ctx->h_counters[0];
+  if (ctx->h_counters[1] != 0) return fail(ctx, VGICP_ERR_TABLE_FULL, "voxel table probe sequence exhausted");
+  return VGICP_OK;
+}
+
+}  // namespace vgicp_internal

@@ -1,0 +1,314 @@
+// vgicp_context.h — the host-side context behind the C ABI (include/vgicp_hip.h), shared by vgicp_capi.hip (one
+// device) and vgicp_multi.hip (one caller thread driving several devices).  Not part of the ABI: callers only ever
+// see the opaque vgicp_ctx*.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <limits>
+#include <mutex>
+#include <thread>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vgicp_hip.h"
+#include "vgicp_device.h"
+
+using namespace vgicp;
+
+// what a frame costs the host besides kernels: copies / memsets enqueued and synchronisations (vgicp_get_frame_stats)
+namespace vgicp { extern thread_local uint64_t g_copy_ops, g_sync_ops; }
+using vgicp::g_copy_ops;
+using vgicp::g_sync_ops;
+#define hipMemcpyAsync(...) (++g_copy_ops, hipMemcpyAsync(__VA_ARGS__))
+#define hipMemsetAsync(...) (++g_copy_ops, hipMemsetAsync(__VA_ARGS__))
+#define hipStreamSynchronize(...) (++g_sync_ops, hipStreamSynchronize(__VA_ARGS__))
+#define hipEventSynchronize(...) (++g_sync_ops, hipEventSynchronize(__VA_ARGS__))
+
+namespace vgicp {
+
+// ---- the few RCCL entry points used, bound at run time so the library loads without RCCL ----
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[VGICP_UNIQUE_ID_BYTES]; } ncclUniqueId;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclDouble = 8;  // ncclFloat64, rccl.h
+constexpr int kNcclSum = 0;
+constexpr int kNcclChar = 0;   // ncclInt8
+
+extern thread_local std::string g_create_error;
+
+inline double now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+inline uint64_t next_pow2(uint64_t v) {
+  uint64_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+constexpr uint64_t kMinSlots = 1024;
+constexpr int kDefaultChunk = 4;
+constexpr int kMaxChunksInFlight = 2;
+constexpr int kPersistentCooldownAligns = 8;  // aligns on the per-launch loop after the single launch gave up
+
+}  // namespace vgicp
+using namespace vgicp;
+
+// A second host thread for the scan upload. hipMemcpyAsync from pageable memory the runtime has never seen spends
+// as long again preparing the pages as the DMA then takes (tools/micro/h2d_cold_probe.hip: 9.6 MB cold 0.35 - 0.56 ms
+// on one thread, 0.27 - 0.28 ms with the two arrays on two threads and two streams; buffers seen before: 0.19 / 0.20
+// ms).  The helper copies the points while the caller's thread copies the covariances; the context's stream waits
+// for the helper's event before the pack kernel.
+struct UploadHelper {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  bool has_job = false, done = true, quit = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;
+  void* dst = nullptr;
+  const void* src = nullptr;
+  size_t bytes = 0;
+  hipError_t result = hipSuccess;
+
+  void run() {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [&] { return has_job || quit; });
+      if (quit) return;
+      has_job = false;
+      lk.unlock();
+      hipError_t e = (hipMemcpyAsync)(dst, src, bytes, hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess) e = hipEventRecord(ev, stream);
+      lk.lock();
+      result = e;
+      done = true;
+      cv.notify_all();
+    }
+  }
+  void post(void* d, const void* s, size_t n) {
+    std::lock_guard<std::mutex> lk(m);
+    dst = d; src = s; bytes = n;
+    done = false;
+    has_job = true;
+    cv.notify_all();
+  }
+  hipError_t wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return done; });
+    return result;
+  }
+};
+
+struct vgicp_multi;  // vgicp_multi.hip: the sub-contexts of an in-process multi-device context
+
+struct vgicp_ctx {
+  int device = -1;
+  vgicp_multi* multi = nullptr;   // this handle IS a multi-device context: every entry point forwards to vgicp_multi.hip
+  vgicp_multi* owner = nullptr;   // this context is one of a multi-device context's sub-contexts (rank = peer_rank)
+  hipStream_t stream = nullptr;
+  mutable std::string err;
+  int cu_count = 0;
+  uint64_t hbm_bytes = 0;
+  std::string arch;
+
+  // voxel table
+  double voxel_size = 0.0;
+  VoxelRecord* table = nullptr;
+  uint64_t slots = 0;
+  uint64_t voxels = 0;      // FULL records
+  uint64_t tombstones = 0;
+  uint32_t* d_counters = nullptr;  // 8 words + 64 of developer histograms (VGICP_DEBUG_PREP=2)
+  uint32_t* h_counters = nullptr;  // pinned
+
+  // batch staging (upsert / erase / hooks)
+  void* d_stage = nullptr;
+  size_t stage_bytes = 0;
+  void* d_cells = nullptr;  // cell table of the scan preparation (vgicp_preprocess)
+  size_t cells_bytes = 0;
+
+  // resident scan
+  double* d_scan_aos = nullptr;  // points (3n) then covs (9n)
+  double* d_scan = nullptr;      // SoA planes
+  size_t scan_capacity = 0;      // points
+  uint32_t n = 0;
+  uint64_t stride = 0;
+  bool scan_ready = false;
+
+  // align state
+  AlignState* d_state = nullptr;  // two, ping-pong: launch j reads [j&1], writes [(j+1)&1]
+  AlignState* h_state = nullptr;  // pinned, kMaxChunksInFlight + 1 slots
+  double* d_rows[2] = {nullptr, nullptr};  // partial rows, ping-pong like the state
+  double* d_sums = nullptr;       // one row: the all-reduce message (multi-GPU)
+  // persistent single-launch align (single GPU)
+  uint32_t persist_round0 = 0;       // rounds the persistent launches of this context have executed, mod 3
+  uint32_t persist_seq = 0;
+  uint32_t persist_grid = 0;         // workgroups of every persistent launch: min(CUs, kExchangeRows), all resident
+  double* d_rows_persist = nullptr;  // [3][kExchangeRows][kSlots] (vgicp_device.h, PersistArgs)
+  double* d_parts_persist = nullptr; // [3][kFolders][kSlots]
+  void* h_exchange_image = nullptr;  // pinned: what the two buffers hold between launches
+  bool persistent_enabled = true;    // cleared by VGICP_PERSISTENT=0 or when a workgroup does not fit a CU
+  double prefetch_margin = 0.03;     // see PersistArgs::prefetch_margin; VGICP_PREFETCH_MARGIN overrides (0 = off)
+  uint32_t persist_spin_limit = 50000;  // polls (>= ~1 us each) before an in-kernel wait gives up
+  int persistent_cooldown = 0;       // aligns left on the per-launch loop after an in-kernel wait timed out
+  uint64_t persistent_launches = 0;  // diagnostics (vgicp_get_counter)
+  uint64_t persistent_fallbacks = 0;
+  uint64_t upload_bytes = 0;
+  double upload_seconds = 0.0;
+  uint64_t prep_indefinite = 0;      // kept points of the last scan preparation with an indefinite covariance
+  UploadHelper* uploader = nullptr;  // created with the first large upload (VGICP_UPLOAD_THREADS=1 keeps one thread)
+  bool uploader_enabled = true;
+  // host buffers uploaded recently (address of the covariances, ring of 1 024): a buffer the runtime has seen before
+  // goes up fastest from ONE thread (9.6 MB: 0.19 ms against 0.33 ms with two), a new one from TWO (0.32 against 0.44)
+  const void* seen_ptr[1024] = {nullptr};
+  size_t seen_bytes[1024] = {0};
+  uint32_t seen_next = 0;
+  // scan preparation without host round trips
+  void* d_tiles = nullptr;           // tile slots of the two device-wide scans
+  uint32_t* h_prep = nullptr;        // pinned: the counter block as a preparation left it (kCounterWords)
+  uint32_t prep_epoch = 0;
+  bool scan_pending = false;         // a prepared scan is resident but the host has not read its size / verdict yet
+  uint32_t n_upper = 0;              // raw points of the pending scan (>= its kept points)
+  uint32_t scan_seq = 0;             // uploads so far; pack_scan_kernel marks an asymmetric covariance with it
+  bool scan_sym_known = false;       // the resident scan went through pack_scan_kernel (not a scan prepared on the device)
+  int64_t prep_deskewed = 0;
+  bool prep_with_deskew = false;
+  double prep_voxel = 0.0;           // > 0: the resident scan was down-sampled on the device to one point per voxel of this size
+  // the deskew's state table on its way to the device: pinned, two slots in turn (an enqueue-only preparation returns
+  // before the copy has run, so the table cannot live on the caller's stack)
+  double* h_state_table[2] = {nullptr, nullptr};
+  size_t state_table_cap[2] = {0, 0};
+  hipEvent_t ev_state_table[2] = {nullptr, nullptr};
+  uint32_t state_table_next = 0;
+  // deferred map insertion (vgicp_map_insert_resident_async): running totals on the device, read at the next sync
+  uint32_t* d_ins_counters = nullptr;
+  uint32_t* h_ins_counters = nullptr;  // pinned
+  uint32_t ins_seen[2] = {0, 0};
+  bool insert_pending = false;
+  uint64_t insert_pending_upper = 0;
+  // frame statistics
+  uint64_t stat_launches0 = 0, stat_copies0 = 0, stat_syncs0 = 0;
+  bool stage_events = false;
+  hipEvent_t ev_stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [6]: behind the prologue
+  bool ev_stage_set[7] = {false, false, false, false, false, false, false};
+  int iter_block = 512;           // threads per workgroup of the iteration kernel (measured best at C2)
+  double* d_log = nullptr;
+  double* h_log = nullptr;  // pinned
+  double* h_log_dev = nullptr;  // the same memory as the device addresses it (the persistent launch writes state + log there)
+  int log_capacity = 0;     // iterations
+  uint64_t* d_stamps = nullptr;  // only with VGICP_DEBUG_STAMPS=1
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_chunk[kMaxChunksInFlight] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev_prof;
+
+  // device-initiated exchange between GPUs: peer-mapped mailboxes (vgicp_peer_*)
+  double* d_mail = nullptr;            // this rank's mailbox, fine-grained device memory, [3][kMaxRanks][kSlots]
+  double* peer_mail[kMaxRanks] = {nullptr};  // every rank's mailbox as mapped here ([peer_rank] = d_mail)
+  double** d_mail_table = nullptr;     // device copy of peer_mail
+  int peer_world = 1, peer_rank = 0;
+  bool peers_connected = false;
+  bool peer_mail_is_ipc = true;        // false: plain pointers of the same process (sub-contexts), nothing to close
+  bool peer_enabled = true;            // cleared for good when a launch gave up waiting for a peer
+  uint32_t mail_round0 = 0;            // rounds executed through the mailboxes so far (same on every rank)
+  uint32_t mail_seq = 0;               // aligns attempted through the mailboxes so far (same on every rank)
+
+  // RCCL
+  RcclApi rccl;
+  ncclComm_t comm = nullptr;
+  int world_size = 1;
+  int rank = 0;
+};
+
+
+// ---- helpers shared by the two translation units ----
+namespace vgicp {
+inline int fail(const vgicp_ctx* ctx, int code, const std::string& text) {
+  if (ctx) ctx->err = text; else g_create_error = text;
+  return code;
+}
+inline int fail_hip(const vgicp_ctx* ctx, hipError_t e, const char* what) {
+  return fail(ctx, VGICP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+}  // namespace vgicp
+
+#define VG_HIP(ctx, call)                                              \
+  do {                                                                 \
+    hipError_t e__ = (call);                                           \
+    if (e__ != hipSuccess) return fail_hip((ctx), e__, #call);         \
+  } while (0)
+
+// ---- what vgicp_multi.hip needs from vgicp_capi.hip besides the public entry points ----
+namespace vgicp_internal {
+// A sub-context gives up an align it cannot finish alone with this status (never seen by a caller of the ABI): the
+// in-kernel exchange between the sub-contexts timed out, or the align asks for the launch-per-round loop — the
+// multi-device context then runs that loop itself, adding the sub-contexts' rows on the host.
+constexpr int kNeedGroupLoop = 1000;
+// vgicp_create with a cap on the persistent launch's workgroups (sub-contexts that share one device split its CUs).
+int create_context(int device_id, uint32_t max_persist_grid, vgicp_ctx** out);
+// Mailboxes of the device-initiated exchange wired by plain pointers (one process: no IPC handles); (re-)initialises
+// every mailbox and the running round / align numbers.  The streams of all sub-contexts must be idle.
+int wire_mailboxes(vgicp_ctx* const* subs, int n);
+// ICP::align over sub-contexts that each hold a shard, one launch per round on every device, the rank rows added on
+// the host in rank order (the same pairwise tree the mailbox path uses): the fallback of the in-kernel exchange and
+// the path of VGICP_FLAG_PROFILE / VGICP_FLAG_NO_PERSISTENT.  The caller's thread drives every device.
+int align_host_summed(vgicp_ctx* const* subs, int n, const double guess[16], const vgicp_params* params,
+                      double out_pose[16], vgicp_stats* stats);
+// The resident scan of `ctx` becomes n points that are already on a device as AoS (points n x 3, covs n x 9; peer
+// memory is fine): copied into the context's own storage and packed into the planes the registration reads.
+// Enqueued on the context's stream (which first waits for `ready`, if given); not synchronised.
+int adopt_device_scan(vgicp_ctx* ctx, int src_device, const double* d_points, const double* d_covs, size_t n,
+                      double prep_voxel, hipEvent_t ready);
+// LocalMap::updateLocalMap's insertion for n points that are already on THIS context's device as AoS.
+int map_insert_device(vgicp_ctx* ctx, const double* d_points, const double* d_covs, size_t n, const double transform[16],
+                      size_t max_points_per_voxel, bool short_lists, bool deferred, size_t* new_voxels);
+int settle_context(vgicp_ctx* ctx);
+bool insertion_lists_stay_short_for(const vgicp_ctx* ctx, double prep_voxel);
+}  // namespace vgicp_internal
+
+// ---- vgicp_multi.hip: the entry points of a multi-device context (ctx->multi != nullptr) ----
+namespace vgicp_multi_api {
+int destroy(vgicp_ctx* ctx);
+int device_info(const vgicp_ctx* ctx, char* name, size_t name_len, int32_t* cu_count, uint64_t* hbm_bytes);
+int get_counter(const vgicp_ctx* ctx, int which, uint64_t* value);
+int map_reset(vgicp_ctx* ctx, double voxel_size, size_t capacity_hint);
+int map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double* means, const double* covs);
+int map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys);
+int map_size(const vgicp_ctx* ctx, size_t* voxels, size_t* table_slots);
+int map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const double* covs, const double transform[16],
+                    size_t max_points_per_voxel, size_t* new_voxels);
+int map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel, size_t* new_voxels,
+                        bool deferred);
+int map_evict(vgicp_ctx* ctx, const double position[3], double distance_threshold, size_t* removed);
+int map_export(vgicp_ctx* ctx, size_t capacity, int32_t* keys, double* means, double* covs, uint64_t* counts,
+               size_t* written);
+int align(vgicp_ctx* ctx, size_t n, const double* points, const double* covs, const double guess[16],
+          const vgicp_params* params, double out_pose[16], vgicp_stats* stats);
+int scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const double* covs);
+int align_resident(vgicp_ctx* ctx, const double guess[16], const vgicp_params* params, double out_pose[16],
+                   vgicp_stats* stats);
+int scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, size_t num_states,
+                 const double* states, const double extrinsic[16], double voxel_size, int knn, size_t* kept,
+                 int64_t* deskewed, bool deferred);
+int scan_info(vgicp_ctx* ctx, size_t* kept, int64_t* deskewed, uint64_t* indefinite);
+int scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double* covs, size_t* n);
+int get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset);
+int set_option(vgicp_ctx* ctx, int option, int value);
+vgicp_ctx* first(const vgicp_ctx* ctx);  // sub-context 0: the hooks that work on one device
+}  // namespace vgicp_multi_api

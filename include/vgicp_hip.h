@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGICP_ABI_VERSION 3
+#define VGICP_ABI_VERSION 4
 
 typedef struct vgicp_ctx vgicp_ctx;
 
@@ -81,6 +81,21 @@ typedef struct vgicp_stats {
 int vgicp_abi_version(void);
 /* Bind a context to one HIP device (one process per GPU; device_id is the LOCAL ordinal). */
 int vgicp_create(int device_id, vgicp_ctx** out);
+/* One context that drives SEVERAL devices from the one caller thread the reference has (src/main.cpp:68-70 runs
+ * Odometry::run on the main thread; src/ErrorStateKF.cpp:130 is where align is called), SURVEY.md 8(b): the handle is
+ * used exactly like a single-device one — ICP::align / LocalMap of the shim do not change — and
+ *   - the voxel map is replicated: upsert / erase / insert / evict batches go to every device;
+ *   - vgicp_align shards the scan by contiguous point blocks in the order of device_ids (rank r owns
+ *     [r n / G, (r + 1) n / G)), every device uploads its shard over its own link and runs the single persistent
+ *     launch; the devices' 28-double rows of a round cross xGMI through mailboxes the kernels write themselves
+ *     (plain peer pointers after hipDeviceEnablePeerAccess: no second process, no IPC handle, no RCCL);
+ *   - scan preparation runs on device_ids[0] and the prepared scan is dealt out by peer copies before the align;
+ *   - vgicp_comm_* and vgicp_peer_* are refused (they are for hosts that run one process per GPU).
+ * device_ids may name a device several times ({0, 0}): those sub-contexts split the device's compute units — how the
+ * path is exercised on a single-GPU box.  n_devices == 1 returns an ordinary context.  At most 16 devices.
+ * When an in-kernel wait for another device gives up, that align (and the next few) runs one launch per round with
+ * the rows added on the host; vgicp_get_counter(VGICP_COUNTER_PERSISTENT_FALLBACKS) counts it. */
+int vgicp_create_multi(const int* device_ids, int n_devices, vgicp_ctx** out);
 int vgicp_destroy(vgicp_ctx* ctx);
 /* Text of the last failure on this context (never NULL; "" when none). ctx may be NULL for
  * failures of vgicp_create itself. */
