@@ -21,6 +21,11 @@ timed region ("mailbox": the kernels' own stores into peer-mapped mailboxes; "rc
 per iteration) and `exchange_us_per_round` what it cost (sharded round minus the same shard registered alone).
 BENCH_SHARE_DEVICE=1 is the dress rehearsal of that line on a box with ONE GPU: N ranks as N processes on device 0,
 rendezvous over gloo, the mailboxes wired by hand (vgicp_peer_export / _connect), 256 / N workgroups per rank.
+IN-PROCESS mode: `python bench.py --gpus N` WITHOUT a launcher (WORLD_SIZE unset) drives all N devices from this one
+process and thread through ONE multi-device context (vgicp_create_multi: what the reference's single-threaded caller
+would hold, src/main.cpp:68-70) — same sharding, same mailboxes (wired by plain peer pointers), no torch.distributed in
+the data path; `config.sharding.wiring` says so.  Under the launcher, rank 0 measures that in-process context too, after
+the per-rank contexts are closed, and reports it as `in_process` beside the launcher's own figure.
 
 The upload is measured honestly: the reference deep-copies a FRESH cloud every frame (src/Registration.cpp:11), so
 the timed loop rotates over freshly allocated host buffers the HIP runtime has never seen (total far above the host's
@@ -30,7 +35,9 @@ last-level cache); `upload` reports the first pass (never-seen pages), later pas
 event pair on the module's own stream (stats.device_seconds); `achieved` = ALGORITHMIC bytes per launch
 (112 B per point-iteration + 96 B per matched point) ÷ that span.  On one GPU a launch is
 the persistent kernel = all 20 rounds.  `traffic` is the PMC-measured HBM traffic per launch from the newest
-profiles/*_summary.json taken at this scan size (tools/profile_gpu.sh), or null; the persistent launch keeps
+profiles/*_summary.json taken at this scan size (tools/profile_gpu.sh) — it is NOT measured by this run, and
+`traffic_source` says which file / tag / library hash it comes from; a summary taken on another build of the kernels
+is not quoted (`traffic: null` with the reason); the persistent launch keeps
 scan and voxel records on chip, so its real HBM traffic is far BELOW the algorithmic bytes and `frac` is a
 statement about time per algorithmic byte, not about HBM utilisation (`traffic_frac` is the latter).
 `cpu_baseline` times the CPU oracle's reference-faithful mode (OpenMP) on the same inputs at several thread
@@ -51,6 +58,10 @@ import time
 # The driver's shell exports this already; a bare shell would otherwise fail in hipIpcGetMemHandle (must be set
 # before anything initialises the GPU)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# BENCH_SHARE_DEVICE=1 (several ranks / sub-contexts on ONE device): every one of them needs a hardware queue of its own
+# for its persistent launch — the runtime's default of 4 per process is too few from 3 sub-contexts on
+if os.environ.get("BENCH_SHARE_DEVICE", "0") == "1":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -75,12 +86,16 @@ def algorithmic_bytes(n_points: int, matches: float) -> float:
 
 
 def measured_traffic(n_points: int, world: int, kernel: str):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary taken at this scan
-    size on one GPU (profiles/*_summary.json, tools/profile_gpu.sh + tools/summarize_profile.py)."""
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary taken at this scan size on one
+    GPU (profiles/*_summary.json, tools/profile_gpu.sh + tools/summarize_profile.py) — quoted only for the library it
+    was measured on.  -> (traffic or None, provenance dict): the summary records the sha256 of libvgicp_hip.so and of
+    the kernel sources at profile time; a loaded library that matches neither gets `traffic: null` and the reason."""
     import glob
+    from eskf_lio_amd import provenance
     if world != 1:
-        return None
-    best = None
+        return None, {"reason": "PMC profiles are taken on one GPU; no per-launch traffic for a sharded run"}
+    lib_now, src_now = provenance.library_sha256(capi.LIB_PATH), provenance.kernel_source_sha256()
+    best, stale = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
@@ -89,9 +104,23 @@ def measured_traffic(n_points: int, world: int, kernel: str):
         except Exception:
             continue
         key = f"{kernel}_total_calibrated"
-        if t and points == n_points and key in t and t[key] == t[key]:
-            best = t[key]
-    return best
+        if not (t and points == n_points and key in t and t[key] == t[key]):
+            continue
+        src = {"file": os.path.relpath(f, ROOT), "tag": d.get("tag"), "library_sha256": d.get("library_sha256"),
+               "kernel_source_sha256": d.get("kernel_source_sha256")}
+        if src["library_sha256"] and src["library_sha256"] == lib_now:
+            src["match"] = "the loaded libvgicp_hip.so is byte for byte the profiled one"
+        elif src["kernel_source_sha256"] and src["kernel_source_sha256"] == src_now:
+            src["match"] = "library rebuilt since; the kernel sources and build flags are the profiled ones"
+        else:
+            stale = src
+            continue
+        best = (t[key], src)
+    if best is not None:
+        return best
+    reason = ("no PMC summary for this scan size under profiles/" if stale is None else
+              f"the newest PMC summary ({stale['file']}) was taken on another build of the kernels: not quoted")
+    return None, {"reason": reason, "library_sha256": lib_now, "kernel_source_sha256": src_now}
 
 
 def cpu_baseline(vmap, pts, covs, guess, budget_s: float):
@@ -202,6 +231,53 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
             "host_syncs_per_frame": fs.host_syncs / frames,
             "align_rounds_per_frame": float(np.mean([r.iterations for r in results])),
         })
+    # the SAME frames through the C++ drop-in classes the way src/Odometry.cpp:73-87 writes them (libvgicp_host.so =
+    # include/eskf_lio_shim/ compiled): cloudPreprocessor.process(states, meas) -> icp.align(*meas.cloud, localMap,
+    # guess) -> localMap.updateLocalMap(meas.cloud, T).  "deferred": grid on the device, the prepared scan handed from
+    # class to class on the device (the chain above behind the reference's interface); "eager": the classes' defaults
+    # (host-authoritative map, the host cloud holds the prepared scan after process()).
+    try:
+        from eskf_lio_amd import host
+        chain_poses = [r.pose for r in results]
+
+        def dropin(host_copy, device_resident):
+            pre = host.CloudPreprocessor(h, ext, host_copy)
+            icp = host.ICP(30, 1e-6, 0.9999)
+            cfg = dict(translation_sq_threshold=-1.0, cosine_threshold=2.0, remove_distant_points=False,
+                       distance_threshold=1e9, removing_period=1e9, device_resident=device_resident)
+            lmap = host.LocalMap(h, cap, cfg)
+            fr = host.Frame(sweeps[0], tt, st)
+            fr.run(pre, icp, lmap, np.eye(4), first_frame=True)
+            fr.end()
+            pose, poses, resident, wall = np.eye(4), [], 0, 0.0
+            for f in range(1, frames + 1):
+                fr = host.Frame(sweeps[f], tt, st)                 # the measurement object: built outside the timed part
+                t0 = time.perf_counter()
+                fr.run(pre, icp, lmap, pose)
+                wall += time.perf_counter() - t0
+                got = fr.end()
+                pose = got["pose"]
+                poses.append(pose)
+                resident += int(got["used_resident"])
+            return wall / frames * 1e3, poses, resident, len(lmap)
+        dropin("deferred", True)                                       # warm-up
+        ms_def, poses_def, res_def, vox_def = dropin("deferred", True)
+        ms_eag, poses_eag, res_eag, _ = dropin("eager", False)
+        out["dropin_ms_per_frame"] = ms_def
+        out["dropin_eager_ms_per_frame"] = ms_eag
+        out["dropin"] = {
+            "what": "the frames above through ESKF_LIO::CloudPreprocessor::process / ICP::align / LocalMap::updateLocalMap "
+                    "(C++ shim, called as src/Odometry.cpp:73-87 does); dropin_ms_per_frame: LocalMapConfig::deviceResident + "
+                    "CloudPreprocessorConfig::HostCopy::Deferred (the scan never returns to the host); dropin_eager: the "
+                    "classes' defaults (host map, host copy of the prepared scan)",
+            "ratio_to_the_abi_chain": ms_def / out["ms_per_frame"],
+            "aligns_that_found_the_scan_resident": f"{res_def} of {frames} (deferred), {res_eag} of {frames} (eager)",
+            "poses_bit_equal_to_the_abi_chain": bool(all(np.array_equal(a, b) for a, b in zip(poses_def, chain_poses))),
+            "eager_pose_delta_max": float(max(np.abs(a - b).max() for a, b in zip(poses_eag, chain_poses))),
+            "map_voxels": vox_def,
+        }
+    except Exception as e:  # noqa: BLE001 - a secondary record
+        out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
     # pass 2: stage events + parity, on a fresh context
     stage = {"prepare_head": [], "prepare": [], "align": [], "insert": []}
     kept_points, mismatches, pose_delta = [], [], 0.0
@@ -275,6 +351,49 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
     return out
 
 
+def in_process_leg(device_ids, vmap, pts, covs, guess, steps):
+    """Secondary record under the launcher: ONE multi-device context (vgicp_create_multi) over `device_ids`, driven by
+    this one thread — the whole scan in host buffers in, the pose out, sharded and exchanged inside the library."""
+    n = pts.shape[0]
+    with capi.Context(list(device_ids)) as ctx:
+        ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+        ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+        for _ in range(5):
+            res = ctx.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0)
+        bufs = [(pts.copy(), covs.copy()) for _ in range(min(steps, 50))]   # buffers the runtime has not uploaded from
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dev = 0.0
+        for k in range(steps):
+            p, c = bufs[k % len(bufs)]
+            res = ctx.align(p, c, guess, ITERATIONS, 1e-6, 2.0)
+            dev += res.device_seconds
+        wall = time.perf_counter() - t0
+        ctx.scan_upload(pts, covs)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rr = ctx.align_resident(guess, ITERATIONS, 1e-6, 2.0)
+        wall_res = time.perf_counter() - t0
+        fallbacks, attempts = ctx.counter(1), ctx.counter(0)
+    with capi.Context(int(device_ids[0])) as one:
+        one.map_reset(vmap.voxel_size, vmap.keys.shape[0])
+        one.map_upsert(vmap.keys, vmap.means, vmap.covs)
+        ref = one.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0)
+    return {
+        "what": f"ONE process, ONE caller thread, one multi-device context (vgicp_create_multi) over devices {list(device_ids)}: "
+                "vgicp_align of the whole scan from host buffers (sharded upload + single persistent launch per device, rows "
+                "exchanged through peer-pointer mailboxes); the reference's caller is single-threaded (src/main.cpp:68-70)",
+        "value": n * ITERATIONS * steps / wall, "unit": "points/s", "ms_per_step": wall / steps * 1e3,
+        "value_resident": n * ITERATIONS * steps / wall_res, "ms_per_step_resident": wall_res / steps * 1e3,
+        "us_per_round": dev / steps / ITERATIONS * 1e6, "steps": steps,
+        "single_launch_per_device": res.launches == 1 and rr.launches == 1, "world_size": res.world_size,
+        "single_launch_attempts": attempts, "fallbacks_to_host_summed_loop": fallbacks,
+        "parity": {"identical_counts": bool((ref.corr_count == res.corr_count).all()),
+                   "pose_delta": float(np.abs(ref.pose - res.pose).max()),
+                   "against": "the whole scan on one single-device context"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,10 +413,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run "
-                             "--nproc-per-node N (one rank per GPU)")
+    # no launcher but several GPUs asked for: ONE process, ONE thread, one multi-device context (vgicp_create_multi)
+    inproc = world == 1 and args.gpus > 1
+    if world != args.gpus and not inproc:
         raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
@@ -306,11 +424,16 @@ def main():
     force_comm = os.environ.get("BENCH_FORCE_COMM", "0") == "1"
     # BENCH_SHARE_DEVICE=1: every rank is a process on device 0 (a box with one GPU): gloo for the host side, the
     # mailboxes of the device-initiated exchange wired by hand, the CUs divided between the ranks
-    share_device = os.environ.get("BENCH_SHARE_DEVICE", "0") == "1" and world > 1
-    use_dist = world > 1 or force_comm
+    share_device = os.environ.get("BENCH_SHARE_DEVICE", "0") == "1" and (world > 1 or inproc)
+    use_dist = (world > 1 or force_comm) and not inproc
+    eff_world = args.gpus if inproc else world                     # devices (or sub-contexts) that share the ONE scan
     if share_device:
         local_rank = 0
-        os.environ.setdefault("VGICP_PERSIST_GRID", str(max(1, 256 // world)))
+        if not inproc:
+            os.environ.setdefault("VGICP_PERSIST_GRID", str(max(1, 256 // world)))
+    if inproc and not share_device and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} device(s) visible "
+                         "(BENCH_SHARE_DEVICE=1 runs the sub-contexts on one device)")
     torch.cuda.set_device(local_rank)
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
@@ -329,8 +452,11 @@ def main():
     lo, hi = shard_bounds(n_points, world, rank)
     my_pts, my_covs = np.ascontiguousarray(pts[lo:hi]), np.ascontiguousarray(covs[lo:hi])
     n_local = hi - lo
+    if inproc:
+        n_local = -(-n_points // eff_world)                        # the largest shard: what a device's launch works on
 
-    ctx = capi.Context(local_rank)
+    device_ids = ([0] * args.gpus if share_device else list(range(args.gpus))) if inproc else None
+    ctx = capi.Context(device_ids if inproc else local_rank)
     ctx.map_reset(vmap.voxel_size, n_voxels)
     ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
     if share_device:
@@ -463,7 +589,7 @@ def main():
         kernel_ms.append(r.kernel_ms[:ITERATIONS])
     kernel_ms = np.array(kernel_ms)
     bracketed_s = float(kernel_ms.mean()) * 1e-3 if kernel_ms.size else None
-    matches = float(res.corr_count.mean()) / world                 # corr_count is summed over the communicator
+    matches = float(res.corr_count.mean()) / eff_world             # corr_count is summed over the communicator
     bytes_per_round = algorithmic_bytes(n_local, matches)
     persistent = res.launches == 1                                 # single GPU: the whole align is ONE launch
     rounds_per_launch = ITERATIONS if persistent else 1
@@ -514,27 +640,27 @@ def main():
                             "alone on the same workgroups, no exchange between ranks; slowest rank of each"}
 
     # which transport carried the exchange of the TIMED aligns: one launch with several ranks = the mailboxes
-    transport = "mailbox" if (persistent and res.world_size > 1) else "rccl"
+    transport = "mailbox" if (persistent and res.world_size > 1) else ("host-sum" if inproc else "rccl")
     out = None
     if rank == 0:
         kernel = "vgicp::persistent_kernel" if persistent else "vgicp::iterate_kernel"
-        traffic = measured_traffic(n_points, world, "persistent_kernel" if persistent else "iterate_kernel")
+        traffic, traffic_source = measured_traffic(n_points, eff_world, "persistent_kernel" if persistent else "iterate_kernel")
         workload = (f"{args.config}: {n_points}-pt uniform-random scan vs {n_voxels}-voxel map (voxel 0.3 m, occupancy 0.5), "
                     f"{ITERATIONS} VGICP iterations per align (cosine_threshold 2.0 forces all); ")
         if args.resident:
             workload += "PROFILING MODE --resident: scan already in HBM (not the headline configuration)"
-        elif world == 1:
+        elif world == 1 and not inproc:
             workload += ("each step = vgicp_align with the scan in host buffers: upload of the 96*N-byte scan + pack + "
                          "20 rounds in one persistent launch; map resident")
         else:
-            workload += (f"ONE scan point-sharded over {world} ranks (contiguous shards, replicated map); each step = "
+            workload += (f"ONE scan point-sharded over {eff_world} ranks (contiguous shards, replicated map); each step = "
                          f"every rank uploads its shard from host buffers and runs the sharded loop, one exchange of the "
                          f"28-double normal-equation row per iteration")
         out = {
             "metric": METRIC,
             "value": n_points * ITERATIONS * args.steps / elapsed,
             "unit": "points/s",
-            "n_gpus": world,
+            "n_gpus": eff_world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -548,14 +674,20 @@ def main():
             "config": {
                 "workload": workload,
                 "points": n_points, "voxels": n_voxels, "iterations": ITERATIONS,
-                "sharding": "single GPU" if not use_dist else {
-                    "layout": f"contiguous point shards over {world} rank(s), replicated map",
+                "sharding": "single GPU" if not (use_dist or inproc) else {
+                    "layout": f"contiguous point shards over {eff_world} rank(s), replicated map",
                     "transport": transport,
                     "transport_detail": {
                         "mailbox": "device-initiated: the ONE persistent launch of every rank stores its 28-double row "
                                    "of each iteration into all ranks' peer-mapped mailboxes and adds what it receives",
+                        "host-sum": "one iterate launch per device and round, the devices' rows added on the host "
+                                    "(the in-process context's fallback: the mailboxes could not be wired or gave up)",
                         "rccl": "one iterate launch + one ncclAllReduce of 32 doubles per iteration"}[transport],
-                    "wiring": "BENCH_SHARE_DEVICE=1: all ranks are processes on ONE device (dress rehearsal), gloo "
+                    "wiring": ("IN-PROCESS: one process, one caller thread, ONE multi-device context (vgicp_create_multi) "
+                               f"over devices {device_ids}; mailboxes wired by plain peer pointers, no launcher, no RCCL"
+                               + ("; BENCH_SHARE_DEVICE=1: the sub-contexts split ONE device (dress rehearsal)" if share_device else ""))
+                              if inproc else
+                              "BENCH_SHARE_DEVICE=1: all ranks are processes on ONE device (dress rehearsal), gloo "
                               "rendezvous, vgicp_peer_export/_connect by hand, "
                               f"VGICP_PERSIST_GRID={os.environ.get('VGICP_PERSIST_GRID')}" if share_device else
                               "one rank per GPU, torch.distributed (nccl = RCCL) rendezvous, vgicp_comm_init",
@@ -573,6 +705,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "traffic_frac": (traffic / span_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "note": "achieved/frac price ALGORITHMIC bytes (SURVEY.md 8(d)) against the launch's duration; the "
                         "persistent launch keeps scan and voxel records on chip, so its HBM traffic (`traffic`, PMC) is "
@@ -593,7 +726,7 @@ def main():
         }
         if replicas is not None:
             out["replicas_aggregate"] = replicas
-        if world == 1 and not use_dist and not args.no_cpu_baseline:
+        if world == 1 and not use_dist and not inproc and not args.no_cpu_baseline:
             base, ref = cpu_baseline(vmap, pts, covs, guess, args.cpu_budget)
             out["cpu_baseline"] = base
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / base["value"]
@@ -601,12 +734,16 @@ def main():
             same_counts = bool((ref.corr_count == res.corr_count).all())
             dt = float(np.linalg.norm(ref.pose[:3, 3] - res.pose[:3, 3]))
             out["parity"] = {"identical_counts": same_counts, "pose_delta_m": dt}
-        if world == 1 and not use_dist and not args.no_frame_chain:
+        if world == 1 and not use_dist and not inproc and not args.no_frame_chain:
             try:
                 out["frame_chain"] = frame_chain_leg(local_rank, frames=args.frames)
             except Exception as e:  # noqa: BLE001 - a secondary record: reported, never raised
                 out["frame_chain"] = {"error": f"{type(e).__name__}: {e}"}
-        if use_dist:
+        if inproc:
+            solo = capi.Context(0)
+            solo.map_reset(vmap.voxel_size, n_voxels)
+            solo.map_upsert(vmap.keys, vmap.means, vmap.covs)
+        if use_dist or inproc:
             # evidence that the sharded, exchanged loop computes what one GPU computes
             one = solo.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0)
             out["multi_gpu_parity"] = {
@@ -630,6 +767,7 @@ def main():
             map5 = synth.make_map(v5)
             pts5, covs5 = synth.make_uniform_scan(n5, map5)
             lo5, hi5 = shard_bounds(n5, world, rank)
+            rank_points5 = -(-n5 // eff_world) if inproc else hi5 - lo5
             ctx.map_reset(map5.voxel_size, v5)
             ctx.map_upsert(map5.keys, map5.means, map5.covs)
             ctx.scan_upload(np.ascontiguousarray(pts5[lo5:hi5]), np.ascontiguousarray(covs5[lo5:hi5]))
@@ -648,14 +786,14 @@ def main():
                     r5 = step_resident()
                 steps5 = 10
                 el5, dev5, r5, _ = timed(lambda k: step_resident(), steps5)
-                per_rank_bytes = algorithmic_bytes(hi5 - lo5, float(r5.corr_count.mean()) / world) * ITERATIONS
+                per_rank_bytes = algorithmic_bytes(rank_points5, float(r5.corr_count.mean()) / eff_world) * ITERATIONS
                 c5 = {"value": n5 * ITERATIONS * steps5 / el5, "unit": "points/s", "ms_per_step": el5 / steps5 * 1e3,
                       "us_per_round": dev5 / steps5 / ITERATIONS * 1e6,
                       "achieved_GBs_per_gpu": per_rank_bytes / (dev5 / steps5) / 1e9,
                       "frac_of_8TBs_per_gpu": per_rank_bytes / (dev5 / steps5) / 1e9 / HBM_PEAK_GBS,
                       "single_launch": r5.launches == 1, "matches_per_iteration": float(r5.corr_count.mean()),
                       "workload": f"C5: {n5}-pt scan vs {v5}-voxel map, {ITERATIONS} rounds per align, scan resident, "
-                                  f"point-sharded over {world} rank(s); algorithmic bytes of a rank / its event span"}
+                                  f"point-sharded over {eff_world} rank(s); algorithmic bytes of a rank / its event span"}
             except Exception as e:  # noqa: BLE001 - a failing collective align is fatal for the run: say so and stop
                 if use_dist:
                     raise
@@ -666,6 +804,16 @@ def main():
         dist.barrier()                 # nobody unmaps a mailbox a peer's kernel may still be writing into
         ctx.peer_disconnect()
     ctx.close()
+    if use_dist and world > 1:
+        # every rank's own context is closed: rank 0 now drives ALL the devices from its one thread through ONE
+        # multi-device context (what the reference's single-threaded caller would hold) — the others wait
+        dist.barrier()
+        if rank == 0 and out is not None:
+            try:
+                ids = [0] * world if share_device else list(range(world))
+                out["in_process"] = in_process_leg(ids, vmap, pts, covs, guess, max(10, min(args.steps, 200)))
+            except Exception as e:  # noqa: BLE001 - a secondary record: reported, never raised
+                out["in_process"] = {"error": f"{type(e).__name__}: {e}"}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

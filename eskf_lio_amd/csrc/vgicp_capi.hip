@@ -250,7 +250,7 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.cosine_threshold = params->cosine_threshold;
   a.translation_sq_threshold = params->translation_sq_threshold;
   a.max_iteration = max_it;
-  persistent_lds_plan(ctx->n, grid, &a.memo_points, &a.stash_points, &a.stash_bytes);
+  persistent_lds_plan(ctx->n, grid, &a.memo_points, &a.stash_points, &a.stash_bytes, ctx->persist_lds_budget);
   if (std::getenv("VGICP_NO_STASH")) a.stash_points = a.stash_bytes = 0;
   if (std::getenv("VGICP_NO_MEMO")) a.memo_points = 0;
   a.prefetch_margin = (a.memo_points == 0 && a.stash_points == 0 && ctx->n <= grid * 448u) ? ctx->prefetch_margin : 0.0;
@@ -300,6 +300,10 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
     // loop for this align and the next few, then try the single launch again.
     ++ctx->persistent_fallbacks;
     if (ctx->owner && multi) {
+      if (std::getenv("VGICP_VERBOSE"))
+        std::fprintf(stderr, "[vgicp] rank %d of %d: persistent launch did not commit (echo %s, outcome %u, a workgroup gave up: %s, "
+                     "rounds reported %d, %u points)\n", ctx->peer_rank, ctx->peer_world, result->seq == a.seq ? "yes" : "no",
+                     result->outcome, someone_gave_up ? "yes" : "no", result->iteration, ctx->n);
       // a sub-context of an in-process multi-device context: every sub-context's launch has ended when its thread
       // returns, so the group itself re-arms all mailboxes and runs this align with the rows added on the host
       const int rc_reset = reset_persistent_exchange(ctx);
@@ -584,6 +588,7 @@ int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgi
     // a launch plan asks for (memo + parked points of a scan bigger than the grid: 150 KB) must fit a CU — checked
     // once here instead of found out by a timeout on every align
     uint32_t resident = 0;
+    VG_CREATE(persistent_prepare_device());
     VG_CREATE(persistent_max_resident(persistent_max_dyn_lds_bytes(), ctx->cu_count, &resident));
     if (resident < ctx->persist_grid) {
       ctx->persistent_enabled = false;
@@ -686,6 +691,7 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipHostFree(ctx->h_ins_counters);
   for (int k = 0; k < 2; ++k) {
     if (ctx->h_state_table[k]) (void)hipHostFree(ctx->h_state_table[k]);
+    if (ctx->h_raw_stage[k]) (void)hipHostFree(ctx->h_raw_stage[k]);
     if (ctx->ev_state_table[k]) (void)hipEventDestroy(ctx->ev_state_table[k]);
   }
   for (auto& e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -744,6 +750,7 @@ int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
       *value = ctx->prep_indefinite;
       break;
     }
+    case VGICP_COUNTER_SCAN_GENERATION: *value = ctx->scan_generation; break;
     default: return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown counter");
   }
   return VGICP_OK;
@@ -1061,6 +1068,7 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
   VG_HIP(ctx, hipSetDevice(ctx->device));
   int rc = ensure_scan(ctx, n);
   if (rc != VGICP_OK) return rc;
+  ++ctx->scan_generation;
   ctx->scan_ready = false;
   ctx->prep_voxel = 0.0;
   ctx->prep_with_deskew = false;   // what vgicp_scan_info reports belongs to a PREPARED scan, not to this one
@@ -1194,6 +1202,7 @@ int vgicp_accumulate(vgicp_ctx* ctx, size_t n, const double* points, const doubl
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (ctx->multi) {  // a hook that works on one device ("local rank only"): the whole scan on sub-context 0
     vgicp_ctx* first = vgicp_multi_api::first(ctx);
+    vgicp_multi_api::scan_replaced(ctx);
     const int rc = vgicp_accumulate(first, n, points, covs, pose, JTJ, JTr, count);
     if (rc != VGICP_OK) ctx->err = first->err;
     return rc;
@@ -1701,6 +1710,7 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   VG_HIP(ctx, hipSetDevice(ctx->device));
   rc = ensure_scan(ctx, n);
   if (rc != VGICP_OK) return rc;
+  ++ctx->scan_generation;
   ctx->scan_ready = false;
   ctx->scan_pending = false;
   ctx->n = 0;
@@ -1739,16 +1749,42 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   unsigned long long* d_idx = reinterpret_cast<unsigned long long*>(base + pb + tb + sb + eb);
   void* scratch = base + pb + tb + sb + eb + ib;
   if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[0], ctx->stream)); ctx->ev_stage_set[0] = true; }
-  VG_HIP(ctx, hipMemcpyAsync(d_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  static const bool trace = std::getenv("VGICP_TRACE_PREPARE") != nullptr;   // developer aid: where the host time of the enqueue goes
+  const double tr0 = trace ? now_seconds() : 0.0;
+  // two pinned slots in turn, guarded by one event each (recorded behind the last copy out of the slot)
+  const uint32_t slot = ctx->state_table_next++ & 1u;
+  if (ctx->ev_state_table[slot]) {
+    // the copies out of this slot two preparations ago: long complete, normally (no host wait then)
+    if (hipEventQuery(ctx->ev_state_table[slot]) != hipSuccess) VG_HIP(ctx, hipEventSynchronize(ctx->ev_state_table[slot]));
+  } else {
+    VG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_state_table[slot], hipEventDisableTiming));
+  }
+  const size_t raw_bytes = n * 3 * sizeof(double) + (with_deskew ? n * sizeof(double) : 0);
+  static const size_t stage_limit = std::getenv("VGICP_STAGE_LIMIT") ? (size_t)std::atoll(std::getenv("VGICP_STAGE_LIMIT")) : (16u << 20);
+  const bool staged = raw_bytes <= stage_limit;   // larger sweeps go up straight from the caller's memory
+  const double* src_points = points;
+  const double* src_time = point_time;
+  if (staged) {
+    if (ctx->raw_stage_cap[slot] < raw_bytes) {
+      if (ctx->h_raw_stage[slot]) VG_HIP(ctx, hipHostFree(ctx->h_raw_stage[slot]));
+      ctx->h_raw_stage[slot] = nullptr;
+      ctx->raw_stage_cap[slot] = 0;
+      const size_t cap = n * 4 * sizeof(double) + n * sizeof(double);   // room for the capture times whether or not this sweep has them, and a quarter more
+      VG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_raw_stage[slot]), cap, 0));
+      ctx->raw_stage_cap[slot] = cap;
+    }
+    std::memcpy(ctx->h_raw_stage[slot], points, n * 3 * sizeof(double));
+    src_points = reinterpret_cast<const double*>(ctx->h_raw_stage[slot]);
+    if (with_deskew) {
+      std::memcpy(ctx->h_raw_stage[slot] + n * 3 * sizeof(double), point_time, n * sizeof(double));
+      src_time = reinterpret_cast<const double*>(ctx->h_raw_stage[slot] + n * 3 * sizeof(double));
+    }
+  }
+  VG_HIP(ctx, hipMemcpyAsync(d_pts, src_points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const double tr1 = trace ? now_seconds() : 0.0;
   DeskewOnDevice dk;
   if (with_deskew) {
-    VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    const uint32_t slot = ctx->state_table_next++ & 1u;
-    if (ctx->ev_state_table[slot]) {
-      // the copy out of this slot two preparations ago: long complete, normally (no host wait then)
-      if (hipEventQuery(ctx->ev_state_table[slot]) != hipSuccess) VG_HIP(ctx, hipEventSynchronize(ctx->ev_state_table[slot]));
-    }
-    else VG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_state_table[slot], hipEventDisableTiming));
+    VG_HIP(ctx, hipMemcpyAsync(d_time, src_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (ctx->state_table_cap[slot] < used * 13) {
       if (ctx->h_state_table[slot]) VG_HIP(ctx, hipHostFree(ctx->h_state_table[slot]));
       ctx->h_state_table[slot] = nullptr;
@@ -1759,7 +1795,6 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     }
     std::memcpy(ctx->h_state_table[slot], host.data(), used * 13 * sizeof(double));
     VG_HIP(ctx, hipMemcpyAsync(d_states, ctx->h_state_table[slot], used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    VG_HIP(ctx, hipEventRecord(ctx->ev_state_table[slot], ctx->stream));
     dk.point_time = d_time;
     dk.state_time = d_states;
     dk.poses = d_states + used;
@@ -1767,9 +1802,14 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     dk.ordered = ordered;
     dk.ends = reinterpret_cast<uint32_t*>(base + pb + tb + sb);
   }
+  VG_HIP(ctx, hipEventRecord(ctx->ev_state_table[slot], ctx->stream));   // behind the last copy out of this slot's pinned buffers
+  const double tr2 = trace ? now_seconds() : 0.0;
   rc = enqueue_prepare(ctx, d_pts, n, voxel_size, knn, extrinsic, dk, scratch, ctx->d_scan_aos,
                        ctx->d_scan_aos + 3 * ctx->scan_capacity, d_idx, ctx->d_scan, ctx->stride);
   if (rc != VGICP_OK) return rc;
+  if (trace)
+    std::fprintf(stderr, "[vgicp trace] prepare enqueue: staging + points copy %.3f ms, times + states copies %.3f ms, kernels %.3f ms\n",
+                 (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, (now_seconds() - tr2) * 1e3);
   if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[1], ctx->stream)); ctx->ev_stage_set[1] = true; }
   ctx->n_upper = (uint32_t)n;
   ctx->scan_sym_known = false;   // covariances made on the device: all twelve planes are read
@@ -2043,6 +2083,27 @@ bool insertion_lists_stay_short_for(const vgicp_ctx* ctx, double prep_voxel) {
   return per_axis * per_axis * per_axis <= 64.0;
 }
 
+// Whether an align of n points / max_it rounds would have to (re)allocate on this context, and the allocation itself.
+// hipFree waits for the whole DEVICE: sub-contexts that share a device must not meet one between their launches (a
+// neighbour's persistent kernel is already running and waiting for this sub-context's), so the multi-device context
+// grows every sub-context's buffers in a phase of its own before anybody launches.
+bool align_needs_allocation(const vgicp_ctx* ctx, size_t n, int max_it) {
+  return !ctx->d_scan || n > ctx->scan_capacity || max_it > ctx->log_capacity || ctx->log_capacity == 0;
+}
+int reserve_for_align(vgicp_ctx* ctx, size_t n, int max_it) {
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = settle(ctx);
+  if (rc != VGICP_OK) return rc;
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!ctx->d_scan || n > ctx->scan_capacity) {
+    rc = ensure_scan(ctx, n);
+    if (rc != VGICP_OK) return rc;
+    ctx->scan_ready = false;   // whatever was resident went with the old buffers
+    ctx->n = 0;
+  }
+  return ensure_log(ctx, std::max(max_it, 1));
+}
+
 int wire_mailboxes(vgicp_ctx* const* subs, int n) {
   if (n < 1 || n > kMaxRanks) return fail(subs[0], VGICP_ERR_BAD_ARGUMENT, "at most 16 devices");
   // every device must be able to store into every other device's mailbox (xGMI / PCIe peer access)
@@ -2218,6 +2279,7 @@ int adopt_device_scan(vgicp_ctx* ctx, int src_device, const double* d_points, co
   if (rc != VGICP_OK) return rc;
   rc = ensure_scan(ctx, n);
   if (rc != VGICP_OK) return rc;
+  ++ctx->scan_generation;
   ctx->scan_ready = false;
   ctx->prep_voxel = prep_voxel;
   ctx->prep_with_deskew = false;

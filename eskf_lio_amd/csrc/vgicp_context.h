@@ -160,6 +160,7 @@ struct vgicp_ctx {
   // persistent single-launch align (single GPU)
   uint32_t persist_round0 = 0;       // rounds the persistent launches of this context have executed, mod 3
   uint32_t persist_seq = 0;
+  uint32_t persist_lds_budget = 0;   // dynamic LDS a persistent workgroup may plan with (0 = the whole CU); sub-contexts that share a device take less
   uint32_t persist_grid = 0;         // workgroups of every persistent launch: min(CUs, kExchangeRows), all resident
   double* d_rows_persist = nullptr;  // [3][kExchangeRows][kSlots] (vgicp_device.h, PersistArgs)
   double* d_parts_persist = nullptr; // [3][kFolders][kSlots]
@@ -186,6 +187,7 @@ struct vgicp_ctx {
   uint32_t prep_epoch = 0;
   bool scan_pending = false;         // a prepared scan is resident but the host has not read its size / verdict yet
   uint32_t n_upper = 0;              // raw points of the pending scan (>= its kept points)
+  uint64_t scan_generation = 0;      // replacements of the resident scan so far (VGICP_COUNTER_SCAN_GENERATION)
   uint32_t scan_seq = 0;             // uploads so far; pack_scan_kernel marks an asymmetric covariance with it
   bool scan_sym_known = false;       // the resident scan went through pack_scan_kernel (not a scan prepared on the device)
   int64_t prep_deskewed = 0;
@@ -193,6 +195,12 @@ struct vgicp_ctx {
   double prep_voxel = 0.0;           // > 0: the resident scan was down-sampled on the device to one point per voxel of this size
   // the deskew's state table on its way to the device: pinned, two slots in turn (an enqueue-only preparation returns
   // before the copy has run, so the table cannot live on the caller's stack)
+  // ... and the raw sweep (points, then capture times): mid-sized copies out of the caller's pageable memory are staged
+  // through these instead of handed to the runtime, which would pin the caller's pages on the fly — measured on the
+  // round's boxes: 1.4 MB of points 0.05 ms staged, but 12-22 ms (first copy of every frame) through the pinning path
+  // once the caller allocates and frees its clouds per frame, as the reference does (examples/frame_chain)
+  char* h_raw_stage[2] = {nullptr, nullptr};
+  size_t raw_stage_cap[2] = {0, 0};
   double* h_state_table[2] = {nullptr, nullptr};
   size_t state_table_cap[2] = {0, 0};
   hipEvent_t ev_state_table[2] = {nullptr, nullptr};
@@ -279,6 +287,8 @@ int adopt_device_scan(vgicp_ctx* ctx, int src_device, const double* d_points, co
 int map_insert_device(vgicp_ctx* ctx, const double* d_points, const double* d_covs, size_t n, const double transform[16],
                       size_t max_points_per_voxel, bool short_lists, bool deferred, size_t* new_voxels);
 int settle_context(vgicp_ctx* ctx);
+bool align_needs_allocation(const vgicp_ctx* ctx, size_t n, int max_it);
+int reserve_for_align(vgicp_ctx* ctx, size_t n, int max_it);
 bool insertion_lists_stay_short_for(const vgicp_ctx* ctx, double prep_voxel);
 }  // namespace vgicp_internal
 
@@ -311,4 +321,5 @@ int scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double* covs,
 int get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset);
 int set_option(vgicp_ctx* ctx, int option, int value);
 vgicp_ctx* first(const vgicp_ctx* ctx);  // sub-context 0: the hooks that work on one device
+void scan_replaced(vgicp_ctx* ctx);
 }  // namespace vgicp_multi_api

@@ -148,13 +148,15 @@ struct PersistArgs {
 hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid);
 // How launch_persistent splits the CU's LDS for a scan of n points on `grid` workgroups: points per
 // thread beyond the first that get a memo (last key + slot, 16 B) and that are parked whole (96 B).
-void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points, uint32_t* stash_bytes);
+void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points, uint32_t* stash_bytes,
+                         uint32_t lds_budget = 0);
 // Sizes (8-byte words) of the rows / parts exchange buffers, and their content between launches.
 size_t persistent_rows_words();
 size_t persistent_parts_words();
 void persistent_exchange_image(uint32_t grid, unsigned long long* rows_words, unsigned long long* parts_words);
 // Whether one 512-thread workgroup of the persistent kernel with this much dynamic LDS fits a CU of the
 // current device: *max_grid = cu_count then, else 0 (the in-kernel exchange needs every workgroup resident).
+hipError_t persistent_prepare_device();  // once per context, on its device: every instantiation may use the whole CU's LDS
 hipError_t persistent_max_resident(uint32_t dyn_lds_bytes, int cu_count, uint32_t* max_grid);
 uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_bytes);
 uint32_t persistent_max_dyn_lds_bytes();  // the most a launch plan ever asks for

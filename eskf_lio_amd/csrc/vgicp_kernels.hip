@@ -1434,17 +1434,22 @@ constexpr uint32_t kPrefetchBytes = kPersistWorkers * (sizeof(int4) + 6 * sizeof
 
 // The plan is made from n, which may be an upper bound of the scan's size (a scan prepared on the device): it is
 // sized for 512 point-carrying threads; a launch that finds fewer points than grid x 448 uses 448 and less of it.
-void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points, uint32_t* stash_bytes) {
+void persistent_lds_plan(uint32_t n, uint32_t grid, uint32_t* memo_points, uint32_t* stash_points, uint32_t* stash_bytes,
+                         uint32_t lds_budget) {
   *memo_points = *stash_points = *stash_bytes = 0;
+  // lds_budget: 0 = the whole CU (kPersistDynLds); contexts that SHARE a device take less, so that two of their
+  // workgroups fit one CU (what is not kept in LDS is re-read: same arithmetic, same bits)
+  const uint32_t budget = (lds_budget == 0 || lds_budget > kPersistDynLds) ? kPersistDynLds : lds_budget;
   if ((uint64_t)n <= (uint64_t)grid * kPersistWorkers) return;  // one point per thread: registers (and the neighbour prefetch area)
   // units of 64 points, dealt out evenly: a workgroup holds at most ceil(units / grid), taken 8 units per pass
   const uint32_t units = (n + 63u) / 64u, most = (units + grid - 1) / grid;
   const uint32_t per_thread = (most + kPersistWide / 64 - 1) / (kPersistWide / 64);  // points per thread (upper bound)
   // the memo first (it saves the table access, the larger term), the rest of the LDS parks whole points
-  const uint32_t memo = per_thread < kMaxMemoPoints ? per_thread : kMaxMemoPoints;
+  uint32_t memo = per_thread < kMaxMemoPoints ? per_thread : kMaxMemoPoints;
+  if (memo * kMemoBytesPerPoint > budget) memo = budget / kMemoBytesPerPoint;
   *memo_points = memo;
   *stash_points = per_thread - 1;  // the first point of a thread lives in registers
-  *stash_bytes = *stash_points ? kPersistDynLds - memo * kMemoBytesPerPoint : 0u;
+  *stash_bytes = *stash_points ? budget - memo * kMemoBytesPerPoint : 0u;
 }
 
 uint32_t persistent_dyn_lds_bytes(uint32_t memo_points, uint32_t stash_bytes) {
@@ -1476,17 +1481,32 @@ void persistent_exchange_image(uint32_t grid, unsigned long long* rows_words, un
 namespace {
 template <bool MULTI, bool STAMPS, bool MANY>
 hipError_t launch_persistent_as(hipStream_t s, const PersistArgs& args, uint32_t grid, size_t dyn, int device) {
-  static bool raised[64] = {false};  // per device: LDS beyond the default 64 KB per workgroup has to be asked for once
-  const void* fn = reinterpret_cast<const void*>(&persistent_kernel<512, MULTI, STAMPS, MANY>);
-  if (!raised[device]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistDynLds);
-    if (e != hipSuccess) return e;
-    raised[device] = true;
-  }
+  (void)device;
   ++g_kernel_launches; hipLaunchKernelGGL((persistent_kernel<512, MULTI, STAMPS, MANY>), dim3(grid), dim3(512), dyn, s, args);
   return hipGetLastError();
 }
+template <bool MULTI, bool STAMPS, bool MANY>
+hipError_t raise_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<512, MULTI, STAMPS, MANY>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistDynLds);
+}
 }  // namespace
+
+// LDS beyond the default 64 KB per workgroup has to be asked for, per device and per instantiation.  Done when a
+// context is created, NOT at the first launch: the launch path of a persistent kernel must not contain a runtime
+// call that may wait for the device — with several sub-contexts on one device another sub-context's launch is
+// already running (and waiting for this one) by then.
+hipError_t persistent_prepare_device() {
+  hipError_t e = raise_lds_limit<false, false, false>();
+  if (e == hipSuccess) e = raise_lds_limit<false, false, true>();
+  if (e == hipSuccess) e = raise_lds_limit<false, true, false>();
+  if (e == hipSuccess) e = raise_lds_limit<false, true, true>();
+  if (e == hipSuccess) e = raise_lds_limit<true, false, false>();
+  if (e == hipSuccess) e = raise_lds_limit<true, false, true>();
+  if (e == hipSuccess) e = raise_lds_limit<true, true, false>();
+  if (e == hipSuccess) e = raise_lds_limit<true, true, true>();
+  return e;
+}
 
 hipError_t launch_persistent(hipStream_t s, const PersistArgs& args, uint32_t grid) {
   int device = 0;

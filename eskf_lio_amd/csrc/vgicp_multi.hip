@@ -108,6 +108,7 @@ struct vgicp_multi {
   std::vector<size_t> lo, hi;
   double prep_voxel = 0.0;
   bool prep_pending = false;      // vgicp_scan_prepare_async on device 0: size not read yet
+  uint64_t scan_generation = 0;   // replacements of the resident scan as the CALLER sees it (dealing it out is not one)
   // whole-scan AoS copies for the map insertion on the devices that hold a shard only (points 3 cap, then covs 9 cap)
   std::vector<double*> d_full;
   std::vector<size_t> full_cap;
@@ -229,6 +230,30 @@ int align_shards(vgicp_ctx* parent, const double* points, const double* covs, co
   const bool host_loop_asked = (params->flags & (VGICP_FLAG_PROFILE | VGICP_FLAG_NO_PERSISTENT)) != 0 || params->max_iteration <= 0;
   bool single = g->mailboxes && !host_loop_asked && g->cooldown == 0;
   if (g->cooldown > 0 && !host_loop_asked) --g->cooldown;
+  if (single && points) {
+    // no allocation between the launches: a sub-context that has to grow its scan buffers does so now, while nobody's
+    // persistent kernel is running (hipFree waits for the whole device; on a shared device that would be a neighbour's
+    // launch, which in turn waits for this sub-context's)
+    bool grow = false;
+    for (int r = 0; r < g->n; ++r)
+      grow = grow || vgicp_internal::align_needs_allocation(g->subs[(size_t)r], g->hi[(size_t)r] - g->lo[(size_t)r], params->max_iteration);
+    if (grow) {
+      const int rc = run_all(parent, [&](int r) {
+        return vgicp_internal::reserve_for_align(g->subs[(size_t)r], g->hi[(size_t)r] - g->lo[(size_t)r], params->max_iteration);
+      });
+      if (rc != VGICP_OK) return rc;
+    }
+  } else if (single) {
+    bool grow = false;
+    for (int r = 0; r < g->n; ++r) grow = grow || vgicp_internal::align_needs_allocation(g->subs[(size_t)r], 0, params->max_iteration);
+    if (grow) {
+      const int rc = run_all(parent, [&](int r) {
+        vgicp_ctx* sub = g->subs[(size_t)r];
+        return vgicp_internal::reserve_for_align(sub, sub->scan_capacity, params->max_iteration);
+      });
+      if (rc != VGICP_OK) return rc;
+    }
+  }
   if (single) {
     std::vector<double> pose((size_t)g->n * 16, 0.0);
     std::vector<vgicp_stats> st((size_t)g->n);
@@ -333,6 +358,9 @@ extern "C" int vgicp_create_multi(const int* device_ids, int n_devices, vgicp_ct
     // their uploads already run side by side (one thread per sub-context); a helper stream per sub-context on ONE
     // device would only make them share hardware queues with a neighbour's persistent launch
     if (m > 1) sub->uploader_enabled = false;
+    // ... and a workgroup of theirs plans with less than half a CU's LDS: launches of several queues that each need
+    // WHOLE compute units were seen not to become resident side by side (4 and 8 queues, 150 KB per workgroup)
+    if (m > 1) sub->persist_lds_budget = 64u * 1024u;
     g->subs.push_back(sub);
     if (hipSetDevice(dev) != hipSuccess || hipEventCreateWithFlags(&g->ev_gather[(size_t)r], hipEventDisableTiming) != hipSuccess)
       return bail(VGICP_ERR_HIP, "hipEventCreate failed");
@@ -368,6 +396,11 @@ extern "C" int vgicp_create_multi(const int* device_ids, int n_devices, vgicp_ct
 namespace vgicp_multi_api {
 
 vgicp_ctx* first(const vgicp_ctx* ctx) { return ctx->multi->subs[0]; }
+
+void scan_replaced(vgicp_ctx* ctx) {   // a hook put its own scan on device 0: nothing is resident as far as the caller goes
+  ++ctx->multi->scan_generation;
+  ctx->multi->resident = Resident::None;
+}
 
 int destroy(vgicp_ctx* ctx) {
   vgicp_multi* g = ctx->multi;
@@ -418,6 +451,7 @@ int get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
     case VGICP_COUNTER_PERSISTENT_FALLBACKS: v = g->fallbacks; break;
     case VGICP_COUNTER_UPLOAD_BYTES: for (const vgicp_ctx* s : g->subs) v += s->upload_bytes; break;
     case VGICP_COUNTER_UPLOAD_NANOSECONDS: for (const vgicp_ctx* s : g->subs) v = std::max<uint64_t>(v, (uint64_t)(s->upload_seconds * 1e9)); break;
+    case VGICP_COUNTER_SCAN_GENERATION: v = g->scan_generation; break;
     case VGICP_COUNTER_PREP_INDEFINITE: return sub_fail(const_cast<vgicp_ctx*>(ctx), g->subs[0], vgicp_get_counter(g->subs[0], which, value));
     default: return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown counter");
   }
@@ -541,6 +575,7 @@ int scan_upload(vgicp_ctx* ctx, size_t n, const double* points, const double* co
   vgicp_multi* g = ctx->multi;
   if (n > 0 && (!points || !covs)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
   shard_bounds(g, n);
+  ++g->scan_generation;
   g->resident = Resident::None;
   g->prep_voxel = 0.0;
   g->prep_pending = false;
@@ -554,6 +589,7 @@ int align(vgicp_ctx* ctx, size_t n, const double* points, const double* covs, co
   vgicp_multi* g = ctx->multi;
   if (n > 0 && (!points || !covs)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
   shard_bounds(g, n);   // every device its own shard, side by side, over its own link
+  ++g->scan_generation;
   g->resident = Resident::None;
   g->prep_voxel = 0.0;
   g->prep_pending = false;
@@ -578,6 +614,7 @@ int scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const double* p
                  int64_t* deskewed, bool deferred) {
   vgicp_multi* g = ctx->multi;
   vgicp_ctx* lead = g->subs[0];
+  ++g->scan_generation;
   g->resident = Resident::None;
   int rc;
   if (deferred) rc = vgicp_scan_prepare_async(lead, n, points, point_time, num_states, states, extrinsic, voxel_size, knn);

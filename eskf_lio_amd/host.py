@@ -51,7 +51,12 @@ def load_library() -> C.CDLL:
     lib.host_icp_align.argtypes = [vp, sz, dp, dp, vp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_uint64), sz]
     lib.host_preprocessor_create.restype = vp
-    lib.host_preprocessor_create.argtypes = [C.c_double, dp]
+    lib.host_preprocessor_create.argtypes = [C.c_double, dp, C.c_int]
+    lib.host_frame_begin.restype = vp
+    lib.host_frame_begin.argtypes = [sz, dp, dp, sz, dp]
+    lib.host_frame_run.argtypes = [vp, vp, vp, vp, dp, C.c_int, C.c_int]
+    lib.host_frame_end.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                   C.POINTER(sz), sz, dp, dp]
     lib.host_preprocessor_process.argtypes = [vp, sz, dp, dp, sz, dp, dp, dp, C.POINTER(sz)]
     lib.host_preprocessor_destroy.argtypes = [vp]
     lib.host_preprocessor_downsample.argtypes = [vp, sz, dp, dp, dp, C.POINTER(sz)]
@@ -186,10 +191,13 @@ class CloudPreprocessor:
     """ESKF_LIO::CloudPreprocessor's scan-preparation half (include/eskf_lio_shim/CloudPreprocessor.hpp;
     reference include/ESKF_LIO/CloudPreprocessor.hpp:35-36, src/CloudPreprocessor.cpp:76-127)."""
 
-    def __init__(self, voxel_size: float, T_il=None):
+    def __init__(self, voxel_size: float, T_il=None, host_copy: Optional[str] = None):
+        """host_copy: "eager" (process() leaves the prepared scan in the host cloud, as the reference does),
+        "deferred" (it stays on the device until somebody materialises it), None = the shim's default."""
         self._lib = load_library()
         t = capi.pose_to_abi(np.eye(4) if T_il is None else T_il)
-        self._h = self._lib.host_preprocessor_create(float(voxel_size), _dp(t))
+        mode = {None: -1, "eager": 0, "deferred": 1}[host_copy]
+        self._h = self._lib.host_preprocessor_create(float(voxel_size), _dp(t), mode)
         if not self._h:
             raise RuntimeError(self._lib.host_last_error().decode())
 
@@ -220,3 +228,42 @@ class CloudPreprocessor:
         _check(self._lib, self._lib.host_preprocessor_process(self._h, n, _dp(pts), _dp(t), st.shape[0], _dp(st),
                                                               _dp(op), _dp(oc), C.byref(kept)))
         return op[:kept.value].copy(), oc[:kept.value].copy()
+
+
+class Frame:
+    """One LiDAR frame through the C++ drop-in classes the way src/Odometry.cpp:73-87 is written:
+    process(states, meas) -> icp.align(*meas.cloud, localMap, guess) -> localMap.updateLocalMap(meas.cloud, T).
+    begin (builds the measurement object) / run (the three calls; what a caller would time) / end (results)."""
+
+    def __init__(self, points, pointTime, states):
+        self._lib = load_library()
+        self._pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        self._t = np.ascontiguousarray(pointTime, dtype=np.float64).reshape(-1)
+        self._st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 8)
+        self._h = self._lib.host_frame_begin(self._pts.shape[0], _dp(self._pts), _dp(self._t), self._st.shape[0],
+                                             _dp(self._st))
+
+    def run(self, preprocessor: "CloudPreprocessor", icp: "ICP", localMap: "LocalMap", guess, first_frame=False,
+            mutate: int = 0):
+        g = capi.pose_to_abi(guess)
+        _check(self._lib, self._lib.host_frame_run(self._h, preprocessor._h, icp._h, localMap._h, _dp(g),
+                                                   1 if first_frame else 0, int(mutate)))
+
+    def end(self, want_cloud: bool = False):
+        """-> dict(pose, iterations, used_resident, corr0, host_points[, points, covs])."""
+        out = np.zeros(16)
+        it, res = C.c_int32(), C.c_int32()
+        corr0 = C.c_uint64()
+        hp = C.c_size_t()
+        n = self._pts.shape[0]
+        pts = np.zeros((n, 3)) if want_cloud else None
+        cvs = np.zeros((n, 9)) if want_cloud else None
+        _check(self._lib, self._lib.host_frame_end(self._h, _dp(out), C.byref(it), C.byref(res), C.byref(corr0),
+                                                   C.byref(hp), n, _dp(pts) if want_cloud else None,
+                                                   _dp(cvs) if want_cloud else None))
+        self._h = None
+        r = dict(pose=capi.pose_from_abi(out), iterations=it.value, used_resident=bool(res.value), corr0=int(corr0.value),
+                 host_points=int(hp.value))
+        if want_cloud:
+            r["points"], r["covs"] = pts[:hp.value].copy(), cvs[:hp.value].copy()
+        return r

@@ -185,8 +185,9 @@ int host_icp_align(
     });
 }
 
-// CloudPreprocessor(config) — cloud_preprocessor.voxel_size, sensors.lidar.extrinsics as a 4x4
-CloudPreprocessor * host_preprocessor_create(double voxel_size, const double T_il[16])
+// CloudPreprocessor(config) — cloud_preprocessor.voxel_size, sensors.lidar.extrinsics as a 4x4;
+// host_copy: 0 = eager (the host cloud holds the prepared scan after process()), 1 = deferred, -1 = the default
+CloudPreprocessor * host_preprocessor_create(double voxel_size, const double T_il[16], int host_copy)
 {
   CloudPreprocessor * out = nullptr;
   guarded(
@@ -194,9 +195,100 @@ CloudPreprocessor * host_preprocessor_create(double voxel_size, const double T_i
       ESKF_LIO::CloudPreprocessorConfig c;
       c.voxelSize = voxel_size;
       if (T_il) {std::memcpy(c.T_il, T_il, sizeof c.T_il);}
+      if (host_copy == 0) {c.hostCopy = ESKF_LIO::CloudPreprocessorConfig::HostCopy::Eager;}
+      if (host_copy == 1) {c.hostCopy = ESKF_LIO::CloudPreprocessorConfig::HostCopy::Deferred;}
       out = new CloudPreprocessor(c);
     });
   return out;
+}
+
+// ---- one LiDAR frame through the drop-in classes exactly as src/Odometry.cpp:73-87 writes it ----
+//   cloudPreprocessor_->process(states, lidarMeas_);                         (:74)
+//   transform = kalmanFilter_->update(...) -> icp_->align(*lidar.cloud, localMap, guess)   (:79, ErrorStateKF.cpp:130)
+//   localMap_->updateLocalMap(std::move(lidarMeasCopy->cloud), transform);   (:86)
+// In three steps so that a caller can time host_frame_run alone (the measurement object is built before).
+struct HostFrame
+{
+  ESKF_LIO::LidarMeasurementPtr meas;
+  std::deque<ESKF_LIO::State> states;
+  Isometry3d pose;
+  int iterations = 0;
+  bool usedResident = false;
+  size_t corr0 = 0;
+};
+
+HostFrame * host_frame_begin(
+  size_t n, const double * points, const double * point_time, size_t num_states, const double * states)
+{
+  HostFrame * f = new HostFrame;
+  f->meas = std::make_shared<ESKF_LIO::LidarMeasurement>();
+  f->meas->cloud = std::make_shared<PointCloud>();
+  f->meas->cloud->points_.resize(n);
+  if (n) {std::memcpy(f->meas->cloud->points_.data(), points, n * 24);}
+  f->meas->pointTime.assign(point_time, point_time + n);
+  f->states.resize(num_states);
+  for (size_t s = 0; s < num_states; ++s) {
+    f->states[s].timestamp = states[8 * s];
+    for (int a = 0; a < 3; ++a) {f->states[s].position(a) = states[8 * s + 1 + a];}
+    for (int a = 0; a < 4; ++a) {f->states[s].attitude.c[a] = states[8 * s + 4 + a];}
+  }
+  return f;
+}
+
+// mutate: 0 = the frame as the reference runs it; 1 = the caller edits the prepared cloud between process() and
+// align() (its FIRST point moves by 1 mm: a sampled element, so the stamp must notice); 2 = the caller resizes it.
+// first_frame: process({}, meas) + updateLocalMap(cloud, guess) without align (src/Odometry.cpp:60-61).
+int host_frame_run(
+  HostFrame * f, const CloudPreprocessor * p, ICP * icp, LocalMap * map, const double guess[16], int first_frame,
+  int mutate)
+{
+  return guarded(
+    [&] {
+      const Isometry3d g = ESKF_LIO::shim::poseFromData(guess);
+      if (first_frame) {
+        p->process({}, f->meas);
+        f->pose = g;
+        map->updateLocalMap(f->meas->cloud, g);
+        return;
+      }
+      p->process(f->states, f->meas);
+      if (mutate) {ESKF_LIO::shim::materialize(map->context(), *f->meas->cloud);}   // an editor needs the data first
+      if (mutate == 1 && !f->meas->cloud->points_.empty()) {f->meas->cloud->points_[0](0) += 1e-3;}
+      if (mutate == 2 && f->meas->cloud->points_.size() > 1) {
+        f->meas->cloud->points_.pop_back();
+        f->meas->cloud->covariances_.pop_back();
+      }
+      f->pose = icp->align(*f->meas->cloud, *map, g);
+      f->usedResident = icp->lastUsedResidentScan();
+      f->iterations = icp->lastStats().iterations;
+      f->corr0 = icp->lastStats().correspondenceCounts.empty() ? 0 : icp->lastStats().correspondenceCounts[0];
+      map->updateLocalMap(f->meas->cloud, f->pose);
+    });
+}
+
+// What the frame left: pose, rounds, first round's correspondence count, whether align found the scan resident,
+// and the host cloud as it is now (size through *host_points; copied when the arrays are given).
+int host_frame_end(
+  HostFrame * f, double out_pose[16], int32_t * iterations, int32_t * used_resident, uint64_t * corr0,
+  size_t * host_points, size_t capacity, double * points, double * covs)
+{
+  const int rc = guarded(
+    [&] {
+      std::memcpy(out_pose, ESKF_LIO::shim::poseData(f->pose), 16 * sizeof(double));
+      if (iterations) {*iterations = f->iterations;}
+      if (used_resident) {*used_resident = f->usedResident ? 1 : 0;}
+      if (corr0) {*corr0 = f->corr0;}
+      const auto & cloud = *f->meas->cloud;
+      if (host_points) {*host_points = cloud.points_.size();}
+      if (points && covs && cloud.covariances_.size() == cloud.points_.size() && cloud.points_.size() <= capacity) {
+        if (!cloud.points_.empty()) {
+          std::memcpy(points, cloud.points_.data(), cloud.points_.size() * 24);
+          std::memcpy(covs, cloud.covariances_.data(), cloud.covariances_.size() * 72);
+        }
+      }
+    });
+  delete f;
+  return rc;
 }
 void host_preprocessor_destroy(CloudPreprocessor * p) {delete p;}
 
@@ -240,6 +332,7 @@ int host_preprocessor_process(
         for (int a = 0; a < 4; ++a) {queue[s].attitude.c[a] = states[8 * s + 4 + a];}
       }
       p->process(queue, meas);
+      ESKF_LIO::shim::materialize(ESKF_LIO::shim::defaultContext(), *meas->cloud);   // a deferred host copy is filled now
       *kept = meas->cloud->points_.size();
       if (*kept) {
         std::memcpy(out_points, meas->cloud->points_.data(), *kept * 24);

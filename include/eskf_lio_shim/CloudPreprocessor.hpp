@@ -12,15 +12,18 @@
 // the iteration order of an unordered_map (src/CloudPreprocessor.cpp:96-101), which no caller may
 // rely on.
 // process() and deskew() (include/ESKF_LIO/CloudPreprocessor.hpp:34,41-43, src/CloudPreprocessor.cpp:8-74)
-// are here too: process() applies the LiDAR->IMU extrinsic, deskews with the IMU states through
-// vgicp_deskew() and prepares the scan, in the reference's order.  Where the reference's deskew would step
+// are here too: process() applies the LiDAR->IMU extrinsic, deskews with the IMU states and prepares the scan, in
+// the reference's order, as ONE enqueue on the device (vgicp_scan_prepare_async) whose result stays resident for
+// ICP::align and LocalMap::updateLocalMap (CloudPreprocessorConfig::hostCopy says what the host cloud then holds).  Where the reference's deskew would step
 // off its state queue (no state at or before the end of the sweep, or none after it: undefined behaviour
 // there) this one throws std::runtime_error.
 #ifndef ESKF_LIO_SHIM_CLOUD_PREPROCESSOR_HPP_
 #define ESKF_LIO_SHIM_CLOUD_PREPROCESSOR_HPP_
 
 #include <cstdint>
+#include <cstdlib>
 #include <deque>
+#include <string>
 #include <vector>
 
 #include "LocalMap.hpp"
@@ -37,6 +40,23 @@ struct CloudPreprocessorConfig
 {
   double voxelSize = 0.3;
   int knn = 30;  // open3d::geometry::KDTreeSearchParamKNN's default
+  // process() leaves the prepared scan RESIDENT on the device (vgicp_scan_prepare*), so that ICP::align and — with
+  // LocalMapConfig::deviceResident — LocalMap::updateLocalMap work on it without another upload.  What the HOST
+  // cloud holds when process() returns:
+  //   Eager     the prepared scan, as the reference leaves it (one synchronisation + one download per frame);
+  //   Deferred  the raw sweep it held before; the prepared scan is on the device only until somebody needs it on the
+  //             host (shim::materialize(ctx, cloud); LocalMap's host-authoritative mode does it by itself).  This is
+  //             the frame chain without host round trips: src/Odometry.cpp:73-87 never reads the cloud between
+  //             process(), update() and updateLocalMap().
+  // Default: Eager; VGICP_HOST_COPY=deferred in the environment (or cloud_preprocessor.host_copy: deferred in the
+  // YAML file) selects Deferred without touching the caller.
+  enum class HostCopy {Eager, Deferred};
+  HostCopy hostCopy = defaultHostCopy();
+  static HostCopy defaultHostCopy()
+  {
+    const char * env = std::getenv("VGICP_HOST_COPY");
+    return (env && (env[0] == 'd' || env[0] == 'D')) ? HostCopy::Deferred : HostCopy::Eager;
+  }
   // sensors.lidar.extrinsics (quaternion + translation) as the 4x4 the reference builds from them
   // (include/ESKF_LIO/CloudPreprocessor.hpp:20-28), column-major; identity by default
   double T_il[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -47,7 +67,7 @@ class CloudPreprocessor
 public:
   explicit CloudPreprocessor(const CloudPreprocessorConfig & config, vgicp_ctx * ctx = nullptr)
   : voxelSize_(config.voxelSize), knn_(config.knn), T_il_(shim::poseFromData(config.T_il)),
-    ctx_(ctx ? ctx : shim::defaultContext())
+    hostCopy_(config.hostCopy), ctx_(ctx ? ctx : shim::defaultContext())
   {
   }
 
@@ -62,20 +82,56 @@ public:
     Eigen::Quaterniond quat = Eigen::Map<Eigen::Quaterniond>(lidar_quat.data());
     T_il_.linear() = quat.toRotationMatrix();
     T_il_.translation() = Eigen::Map<Eigen::Vector3d>(lidar_trans.data());
+    if (config["cloud_preprocessor"]["host_copy"].IsDefined()) {   // optional key, not in the reference's file
+      const auto mode = config["cloud_preprocessor"]["host_copy"].as<std::string>();
+      hostCopy_ = (mode == "deferred") ? CloudPreprocessorConfig::HostCopy::Deferred :
+        CloudPreprocessorConfig::HostCopy::Eager;
+    }
   }
 #endif
 
-  // reference src/CloudPreprocessor.cpp:8-23
+  // reference src/CloudPreprocessor.cpp:8-23: extrinsic, deskew, down-sampling + covariances — here ONE enqueue
+  // (vgicp_scan_prepare_async: 32 bytes per raw point go up, every step runs on the device) that leaves the
+  // prepared scan resident, plus the host copy the configuration asks for.
   void process(const std::deque<State> & states, LidarMeasurementPtr lidarMeas) const
   {
-    auto & cloudPoints = lidarMeas->cloud->points_;
-    lidarMeas->cloud->Transform(T_il_.matrix());
-    if (!states.empty()) {
-      deskew(states, lidarMeas->pointTime, cloudPoints);
+    PointCloud & cloud = *lidarMeas->cloud;
+    const size_t n = cloud.points_.size();
+    std::vector<double> packed(states.size() * 8);
+    size_t k = 0;
+    for (const auto & state : states) {
+      packed[k++] = state.timestamp;
+      for (int a = 0; a < 3; ++a) {packed[k++] = state.position(a);}
+      const double * q = shim::quatData(state.attitude);
+      for (int a = 0; a < 4; ++a) {packed[k++] = q[a];}
     }
-    lidarMeas->pointTime.clear();
+    static_assert(sizeof(Vector3d) == 3 * sizeof(double), "points must be packed xyz triples");
+    const int rc = vgicp_scan_prepare_async(
+      ctx_, n, n ? reinterpret_cast<const double *>(cloud.points_.data()) : nullptr,
+      lidarMeas->pointTime.data(), states.size(), packed.data(), shim::poseData(T_il_), voxelSize_, knn_);
+    if (rc == VGICP_ERR_BAD_ARGUMENT && !states.empty() && n) {
+      // where the reference's deskew would step off its state queue (undefined behaviour there)
+      throw std::runtime_error(std::string("process: ") + vgicp_last_error(ctx_));
+    }
+    shim::check(ctx_, rc, "vgicp_scan_prepare_async");
+    lidarMeas->pointTime.clear();          // as the reference: the capture times are consumed (copied when the call returned)
     lidarMeas->pointTime.shrink_to_fit();
-    voxelDownsampleAndEstimateCovariances(*lidarMeas->cloud);
+    if (hostCopy_ == CloudPreprocessorConfig::HostCopy::Deferred) {
+      cloud.covariances_.clear();
+      shim::stampResident(ctx_, cloud, 0, false);   // the host keeps the raw sweep; the prepared scan is on the device
+      return;
+    }
+    size_t kept = 0;
+    shim::check(ctx_, vgicp_scan_info(ctx_, &kept, nullptr, nullptr), "vgicp_scan_info");   // the frame's extra synchronisation
+    cloud.points_.resize(kept);
+    cloud.covariances_.resize(kept);
+    if (kept) {
+      shim::check(
+        ctx_, vgicp_scan_download(
+          ctx_, kept, reinterpret_cast<double *>(cloud.points_.data()),
+          reinterpret_cast<double *>(cloud.covariances_.data()), &kept), "vgicp_scan_download");
+    }
+    shim::stampResident(ctx_, cloud, kept, true);
   }
 
   void voxelDownsampleAndEstimateCovariances(PointCloud & cloud) const
@@ -134,6 +190,7 @@ private:
   double voxelSize_;
   int knn_;
   Isometry3d T_il_;
+  CloudPreprocessorConfig::HostCopy hostCopy_ = CloudPreprocessorConfig::HostCopy::Eager;
   vgicp_ctx * ctx_;
 };
 }  // namespace ESKF_LIO

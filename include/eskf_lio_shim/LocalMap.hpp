@@ -72,20 +72,146 @@ inline void check(vgicp_ctx * ctx, int rc, const char * what)
   }
 }
 
-// One device context per process, created on first use (device = $VGICP_DEVICE or 0).
+// One context per process, created on first use: device $VGICP_DEVICE (default 0), or — VGICP_DEVICES=0,1,2,3 — ONE
+// context that drives several devices from this thread (vgicp_create_multi: replicated map, point-sharded align;
+// an ordinal may repeat, "0,0", to split one device).  The reference's single caller thread (src/main.cpp:68-70)
+// reaches the multi-GPU path through the unchanged ICP::align that way.
 inline vgicp_ctx * defaultContext()
 {
   static vgicp_ctx * ctx = [] {
-      int dev = 0;
-      if (const char * env = std::getenv("VGICP_DEVICE")) {dev = std::atoi(env);}
       vgicp_ctx * c = nullptr;
-      const int rc = vgicp_create(dev, &c);
+      int rc;
+      if (const char * list = std::getenv("VGICP_DEVICES")) {
+        std::vector<int> ids;
+        for (const char * p = list; *p; ) {
+          char * end = nullptr;
+          const long v = std::strtol(p, &end, 10);
+          if (end == p) {break;}
+          ids.push_back(static_cast<int>(v));
+          p = (*end == ',') ? end + 1 : end;
+        }
+        if (ids.empty()) {throw std::runtime_error("VGICP_DEVICES names no device");}
+        rc = vgicp_create_multi(ids.data(), static_cast<int>(ids.size()), &c);
+      } else {
+        int dev = 0;
+        if (const char * env = std::getenv("VGICP_DEVICE")) {dev = std::atoi(env);}
+        rc = vgicp_create(dev, &c);
+      }
       if (rc != VGICP_OK) {
         throw std::runtime_error(std::string("vgicp_create failed: ") + vgicp_last_error(nullptr));
       }
       return c;
     }();
   return ctx;
+}
+
+// ---- "this host cloud IS the scan that is resident on the device" --------------------------------------------
+// CloudPreprocessor::process leaves the prepared scan on the device and stamps the host cloud; ICP::align and
+// LocalMap::updateLocalMap (src/Odometry.cpp:74,79,86 hand the SAME cloud from one to the next) recognise the stamp
+// and work on the resident scan instead of uploading the cloud again.  The stamp is the cloud's address, its
+// buffers' addresses and sizes, a hash over 64 evenly spaced elements (first and last included) and the library's
+// scan generation (VGICP_COUNTER_SCAN_GENERATION: anything else that replaced the resident scan voids it).  A
+// cloud that was resized, reallocated, or edited at a sampled element falls back to the upload path; an edit of
+// an unsampled element in place is NOT seen — callers that edit a prepared cloud in place call shim::forget(cloud).
+struct ResidentStamp
+{
+  vgicp_ctx * ctx = nullptr;
+  const void * cloud = nullptr;
+  const void * pointData = nullptr;
+  const void * covData = nullptr;
+  size_t pointCount = 0, covCount = 0;
+  uint64_t hash = 0, generation = 0;
+  size_t kept = 0;           // points of the resident scan, when known (0 while the preparation has not reported)
+  bool hostIsCurrent = false;  // the host buffers hold the prepared scan (false: the raw sweep, the scan is on the device only)
+};
+inline std::vector<ResidentStamp> & residentStamps()
+{
+  static std::vector<ResidentStamp> stamps;
+  return stamps;
+}
+inline uint64_t sampleHash(const PointCloud & cloud)
+{
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](const void * p, size_t bytes) {
+      const unsigned char * b = static_cast<const unsigned char *>(p);
+      for (size_t i = 0; i < bytes; ++i) {h = (h ^ b[i]) * 1099511628211ull;}
+    };
+  const size_t n = cloud.points_.size(), m = cloud.covariances_.size();
+  for (size_t k = 0; k < 64 && n; ++k) {mix(&cloud.points_[k * (n - 1) / 63], sizeof(Vector3d));}
+  for (size_t k = 0; k < 64 && m; ++k) {mix(&cloud.covariances_[k * (m - 1) / 63], sizeof(Matrix3d));}
+  return h;
+}
+inline uint64_t scanGeneration(vgicp_ctx * ctx)
+{
+  uint64_t g = 0;
+  check(ctx, vgicp_get_counter(ctx, VGICP_COUNTER_SCAN_GENERATION, &g), "vgicp_get_counter");
+  return g;
+}
+inline ResidentStamp * findStamp(vgicp_ctx * ctx)
+{
+  for (auto & st : residentStamps()) {
+    if (st.ctx == ctx) {return &st;}
+  }
+  return nullptr;
+}
+inline void stampResident(vgicp_ctx * ctx, const PointCloud & cloud, size_t kept, bool hostIsCurrent)
+{
+  ResidentStamp * st = findStamp(ctx);
+  if (!st) {
+    residentStamps().push_back(ResidentStamp{});
+    st = &residentStamps().back();
+  }
+  st->ctx = ctx;
+  st->cloud = &cloud;
+  st->pointData = cloud.points_.data();
+  st->covData = cloud.covariances_.data();
+  st->pointCount = cloud.points_.size();
+  st->covCount = cloud.covariances_.size();
+  st->hash = sampleHash(cloud);
+  st->generation = scanGeneration(ctx);
+  st->kept = kept;
+  st->hostIsCurrent = hostIsCurrent;
+}
+// The stamp of `cloud` if it still is the resident scan of ctx, else nullptr.
+inline ResidentStamp * residentStampOf(vgicp_ctx * ctx, const PointCloud & cloud)
+{
+  ResidentStamp * st = findStamp(ctx);
+  if (!st || st->cloud != &cloud || st->pointData != cloud.points_.data() ||
+    st->covData != cloud.covariances_.data() || st->pointCount != cloud.points_.size() ||
+    st->covCount != cloud.covariances_.size())
+  {
+    return nullptr;
+  }
+  if (st->generation != scanGeneration(ctx) || st->hash != sampleHash(cloud)) {return nullptr;}
+  return st;
+}
+inline void forget(vgicp_ctx * ctx)
+{
+  if (ResidentStamp * st = findStamp(ctx)) {st->cloud = nullptr;}
+}
+inline void forget(const PointCloud & cloud)
+{
+  for (auto & st : residentStamps()) {
+    if (st.cloud == &cloud) {st.cloud = nullptr;}
+  }
+}
+// The host buffers of a cloud whose prepared scan lives on the device only (CloudPreprocessorConfig::HostCopy::
+// Deferred) are filled now: one synchronisation and one download.  No-op for any other cloud.
+inline void materialize(vgicp_ctx * ctx, PointCloud & cloud)
+{
+  ResidentStamp * st = residentStampOf(ctx, cloud);
+  if (!st || st->hostIsCurrent) {return;}
+  size_t n = 0;
+  check(ctx, vgicp_scan_download(ctx, 0, nullptr, nullptr, &n), "vgicp_scan_download");
+  cloud.points_.resize(n);
+  cloud.covariances_.resize(n);
+  if (n) {
+    check(
+      ctx, vgicp_scan_download(
+        ctx, n, reinterpret_cast<double *>(cloud.points_.data()),
+        reinterpret_cast<double *>(cloud.covariances_.data()), &n), "vgicp_scan_download");
+  }
+  stampResident(ctx, cloud, n, true);
 }
 }  // namespace shim
 
@@ -211,6 +337,35 @@ public:
   // reference: src/LocalMap.cpp:10-76. The cloud is moved into the world frame in place, as there.
   void updateLocalMap(PointCloudPtr cloud, const Isometry3d & transform, bool initialize = false)
   {
+    // The cloud CloudPreprocessor::process prepared and ICP::align registered is still resident on the device
+    // (src/Odometry.cpp:74,79,86 pass the same cloud along): with the grid on the device the insertion runs there
+    // on that resident scan, enqueued only — no upload, nothing waited for.  The host cloud is moved into the world
+    // frame as the reference does only when it holds the prepared scan (eager host copy).
+    shim::ResidentStamp * resident = deviceResident_ ? shim::residentStampOf(ctx_, *cloud) : nullptr;
+    if (resident) {
+      const bool hostIsCurrent = resident->hostIsCurrent;
+      trajectory_.push_back(transform);
+      const bool insert = initialize || !hasPrevTransform_ || needsMapUpdate(transform);
+      if (insert) {
+        shim::check(
+          ctx_, vgicp_map_insert_resident_async(ctx_, shim::poseData(transform), maxNumPointsPerVoxel_),
+          "vgicp_map_insert_resident_async");
+        if (removeDistantPoints_ && now() - currentRemoveTime_ > removePeriod_) {
+          const Vector3d position = transform.translation();
+          const double pos[3] = {position(0), position(1), position(2)};
+          size_t numRemovedVoxels = 0;
+          shim::check(ctx_, vgicp_map_evict(ctx_, pos, distanceThreshold_, &numRemovedVoxels), "vgicp_map_evict");
+          currentRemoveTime_ = now();
+          std::cout << "removed " << numRemovedVoxels << " voxels\n";
+        }
+        hasPrevTransform_ = true;
+      }
+      prevTransform_ = transform;
+      if (hostIsCurrent) {cloud->Transform(transform.matrix());}   // in place, as src/LocalMap.cpp:15 (the stamp is void now)
+      shim::forget(ctx_);
+      return;
+    }
+    shim::materialize(ctx_, *cloud);   // a cloud whose prepared scan is on the device only: the host map needs the data
     cloud->Transform(transform.matrix());
     trajectory_.push_back(transform);
 

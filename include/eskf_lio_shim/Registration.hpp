@@ -16,6 +16,8 @@
 
 #include <cstdint>
 #include <iostream>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "LocalMap.hpp"
@@ -78,10 +80,27 @@ public:
     vgicp_stats stats{};
     stats.corr_count = counts.data();
     double pose[16];
-    const size_t n = cloud.points_.size();
-    const double * pts = n ? cloud.points_.data()->data() : nullptr;
-    const double * covs = n ? cloud.covariances_.data()->data() : nullptr;
-    const int rc = vgicp_align(ctx, n, pts, covs, shim::poseData(guess), &params, pose, &stats);
+    // The cloud CloudPreprocessor::process just prepared is resident on the device already (src/Odometry.cpp:74 ->
+    // src/ErrorStateKF.cpp:130 hand it over untouched): no second upload of its 96 bytes per point, and the frame's
+    // one synchronisation is this call's.  Any other cloud — or that one after somebody changed it — goes up as it is.
+    int rc;
+    if (shim::ResidentStamp * resident = shim::residentStampOf(ctx, cloud)) {
+      (void)resident;
+      rc = vgicp_align_resident(ctx, shim::poseData(guess), &params, pose, &stats);
+      lastUsedResidentScan_ = true;
+    } else {
+      const size_t n = cloud.points_.size();
+      if (cloud.covariances_.size() != n) {
+        throw std::runtime_error(
+                "ICP::align: the cloud has " + std::to_string(n) + " points but " +
+                std::to_string(cloud.covariances_.size()) + " covariances (a cloud prepared with a deferred host "
+                "copy and changed since? call shim::materialize first)");
+      }
+      const double * pts = n ? cloud.points_.data()->data() : nullptr;
+      const double * covs = n ? cloud.covariances_.data()->data() : nullptr;
+      rc = vgicp_align(ctx, n, pts, covs, shim::poseData(guess), &params, pose, &stats);
+      lastUsedResidentScan_ = false;
+    }
     if (rc != VGICP_OK && rc != VGICP_ERR_DEGENERATE) {shim::check(ctx, rc, "vgicp_align");}
 
     lastStats_.iterations = stats.iterations;
@@ -97,6 +116,8 @@ public:
   }
 
   const Stats & lastStats() const {return lastStats_;}
+  // whether the last align() found its cloud resident on the device (prepared there by CloudPreprocessor::process)
+  bool lastUsedResidentScan() const {return lastUsedResidentScan_;}
 
 private:
   ICP() = delete;
@@ -106,6 +127,7 @@ private:
   double cosineThreshold_;
   int chunkIterations_ = 0;
   Stats lastStats_;
+  bool lastUsedResidentScan_ = false;
 };
 
 }  // namespace ESKF_LIO

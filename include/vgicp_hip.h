@@ -114,8 +114,12 @@ enum {
   VGICP_COUNTER_PERSISTENT_FALLBACKS = 1,
   VGICP_COUNTER_UPLOAD_BYTES = 2,
   VGICP_COUNTER_UPLOAD_NANOSECONDS = 3,
-  VGICP_COUNTER_PREP_INDEFINITE = 4   /* kept points of the LAST vgicp_preprocess / vgicp_scan_prepare whose
+  VGICP_COUNTER_PREP_INDEFINITE = 4,  /* kept points of the LAST vgicp_preprocess / vgicp_scan_prepare whose
                                          regularised covariance has a negative eigenvalue (see vgicp_preprocess) */
+  VGICP_COUNTER_SCAN_GENERATION = 5   /* goes up whenever the RESIDENT scan is replaced (vgicp_align, vgicp_scan_upload,
+                                         vgicp_scan_prepare*, vgicp_accumulate): a host object that remembers "my cloud is
+                                         the resident scan" (the shim's CloudPreprocessor / ICP pair) checks it; no
+                                         synchronisation */
 };
 int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value);
 
@@ -274,11 +278,14 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
  *                                 synchronises: vgicp_align_resident, vgicp_map_size, ...).
  * vgicp_scan_info returns what the last preparation found (it synchronises if that is still pending). Any other
  * entry point first brings a pending preparation / insertion up to date.
- * Lifetime of the caller's buffers: `points` and `point_time` of vgicp_scan_prepare_async must stay valid and unchanged
- * until the next call that synchronises (vgicp_align_resident, vgicp_scan_info, ...).  From pageable memory the copy
- * has in fact been made when the call returns, but a buffer registered with vgicp_host_register is read by the DMA
- * engine later, in stream order.  `states` and `extrinsic` are copied before the call returns.  At most 16 000 IMU
- * states may fall inside one sweep (VGICP_ERR_BAD_ARGUMENT beyond; vgicp_deskew has no such limit). */
+ * Lifetime of the caller's buffers: a sweep of up to 16 MB (points + capture times; VGICP_STAGE_LIMIT bytes in the
+ * environment) is copied into page-locked staging memory of the context before the call returns — the caller's
+ * buffers are free again at once, and the runtime never pins the caller's pages (which costs 12-22 ms on the first
+ * copy of every frame for a caller that allocates and frees its clouds per frame, as the reference does).  A LARGER
+ * sweep is read straight from `points` / `point_time`, which then must stay valid and unchanged until the next call
+ * that synchronises (vgicp_align_resident, vgicp_scan_info, ...).  `states` and `extrinsic` are always copied before
+ * the call returns.  At most 16 000 IMU states may fall inside one sweep (VGICP_ERR_BAD_ARGUMENT beyond; vgicp_deskew
+ * has no such limit). */
 int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
                              size_t num_states, const double* states, const double extrinsic[16],
                              double voxel_size, int knn);

@@ -7,6 +7,7 @@ namespace YAML {
 class Node {
  public:
   Node operator[](const std::string&) const { return Node(); }
+  bool IsDefined() const { return false; }   // yaml-cpp: whether the key exists
   template <typename T>
   T as() const { return T(); }
 };

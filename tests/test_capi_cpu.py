@@ -65,6 +65,12 @@ def test_no_device_means_loud_failure_not_fallback():
     with pytest.raises(capi.VgicpError) as e:
         capi.Context(0)
     assert e.value.code == capi.ERR_NO_DEVICE
+    with pytest.raises(capi.VgicpError) as e:                       # the multi-device context: the same, no host-side stand-in
+        capi.Context([0, 0])
+    assert e.value.code == capi.ERR_NO_DEVICE
+    with pytest.raises(capi.VgicpError) as e:
+        capi.Context([0] * 17)                                      # at most 16 devices
+    assert e.value.code == capi.ERR_BAD_ARGUMENT
     lib = capi.load_library()
     # NULL context: every entry point rejects it instead of crashing
     assert lib.vgicp_map_reset(None, 0.3, 0) == capi.ERR_BAD_ARGUMENT
@@ -124,10 +130,50 @@ def test_bench_refuses_to_run_without_a_gpu_and_prices_bytes_as_designed():
     sys.path.insert(0, root)
     import bench
     assert bench.algorithmic_bytes(100_000, 49_912.8) == 112 * 100_000 + 96 * 49_912.8
-    c2 = bench.measured_traffic(100_000, 1, "persistent_kernel")
-    c5 = bench.measured_traffic(1_000_000, 1, "persistent_kernel")
-    assert c2 is not None and c5 is not None and c5 > 50 * c2        # per launch of 20 rounds
-    assert bench.measured_traffic(100_000, 8, "persistent_kernel") is None
+    # the committed summaries: quoted only with their provenance, or not at all with the reason
+    quoted = {}
+    for n in (100_000, 1_000_000):
+        t, src = bench.measured_traffic(n, 1, "persistent_kernel")
+        if t is None:
+            assert "reason" in src
+        else:
+            assert src["file"].startswith("profiles/") and src["tag"] and "match" in src
+            quoted[n] = t
+    if len(quoted) == 2:
+        assert quoted[1_000_000] > 50 * quoted[100_000]              # per launch of 20 rounds
+    t8, src8 = bench.measured_traffic(100_000, 8, "persistent_kernel")
+    assert t8 is None and "reason" in src8
+
+
+def test_traffic_is_quoted_only_for_the_build_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from profiles/, not from the run: a summary taken on these kernel sources (or this very
+    library) is quoted with file / tag / hashes, one taken on another build is refused with the reason."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from eskf_lio_amd import provenance
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    body = {"traffic": {"persistent_kernel_total_calibrated": 123.0}, "bench": {"config": {"points": 100_000}}}
+    (prof / "a_old_summary.json").write_text(json.dumps(dict(body, tag="a_old")))                     # no hashes at all
+    t, src = bench.measured_traffic(100_000, 1, "persistent_kernel")
+    assert t is None and "another build" in src["reason"] and src["kernel_source_sha256"] == provenance.kernel_source_sha256()
+    (prof / "b_src_summary.json").write_text(json.dumps(dict(body, tag="b_src", library_sha256="0" * 64,
+                                                             kernel_source_sha256=provenance.kernel_source_sha256())))
+    t, src = bench.measured_traffic(100_000, 1, "persistent_kernel")
+    assert t == 123.0 and src["tag"] == "b_src" and "kernel sources" in src["match"] and src["file"] == "profiles/b_src_summary.json"
+    (prof / "c_lib_summary.json").write_text(json.dumps(dict(body, tag="c_lib", library_sha256=provenance.library_sha256(),
+                                                             kernel_source_sha256="1" * 64)))
+    t, src = bench.measured_traffic(100_000, 1, "persistent_kernel")
+    assert t == 123.0 and src["tag"] == "c_lib" and "byte for byte" in src["match"]
+    (prof / "d_new_summary.json").write_text(json.dumps(dict(body, tag="d_new", library_sha256="2" * 64,
+                                                             kernel_source_sha256="3" * 64)))
+    t, src = bench.measured_traffic(100_000, 1, "persistent_kernel")
+    assert t == 123.0 and src["tag"] == "c_lib"                      # the newest one that matches, never a stale one
+    assert bench.measured_traffic(5_000, 1, "persistent_kernel")[0] is None
 
 
 def test_module_fallback_solve_is_the_oracles_ldlt_bit_for_bit(oracle):

@@ -945,6 +945,10 @@ def test_cpp_frame_chain_classes_and_resident_abi_agree():
     # synchronisation per frame
     tail = [ln for ln in out.stdout.splitlines() if ln.startswith("the same without waiting")]
     assert len(tail) == 1 and "1.0 host synchronisations per frame" in tail[0], out.stdout
+    # chain A of the example: the drop-in CLASSES ride that chain (device-resident grid, deferred host copy): every
+    # align found its cloud resident, and the poses are the non-waiting chain's bits (the example's exit code)
+    classes = [ln for ln in out.stdout.splitlines() if ln.startswith("drop-in classes, scan handed along")]
+    assert len(classes) == 1 and "5 of 5 aligns found their cloud resident" in classes[0], out.stdout
 
 
 def test_bench_line_keeps_its_contract():
@@ -972,7 +976,17 @@ def test_bench_line_keeps_its_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
     assert d["parity"]["identical_counts"] is True and d["parity"]["pose_delta_m"] < 1e-9
     assert d["config"]["persistent_fallbacks"] == 0
-
+    # `traffic` is a quotation from profiles/, never this run's measurement: the line says where it comes from, and a
+    # profile taken on another build of the kernels is not quoted at all
+    src = r["traffic_source"]
+    if r["traffic"] is None:
+        assert "reason" in src and r["traffic_frac"] is None
+    else:
+        assert src["file"].startswith("profiles/") and src["tag"] and "match" in src
+        assert src["library_sha256"] or src["kernel_source_sha256"]
+    fc = d["frame_chain"]
+    assert "error" not in fc and "error" not in fc["dropin"], fc
+    assert fc["dropin"]["poses_bit_equal_to_the_abi_chain"] is True and fc["dropin_ms_per_frame"] > 0
 
     up = d["config"]["upload"]
     assert up["buffers"] == 5 and up["ms_per_step_cold"] > 0 and up["ms_per_step_reused"] > 0

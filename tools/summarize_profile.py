@@ -41,7 +41,12 @@ def short(name):
     return name[:40]
 
 
-summary = {"tag": tag}
+sys.path.insert(0, ROOT)
+from eskf_lio_amd import provenance  # noqa: E402
+
+# what was measured: the library as built and the sources that decide the kernels' code (bench.py refuses to quote
+# this summary's traffic for a library that matches neither)
+summary = {"tag": tag, "library_sha256": provenance.library_sha256(), "kernel_source_sha256": provenance.kernel_source_sha256()}
 stats = one("trace/**/*kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
