@@ -459,7 +459,7 @@ def main():
     ctx = capi.Context(device_ids if inproc else local_rank)
     ctx.map_reset(vmap.voxel_size, n_voxels)
     ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
-    if share_device:
+    if share_device and not inproc:
         ctx.peer_connect(world, rank, gather_bytes(ctx.peer_export(), world))
         dist.barrier()                                             # every mailbox initialised before any kernel writes
     elif use_dist:
@@ -584,7 +584,7 @@ def main():
     # per-launch variant: every iteration launch bracketed by HIP events on the module's stream
     # (not with BENCH_SHARE_DEVICE: that rehearsal has no RCCL communicator for the launch-per-round loop to use)
     kernel_ms = []
-    for _ in range(0 if share_device else max(3, min(args.steps, 20))):
+    for _ in range(0 if (share_device and not inproc) else max(3, min(args.steps, 20))):
         r = step_resident(capi.FLAG_PROFILE)
         kernel_ms.append(r.kernel_ms[:ITERATIONS])
     kernel_ms = np.array(kernel_ms)
@@ -800,7 +800,7 @@ def main():
                 c5 = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0 and out is not None:
             out["c5_resident"] = c5
-    if share_device:
+    if share_device and not inproc:
         dist.barrier()                 # nobody unmaps a mailbox a peer's kernel may still be writing into
         ctx.peer_disconnect()
     ctx.close()

@@ -351,3 +351,26 @@ def test_dropin_align_falls_back_when_the_cloud_changed():
             got = fr.end()
             assert not got["used_resident"]
             assert got["iterations"] == want.iterations and np.array_equal(got["pose"], want_pose)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_line_in_process_multi_device(world):
+    """`python bench.py --gpus N` WITHOUT a launcher: one process, one thread, one multi-device context.  On this pool's
+    one-GPU boxes the sub-contexts share device 0 (BENCH_SHARE_DEVICE=1); the line keeps the driver's contract, says how
+    it was wired, and the sharded result is the single-device one."""
+    env = dict(os.environ, BENCH_SHARE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
+                          "--no-c5"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["n_gpus"] == world and d["scaling"] == "strong" and d["steps"] == 6
+    sh = d["config"]["sharding"]
+    assert sh["transport"] == "mailbox" and "IN-PROCESS" in sh["wiring"] and "vgicp_create_multi" in sh["wiring"]
+    assert d["multi_gpu_parity"]["identical_counts"] is True and d["multi_gpu_parity"]["pose_delta"] <= MULTI_POSE_TOL
+    assert d["config"]["persistent_fallbacks"] == 0 and d["roofline"]["rounds_per_launch"] == 20
+    assert d["roofline"]["traffic"] is None and "reason" in d["roofline"]["traffic_source"]
