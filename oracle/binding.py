@@ -68,6 +68,8 @@ def load() -> C.CDLL:
     lib.oracle_preprocess.argtypes = [sz, dp, C.c_double, C.c_int, dp, dp, up]
     lib.oracle_preprocess_ex.restype = sz
     lib.oracle_preprocess_ex.argtypes = [sz, dp, C.c_double, C.c_int, dp, dp, up, up]
+    lib.oracle_preprocess_ordered.restype = sz
+    lib.oracle_preprocess_ordered.argtypes = [sz, dp, C.c_double, C.c_int, C.c_int, dp, dp, up, up]
     lib.oracle_jacobi_svd3.restype = C.c_int
     lib.oracle_jacobi_svd3.argtypes = [dp, dp, dp, dp]
     lib.oracle_regularize.restype = C.c_int
@@ -235,6 +237,23 @@ def preprocess(points, voxel_size: float, knn: int = 30):
     ix = np.zeros(n, dtype=np.uint64)
     m = load().oracle_preprocess(n, _dp(points), float(voxel_size), int(knn), _dp(op), _dp(oc),
                                  ix.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return op[:m].copy(), oc[:m].copy(), ix[:m].copy()
+
+
+ORDER_ASCENDING, ORDER_REFERENCE_HASH = 0, 1
+
+
+def preprocess_ordered(points, voxel_size: float, knn: int = 30, order: int = ORDER_ASCENDING):
+    """preprocess() with the output order chosen: ORDER_ASCENDING (input index; what the HIP path emits) or
+    ORDER_REFERENCE_HASH (the iteration order of the reference's unordered_map, src/CloudPreprocessor.cpp:85-99, as
+    libstdc++ produces it).  Same kept set and covariances, another sequence."""
+    points = _f64(points, 3)
+    n = points.shape[0]
+    op, oc = np.zeros((n, 3)), np.zeros((n, 9))
+    ix = np.zeros(n, dtype=np.uint64)
+    bad = C.c_uint64(0)
+    m = load().oracle_preprocess_ordered(n, _dp(points), float(voxel_size), int(knn), int(order), _dp(op), _dp(oc),
+                                         ix.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(bad))
     return op[:m].copy(), oc[:m].copy(), ix[:m].copy()
 
 

@@ -789,6 +789,19 @@ extern "C" size_t oracle_preprocess(size_t n, const double* points, double voxel
 extern "C" size_t oracle_preprocess_ex(size_t n, const double* points, double voxel_size, int knn,
                                        double* out_points, double* out_covs, uint64_t* out_index,
                                        uint64_t* indefinite) {
+  return oracle_preprocess_ordered(n, points, voxel_size, knn, ORACLE_ORDER_ASCENDING, out_points, out_covs, out_index, indefinite);
+}
+
+// order: ORACLE_ORDER_ASCENDING — the kept points in ascending input index (what the HIP path emits, order-independent
+// by construction); ORACLE_ORDER_REFERENCE_HASH — in the iteration order of the reference's own container
+// (src/CloudPreprocessor.cpp:85-99: std::unordered_map<Vector3i, int, open3d::utility::hash_eigen> filled in scan
+// order, then iterated): libstdc++'s node order for that hash and that insertion sequence, i.e. the order on the
+// reference's platform (Ubuntu 22.04 / GCC 11, README.md:13-14, the same libstdc++ as this container's), which the
+// C++ standard leaves unspecified.  Exists to MEASURE what the documented deviation costs downstream (the map's
+// running means depend on insertion order, include/ESKF_LIO/LocalMap.hpp:79-87), not as a parity target.
+extern "C" size_t oracle_preprocess_ordered(size_t n, const double* points, double voxel_size, int knn, int order,
+                                            double* out_points, double* out_covs, uint64_t* out_index,
+                                            uint64_t* indefinite) {
   uint64_t flipped = 0;
   const V3* P = reinterpret_cast<const V3*>(points);
   // first point per voxel (src/CloudPreprocessor.cpp:87-92)
@@ -796,8 +809,8 @@ extern "C" size_t oracle_preprocess_ex(size_t n, const double* points, double vo
   for (size_t i = 0; i < n; ++i) first.emplace(voxel_key(P[i], voxel_size), i);
   std::vector<size_t> kept;
   kept.reserve(first.size());
-  for (const auto& kv : first) kept.push_back(kv.second);
-  std::sort(kept.begin(), kept.end());
+  for (const auto& kv : first) kept.push_back(kv.second);   // src/CloudPreprocessor.cpp:96-99, the container's own order
+  if (order != ORACLE_ORDER_REFERENCE_HASH) std::sort(kept.begin(), kept.end());
   const size_t m = kept.size();
   const size_t K = std::min<size_t>(static_cast<size_t>(knn > 0 ? knn : 0), n);
 #pragma omp parallel reduction(+ : flipped)

@@ -106,6 +106,11 @@ size_t oracle_preprocess(size_t n, const double* points, double voxel_size, int 
                          double* out_points, double* out_covs, uint64_t* out_index);
 size_t oracle_preprocess_ex(size_t n, const double* points, double voxel_size, int knn,
                             double* out_points, double* out_covs, uint64_t* out_index, uint64_t* indefinite);
+/* The same with the output order chosen: ascending input index (the default everywhere else) or the iteration order
+ * of the reference's std::unordered_map (src/CloudPreprocessor.cpp:85-99) as libstdc++ produces it. */
+enum { ORACLE_ORDER_ASCENDING = 0, ORACLE_ORDER_REFERENCE_HASH = 1 };
+size_t oracle_preprocess_ordered(size_t n, const double* points, double voxel_size, int knn, int order,
+                                 double* out_points, double* out_covs, uint64_t* out_index, uint64_t* indefinite);
 /* Test hooks. oracle_jacobi_svd3: the JacobiSVD restatement on ANY real 3x3 (column-major in and out):
  * A = U diag(sv) V^T, sv descending; returns the number of columns with U.col(k) . V.col(k) < 0 (negative
  * eigenvalues of a symmetric A), -1 for a non-finite input.
