@@ -51,9 +51,15 @@ int ensure_table(vgicp_ctx* ctx, uint64_t incoming) {
   if (rc != VGICP_OK) return rc;
   if (ctx->table) {
     if (ctx->voxels > 0) {
+      // one scratch word per OLD slot between the claim and the write launch (its own allocation: the staging area may
+      // hold the batch that made the table grow)
+      uint32_t* claimed = nullptr;
+      VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&claimed), ctx->slots * sizeof(uint32_t)));
       VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
       VG_HIP(ctx, launch_rehash(ctx->stream, ctx->table, ctx->slots, fresh, (uint32_t)(slots - 1),
-                                ctx->d_counters));
+                                ctx->d_counters, claimed));
+      VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      VG_HIP(ctx, hipFree(claimed));
     }
     VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VG_HIP(ctx, hipFree(ctx->table));
@@ -789,8 +795,8 @@ int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double
   int rc = ensure_table(ctx, n);
   if (rc != VGICP_OK) return rc;
   const size_t kb = n * 3 * sizeof(int32_t), mb = n * 3 * sizeof(double), cb = n * 9 * sizeof(double);
-  const size_t koff = 0, moff = (kb + 255) & ~size_t(255), coff = moff + mb;
-  rc = ensure_stage(ctx, coff + cb);
+  const size_t koff = 0, moff = (kb + 255) & ~size_t(255), coff = moff + mb, qoff = (coff + cb + 255) & ~size_t(255);
+  rc = ensure_stage(ctx, qoff + n * sizeof(uint32_t));
   if (rc != VGICP_OK) return rc;
   char* base = static_cast<char*>(ctx->d_stage);
   VG_HIP(ctx, hipMemcpyAsync(base + koff, keys, kb, hipMemcpyHostToDevice, ctx->stream));
@@ -800,7 +806,8 @@ int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double
   VG_HIP(ctx, launch_upsert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), (uint32_t)n,
                             reinterpret_cast<const int32_t*>(base + koff),
                             reinterpret_cast<const double*>(base + moff),
-                            reinterpret_cast<const double*>(base + coff), ctx->d_counters));
+                            reinterpret_cast<const double*>(base + coff), ctx->d_counters,
+                            reinterpret_cast<uint32_t*>(base + qoff)));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t),
                              hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));

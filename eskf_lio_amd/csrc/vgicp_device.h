@@ -175,13 +175,14 @@ hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosin
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
                             uint32_t n, double* soa, uint64_t stride, uint32_t* asym, uint32_t seq);
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots);
+// claimed: scratch of n words (upsert) / old_slots words (rehash): claim launch -> write launch
 hipError_t launch_upsert(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
                          const int32_t* keys, const double* means, const double* covs,
-                         uint32_t* counters /* [0] new inserts, [1] failures */);
+                         uint32_t* counters /* [0] new inserts, [1] failures */, uint32_t* claimed);
 hipError_t launch_erase(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
                         const int32_t* keys, uint32_t* counters /* [0] erased */);
 hipError_t launch_rehash(hipStream_t s, const VoxelRecord* old_table, uint64_t old_slots,
-                         VoxelRecord* table, uint32_t mask, uint32_t* counters);
+                         VoxelRecord* table, uint32_t mask, uint32_t* counters, uint32_t* claimed);
 hipError_t launch_voxel_index(hipStream_t s, const double* points_aos, uint32_t n, double voxel_size,
                               int32_t* keys);
 // Correspondence materialisation in ascending point order (three small passes).

@@ -1219,117 +1219,102 @@ __global__ void table_clear_kernel(VoxelRecord* table, uint64_t slots) {
   reinterpret_cast<int4*>(table)[g] = make_int4(0, 0, 0, 0);
 }
 
-// Find-or-claim the slot of a key (one lane per record calls it): the slot index, whether the record is new
-// (claimed: its state word holds SLOT_LOCKED until the caller publishes SLOT_FULL), or 0xFFFFFFFF when the probe
-// sequence is exhausted.  Keys are unique within a batch, so a LOCKED slot always belongs to a different key.
-__device__ __forceinline__ uint32_t claim_slot(VoxelRecord* table, uint32_t mask, int32_t kx, int32_t ky, int32_t kz, bool* fresh) {
+// Batched upsert / rebuild in TWO launches, so that nothing inside a launch depends on what another workgroup of the
+// same launch wrote except the one state word that is claimed by compare-and-swap:
+//   claim   one thread per record: walk the probe sequence with ONE compare-and-swap per slot (EMPTY -> LOCKED).
+//           Won: the slot is this record's (fresh).  Lost to LOCKED: another key of this batch (keys are unique within
+//           a batch) — next slot.  Lost to FULL: a record from an earlier launch, its key is plain memory by now —
+//           mine (update in place) or next slot.  The slot index (and the fresh bit) goes to a scratch word per record.
+//   write   eight lanes per record, 16 bytes each (a record is one 128-byte line: {key, state} | mean + covariance =
+//           six 16-byte pieces | {count, spare}): plain coalesced stores, FULL included — the kernel boundary publishes.
+// One thread per record with a CAS, a release store and twelve scalar 8-byte stores into a random line measured 1.8 ms
+// per million voxels (profiles/r08_c2_kernel_stats.csv); eight lanes per record in ONE launch needs the key visible
+// before the state inside the launch: write-through key stores + wait cost 1.45 ms, a release fence per wave (it writes
+// the XCD's L2 back) 5.5 ms.
+constexpr uint32_t kClaimFresh = 0x80000000u;   // bit 31 of the scratch word: the record is new
+constexpr uint32_t kClaimFailed = 0x7FFFFFFFu;  // probe sequence exhausted
+
+__device__ __forceinline__ uint32_t claim_slot(VoxelRecord* table, uint32_t mask, int32_t kx, int32_t ky, int32_t kz) {
   uint32_t slot = voxel_hash(kx, ky, kz) & mask;
-  *fresh = false;
   for (uint32_t probes = 0; probes <= mask; ++probes) {
     VoxelRecord* rec = table + slot;
-    int32_t state = __hip_atomic_load(&rec->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (state == SLOT_EMPTY) {
-      int32_t expected = SLOT_EMPTY;
-      if (__hip_atomic_compare_exchange_strong(&rec->state, &expected, SLOT_LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT)) {
-        *fresh = true;
-        return slot;
-      }
-      state = expected;  // lost the race: look at what the winner left
-    }
-    if (state == SLOT_FULL) {
-      // the key of a record another workgroup published in this very launch: read past this XCD's L2 (the writer
-      // stored it write-through and waited for it before the state word)
-      const int32_t a = __hip_atomic_load(&rec->key[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int32_t b = __hip_atomic_load(&rec->key[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int32_t c = __hip_atomic_load(&rec->key[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a == kx && b == ky && c == kz) return slot;
-    }
+    int32_t seen = SLOT_EMPTY;
+    if (__hip_atomic_compare_exchange_strong(&rec->state, &seen, SLOT_LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT))
+      return slot | kClaimFresh;
+    if (seen == SLOT_FULL && rec->key[0] == kx && rec->key[1] == ky && rec->key[2] == kz) return slot;
     slot = (slot + 1) & mask;
   }
-  return 0xFFFFFFFFu;
+  return kClaimFailed;
 }
 
-// EIGHT lanes per record, 16 bytes each (a record is one 128-byte line: {key, state} | mean + covariance = six
-// 16-byte pieces | {count, spare}): the group's first lane finds or claims the slot, the eight lanes then write the
-// line with one 16-byte store each — one thread per record with twelve scalar 8-byte stores into a random line
-// measured 1.8 ms per million voxels, 1.6 % of the HBM rate (profiles/r08_c2_kernel_stats.csv).  Inside the launch
-// only key and state of a record are ever read by others (claim_slot of another key probing past it): the key goes
-// out write-through, is waited for, and the state word follows — no fence (an agent-scope release per wave writes
-// the XCD's L2 back: 5.5 ms per million voxels when tried); the payload is plain stores, read by later launches only.
-__device__ __forceinline__ void write_record_cooperatively(VoxelRecord* table, uint32_t slot, bool fresh, uint32_t sub,
-                                                           int32_t kx, int32_t ky, int32_t kz, double2 piece, uint64_t count) {
-  const bool valid = slot != 0xFFFFFFFFu;
-  if (valid) {
-    double2* line = reinterpret_cast<double2*>(table + slot);
-    if (sub >= 1 && sub <= 6) line[sub] = piece;
-    if (sub == 7 && fresh) reinterpret_cast<ulonglong2*>(line)[7] = make_ulonglong2(count, 0ull);
+__global__ __launch_bounds__(256) void upsert_claim_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
+                                                           const int32_t* __restrict__ keys, uint32_t* __restrict__ claimed,
+                                                           uint32_t* counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = 0;
+  if (i < n) {
+    c = claim_slot(table, mask, keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2]);
+    claimed[i] = c;
   }
-  if (valid && sub == 0 && fresh) {
-    VoxelRecord* rec = table + slot;
-    __hip_atomic_store(&rec->key[0], kx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&rec->key[1], ky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&rec->key[2], kz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&rec->state, SLOT_FULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  wave_count(&counters[0], i < n && c != kClaimFailed && (c & kClaimFresh) != 0);
+  wave_count(&counters[1], i < n && c == kClaimFailed);
 }
 
-__global__ __launch_bounds__(256) void upsert_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
-                                                     const int32_t* __restrict__ keys, const double* __restrict__ means,
-                                                     const double* __restrict__ covs, uint32_t* counters) {
+__global__ __launch_bounds__(256) void upsert_write_kernel(VoxelRecord* table, uint32_t n, const uint32_t* __restrict__ claimed,
+                                                           const int32_t* __restrict__ keys, const double* __restrict__ means,
+                                                           const double* __restrict__ covs) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t i = t >> 3, sub = t & 7u, lane = threadIdx.x & 63u;
-  const bool have = i < n;
-  // piece `sub` of the payload: doubles 2 (sub - 1), 2 (sub - 1) + 1 of {mean[3], cov[9]}
-  double2 piece = make_double2(0.0, 0.0);
-  int32_t kx = 0, ky = 0, kz = 0;
-  if (have && sub >= 1 && sub <= 6) {
+  const uint32_t i = t >> 3, sub = t & 7u;
+  if (i >= n) return;
+  const uint32_t c = claimed[i];
+  if (c == kClaimFailed) return;
+  const bool fresh = (c & kClaimFresh) != 0;
+  double2* line = reinterpret_cast<double2*>(table + (c & ~kClaimFresh));
+  if (sub == 0) {
+    if (fresh) reinterpret_cast<int4*>(line)[0] = make_int4(keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2], SLOT_FULL);
+  } else if (sub == 7) {
+    // numPoints of a voxel mirrored from the host is not part of the batch: a new record starts at 1
+    if (fresh) reinterpret_cast<ulonglong2*>(line)[7] = make_ulonglong2(1ull, 0ull);
+  } else {
+    // piece `sub` of the payload: doubles 2 (sub - 1), 2 (sub - 1) + 1 of {mean[3], cov[9]}
     const uint32_t p = 2u * (sub - 1u);
+    double2 piece;
     piece.x = p < 3u ? means[3 * (size_t)i + p] : covs[9 * (size_t)i + (p - 3u)];
     piece.y = p + 1u < 3u ? means[3 * (size_t)i + p + 1u] : covs[9 * (size_t)i + (p + 1u - 3u)];
+    line[sub] = piece;
   }
-  uint32_t slot = 0xFFFFFFFFu;
-  bool fresh = false;
-  if (have && sub == 0) {
-    kx = keys[3 * (size_t)i]; ky = keys[3 * (size_t)i + 1]; kz = keys[3 * (size_t)i + 2];
-    slot = claim_slot(table, mask, kx, ky, kz, &fresh);
-  }
-  const uint32_t lead = lane & ~7u;
-  slot = (uint32_t)__shfl((int)slot, (int)lead, 64);
-  fresh = __shfl((int)fresh, (int)lead, 64) != 0;
-  // numPoints of a voxel mirrored from the host is not part of the batch: a new record starts at 1
-  write_record_cooperatively(table, have ? slot : 0xFFFFFFFFu, fresh, sub, kx, ky, kz, piece, 1ull);
-  wave_count(&counters[0], have && sub == 0 && fresh);
-  wave_count(&counters[1], have && sub == 0 && slot == 0xFFFFFFFFu);
 }
 
-// The same eight-lanes-per-record scheme for the rebuild: the group reads one old slot (a coalesced 128-byte line)
-// and, if it is FULL, writes it into the new table.
-__global__ __launch_bounds__(256) void rehash_kernel(const VoxelRecord* __restrict__ old_table, uint64_t old_slots,
-                                                     VoxelRecord* table, uint32_t mask, uint32_t* counters) {
+// The rebuild into a larger table: one thread per OLD slot claims (the new table holds nothing else, every claim wins a
+// fresh slot), eight lanes per old slot then copy the 128-byte line.
+__global__ __launch_bounds__(256) void rehash_claim_kernel(const VoxelRecord* __restrict__ old_table, uint64_t old_slots,
+                                                           VoxelRecord* table, uint32_t mask, uint32_t* __restrict__ claimed,
+                                                           uint32_t* counters) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = 0;
+  bool full = false;
+  if (i < old_slots) {
+    const int4 head = *reinterpret_cast<const int4*>(old_table + i);
+    full = head.w == SLOT_FULL;
+    c = full ? claim_slot(table, mask, head.x, head.y, head.z) : kClaimFailed;
+    claimed[i] = c;
+  }
+  wave_count(&counters[0], full && c != kClaimFailed);
+  wave_count(&counters[1], full && c == kClaimFailed);
+}
+
+__global__ __launch_bounds__(256) void rehash_write_kernel(const VoxelRecord* __restrict__ old_table, uint64_t old_slots,
+                                                           VoxelRecord* table, const uint32_t* __restrict__ claimed) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t i = t >> 3;
-  const uint32_t sub = (uint32_t)(t & 7u), lane = threadIdx.x & 63u;
-  const bool have = i < old_slots;
-  double2 piece = make_double2(0.0, 0.0);
-  if (have) piece = reinterpret_cast<const double2*>(old_table + i)[sub];
-  // lane 0 of the group holds {key, state}, lane 7 {count, spare}
-  const uint32_t lead = lane & ~7u;
-  const int4 head = make_int4(__shfl(__double2loint(piece.x), (int)lead, 64), __shfl(__double2hiint(piece.x), (int)lead, 64),
-                              __shfl(__double2loint(piece.y), (int)lead, 64), __shfl(__double2hiint(piece.y), (int)lead, 64));
-  const uint32_t tail_lo = (uint32_t)__shfl(__double2loint(piece.x), (int)(lead + 7u), 64);
-  const uint32_t tail_hi = (uint32_t)__shfl(__double2hiint(piece.x), (int)(lead + 7u), 64);
-  const bool full = have && head.w == SLOT_FULL;
-  uint32_t slot = 0xFFFFFFFFu;
-  bool fresh = false;
-  if (full && sub == 0) slot = claim_slot(table, mask, head.x, head.y, head.z, &fresh);
-  slot = (uint32_t)__shfl((int)slot, (int)lead, 64);
-  fresh = __shfl((int)fresh, (int)lead, 64) != 0;
-  write_record_cooperatively(table, full ? slot : 0xFFFFFFFFu, fresh, sub, head.x, head.y, head.z, piece,
-                             ((uint64_t)tail_hi << 32) | tail_lo);
-  wave_count(&counters[0], full && sub == 0 && fresh);
-  wave_count(&counters[1], full && sub == 0 && slot == 0xFFFFFFFFu);
+  const uint32_t sub = (uint32_t)(t & 7u);
+  if (i >= old_slots) return;
+  const uint32_t c = claimed[i];
+  if (c == kClaimFailed) return;
+  double2 piece = reinterpret_cast<const double2*>(old_table + i)[sub];
+  if (sub == 7) piece.y = 0.0;   // the spare word (per-voxel list head of an insertion) does not travel
+  reinterpret_cast<double2*>(table + (c & ~kClaimFresh))[sub] = piece;
 }
 
 __global__ void erase_kernel(VoxelRecord* table, uint32_t mask, uint32_t n,
@@ -1638,10 +1623,11 @@ hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots)
 
 hipError_t launch_upsert(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
                          const int32_t* keys, const double* means, const double* covs,
-                         uint32_t* counters) {
+                         uint32_t* counters, uint32_t* claimed) {
   if (n == 0) return hipSuccess;
-  ++g_kernel_launches; hipLaunchKernelGGL(upsert_kernel, dim3(blocks_for((uint64_t)n * 8, 256)), dim3(256), 0, s, table, mask, n, keys,
-                     means, covs, counters);
+  ++g_kernel_launches; hipLaunchKernelGGL(upsert_claim_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, table, mask, n, keys, claimed, counters);
+  ++g_kernel_launches; hipLaunchKernelGGL(upsert_write_kernel, dim3(blocks_for((uint64_t)n * 8, 256)), dim3(256), 0, s, table, n, claimed, keys,
+                     means, covs);
   return hipGetLastError();
 }
 
@@ -1654,9 +1640,11 @@ hipError_t launch_erase(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32
 }
 
 hipError_t launch_rehash(hipStream_t s, const VoxelRecord* old_table, uint64_t old_slots,
-                         VoxelRecord* table, uint32_t mask, uint32_t* counters) {
-  ++g_kernel_launches; hipLaunchKernelGGL(rehash_kernel, dim3(blocks_for(old_slots * 8, 256)), dim3(256), 0, s, old_table,
-                     old_slots, table, mask, counters);
+                         VoxelRecord* table, uint32_t mask, uint32_t* counters, uint32_t* claimed) {
+  ++g_kernel_launches; hipLaunchKernelGGL(rehash_claim_kernel, dim3(blocks_for(old_slots, 256)), dim3(256), 0, s, old_table,
+                     old_slots, table, mask, claimed, counters);
+  ++g_kernel_launches; hipLaunchKernelGGL(rehash_write_kernel, dim3(blocks_for(old_slots * 8, 256)), dim3(256), 0, s, old_table,
+                     old_slots, table, claimed);
   return hipGetLastError();
 }
 
