@@ -67,6 +67,7 @@ int ensure_table(vgicp_ctx* ctx, uint64_t incoming) {
   ctx->table = fresh;
   ctx->slots = slots;
   ctx->tombstones = 0;
+  ++ctx->map_version;
   return VGICP_OK;
 }
 
@@ -221,6 +222,37 @@ int reset_persistent_exchange(vgicp_ctx* ctx) {
   return VGICP_OK;
 }
 
+// A table that is far larger than what caches and TLBs reach (2^24 slots = 2 GiB and more: BASELINE config C5 has
+// 8.6 GB) gets a dense copy of its FULL records for the several-points-per-thread launch: tools/micro/gather_pieces
+// measured 6.7 ns per random 128-byte line and CU out of a 5-10 GB table against 5.4 ns out of 2.5 GB, and a cliff for
+// more lines in flight above 4 GB.  Smaller tables (C2: 512 MB) never use it.  VGICP_DENSE_SLOTS (read when the context is created) overrides the threshold, 0 = never.
+bool wants_dense(const vgicp_ctx* ctx, uint32_t n_upper) {
+  return ctx->table && ctx->dense_slots_threshold != 0 && ctx->slots >= ctx->dense_slots_threshold && ctx->voxels > 0 &&
+         (uint64_t)n_upper > (uint64_t)ctx->persist_grid * 448u;
+}
+int ensure_dense(vgicp_ctx* ctx) {
+  if (ctx->dense_version == ctx->map_version && ctx->d_dense) return VGICP_OK;
+  if (ctx->voxels > ctx->dense_capacity) {
+    if (ctx->d_dense) VG_HIP(ctx, hipFree(ctx->d_dense));
+    ctx->d_dense = nullptr;
+    ctx->dense_capacity = 0;
+    const uint64_t cap = ctx->voxels + ctx->voxels / 8;
+    VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_dense), cap * sizeof(VoxelRecord)));
+    ctx->dense_capacity = cap;
+  }
+  const uint32_t nb = table_dense_blocks(ctx->slots);
+  if (nb + 1 > ctx->dense_counts_capacity) {
+    if (ctx->d_dense_counts) VG_HIP(ctx, hipFree(ctx->d_dense_counts));
+    ctx->d_dense_counts = nullptr;
+    ctx->dense_counts_capacity = 0;
+    VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_dense_counts), (size_t)(nb + 1) * sizeof(uint32_t)));
+    ctx->dense_counts_capacity = nb + 1;
+  }
+  VG_HIP(ctx, launch_table_dense(ctx->stream, ctx->table, ctx->slots, ctx->d_dense, ctx->d_dense_counts));
+  ctx->dense_version = ctx->map_version;
+  return VGICP_OK;
+}
+
 // The whole align in one launch (single GPU). Returns VGICP_OK and *ran = true when the kernel
 // completed; *ran = false when it gave up (the caller then uses launches).
 int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params* params,
@@ -240,6 +272,11 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   if (std::getenv("VGICP_NO_SYM")) a.asym_dev = nullptr;  // developer A/B: always read all twelve planes
   a.mask = (uint32_t)(ctx->slots - 1);
   a.table = ctx->table;
+  if (wants_dense(ctx, ctx->n)) {
+    const int rc_dense = ensure_dense(ctx);   // a no-op unless the map changed since the last align
+    if (rc_dense != VGICP_OK) return rc_dense;
+    a.dense = ctx->d_dense;
+  }
   a.voxel_size = ctx->voxel_size;
   a.rows = ctx->d_rows_persist;
   a.parts = ctx->d_parts_persist;
@@ -586,6 +623,7 @@ int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgi
     if (v >= 1 && v <= (long)ctx->persist_grid) ctx->persist_grid = (uint32_t)v;
   }
   if (const char* pe = std::getenv("VGICP_PERSISTENT")) ctx->persistent_enabled = pe[0] != '0';
+  if (const char* ds = std::getenv("VGICP_DENSE_SLOTS")) ctx->dense_slots_threshold = std::strtoull(ds, nullptr, 10);
   if (const char* pm = std::getenv("VGICP_PREFETCH_MARGIN")) ctx->prefetch_margin = std::atof(pm);
   if (const char* sl = std::getenv("VGICP_SPIN_LIMIT")) ctx->persist_spin_limit = (uint32_t)std::strtoul(sl, nullptr, 10);
   if (const char* ut = std::getenv("VGICP_UPLOAD_THREADS")) ctx->uploader_enabled = std::atoi(ut) != 1;
@@ -689,6 +727,8 @@ int vgicp_destroy(vgicp_ctx* ctx) {
     (void)hipFree(ctx->d_stamps);
   }
   (void)hipFree(ctx->table);
+  (void)hipFree(ctx->d_dense);
+  (void)hipFree(ctx->d_dense_counts);
   (void)hipFree(ctx->d_counters);
   (void)hipHostFree(ctx->h_counters);
   (void)hipHostFree(ctx->h_prep);
@@ -773,6 +813,7 @@ int vgicp_map_reset(vgicp_ctx* ctx, double voxel_size, size_t capacity_hint) {
   if (ctx->table) VG_HIP(ctx, hipFree(ctx->table));
   ctx->table = nullptr;
   ctx->slots = ctx->voxels = ctx->tombstones = 0;
+  ++ctx->map_version;
   ctx->voxel_size = voxel_size;
   const uint64_t slots = next_pow2(std::max<uint64_t>(kMinSlots, (uint64_t)capacity_hint * 4));
   int rc = alloc_table(ctx, slots, &ctx->table);
@@ -803,6 +844,7 @@ int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double
   VG_HIP(ctx, hipMemcpyAsync(base + moff, means, mb, hipMemcpyHostToDevice, ctx->stream));
   VG_HIP(ctx, hipMemcpyAsync(base + coff, covs, cb, hipMemcpyHostToDevice, ctx->stream));
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  ++ctx->map_version;
   VG_HIP(ctx, launch_upsert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), (uint32_t)n,
                             reinterpret_cast<const int32_t*>(base + koff),
                             reinterpret_cast<const double*>(base + moff),
@@ -830,6 +872,7 @@ int vgicp_map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys) {
   if (rc != VGICP_OK) return rc;
   VG_HIP(ctx, hipMemcpyAsync(ctx->d_stage, keys, kb, hipMemcpyHostToDevice, ctx->stream));
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  ++ctx->map_version;
   VG_HIP(ctx, launch_erase(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), (uint32_t)n,
                            static_cast<const int32_t*>(ctx->d_stage), ctx->d_counters));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t),
@@ -874,6 +917,7 @@ int vgicp_map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const 
   VG_HIP(ctx, hipMemcpyAsync(base, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   VG_HIP(ctx, hipMemcpyAsync(base + pb, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  ++ctx->map_version;
   VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size,
                                 reinterpret_cast<const double*>(base), reinterpret_cast<const double*>(base + pb),
                                 (uint32_t)n, pose12, (uint64_t)max_points_per_voxel, base + pb + cb, sb,
@@ -919,6 +963,7 @@ int vgicp_map_insert_resident(vgicp_ctx* ctx, const double transform[16], size_t
   double pose12[12];
   pose_to_state(transform, pose12);
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  ++ctx->map_version;
   VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size,
                                 ctx->d_scan_aos, ctx->d_scan_aos + 3 * ctx->scan_capacity, (uint32_t)n, pose12,
                                 (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_counters,
@@ -954,6 +999,7 @@ int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], 
   double pose12[12];
   pose_to_state(transform, pose12);
   if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[4], ctx->stream)); ctx->ev_stage_set[4] = true; }
+  ++ctx->map_version;
   VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size,
                                 ctx->d_scan_aos, ctx->d_scan_aos + 3 * ctx->scan_capacity, (uint32_t)n, pose12,
                                 (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_ins_counters,
@@ -1018,6 +1064,7 @@ int vgicp_map_evict(vgicp_ctx* ctx, const double position[3], double distance_th
   if (!position) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL pointer");
   VG_HIP(ctx, hipSetDevice(ctx->device));
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  ++ctx->map_version;
   VG_HIP(ctx, launch_map_evict(ctx->stream, ctx->table, ctx->slots, ctx->voxel_size, position,
                                distance_threshold, ctx->d_counters));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2095,6 +2142,7 @@ bool insertion_lists_stay_short_for(const vgicp_ctx* ctx, double prep_voxel) {
 // neighbour's persistent kernel is already running and waiting for this sub-context's), so the multi-device context
 // grows every sub-context's buffers in a phase of its own before anybody launches.
 bool align_needs_allocation(const vgicp_ctx* ctx, size_t n, int max_it) {
+  if (wants_dense(ctx, (uint32_t)n) && (ctx->dense_version != ctx->map_version || !ctx->d_dense)) return true;
   return !ctx->d_scan || n > ctx->scan_capacity || max_it > ctx->log_capacity || ctx->log_capacity == 0;
 }
 int reserve_for_align(vgicp_ctx* ctx, size_t n, int max_it) {
@@ -2107,6 +2155,11 @@ int reserve_for_align(vgicp_ctx* ctx, size_t n, int max_it) {
     if (rc != VGICP_OK) return rc;
     ctx->scan_ready = false;   // whatever was resident went with the old buffers
     ctx->n = 0;
+  }
+  if (wants_dense(ctx, (uint32_t)n)) {
+    rc = ensure_dense(ctx);
+    if (rc != VGICP_OK) return rc;
+    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   return ensure_log(ctx, std::max(max_it, 1));
 }
@@ -2335,7 +2388,8 @@ int map_insert_device(vgicp_ctx* ctx, const double* d_points, const double* d_co
   pose_to_state(transform, pose12);
   if (deferred) {
     if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[4], ctx->stream)); ctx->ev_stage_set[4] = true; }
-    VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size, d_points, d_covs,
+    ++ctx->map_version;
+  VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size, d_points, d_covs,
                                   (uint32_t)n, pose12, (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_ins_counters,
                                   short_lists));
     VG_HIP(ctx, hipMemcpyAsync(ctx->h_ins_counters, ctx->d_ins_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2345,6 +2399,7 @@ int map_insert_device(vgicp_ctx* ctx, const double* d_points, const double* d_co
     return VGICP_OK;
   }
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+  ++ctx->map_version;
   VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size, d_points, d_covs,
                                 (uint32_t)n, pose12, (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_counters, short_lists));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -138,6 +138,14 @@ struct vgicp_ctx {
   uint32_t* d_counters = nullptr;  // 8 words + 64 of developer histograms (VGICP_DEBUG_PREP=2)
   uint32_t* h_counters = nullptr;  // pinned
 
+  // dense copy of the FULL records for tables far beyond the caches' reach (PersistArgs::dense): rebuilt lazily before
+  // an align when the map has changed since (map_version counts every mutation)
+  VoxelRecord* d_dense = nullptr;
+  uint64_t dense_capacity = 0;      // records
+  uint32_t* d_dense_counts = nullptr;
+  uint32_t dense_counts_capacity = 0;
+  uint64_t map_version = 1, dense_version = 0;
+  uint64_t dense_slots_threshold = 1ull << 24;   // tables of this many slots (2 GiB) and more; VGICP_DENSE_SLOTS at creation, 0 = never
   // batch staging (upsert / erase / hooks)
   void* d_stage = nullptr;
   size_t stage_bytes = 0;

@@ -135,6 +135,10 @@ struct PersistArgs {
   uint32_t scan_seq;         // NOT bitwise symmetric; while it differs, the planes above the diagonal are not read
   uint32_t stash_bytes;      // LDS behind the memos that may hold parked points; how many fit depends on the planes
                              // a parked point needs (9 or 12) and on the point-carrying threads (448 or 512)
+  const VoxelRecord* dense;  // nullptr, or the FULL records of the table packed densely (launch_table_dense), for tables
+                             // far larger than the caches' and TLBs' reach: a record's index there sits in the upper
+                             // half of its spare word; a point that stays in its voxel then reads its payload from
+                             // this array (1.3 GB at 10M voxels) instead of from the sparse table (8.6 GB)
   const uint32_t* n_dev;   // nullptr, or where the device holds the scan's size (a scan prepared on the device whose
                            // kept count the host has not read yet: no host round trip between preparation and align)
   double prefetch_margin;  // > 0 (only with memo_points == stash_points == 0): a point closer than this many
@@ -175,6 +179,10 @@ hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosin
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
                             uint32_t n, double* soa, uint64_t stride, uint32_t* asym, uint32_t seq);
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots);
+// Pack the FULL records of `table` into `dense` in slot order (128 bytes each) and leave every record's index there in
+// the upper half of its spare word.  block_counts: scratch of table_dense_blocks(slots) + 1 words.
+uint32_t table_dense_blocks(uint64_t slots);
+hipError_t launch_table_dense(hipStream_t s, VoxelRecord* table, uint64_t slots, VoxelRecord* dense, uint32_t* block_counts);
 // claimed: scratch of n words (upsert) / old_slots words (rehash): claim launch -> write launch
 hipError_t launch_upsert(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
                          const int32_t* keys, const double* means, const double* covs,

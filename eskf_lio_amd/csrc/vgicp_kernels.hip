@@ -793,6 +793,7 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
     first = u0 * 64u + wt;
     end_pts = u1 * 64u < n_pts ? u1 * 64u : n_pts;
   }
+  const VoxelRecord* pay_base = a.dense ? a.dense : a.table;  // uniform: where a remembered record's payload is read from
   int4* memo = reinterpret_cast<int4*>(dyn_lds);
   double* stash = reinterpret_cast<double*>(dyn_lds + (size_t)a.memo_points * W * sizeof(int4));
   // parked points hold the planes that are read: 9 of a scan whose covariances are all bitwise symmetric, else 12
@@ -888,18 +889,22 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
                                  (int)same_voxel_coord(p[2], m.z, a.voxel_size, same_margin)) != 0;
             if (stayed) {
               got = (uint32_t)m.w != kMemoMiss;
-              if (got) load_payload(a.table + (uint32_t)m.w, m2, S);
+              if (got) load_payload(pay_base + (uint32_t)m.w, m2, S);
             } else {
               const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
               const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
               const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
               if (it != 0 && m.x == kx && m.y == ky && m.z == kz) {  // a point right below a face: key unchanged after all
                 got = (uint32_t)m.w != kMemoMiss;
-                if (got) load_payload(a.table + (uint32_t)m.w, m2, S);
+                if (got) load_payload(pay_base + (uint32_t)m.w, m2, S);
               } else {
                 const VoxelRecord* rec = find_voxel(a.table, a.mask, kx, ky, kz);
                 got = rec != nullptr;
-                *mslot = make_int4(kx, ky, kz, got ? (int32_t)(uint32_t)(rec - a.table) : (int32_t)kMemoMiss);
+                // what the memo remembers: the record's slot, or (dense copy in use) its index there, which the
+                // compaction left in the upper half of the record's spare word — the same 128-byte line as the key
+                uint32_t where = kMemoMiss;
+                if (got) where = a.dense ? reinterpret_cast<const uint32_t*>(&rec->reserved)[1] : (uint32_t)(rec - a.table);
+                *mslot = make_int4(kx, ky, kz, (int32_t)where);
                 if (got) load_payload(rec, m2, S);
               }
             }
@@ -1443,6 +1448,44 @@ __global__ __launch_bounds__(kMatchBlock) void match_write_kernel(
   if (src_index) src_index[pos] = i;
 }
 
+// ---- dense copy of the FULL records (count per block -> scan -> copy) ----
+constexpr int kDenseBlock = 256;
+__global__ __launch_bounds__(kDenseBlock) void dense_count_kernel(const VoxelRecord* __restrict__ table, uint64_t slots,
+                                                                  uint32_t* __restrict__ block_counts) {
+  const uint64_t i = (uint64_t)blockIdx.x * kDenseBlock + threadIdx.x;
+  const bool full = i < slots && table[i].state == SLOT_FULL;
+  const int total = __syncthreads_count(full ? 1 : 0);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = (uint32_t)total;
+}
+__global__ __launch_bounds__(kDenseBlock) void dense_write_kernel(VoxelRecord* table, uint64_t slots,
+                                                                  const uint32_t* __restrict__ block_offsets,
+                                                                  VoxelRecord* __restrict__ dense) {
+  __shared__ uint32_t wave_hits[kDenseBlock / 64];
+  __shared__ uint32_t src[kDenseBlock];   // local slot numbers of the block's FULL records, in slot order
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * kDenseBlock + tid;
+  const bool full = i < slots && table[i].state == SLOT_FULL;
+  const unsigned long long ballot = __ballot(full);
+  if (lane == 0) wave_hits[wave] = (uint32_t)__popcll(ballot);
+  __syncthreads();
+  uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull)), total = 0;
+  for (uint32_t w = 0; w < kDenseBlock / 64; ++w) {
+    if (w < wave) rank += wave_hits[w];
+    total += wave_hits[w];
+  }
+  const uint32_t base = block_offsets[blockIdx.x];
+  if (full) {
+    src[rank] = tid;
+    reinterpret_cast<uint32_t*>(&table[i].reserved)[1] = base + rank;   // where this record's copy lives
+  }
+  __syncthreads();
+  // eight lanes per record, 16 bytes each: coalesced 128-byte lines both ways
+  for (uint32_t r = tid >> 3; r < total; r += kDenseBlock / 8) {
+    const double2 piece = reinterpret_cast<const double2*>(table + ((uint64_t)blockIdx.x * kDenseBlock + src[r]))[tid & 7u];
+    reinterpret_cast<double2*>(dense + base + r)[tid & 7u] = piece;
+  }
+}
+
 inline uint32_t blocks_for(uint64_t work, uint32_t block) { return (uint32_t)((work + block - 1) / block); }
 
 }  // namespace
@@ -1618,6 +1661,16 @@ hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const doubl
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots) {
   ++g_kernel_launches; hipLaunchKernelGGL(table_clear_kernel, dim3(blocks_for(slots * 8, 256)), dim3(256), 0, s, table,
                      slots);
+  return hipGetLastError();
+}
+
+uint32_t table_dense_blocks(uint64_t slots) { return blocks_for(slots, kDenseBlock); }
+
+hipError_t launch_table_dense(hipStream_t s, VoxelRecord* table, uint64_t slots, VoxelRecord* dense, uint32_t* block_counts) {
+  const uint32_t nb = table_dense_blocks(slots);
+  ++g_kernel_launches; hipLaunchKernelGGL(dense_count_kernel, dim3(nb), dim3(kDenseBlock), 0, s, table, slots, block_counts);
+  ++g_kernel_launches; hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nb, block_counts + nb);
+  ++g_kernel_launches; hipLaunchKernelGGL(dense_write_kernel, dim3(nb), dim3(kDenseBlock), 0, s, table, slots, block_counts, dense);
   return hipGetLastError();
 }
 

@@ -353,6 +353,53 @@ def test_persistent_launch_with_many_points_per_thread(c1_inputs, monkeypatch, g
         assert ctx.counter(1) == 0
 
 
+def test_dense_copy_of_the_records_returns_the_same_bits(c1_inputs, oracle, monkeypatch):
+    """Tables far beyond the caches' reach (2^24 slots and more: C5) get a dense copy of their FULL records that the
+    several-points-per-thread launch reads a remembered voxel's payload from.  Forced here on a small table
+    (VGICP_DENSE_SLOTS=1): the same bits as without it, before and after every kind of map mutation (the copy is
+    rebuilt lazily), and against the oracle."""
+    from eskf_lio_amd import capi, synth
+    vmap = c1_inputs[0]
+    pts, covs = synth.make_uniform_scan(40_000, vmap, seed=21)
+    g = synth.default_guess()
+    rng = np.random.default_rng(8)
+    extra = (vmap.means[rng.choice(50_000, 6_000)] + 0.4, covs[rng.choice(40_000, 6_000)])
+
+    def drive(dense_slots):
+        monkeypatch.setenv("VGICP_PERSIST_GRID", "16")                 # 16 x 448 < 40 000: several points per thread
+        monkeypatch.setenv("VGICP_DENSE_SLOTS", dense_slots)
+        out = []
+        with capi.Context(0) as ctx:
+            monkeypatch.delenv("VGICP_PERSIST_GRID")
+            monkeypatch.delenv("VGICP_DENSE_SLOTS")
+            ctx.map_reset(vmap.voxel_size, 0)
+            ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+            out.append(ctx.align(pts, covs, g, 6, 1e-6, 2.0))
+            out.append(ctx.align(pts, covs, g, 6, 1e-6, 2.0))          # copy still valid: no rebuild
+            ctx.map_insert_scan(extra[0], extra[1], np.eye(4), 5)      # new voxels and changed means
+            out.append(ctx.align(pts, covs, g, 6, 1e-6, 2.0))
+            ctx.map_erase(vmap.keys[:5_000])
+            out.append(ctx.align(pts, covs, g, 6, 1e-6, 2.0))
+            ctx.map_evict(np.zeros(3), 4.0)
+            out.append(ctx.align(pts, covs, g, 6, 1e-6, 2.0))
+            ctx.map_upsert(vmap.keys[:5_000], vmap.means[:5_000] + 0.01, vmap.covs[:5_000])
+            out.append(ctx.align(pts, covs, g, 6, 1e-6, 2.0))
+            assert ctx.counter(1) == 0
+        return out
+    plain, dense = drive("0"), drive("1")
+    for a, b in zip(plain, dense):
+        assert a.launches == b.launches == 1
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.normal_eq, b.normal_eq) and np.array_equal(a.corr_count, b.corr_count)
+    assert not np.array_equal(dense[0].normal_eq, dense[2].normal_eq)   # the mutations mattered
+    assert not np.array_equal(dense[2].normal_eq, dense[3].normal_eq) and not np.array_equal(dense[3].normal_eq, dense[4].normal_eq)
+    om = oracle.OracleMap(vmap.voxel_size, 1)
+    om.insert(vmap.means, vmap.covs)
+    ref = om.align(pts, covs, g, 6, 1e-6, 2.0)
+    assert np.array_equal(ref.corr_count, dense[0].corr_count)
+    dt, dr = pose_error(dense[0].pose, ref.pose)
+    assert dt <= TIGHT_POSE_TOL and dr <= TIGHT_POSE_TOL
+
+
 def test_persistent_launch_that_gives_up_falls_back_and_recovers(c1_inputs, monkeypatch):
     """A persistent launch whose in-kernel wait runs out (forced here with a poll budget of zero; in the field:
     another process holds compute units) must leave no trace: the align is re-run with one launch per
