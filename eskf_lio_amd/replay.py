@@ -60,8 +60,10 @@ class LidarMeasurement:
 # ---- CDR (little endian, XCDR1 as rosbag2 stores it) ------------------------------------------------
 class _CdrReader:
     def __init__(self, blob: bytes):
-        if len(blob) < 4 or blob[1] not in (0, 1):
-            raise ValueError("not a CDR payload")
+        # encapsulation header: representation identifier {0x00, 0x00 = CDR_BE | 0x01 = CDR_LE}, then two option bytes.
+        # Parameter-list CDR (0x0002 / 0x0003) and the XCDR2 identifiers (0x0006 ...) are other wire formats: refused.
+        if len(blob) < 4 or blob[0] != 0 or blob[1] not in (0, 1):
+            raise ValueError("not a plain-CDR payload (encapsulation header %s)" % bytes(blob[:4]).hex())
         self.little = blob[1] == 1
         self.buf = memoryview(blob)[4:]
         self.pos = 0

@@ -295,3 +295,64 @@ def test_scan_prepare_equals_the_separate_calls(gpu_ctx, oracle):
         gpu_ctx.scan_download()
     assert gpu_ctx.scan_prepare(np.zeros((0, 3)), None, None, None, 0.3, 30) == (0, 0)
     assert gpu_ctx.scan_download()[0].shape == (0, 3)
+
+
+# ---- wire formats against fixtures that the package's own writer never touched ------------------------------------
+def test_wire_format_readers_against_hand_assembled_fixtures():
+    """tests/golden/make_wire_fixtures.py lays a sensor_msgs/Imu, a sensor_msgs/PointCloud2 (32-byte point step with
+    padding, `intensity` and `ring` BEFORE `timestamp`, height 2 x width 3) and a minimal rosbag2 sqlite3 file out by
+    hand from the OMG CDR and message definitions — it imports nothing from the package.  The readers
+    (reference include/ESKF_LIO/Subscriber.hpp:38-52,80-103) must return exactly what was put in: little and big
+    endian; a float32 widened to double as the subscriber does; the bag in player order with the unrelated topic skipped."""
+    import json
+    from eskf_lio_amd import replay
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    want = json.load(open(os.path.join(gold, "wire_expected.json")))
+
+    def blob(name):
+        return open(os.path.join(gold, name), "rb").read()
+    for name in ("imu_le.cdr", "imu_be.cdr"):
+        m = replay.decode_imu(blob(name))
+        assert m.timestamp == want["imu"]["timestamp"]
+        assert m.angularVelocity.tolist() == want["imu"]["angular_velocity"]
+        assert m.acceleration.tolist() == want["imu"]["linear_acceleration"]
+    for name in ("cloud_le.cdr", "cloud_be.cdr"):
+        c = replay.decode_pointcloud2(blob(name))
+        assert c.points.dtype == np.float64 and c.points.tolist() == want["cloud"]["points"]
+        assert c.points[2, 0] == float(np.float32(0.1)) != 0.1          # widened from float32, not re-parsed
+        assert c.pointTime.tolist() == want["cloud"]["point_time"]
+        assert c.startTime == want["cloud"]["point_time"][0] and c.endTime == want["cloud"]["point_time"][-1]
+    with pytest.raises(ValueError):
+        replay.decode_pointcloud2(blob("cloud_bad_datatype.cdr"))       # x declared FLOAT64
+    with pytest.raises(ValueError):
+        replay.decode_pointcloud2(blob("cloud_pl_cdr.cdr"))             # parameter-list CDR: another wire format
+    with pytest.raises(ValueError):
+        replay.decode_imu(b"\x00\x07\x00\x00" + b"\x00" * 64)           # XCDR2 identifier
+    with pytest.raises(Exception):
+        replay.decode_imu(blob("imu_le.cdr")[:100])                     # truncated
+    events = replay.read_rosbag2(os.path.join(gold, "mini_bag.db3"))
+    kinds = [["imu" if isinstance(m, replay.ImuMeasurement) else "cloud", round(t, 6)] for t, m in events]
+    assert kinds == want["bag_order"]
+    assert events[1][1].acceleration.tolist() == want["imu"]["linear_acceleration"]
+    assert events[0][1].points.tolist() == want["cloud"]["points"]
+
+
+def test_the_package_writer_agrees_with_the_hand_assembled_layout():
+    """The other direction: what replay's own encoder produces for the same Imu content is byte for byte the
+    hand-assembled little-endian message (so the writer that builds the synthetic bags speaks the same format)."""
+    import json
+    from eskf_lio_amd import replay
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    want = json.load(open(os.path.join(gold, "wire_expected.json")))
+    hand = open(os.path.join(gold, "imu_le.cdr"), "rb").read()
+    m = replay.ImuMeasurement(want["imu"]["timestamp"], np.array(want["imu"]["angular_velocity"]),
+                              np.array(want["imu"]["linear_acceleration"]))
+    mine = replay.encode_imu(m, frame_id="imu_sensor_frame")
+    # encapsulation + seconds, then (skipping the nanoseconds: a double holds 1.6e9 s to ~2e-7 s only) frame id + padding
+    assert len(mine) == len(hand) and mine[:8] == hand[:8] and mine[12:36] == hand[12:36]
+    import struct
+    assert abs(struct.unpack("<I", mine[8:12])[0] - struct.unpack("<I", hand[8:12])[0]) <= 250
+    # the fields the subscriber reads sit at the same byte offsets: angular_velocity at 140, linear_acceleration at 236
+    assert mine[140:164] == hand[140:164] and mine[236:260] == hand[236:260]
+    back = replay.decode_imu(mine)
+    assert back.timestamp == m.timestamp and back.angularVelocity.tolist() == m.angularVelocity.tolist()
