@@ -624,7 +624,8 @@ class DeviceBackend:
     device-resident voxel grid; the motion gate of LocalMap::needsMapUpdate (src/LocalMap.cpp:132-147) is a
     few flops and stays on the host."""
 
-    def __init__(self, config: dict, device: int = 0):
+    def __init__(self, config: dict, device=0):
+        """device: one ordinal, or a list of ordinals for ONE multi-device context (vgicp_create_multi)."""
         from . import capi
         self.ctx = capi.Context(device)
         lm = config["local_map"]

@@ -254,11 +254,14 @@ def test_gpu_driven_replay_matches_the_oracle_driven_one(stream, oracle_run, dev
 
 
 @pytest.mark.gpu
-def test_resident_frame_chain_matches_the_oracle_driven_replay(stream, oracle_run):
+@pytest.mark.parametrize("device", [0, [0, 0]])
+def test_resident_frame_chain_matches_the_oracle_driven_replay(stream, oracle_run, device):
     """vgicp_scan_prepare -> vgicp_align_resident -> vgicp_map_insert_resident: the scan never returns to the
-    host between the raw sweep and the pose; trajectory and round counts equal the CPU chain's."""
+    host between the raw sweep and the pose; trajectory and round counts equal the CPU chain's.  [0, 0]: the same
+    loop over ONE multi-device context (vgicp_create_multi, two sub-contexts on device 0): prepared on the first,
+    dealt out, registered sharded, inserted into every replica."""
     events, _ = stream
-    backend = replay.DeviceBackend(replay.DEFAULT_CONFIG)
+    backend = replay.DeviceBackend(replay.DEFAULT_CONFIG, device)
     traj = replay.Odometry(replay.DEFAULT_CONFIG, backend).run([(a, _clone(m)) for a, m in events])
     ref_traj, ref_backend = oracle_run
     assert backend.iterations == ref_backend.iterations and len(traj) == len(ref_traj)

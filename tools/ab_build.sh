@@ -15,6 +15,7 @@ KS=${KERNEL_SCHED--mllvm -amdgpu-sched-strategy=max-memory-clause}
 /opt/rocm/bin/hipcc $FLAGS -Wno-unused-function -c -o /tmp/ab_$NAME/m.o vgicp_mapupdate.hip &
 /opt/rocm/bin/hipcc $FLAGS -ffp-contract=off -Wno-unused-function -c -o /tmp/ab_$NAME/p.o vgicp_preprocess.hip &
 /opt/rocm/bin/hipcc $FLAGS -c -o /tmp/ab_$NAME/c.o vgicp_capi.hip &
+/opt/rocm/bin/hipcc $FLAGS -c -o /tmp/ab_$NAME/u.o vgicp_multi.hip &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvgicp_hip.so" /tmp/ab_$NAME/{k,m,p,c}.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvgicp_hip.so" /tmp/ab_$NAME/{k,m,p,c,u}.o -ldl
 echo "built $OUT/libvgicp_hip.so"
