@@ -360,6 +360,8 @@ def in_process_leg(device_ids, vmap, pts, covs, guess, steps):
         ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
         for _ in range(5):
             res = ctx.align(pts, covs, guess, ITERATIONS, 1e-6, 2.0)
+        if ctx.counter(1) > 0:
+            steps = min(steps, 10)   # the single launch gives up on this node (every give-up waits ~1 s): say so, quickly
         bufs = [(pts.copy(), covs.copy()) for _ in range(min(steps, 50))]   # buffers the runtime has not uploaded from
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -405,11 +407,21 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary C5 (1M points / 10M voxels) leg")
     ap.add_argument("--no-frame-chain", action="store_true", help="skip the secondary frame-chain record")
     ap.add_argument("--frames", type=int, default=30, help="frames of the frame-chain record")
+    ap.add_argument("--in-process-leg", default=None, metavar="IDS",
+                    help="internal: measure ONE multi-device context over these comma-separated device ordinals and print "
+                         "its record as one JSON line (what rank 0 runs in a child process under the launcher)")
     ap.add_argument("--resident", action="store_true",
                     help="time vgicp_align_resident (scan already in HBM) as the step: profiling aid, the JSON "
                          "line then says so in config.workload")
     args = ap.parse_args()
 
+    if args.in_process_leg is not None:
+        ids = [int(x) for x in args.in_process_leg.split(",")]
+        n_points, n_voxels = synth.CONFIGS[args.config]
+        vmap = synth.make_map(n_voxels)
+        pts, covs = synth.make_uniform_scan(n_points, vmap)
+        print(json.dumps(in_process_leg(ids, vmap, pts, covs, synth.default_guess(), args.steps)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -809,9 +821,19 @@ def main():
         # multi-device context (what the reference's single-threaded caller would hold) — the others wait
         dist.barrier()
         if rank == 0 and out is not None:
+            # in a CHILD process with a time limit: this path has never met a multi-GPU node, and whatever it does there —
+            # a hang included — must not cost the launcher's own line
             try:
+                import subprocess
                 ids = [0] * world if share_device else list(range(world))
-                out["in_process"] = in_process_leg(ids, vmap, pts, covs, guess, max(10, min(args.steps, 200)))
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                         "VGICP_PERSIST_GRID", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-process-leg", ",".join(map(str, ids)),
+                                        "--config", args.config, "--steps", str(max(10, min(args.steps, 100)))],
+                                       capture_output=True, text=True, timeout=240, env=env)
+                lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+                out["in_process"] = json.loads(lines[-1]) if child.returncode == 0 and lines else {
+                    "error": f"child exited with {child.returncode}: {child.stderr[-400:]}"}
             except Exception as e:  # noqa: BLE001 - a secondary record: reported, never raised
                 out["in_process"] = {"error": f"{type(e).__name__}: {e}"}
     if use_dist:
