@@ -16,6 +16,7 @@ thread_local std::string g_create_error;
 namespace {
 
 int settle(vgicp_ctx* ctx);         // defined with the scan preparation below
+int fetch_insert_totals(vgicp_ctx* ctx);
 int settle_scan(vgicp_ctx* ctx);
 int settle_insert(vgicp_ctx* ctx);
 
@@ -308,6 +309,7 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   AlignState* header = reinterpret_cast<AlignState*>(ctx->h_log - kSlots);
   header->abort_seq = 0;
   header->outcome = kOutcomeNone;
+  { const int rc_copy = fetch_insert_totals(ctx); if (rc_copy != VGICP_OK) return rc_copy; }   // normally carried by the preparation's copy
   // one launch, one synchronisation
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
   VG_HIP(ctx, launch_persistent(ctx->stream, a, grid));
@@ -590,14 +592,15 @@ int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgi
   } while (0)
   VG_CREATE(hipSetDevice(device_id));
   VG_CREATE(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), kCounterWords * sizeof(uint32_t)));
+  // the insertion's running totals (4 words) sit right behind the counter block: ONE copy after a preparation brings
+  // both back, so a deferred insertion needs no copy of its own in the frame chain
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), (kCounterWords + 4) * sizeof(uint32_t)));
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), kCounterWords * sizeof(uint32_t), 0));
-  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_prep), kCounterWords * sizeof(uint32_t), 0));
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_prep), (kCounterWords + 4) * sizeof(uint32_t), 0));
   VG_CREATE(hipMalloc(&ctx->d_tiles, preprocess_tile_bytes()));
   VG_CREATE(hipMemset(ctx->d_tiles, 0, preprocess_tile_bytes()));
-  VG_CREATE(hipMemset(ctx->d_counters, 0, kCounterWords * sizeof(uint32_t)));
-  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_ins_counters), 4 * sizeof(uint32_t)));
-  VG_CREATE(hipMemset(ctx->d_ins_counters, 0, 4 * sizeof(uint32_t)));
+  VG_CREATE(hipMemset(ctx->d_counters, 0, (kCounterWords + 4) * sizeof(uint32_t)));
+  ctx->d_ins_counters = ctx->d_counters + kCounterWords;
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_ins_counters), 4 * sizeof(uint32_t), 0));
   ctx->h_ins_counters[0] = ctx->h_ins_counters[1] = 0;
   if (const char* se = std::getenv("VGICP_STAGE_EVENTS"); se && se[0] == '1') {
@@ -733,7 +736,6 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipHostFree(ctx->h_counters);
   (void)hipHostFree(ctx->h_prep);
   (void)hipFree(ctx->d_tiles);
-  (void)hipFree(ctx->d_ins_counters);
   (void)hipHostFree(ctx->h_ins_counters);
   for (int k = 0; k < 2; ++k) {
     if (ctx->h_state_table[k]) (void)hipHostFree(ctx->h_state_table[k]);
@@ -1004,9 +1006,9 @@ int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], 
                                 ctx->d_scan_aos, ctx->d_scan_aos + 3 * ctx->scan_capacity, (uint32_t)n, pose12,
                                 (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_ins_counters,
                                 insertion_lists_stay_short(ctx)));
-  VG_HIP(ctx, hipMemcpyAsync(ctx->h_ins_counters, ctx->d_ins_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[5], ctx->stream)); ctx->ev_stage_set[5] = true; }
   ctx->insert_pending = true;
+  ctx->ins_copy_enqueued = false;   // the next preparation's counter copy carries the totals (or settle() fetches them)
   ctx->insert_pending_upper = n;
   return VGICP_OK;
 }
@@ -1472,7 +1474,11 @@ int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, 
   a.ev_after_prologue = ctx->stage_events ? ctx->ev_stage[6] : nullptr;
   if (ctx->stage_events) ctx->ev_stage_set[6] = true;
   VG_HIP(ctx, launch_prepare(ctx->stream, a));
-  VG_HIP(ctx, hipMemcpyAsync(ctx->h_prep, ctx->d_counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_prep, ctx->d_counters, (kCounterWords + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->insert_pending && !ctx->ins_copy_enqueued) {   // the deferred insertion's totals travel with this copy
+    ctx->ins_copy_enqueued = true;
+    ctx->ins_from_prep = true;
+  }
   return VGICP_OK;
 }
 
@@ -1503,15 +1509,25 @@ int resolve_prepare(vgicp_ctx* ctx, uint32_t* kept) {
   return VGICP_OK;
 }
 
+// A deferred insertion whose totals no copy has picked up yet (no preparation followed it): a copy of its own, now.
+int fetch_insert_totals(vgicp_ctx* ctx) {
+  if (!ctx->insert_pending || ctx->ins_copy_enqueued) return VGICP_OK;
+  VG_HIP(ctx, hipMemcpyAsync(ctx->h_ins_counters, ctx->d_ins_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->ins_copy_enqueued = true;
+  ctx->ins_from_prep = false;
+  return VGICP_OK;
+}
+
 // The deferred map insertion's counts (running totals), once the stream has been synchronised.
 int settle_insert(vgicp_ctx* ctx) {
   if (!ctx->insert_pending) return VGICP_OK;
   ctx->insert_pending = false;
   ctx->insert_pending_upper = 0;
-  const uint32_t created = ctx->h_ins_counters[0] - ctx->ins_seen[0];
-  const uint32_t failed = ctx->h_ins_counters[1] - ctx->ins_seen[1];
-  ctx->ins_seen[0] = ctx->h_ins_counters[0];
-  ctx->ins_seen[1] = ctx->h_ins_counters[1];
+  const uint32_t* totals = ctx->ins_from_prep ? ctx->h_prep + kCounterWords : ctx->h_ins_counters;
+  const uint32_t created = totals[0] - ctx->ins_seen[0];
+  const uint32_t failed = totals[1] - ctx->ins_seen[1];
+  ctx->ins_seen[0] = totals[0];
+  ctx->ins_seen[1] = totals[1];
   ctx->voxels += created;
   if (failed) return fail(ctx, VGICP_ERR_TABLE_FULL, "voxel table probe sequence exhausted (deferred map insertion)");
   return VGICP_OK;
@@ -1537,6 +1553,7 @@ int settle_scan(vgicp_ctx* ctx) {
 int settle(vgicp_ctx* ctx) {
   if (!ctx->scan_pending && !ctx->insert_pending) return VGICP_OK;
   VG_HIP(ctx, hipSetDevice(ctx->device));
+  { const int rc_copy = fetch_insert_totals(ctx); if (rc_copy != VGICP_OK) return rc_copy; }
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int rc_scan = settle_scan(ctx);
   const int rc_ins = settle_insert(ctx);
@@ -2401,9 +2418,9 @@ int map_insert_device(vgicp_ctx* ctx, const double* d_points, const double* d_co
   VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size, d_points, d_covs,
                                   (uint32_t)n, pose12, (uint64_t)max_points_per_voxel, ctx->d_stage, sb, ctx->d_ins_counters,
                                   short_lists));
-    VG_HIP(ctx, hipMemcpyAsync(ctx->h_ins_counters, ctx->d_ins_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[5], ctx->stream)); ctx->ev_stage_set[5] = true; }
     ctx->insert_pending = true;
+    ctx->ins_copy_enqueued = false;
     ctx->insert_pending_upper = n;
     return VGICP_OK;
   }

@@ -218,6 +218,8 @@ struct vgicp_ctx {
   uint32_t* h_ins_counters = nullptr;  // pinned
   uint32_t ins_seen[2] = {0, 0};
   bool insert_pending = false;
+  bool ins_copy_enqueued = false;    // some device-to-host copy behind the pending insertion carries its totals ...
+  bool ins_from_prep = false;        // ... in the tail of h_prep (the next preparation's counter copy) rather than h_ins_counters
   uint64_t insert_pending_upper = 0;
   // frame statistics
   uint64_t stat_launches0 = 0, stat_copies0 = 0, stat_syncs0 = 0;
