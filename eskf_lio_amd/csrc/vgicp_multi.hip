@@ -245,11 +245,11 @@ int align_shards(vgicp_ctx* parent, const double* points, const double* covs, co
     }
   } else if (single) {
     bool grow = false;
-    for (int r = 0; r < g->n; ++r) grow = grow || vgicp_internal::align_needs_allocation(g->subs[(size_t)r], 0, params->max_iteration);
-    if (grow) {
+    for (int r = 0; r < g->n; ++r) grow = grow || vgicp_internal::align_needs_allocation(g->subs[(size_t)r], g->subs[(size_t)r]->n, params->max_iteration);
+    if (grow) {   // the log, or the dense record copy of a large table (the resident shards themselves stay where they are)
       const int rc = run_all(parent, [&](int r) {
         vgicp_ctx* sub = g->subs[(size_t)r];
-        return vgicp_internal::reserve_for_align(sub, sub->scan_capacity, params->max_iteration);
+        return vgicp_internal::reserve_for_align(sub, sub->n, params->max_iteration);
       });
       if (rc != VGICP_OK) return rc;
     }
