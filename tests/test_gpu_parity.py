@@ -1120,8 +1120,11 @@ def test_two_gpu_sharded_align():
     import socket
     import subprocess
     import sys
-    import torch
-    if torch.cuda.device_count() < 2:
+    # counted in a child: importing torch HERE, after libvgicp_hip.so, would load torch's bundled HIP runtime beside
+    # /opt/rocm's (same soname, different files) and the process would abort at exit
+    count = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=300)
+    if count.returncode != 0 or int(count.stdout.strip().splitlines()[-1]) < 2:
         pytest.skip("needs two GPUs (the round's boxes have one); the 8-GPU scaling run is the driver's")
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
