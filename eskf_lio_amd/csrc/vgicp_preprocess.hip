@@ -52,7 +52,17 @@ constexpr int kCoordOffset = 1 << (kCoordBits - 1);  // cell indices are offset 
 constexpr int kCoordMax = (1 << kCoordBits) - 1;
 constexpr int kSearchBlock = 64;       // one wave = one query per workgroup
 constexpr int kPool = 256;             // cells waiting per query
-constexpr uint32_t kLeafPoints = 128;  // a cell with at most this many points is measured, not descended (64: +13 % time)
+// a waiting cell with at most this many points is measured, not opened.  Opening costs a turn per child that has to be
+// taken afterwards (a trip to memory each, about 1 us for a wave on its own), measuring 64 points costs about as much:
+// where a dense surface is seen from a sparse place (a query metres from a wall) the small threshold made the search
+// take a hundred tiny cells one by one, and the kernel ended on a handful of such queries running alone
+// (frame sweep, 29 151 queries: 128 -> 203 us, longest query 168 us; 256 -> 160 / 126; 512 -> 148 / 99; 1024 -> 153 / 98;
+// 64 -> +13 % on 128.  profiles/r10_knn_leaf.txt)
+#ifndef VGICP_LEAF_POINTS
+#define VGICP_LEAF_POINTS 512
+#endif
+constexpr uint32_t kLeafPoints = VGICP_LEAF_POINTS;
+constexpr uint32_t kHomePoints = 128;  // the query's own cell is measured whole when it holds at most this many
 constexpr int kCovBlock = 128;
 constexpr unsigned long long kEmptyCell = ~0ull;
 constexpr unsigned long long kKeyMask = (1ull << 60) - 1;
@@ -638,7 +648,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
                  home_end = (uint32_t)__builtin_amdgcn_readlane((int)own_end, home_level);
   // (not when it is crowded -- thousands of returns in one finest cell next to the sensor: measuring all of them in
   // sorted order costs more insertions than the best-first search needs; 64: 270 us, 128 / 256: 250 us, no cap: 308 us)
-  const bool has_home = enough != 0 && home_end - home_start <= kLeafPoints;
+  const bool has_home = enough != 0 && home_end - home_start <= kHomePoints;
 
   // The k-list: lane l < K holds the l-th nearest so far, by (distance, index). It starts FULL: K consecutive
   // points of the sorted order around the query (w0 .. w0 + K - 1, inside home when there is one) are real points

@@ -13,6 +13,8 @@ from eskf_lio_amd import capi, synth  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 h = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
 pts = synth.make_lidar_scan(n, seed=11)
+if os.environ.get("VGICP_TRACE_SCENE") == "frame":  # the sweep of bench.py's frame chain
+    pts = synth.make_lidar_scan(n, seed=0x46524D, extent=25.0)
 with capi.Context(0) as ctx:
     for rep in range(3):
         kp, kc, ki = ctx.preprocess(pts, h, 30)
