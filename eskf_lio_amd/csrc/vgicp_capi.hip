@@ -20,6 +20,72 @@ int fetch_insert_totals(vgicp_ctx* ctx);
 int settle_scan(vgicp_ctx* ctx);
 int settle_insert(vgicp_ctx* ctx);
 
+// ---- copies between the CALLER'S pageable memory and the device -------------------------------------------------
+// hipMemcpyAsync registers a pageable range of more than 1 MB with the driver and lets the DMA engine read it in
+// place.  That is the fastest way to move a buffer once -- and a trap for a caller that allocates and frees its buffers
+// per frame, as the reference does: when such a range is unmapped (free() of anything above glibc's mmap threshold),
+// the driver takes ALL queues of the process off the device until the registration is torn down: 20 - 24 ms in which
+// nothing runs (profiles/r10_sync_stall.txt: 23 of 30 ten-frame runs saw it; none with a malloc that keeps its memory).
+// So copies of 512 KB - 16 MB go through a page-locked arena of the context instead (smaller ones the runtime stages
+// itself; larger ones -- a 10 M-voxel map, a 100 k-point scan -- go up directly, once).  VGICP_STAGE_LIMIT=0: never.
+constexpr size_t kArenaBytes = 16u << 20, kArenaMin = 512u << 10;
+void arena_reset(vgicp_ctx* ctx) {
+  ctx->arena_used = 0;
+  ctx->pending_out.clear();
+}
+char* arena_take(vgicp_ctx* ctx, size_t bytes) {
+  static const bool off = std::getenv("VGICP_STAGE_LIMIT") && std::atoll(std::getenv("VGICP_STAGE_LIMIT")) == 0;
+  if (off || bytes <= kArenaMin || bytes > kArenaBytes - ctx->arena_used) return nullptr;
+  if (!ctx->h_arena && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_arena), kArenaBytes, 0) != hipSuccess) {
+    ctx->h_arena = nullptr;
+    return nullptr;
+  }
+  char* p = ctx->h_arena + ctx->arena_used;
+  ctx->arena_used += (bytes + 255) & ~size_t(255);
+  return p;
+}
+// page-locked memory (hipHostMalloc / vgicp_host_register): the DMA engine reads it in place, nothing to stage
+bool is_pagelocked(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+int user_h2d(vgicp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return VGICP_OK;
+  char* p = bytes > kArenaMin && is_pagelocked(src) ? nullptr : arena_take(ctx, bytes);
+  if (!p) {
+    VG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return VGICP_OK;
+  }
+  const size_t piece = 384u << 10;   // each piece travels while the CPU copies the next
+  for (size_t off = 0; off < bytes; off += piece) {
+    const size_t len = std::min(piece, bytes - off);
+    std::memcpy(p + off, static_cast<const char*>(src) + off, len);
+    VG_HIP(ctx, hipMemcpyAsync(static_cast<char*>(dst) + off, p + off, len, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return VGICP_OK;
+}
+// device -> the caller's memory; complete only after the stream has been synchronised AND user_copies_finish ran
+int user_d2h(vgicp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return VGICP_OK;
+  char* p = bytes > kArenaMin && is_pagelocked(dst) ? nullptr : arena_take(ctx, bytes);
+  if (!p) {
+    VG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return VGICP_OK;
+  }
+  VG_HIP(ctx, hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->pending_out.push_back({dst, p, bytes});
+  return VGICP_OK;
+}
+void user_copies_finish(vgicp_ctx* ctx) {
+  for (const auto& o : ctx->pending_out) std::memcpy(o.dst, o.src, o.bytes);
+  ctx->pending_out.clear();
+}
+#define VG_RC(call) do { const int rc__ = (call); if (rc__ != VGICP_OK) return rc__; } while (0)
+
 int ensure_stage(vgicp_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->stage_bytes) return VGICP_OK;
   if (ctx->d_stage) VG_HIP(ctx, hipFree(ctx->d_stage));
@@ -311,12 +377,19 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   header->outcome = kOutcomeNone;
   { const int rc_copy = fetch_insert_totals(ctx); if (rc_copy != VGICP_OK) return rc_copy; }   // normally carried by the preparation's copy
   // one launch, one synchronisation
+  static const bool trace_align = std::getenv("VGICP_TRACE_ALIGN") != nullptr;   // developer aid: where the host time of an align goes
+  const double ta0 = trace_align ? now_seconds() : 0.0;
   VG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
   VG_HIP(ctx, launch_persistent(ctx->stream, a, grid));
   VG_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
   if (ctx->stage_events) VG_HIP(ctx, hipEventRecord(ctx->ev_stage[3], ctx->stream));
+  const double ta1 = trace_align ? now_seconds() : 0.0;
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const double ta2 = trace_align ? now_seconds() : 0.0;
   VG_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_begin, ctx->ev_end));
+  if (trace_align && ta2 - ta0 > 2e-3)
+    std::fprintf(stderr, "[vgicp trace] align: enqueue %.3f ms, hipStreamSynchronize %.3f ms, the launch itself %.3f ms (events)\n",
+                 (ta1 - ta0) * 1e3, (ta2 - ta1) * 1e3, (double)*device_ms);
   std::memcpy(result, header, sizeof(AlignState));
   ++ctx->persistent_launches;
   {
@@ -740,6 +813,7 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   for (int k = 0; k < 2; ++k) {
     if (ctx->h_state_table[k]) (void)hipHostFree(ctx->h_state_table[k]);
     if (ctx->h_raw_stage[k]) (void)hipHostFree(ctx->h_raw_stage[k]);
+    if (k == 0 && ctx->h_arena) (void)hipHostFree(ctx->h_arena);
     if (ctx->ev_state_table[k]) (void)hipEventDestroy(ctx->ev_state_table[k]);
   }
   for (auto& e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -842,9 +916,10 @@ int vgicp_map_upsert(vgicp_ctx* ctx, size_t n, const int32_t* keys, const double
   rc = ensure_stage(ctx, qoff + n * sizeof(uint32_t));
   if (rc != VGICP_OK) return rc;
   char* base = static_cast<char*>(ctx->d_stage);
-  VG_HIP(ctx, hipMemcpyAsync(base + koff, keys, kb, hipMemcpyHostToDevice, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(base + moff, means, mb, hipMemcpyHostToDevice, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(base + coff, covs, cb, hipMemcpyHostToDevice, ctx->stream));
+  arena_reset(ctx);
+  VG_RC(user_h2d(ctx, base + koff, keys, kb));
+  VG_RC(user_h2d(ctx, base + moff, means, mb));
+  VG_RC(user_h2d(ctx, base + coff, covs, cb));
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
   ++ctx->map_version;
   VG_HIP(ctx, launch_upsert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), (uint32_t)n,
@@ -872,7 +947,8 @@ int vgicp_map_erase(vgicp_ctx* ctx, size_t n, const int32_t* keys) {
   const size_t kb = n * 3 * sizeof(int32_t);
   int rc = ensure_stage(ctx, kb);
   if (rc != VGICP_OK) return rc;
-  VG_HIP(ctx, hipMemcpyAsync(ctx->d_stage, keys, kb, hipMemcpyHostToDevice, ctx->stream));
+  arena_reset(ctx);
+  VG_RC(user_h2d(ctx, ctx->d_stage, keys, kb));
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
   ++ctx->map_version;
   VG_HIP(ctx, launch_erase(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), (uint32_t)n,
@@ -916,8 +992,9 @@ int vgicp_map_insert_scan(vgicp_ctx* ctx, size_t n, const double* points, const 
   char* base = static_cast<char*>(ctx->d_stage);
   double pose12[12];
   pose_to_state(transform, pose12);
-  VG_HIP(ctx, hipMemcpyAsync(base, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(base + pb, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  arena_reset(ctx);
+  VG_RC(user_h2d(ctx, base, points, n * 3 * sizeof(double)));
+  VG_RC(user_h2d(ctx, base + pb, covs, n * 9 * sizeof(double)));
   VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
   ++ctx->map_version;
   VG_HIP(ctx, launch_map_insert(ctx->stream, ctx->table, (uint32_t)(ctx->slots - 1), ctx->voxel_size,
@@ -1101,11 +1178,13 @@ int vgicp_map_export(vgicp_ctx* ctx, size_t capacity, int32_t* keys, double* mea
                                 reinterpret_cast<int32_t*>(b), reinterpret_cast<double*>(b + kb),
                                 reinterpret_cast<double*>(b + kb + mb), reinterpret_cast<uint64_t*>(b + kb + mb + cb),
                                 ctx->d_counters));
-  VG_HIP(ctx, hipMemcpyAsync(keys, b, cap * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(means, b + kb, cap * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(covs, b + kb + mb, cap * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(counts, b + kb + mb + cb, cap * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  arena_reset(ctx);
+  VG_RC(user_d2h(ctx, keys, b, cap * 3 * sizeof(int32_t)));
+  VG_RC(user_d2h(ctx, means, b + kb, cap * 3 * sizeof(double)));
+  VG_RC(user_d2h(ctx, covs, b + kb + mb, cap * 9 * sizeof(double)));
+  VG_RC(user_d2h(ctx, counts, b + kb + mb + cb, cap * sizeof(uint64_t)));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  user_copies_finish(ctx);
   *written = cap;
   return VGICP_OK;
 }
@@ -1159,7 +1238,17 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
     ctx->seen_bytes[ctx->seen_next & 1023u] = n * 9 * sizeof(double);
     ++ctx->seen_next;
   }
-  if (ctx->uploader && ctx->uploader_enabled && !seen_before && n * 3 * sizeof(double) >= (512u << 10)) {
+  // a scan of up to 4 MB (42 k points: what a LiDAR sweep keeps) goes through the page-locked arena: the caller of the
+  // reference allocates and frees its clouds per frame, and a range the runtime registered stalls every queue of the
+  // process for ~20 ms when it is unmapped (above).  Larger scans go up directly, as measured in DESIGN.md 6.
+  static const bool stage_off = std::getenv("VGICP_STAGE_LIMIT") && std::atoll(std::getenv("VGICP_STAGE_LIMIT")) == 0;
+  static const size_t upload_stage_limit =   // VGICP_UPLOAD_STAGE_LIMIT=bytes: up to the arena's 16 MB (a 100 k-point scan is 9.6 MB)
+      std::getenv("VGICP_UPLOAD_STAGE_LIMIT") ? std::min<size_t>((size_t)std::atoll(std::getenv("VGICP_UPLOAD_STAGE_LIMIT")), kArenaBytes) : (4u << 20);
+  if (!stage_off && n * kScanPlanes * sizeof(double) <= upload_stage_limit && !is_pagelocked(points) && !is_pagelocked(covs)) {
+    arena_reset(ctx);
+    VG_RC(user_h2d(ctx, aos_pts, points, n * 3 * sizeof(double)));
+    VG_RC(user_h2d(ctx, aos_cov, covs, n * 9 * sizeof(double)));
+  } else if (ctx->uploader && ctx->uploader_enabled && !seen_before && n * 3 * sizeof(double) >= (512u << 10)) {
     ctx->uploader->post(aos_pts, points, n * 3 * sizeof(double));
     ++g_copy_ops;
     const hipError_t e_cov = hipMemcpyAsync(aos_cov, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -1367,8 +1456,9 @@ int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* co
   uint64_t* o_ix = reinterpret_cast<uint64_t*>(b + 3 * pb + 3 * cb);
   uint32_t* counts = reinterpret_cast<uint32_t*>(b + 3 * pb + 3 * cb + ib);
   uint32_t* d_total = reinterpret_cast<uint32_t*>(b + 3 * pb + 3 * cb + ib + nbb);
-  VG_HIP(ctx, hipMemcpyAsync(in_pts, points, pb, hipMemcpyHostToDevice, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(in_cov, covs, cb, hipMemcpyHostToDevice, ctx->stream));
+  arena_reset(ctx);
+  VG_RC(user_h2d(ctx, in_pts, points, pb));
+  VG_RC(user_h2d(ctx, in_cov, covs, cb));
   VG_HIP(ctx, launch_match(ctx->stream, in_pts, in_cov, (uint32_t)n, ctx->table,
                            (uint32_t)(ctx->slots - 1), ctx->voxel_size, counts, d_total, o_sp, o_sc,
                            o_mp, o_mc, o_ix));
@@ -1376,13 +1466,14 @@ int vgicp_match(vgicp_ctx* ctx, size_t n, const double* points, const double* co
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const size_t m = ctx->h_counters[0];
   if (m > 0) {
-    VG_HIP(ctx, hipMemcpyAsync(src_points, o_sp, m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    VG_HIP(ctx, hipMemcpyAsync(src_covs, o_sc, m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    VG_HIP(ctx, hipMemcpyAsync(map_points, o_mp, m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    VG_HIP(ctx, hipMemcpyAsync(map_covs, o_mc, m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (src_index)
-      VG_HIP(ctx, hipMemcpyAsync(src_index, o_ix, m * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    arena_reset(ctx);   // the inputs have been consumed (synchronised above)
+    VG_RC(user_d2h(ctx, src_points, o_sp, m * 3 * sizeof(double)));
+    VG_RC(user_d2h(ctx, src_covs, o_sc, m * 9 * sizeof(double)));
+    VG_RC(user_d2h(ctx, map_points, o_mp, m * 3 * sizeof(double)));
+    VG_RC(user_d2h(ctx, map_covs, o_mc, m * 9 * sizeof(double)));
+    if (src_index) VG_RC(user_d2h(ctx, src_index, o_ix, m * sizeof(uint64_t)));
     VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    user_copies_finish(ctx);
   }
   *matched = m;
   return VGICP_OK;
@@ -1406,11 +1497,13 @@ int vgicp_voxel_index(vgicp_ctx* ctx, size_t n, const double* points, int32_t* k
   int rc = ensure_stage(ctx, pb + kb);
   if (rc != VGICP_OK) return rc;
   char* b = static_cast<char*>(ctx->d_stage);
-  VG_HIP(ctx, hipMemcpyAsync(b, points, pb, hipMemcpyHostToDevice, ctx->stream));
+  arena_reset(ctx);
+  VG_RC(user_h2d(ctx, b, points, pb));
   VG_HIP(ctx, launch_voxel_index(ctx->stream, reinterpret_cast<const double*>(b), (uint32_t)n,
                                  ctx->voxel_size, reinterpret_cast<int32_t*>(b + pb)));
-  VG_HIP(ctx, hipMemcpyAsync(keys, b + pb, kb, hipMemcpyDeviceToHost, ctx->stream));
+  VG_RC(user_d2h(ctx, keys, b + pb, kb));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  user_copies_finish(ctx);
   return VGICP_OK;
 }
 
@@ -1598,7 +1691,8 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
   double* d_out_pts = reinterpret_cast<double*>(base + pb);
   double* d_out_covs = reinterpret_cast<double*>(base + 2 * pb);
   unsigned long long* d_out_idx = reinterpret_cast<unsigned long long*>(base + 2 * pb + cb);
-  VG_HIP(ctx, hipMemcpyAsync(base, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  arena_reset(ctx);
+  VG_RC(user_h2d(ctx, base, points, n * 3 * sizeof(double)));
   rc = enqueue_prepare(ctx, reinterpret_cast<double*>(base), n, voxel_size, knn, nullptr, DeskewOnDevice(),
                        base + 2 * pb + cb + ib, d_out_pts, d_out_covs, d_out_idx, nullptr, 0);
   if (rc != VGICP_OK) return rc;
@@ -1609,11 +1703,12 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
   if (rc != VGICP_OK) return rc;
   if (m > (out_points && out_covs ? capacity : 0))
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "output capacity smaller than the number of occupied voxels");
-  VG_HIP(ctx, hipMemcpyAsync(out_points, d_out_pts, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(out_covs, d_out_covs, (size_t)m * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (out_index)
-    VG_HIP(ctx, hipMemcpyAsync(out_index, d_out_idx, (size_t)m * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  arena_reset(ctx);   // the input has been consumed (synchronised above)
+  VG_RC(user_d2h(ctx, out_points, d_out_pts, (size_t)m * 3 * sizeof(double)));
+  VG_RC(user_d2h(ctx, out_covs, d_out_covs, (size_t)m * 9 * sizeof(double)));
+  if (out_index) VG_RC(user_d2h(ctx, out_index, d_out_idx, (size_t)m * sizeof(uint64_t)));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  user_copies_finish(ctx);
   return VGICP_OK;
 }
 
@@ -1754,13 +1849,15 @@ int vgicp_deskew(vgicp_ctx* ctx, size_t n, double* points, const double* point_t
   double* d_time = reinterpret_cast<double*>(base + pb);
   double* d_states = reinterpret_cast<double*>(base + pb + tb);
   uint32_t* d_ends = reinterpret_cast<uint32_t*>(base + pb + tb + sb);
-  VG_HIP(ctx, hipMemcpyAsync(d_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  arena_reset(ctx);
+  VG_RC(user_h2d(ctx, d_pts, points, n * 3 * sizeof(double)));
+  VG_RC(user_h2d(ctx, d_time, point_time, n * sizeof(double)));
   VG_HIP(ctx, hipMemcpyAsync(d_states, host.data(), used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   VG_HIP(ctx, launch_deskew(ctx->stream, d_pts, (uint32_t)n, d_time, d_states, (uint32_t)used, d_states + used, d_ends, ordered));
-  VG_HIP(ctx, hipMemcpyAsync(points, d_pts, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VG_RC(user_d2h(ctx, points, d_pts, n * 3 * sizeof(double)));
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_counters, d_ends + (used - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  user_copies_finish(ctx);
   *transformed = (int64_t)ctx->h_counters[0];
   return VGICP_OK;
 }
@@ -1962,10 +2059,11 @@ int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double*
   if (capacity < ctx->n) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "capacity smaller than the resident scan");
   if (!points || !covs) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL output pointer");
   VG_HIP(ctx, hipSetDevice(ctx->device));
-  VG_HIP(ctx, hipMemcpyAsync(points, ctx->d_scan_aos, (size_t)ctx->n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  VG_HIP(ctx, hipMemcpyAsync(covs, ctx->d_scan_aos + 3 * ctx->scan_capacity, (size_t)ctx->n * 9 * sizeof(double),
-                             hipMemcpyDeviceToHost, ctx->stream));
+  arena_reset(ctx);
+  VG_RC(user_d2h(ctx, points, ctx->d_scan_aos, (size_t)ctx->n * 3 * sizeof(double)));
+  VG_RC(user_d2h(ctx, covs, ctx->d_scan_aos + 3 * ctx->scan_capacity, (size_t)ctx->n * 9 * sizeof(double)));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  user_copies_finish(ctx);
   return VGICP_OK;
 }
 

@@ -207,6 +207,14 @@ struct vgicp_ctx {
   // through these instead of handed to the runtime, which would pin the caller's pages on the fly — measured on the
   // round's boxes: 1.4 MB of points 0.05 ms staged, but 12-22 ms (first copy of every frame) through the pinning path
   // once the caller allocates and frees its clouds per frame, as the reference does (examples/frame_chain)
+  // ... and for every OTHER copy between the caller's pageable memory and the device (map batches, hooks, scan_download,
+  // the scan of a vgicp_align up to 4 MB): one page-locked arena.  A copy of more than 512 KB goes through it (h2d: CPU
+  // copy in, then DMA; d2h: DMA, then CPU copy out after the call's synchronisation) -- never through the runtime's
+  // pin-on-the-fly path, whose registrations stall the whole process when the caller frees the buffer
+  char* h_arena = nullptr;
+  size_t arena_used = 0;
+  struct PendingOut { void* dst; const char* src; size_t bytes; };
+  std::vector<PendingOut> pending_out;
   char* h_raw_stage[2] = {nullptr, nullptr};
   size_t raw_stage_cap[2] = {0, 0};
   double* h_state_table[2] = {nullptr, nullptr};

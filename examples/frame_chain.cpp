@@ -191,6 +191,13 @@ int main(int argc, char ** argv)
         const auto a2 = std::chrono::steady_clock::now();
         if (icp.lastUsedResidentScan()) {++residentAligns;}
         localMap.updateLocalMap(meas->cloud, estimateA);                       // :86
+        if (std::getenv("FRAME_CHAIN_VERBOSE")) {
+          vgicp_frame_stats vs{};
+          (void)vgicp_get_frame_stats(shim::defaultContext(), &vs, 0);
+          std::printf("  [chain A] frame %d stages: process %.3f align %.3f update %.3f ms; device spans (VGICP_STAGE_EVENTS=1): prepare %.1f us (head %.1f), align %.1f us\n", f,
+                      std::chrono::duration<double, std::milli>(a1 - a0).count(), std::chrono::duration<double, std::milli>(a2 - a1).count(),
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a2).count(), vs.prepare_us, vs.prepare_head_us, vs.align_us);
+        }
         if (f > 1) {
           stageMs[0] += std::chrono::duration<double, std::milli>(a1 - a0).count();
           stageMs[1] += std::chrono::duration<double, std::milli>(a2 - a1).count();
@@ -198,6 +205,9 @@ int main(int argc, char ** argv)
         }
       }
       if (f > 1) {classesMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count();}
+      if (std::getenv("FRAME_CHAIN_VERBOSE")) {
+        std::printf("  [chain A] frame %d: %.3f ms\n", f, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
+      }
       // ---- A2: the same classes with their defaults (host map, eager host copy) ----
       const auto a20 = std::chrono::steady_clock::now();
       if (f == 0) {
