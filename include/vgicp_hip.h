@@ -280,8 +280,11 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
  * entry point first brings a pending preparation / insertion up to date.
  * Lifetime of the caller's buffers: a sweep of up to 16 MB (points + capture times; VGICP_STAGE_LIMIT bytes in the
  * environment) is copied into page-locked staging memory of the context before the call returns — the caller's
- * buffers are free again at once, and the runtime never pins the caller's pages (which costs 12-22 ms on the first
- * copy of every frame for a caller that allocates and frees its clouds per frame, as the reference does).  A LARGER
+ * buffers are free again at once, and the runtime never registers the caller's pages.  (A registered range that the
+ * caller frees takes every queue of the process off the device for ~20 ms: the fate of a caller that allocates and
+ * frees its clouds per frame, as the reference does.  For the same reason every synchronous entry point of this
+ * header moves buffers of 0.5 - 16 MB -- and the scan of a vgicp_align up to 4 MB, VGICP_UPLOAD_STAGE_LIMIT -- through
+ * a page-locked arena of the context; page-locked buffers, vgicp_host_register, go directly.)  A LARGER
  * sweep is read straight from `points` / `point_time`, which then must stay valid and unchanged until the next call
  * that synchronises (vgicp_align_resident, vgicp_scan_info, ...).  `states` and `extrinsic` are always copied before
  * the call returns.  At most 16 000 IMU states may fall inside one sweep (VGICP_ERR_BAD_ARGUMENT beyond; vgicp_deskew
