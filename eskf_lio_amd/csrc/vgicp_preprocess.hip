@@ -963,9 +963,15 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     out_idx[o] = qi;
 #ifdef VGICP_PREP_TRACE  // developer build only (tools/ab_build.sh trace -DVGICP_PREP_TRACE): the index output carries a trace record
     {
+      // the 10-bit field: cells taken (1), insertions (2), points in the query's own level-5 / level-4 cell (4 / 6), the
+      // finest level whose own cell holds K points (5)
+      const uint32_t trace_field = VGICP_PREP_TRACE == 2 ? inserts
+                                 : VGICP_PREP_TRACE == 4 ? (uint32_t)__builtin_amdgcn_readlane((int)(own_end - own_start), 5)
+                                 : VGICP_PREP_TRACE == 6 ? (uint32_t)__builtin_amdgcn_readlane((int)(own_end - own_start), 4)
+                                 : VGICP_PREP_TRACE == 5 ? (enough ? (uint32_t)home_level : 15u) : pops;
       const uint64_t t_end = wall_clock64();
       uint64_t dt = t_end - t_trace; if (dt > 0xFFFFFu) dt = 0xFFFFFu;
-      out_idx[o] = (dt << 44) | ((uint64_t)((VGICP_PREP_TRACE == 2 ? inserts : pops) > 1023u ? 1023u : (VGICP_PREP_TRACE == 2 ? inserts : pops)) << 34) | ((uint64_t)((VGICP_PREP_TRACE == 3 ? (int)(blockIdx.x % 8u) : level) & 15) << 30) | ((t_trace / 10u) & 0x3FFFFFFFu);
+      out_idx[o] = (dt << 44) | ((uint64_t)(trace_field > 1023u ? 1023u : trace_field) << 34) | ((uint64_t)((VGICP_PREP_TRACE == 3 ? (int)(blockIdx.x % 8u) : level) & 15) << 30) | ((t_trace / 10u) & 0x3FFFFFFFu);
     }
 #endif
     if (debug) {
