@@ -72,6 +72,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from eskf_lio_amd import capi, synth  # noqa: E402
+
+_KEEP_ALIVE = []   # host buffers the HIP runtime has registered stay mapped until the process ends
 from eskf_lio_amd.distributed import gather_bytes, shard_bounds, share_unique_id  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s achievable)
@@ -363,6 +365,7 @@ def in_process_leg(device_ids, vmap, pts, covs, guess, steps):
         if ctx.counter(1) > 0:
             steps = min(steps, 10)   # the single launch gives up on this node (every give-up waits ~1 s): say so, quickly
         bufs = [(pts.copy(), covs.copy()) for _ in range(min(steps, 50))]   # buffers the runtime has not uploaded from
+        _KEEP_ALIVE.append(bufs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         dev = 0.0
@@ -568,6 +571,14 @@ def main():
         el_reg, _, _, _ = timed(lambda k: align_host(my_pts, my_covs), reused)
         ctx.host_unregister(my_pts)
         ctx.host_unregister(my_covs)
+        # ... and with the scan copied through page-locked memory of the context instead of being registered in place:
+        # what a caller that FREES its 9.6 MB clouds per frame should ask for (a freed registered buffer stalls every
+        # queue of the process for ~20 ms; scans up to 4 MB take this path by default)
+        ctx.set_option(capi.OPTION_UPLOAD_STAGE_KB, 16384)
+        for _ in range(3):
+            step_cold(0)
+        el_staged, _, _, _ = timed(step_cold, again)
+        ctx.set_option(capi.OPTION_UPLOAD_STAGE_KB, 4096)
         upload_report = {
             "bytes_per_step": scan_bytes,
             "buffers": n_cold,
@@ -579,15 +590,21 @@ def main():
             "ms_per_step_second_pass": el_again / again * 1e3,
             "ms_per_step_reused": el_reused / reused * 1e3,
             "ms_per_step_registered": el_reg / reused * 1e3,
+            "ms_per_step_staged": el_staged / again * 1e3,
             "host_threads": "2 (points on a helper thread and stream, covariances on the caller's)"
                             if os.environ.get("VGICP_UPLOAD_THREADS", "2") != "1" else "1",
             "upload_ms_cold": ns_cold / 1e6 / args.steps,
             "upload_ms_second_pass": ns_again / 1e6 / again,
             "upload_ms_reused": ns_reused / 1e6 / reused,
             "what": "host side of the two hipMemcpyAsync from the caller's pageable buffers + the enqueue of the pack "
-                    "kernel, in front of the persistent launch; `value` is the cold figure",
+                    "kernel, in front of the persistent launch; `value` is the cold figure.  The runtime REGISTERS such a "
+                    "buffer with the driver; a caller that frees it per frame pays ~20 ms when it is unmapped "
+                    "(profiles/r10_sync_stall.txt) and should take the staged path (`ms_per_step_staged`: "
+                    "VGICP_OPTION_UPLOAD_STAGE_KB / VGICP_UPLOAD_STAGE_LIMIT; the default for scans up to 4 MB)",
         }
-        del cold
+        # NOT freed here: unmapping a buffer the HIP runtime has registered takes every queue of the process off the device
+        # for ~20 ms (profiles/r10_sync_stall.txt) and would land in the legs that follow; they go with the process
+        _KEEP_ALIVE.append(cold)
         for _ in range(2):
             step_resident()
         elapsed_res, _, _, _ = timed(lambda k: step_resident(), args.steps)
@@ -783,7 +800,7 @@ def main():
             ctx.map_reset(map5.voxel_size, v5)
             ctx.map_upsert(map5.keys, map5.means, map5.covs)
             ctx.scan_upload(np.ascontiguousarray(pts5[lo5:hi5]), np.ascontiguousarray(covs5[lo5:hi5]))
-            del map5, pts5, covs5
+            _KEEP_ALIVE.append((map5, pts5, covs5))   # freed with the process, not in front of the timed aligns (see `cold`)
             ready, why = 1.0, ""
         except Exception as e:  # noqa: BLE001 - reported in the JSON line
             ready, why = 0.0, f"{type(e).__name__}: {e}"

@@ -59,6 +59,7 @@ class FrameStats(C.Structure):
 
 
 OPTION_STAGE_EVENTS = 1
+OPTION_UPLOAD_STAGE_KB = 2   # scans up to this many KiB go through page-locked memory of the context (vgicp_hip.h)
 
 
 class Stats(C.Structure):

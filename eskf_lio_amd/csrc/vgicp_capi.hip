@@ -703,6 +703,7 @@ int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgi
   if (const char* pm = std::getenv("VGICP_PREFETCH_MARGIN")) ctx->prefetch_margin = std::atof(pm);
   if (const char* sl = std::getenv("VGICP_SPIN_LIMIT")) ctx->persist_spin_limit = (uint32_t)std::strtoul(sl, nullptr, 10);
   if (const char* ut = std::getenv("VGICP_UPLOAD_THREADS")) ctx->uploader_enabled = std::atoi(ut) != 1;
+  if (const char* ul = std::getenv("VGICP_UPLOAD_STAGE_LIMIT")) ctx->upload_stage_limit = std::min<size_t>((size_t)std::atoll(ul), 16u << 20);
   {
     // the in-kernel exchange needs every workgroup resident: one 512-thread workgroup with the LARGEST dynamic LDS
     // a launch plan asks for (memo + parked points of a scan bigger than the grid: 150 KB) must fit a CU — checked
@@ -1129,6 +1130,10 @@ int vgicp_set_option(vgicp_ctx* ctx, int option, int value) {
       ctx->stage_events = value != 0;
       for (bool& b : ctx->ev_stage_set) b = false;
       return VGICP_OK;
+    case VGICP_OPTION_UPLOAD_STAGE_KB:
+      if (value < 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "negative size");
+      ctx->upload_stage_limit = std::min<size_t>((size_t)value << 10, kArenaBytes);
+      return VGICP_OK;
     default:
       return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown option");
   }
@@ -1242,9 +1247,9 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
   // reference allocates and frees its clouds per frame, and a range the runtime registered stalls every queue of the
   // process for ~20 ms when it is unmapped (above).  Larger scans go up directly, as measured in DESIGN.md 6.
   static const bool stage_off = std::getenv("VGICP_STAGE_LIMIT") && std::atoll(std::getenv("VGICP_STAGE_LIMIT")) == 0;
-  static const size_t upload_stage_limit =   // VGICP_UPLOAD_STAGE_LIMIT=bytes: up to the arena's 16 MB (a 100 k-point scan is 9.6 MB)
-      std::getenv("VGICP_UPLOAD_STAGE_LIMIT") ? std::min<size_t>((size_t)std::atoll(std::getenv("VGICP_UPLOAD_STAGE_LIMIT")), kArenaBytes) : (4u << 20);
-  if (!stage_off && n * kScanPlanes * sizeof(double) <= upload_stage_limit && !is_pagelocked(points) && !is_pagelocked(covs)) {
+  const size_t whole_bytes = ctx->upload_whole_hint ? ctx->upload_whole_hint : n * kScanPlanes * sizeof(double);
+  if (!stage_off && whole_bytes <= ctx->upload_stage_limit && n * kScanPlanes * sizeof(double) <= kArenaBytes &&
+      !is_pagelocked(points) && !is_pagelocked(covs)) {
     arena_reset(ctx);
     VG_RC(user_h2d(ctx, aos_pts, points, n * 3 * sizeof(double)));
     VG_RC(user_h2d(ctx, aos_cov, covs, n * 9 * sizeof(double)));

@@ -213,6 +213,8 @@ struct vgicp_ctx {
   // pin-on-the-fly path, whose registrations stall the whole process when the caller frees the buffer
   char* h_arena = nullptr;
   size_t arena_used = 0;
+  size_t upload_stage_limit = 4u << 20;   // scans up to this many bytes go through the arena (VGICP_UPLOAD_STAGE_LIMIT, VGICP_OPTION_UPLOAD_STAGE_KB)
+  size_t upload_whole_hint = 0;           // a sub-context's shard: the size of the caller's WHOLE scan decides, not the shard's
   struct PendingOut { void* dst; const char* src; size_t bytes; };
   std::vector<PendingOut> pending_out;
   char* h_raw_stage[2] = {nullptr, nullptr};

@@ -215,7 +215,11 @@ int upload_shards(vgicp_ctx* parent, const double* points, const double* covs) {
   vgicp_multi* g = parent->multi;
   return run_all(parent, [&](int r) {
     const size_t lo = g->lo[(size_t)r], cnt = g->hi[(size_t)r] - lo;
-    return vgicp_scan_upload(g->subs[(size_t)r], cnt, cnt ? points + 3 * lo : nullptr, cnt ? covs + 9 * lo : nullptr);
+    vgicp_ctx* sub = g->subs[(size_t)r];
+    sub->upload_whole_hint = g->hi[(size_t)g->n - 1] * kScanPlanes * sizeof(double);   // staged or direct: the caller's whole buffer decides
+    const int rc_up = vgicp_scan_upload(sub, cnt, cnt ? points + 3 * lo : nullptr, cnt ? covs + 9 * lo : nullptr);
+    sub->upload_whole_hint = 0;
+    return rc_up;
   });
 }
 
@@ -265,8 +269,11 @@ int align_shards(vgicp_ctx* parent, const double* points, const double* covs, co
       vgicp_ctx* sub = g->subs[(size_t)r];
       if (!points) return vgicp_align_resident(sub, guess, params, pose.data() + 16 * (size_t)r, &st[(size_t)r]);
       const size_t lo = g->lo[(size_t)r], cnt = g->hi[(size_t)r] - lo;
-      return vgicp_align(sub, cnt, cnt ? points + 3 * lo : nullptr, cnt ? covs + 9 * lo : nullptr, guess, params,
-                         pose.data() + 16 * (size_t)r, &st[(size_t)r]);
+      sub->upload_whole_hint = g->hi[(size_t)g->n - 1] * kScanPlanes * sizeof(double);   // staged or direct: the caller's whole buffer decides
+      const int rc_sub = vgicp_align(sub, cnt, cnt ? points + 3 * lo : nullptr, cnt ? covs + 9 * lo : nullptr, guess, params,
+                                     pose.data() + 16 * (size_t)r, &st[(size_t)r]);
+      sub->upload_whole_hint = 0;
+      return rc_sub;
     }, &rcs);
     if (points) g->resident = Resident::Sharded;   // whatever the outcome below, the shards are up
     bool need_loop = false;

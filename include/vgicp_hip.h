@@ -313,6 +313,11 @@ typedef struct vgicp_frame_stats {
 } vgicp_frame_stats;
 int vgicp_get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset);
 #define VGICP_OPTION_STAGE_EVENTS 1
+/* value = KiB: scans of up to this size handed to vgicp_align / vgicp_scan_upload are copied through page-locked
+ * memory of the context instead of being registered with the driver in place (default 4096 = 42 k points, at most
+ * 16384; VGICP_UPLOAD_STAGE_LIMIT=bytes in the environment sets the default).  Raise it when scans of that size live
+ * in buffers that are freed per frame: freeing a registered buffer stalls every queue of the process for ~20 ms. */
+#define VGICP_OPTION_UPLOAD_STAGE_KB 2
 int vgicp_set_option(vgicp_ctx* ctx, int option, int value);
 
 /* Copies the resident scan (vgicp_scan_upload / vgicp_scan_prepare) to the host: points n x 3, covs n x 9
