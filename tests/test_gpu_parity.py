@@ -428,9 +428,10 @@ def test_persistent_launch_that_gives_up_falls_back_and_recovers(c1_inputs, monk
 
 
 def test_upload_paths_return_the_same_bits(c1_inputs, monkeypatch):
-    """vgicp_align's upload: the points on a helper thread and stream with the covariances on the caller's (scans of
-    512 KB of points and more), everything on the caller's thread (VGICP_UPLOAD_THREADS=1), and buffers page-locked by
-    the caller (vgicp_host_register) — three ways to the same resident scan, hence the same bits."""
+    """vgicp_align's upload: through page-locked memory of the context (the default up to 4 MB), registered in place
+    with the points on a helper thread and stream and the covariances on the caller's (scans of 512 KB of points and
+    more), everything on the caller's thread (VGICP_UPLOAD_THREADS=1), and buffers page-locked by the caller
+    (vgicp_host_register) — four ways to the same resident scan, hence the same bits."""
     from eskf_lio_amd import capi, synth
     vmap, _, _ = c1_inputs
     pts, covs = synth.make_uniform_scan(40_000, vmap, seed=99)          # 960 KB of points: the helper thread takes them
@@ -441,6 +442,13 @@ def test_upload_paths_return_the_same_bits(c1_inputs, monkeypatch):
         with capi.Context(0) as ctx:
             ctx.map_reset(vmap.voxel_size, vmap.keys.shape[0])
             ctx.map_upsert(vmap.keys, vmap.means, vmap.covs)
+            # a scan of this size (3.84 MB) goes through page-locked memory of the context by default
+            # (VGICP_OPTION_UPLOAD_STAGE_KB, 4 MB): once that way ...
+            p, c = pts.copy(), covs.copy()
+            results.append(ctx.align(p, c, g, 6, 1e-6, 2.0))
+            dp, dc = ctx.scan_download()                                  # (back through the same arena)
+            assert np.array_equal(dp, pts) and np.array_equal(dc, covs)
+            ctx.set_option(capi.OPTION_UPLOAD_STAGE_KB, 0)                # ... then registered in place by the runtime
             for k in range(4):
                 p, c = pts.copy(), covs.copy()                            # fresh host buffers every time
                 results.append(ctx.align(p, c, g, 6, 1e-6, 2.0))
