@@ -6,6 +6,8 @@
 // the thread merge at reference src/Registration.cpp:71-75).
 // No PyTorch, no oracle, no CPU fallback: without a gfx950 device every compute entry point fails
 // with VGICP_ERR_NO_DEVICE / VGICP_ERR_HIP.
+#include <immintrin.h>
+
 #include "vgicp_context.h"
 
 namespace vgicp {
@@ -29,6 +31,33 @@ int settle_insert(vgicp_ctx* ctx);
 // So copies of 512 KB - 16 MB go through a page-locked arena of the context instead (smaller ones the runtime stages
 // itself; larger ones -- a 10 M-voxel map, a 100 k-point scan -- go up directly, once).  VGICP_STAGE_LIMIT=0: never.
 constexpr size_t kArenaBytes = 16u << 20, kArenaMin = 512u << 10;
+
+// The CPU copy into page-locked staging memory sets the pace of a frame's first phase (the device idles until the sweep
+// has arrived).  The destination is read next by the DMA engine, never by this CPU: streaming stores write it without
+// first fetching the lines (no read-for-ownership) and without evicting the caller's data from the caches.
+// VGICP_STAGE_COPY=memcpy keeps libc's copy.
+__attribute__((target("avx2"))) void stage_copy_avx2(char* dst, const char* src, size_t bytes) {
+  size_t i = 0;
+  // dst is 64-byte aligned at every call site (page-locked buffers, offsets in multiples of 256 bytes)
+  for (; i + 128 <= bytes; i += 128) {
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i));
+    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 32));
+    const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 64));
+    const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 96));
+    _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), a);
+    _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 32), b);
+    _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 64), c);
+    _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 96), d);
+  }
+  _mm_sfence();
+  if (i < bytes) std::memcpy(dst + i, src + i, bytes - i);
+}
+void stage_copy(void* dst, const void* src, size_t bytes) {
+  static const bool streaming = __builtin_cpu_supports("avx2") &&
+                                !(std::getenv("VGICP_STAGE_COPY") && std::strcmp(std::getenv("VGICP_STAGE_COPY"), "memcpy") == 0);
+  if (streaming && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0) stage_copy_avx2(static_cast<char*>(dst), static_cast<const char*>(src), bytes);
+  else std::memcpy(dst, src, bytes);
+}
 void arena_reset(vgicp_ctx* ctx) {
   ctx->arena_used = 0;
   ctx->pending_out.clear();
@@ -63,7 +92,7 @@ int user_h2d(vgicp_ctx* ctx, void* dst, const void* src, size_t bytes) {
   const size_t piece = 384u << 10;   // each piece travels while the CPU copies the next
   for (size_t off = 0; off < bytes; off += piece) {
     const size_t len = std::min(piece, bytes - off);
-    std::memcpy(p + off, static_cast<const char*>(src) + off, len);
+    stage_copy(p + off, static_cast<const char*>(src) + off, len);
     VG_HIP(ctx, hipMemcpyAsync(static_cast<char*>(dst) + off, p + off, len, hipMemcpyHostToDevice, ctx->stream));
   }
   return VGICP_OK;
@@ -1953,11 +1982,11 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     const size_t pts_bytes = n * 3 * sizeof(double), piece = 384u << 10;
     for (size_t off = 0; off < pts_bytes; off += piece) {
       const size_t len = std::min(piece, pts_bytes - off);
-      std::memcpy(stage + off, reinterpret_cast<const char*>(points) + off, len);
+      stage_copy(stage + off, reinterpret_cast<const char*>(points) + off, len);
       VG_HIP(ctx, hipMemcpyAsync(reinterpret_cast<char*>(d_pts) + off, stage + off, len, hipMemcpyHostToDevice, ctx->stream));
     }
     if (with_deskew) {
-      std::memcpy(stage + pts_bytes, point_time, n * sizeof(double));
+      stage_copy(stage + pts_bytes, point_time, n * sizeof(double));
       src_time = reinterpret_cast<const double*>(stage + pts_bytes);
     }
   } else {

@@ -215,8 +215,15 @@ int main(int argc, char ** argv)
         localMap2.updateLocalMap(meas2->cloud, Isometry3d::Identity());
       } else {
         preprocessor2.process(states, meas2);
+        const auto e1 = std::chrono::steady_clock::now();
         estimateA2 = icp2.align(*meas2->cloud, localMap2, toIsometry(motion(end - 0.1)));
+        const auto e2 = std::chrono::steady_clock::now();
         localMap2.updateLocalMap(meas2->cloud, estimateA2);
+        if (std::getenv("FRAME_CHAIN_VERBOSE")) {
+          std::printf("  [chain A2] frame %d stages: process %.3f align %.3f update %.3f ms\n", f,
+                      std::chrono::duration<double, std::milli>(e1 - a20).count(), std::chrono::duration<double, std::milli>(e2 - e1).count(),
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e2).count());
+        }
       }
       if (f > 1) {classesEagerMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a20).count();}
 
