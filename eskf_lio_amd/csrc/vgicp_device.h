@@ -213,6 +213,7 @@ size_t map_insert_scratch_bytes(uint32_t n);
 //   [73] = the call's epoch when a point lies beyond the search grid (the scan is refused)
 //   [74] what the deskew reports (leading points moved)   [75] = epoch when a device-wide scan gave up waiting
 //   [76], [77] tile tickets of the two single-launch scans
+//   [78], [79] queries of the neighbour search that start first (sparse neighbourhood) / after them
 constexpr int kCounterWords = 96;
 constexpr int kIndefiniteCounter = 72;
 constexpr int kBeyondGrid = 73;
@@ -220,6 +221,8 @@ constexpr int kDeskewedCounter = 74;
 constexpr int kScanTimeout = 75;
 constexpr int kTicketA = 76;
 constexpr int kTicketB = 77;
+constexpr int kHeavyQueries = 78;
+constexpr int kLightQueries = 79;
 constexpr uint32_t kPrepareMaxStates = 16000;  // IMU states that can own points of ONE sweep in the fused preparation (LDS)
 constexpr uint32_t kMaxScanTiles = 4096;  // x 2 048 points: scans up to 8 M points
 size_t preprocess_scratch_bytes(uint32_t n);

@@ -179,6 +179,8 @@ __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
   if (blockIdx.x == 0 && tid == 0) {
     a.counters[kTicketA] = 0u;
     a.counters[kTicketB] = 0u;
+    a.counters[kHeavyQueries] = 0u;
+    a.counters[kLightQueries] = 0u;
     a.counters[kIndefiniteCounter] = 0u;
     a.counters[kDeskewedCounter] = a.states ? ends_sh[a.states - 1] : 0u;
   }
@@ -569,11 +571,68 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
   return ((unsigned long long)uniform_u32((uint32_t)(v >> 32)) << 32) | uniform_u32((uint32_t)v);
 }
 
+// Which queries start first.  A query in a sparse neighbourhood takes several times the average (it starts high up in
+// the octree and takes many cells); dispatched in Morton order, the ones that happen to come last keep the kernel
+// waiting 40 - 50 us for a handful of waves.  So the search starts them FIRST: a query whose own level-4 cell (1.2 m at
+// 0.3 m voxels) holds fewer than kHeavyBelow points goes to the head of the launch (list scheduling of the measured
+// durations: frame sweep 147 -> 136 us, 100k-point sweep 244 -> 216 us, profiles/r10_knn_leaf.txt), the others follow in
+// (nearly) Morton order -- a workgroup's 1 024 queries stay together, the workgroups' blocks land in the order their atomics do.
+// The order of the queries changes nothing in what the search writes: every query owns its output slot.
+constexpr int kHeavyLevel = 4;
+constexpr uint32_t kHeavyBelow = 4;
+constexpr int kSplitBlock = 1024;  // one atomic per list and workgroup: same-address atomics cost ~20 ns apiece
+__global__ __launch_bounds__(kSplitBlock) void query_split_kernel(const double* __restrict__ spts, uint32_t n, double h,
+                                                                 const CellEntry* __restrict__ table, uint32_t mask,
+                                                                 const uint32_t* __restrict__ queries, uint32_t epoch,
+                                                                 uint32_t* __restrict__ heavy, uint32_t* __restrict__ light,
+                                                                 uint32_t* counters) {
+  __shared__ uint32_t wave_heavy[kSplitBlock / 64], wave_light[kSplitBlock / 64], base_sh[2];
+  const uint32_t m = counters[0];
+  if (counters[kBeyondGrid] == epoch || counters[kScanTimeout] == epoch) return;
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = r < m && r < n;
+  uint32_t qj = 0;
+  bool is_heavy = false;
+  if (valid) {
+    qj = queries[r];
+    const double fine = h / (double)(1 << kFineShift);
+    const double2* rec = reinterpret_cast<const double2*>(spts + 4 * (size_t)qj);
+    const double2 xy = rec[0];
+    const double z = rec[1].x;
+    const unsigned long long mq = morton3(cell_coord(xy.x, fine), cell_coord(xy.y, fine), cell_coord(z, fine));
+    const CellEntry* e = find_cell(table, mask, cell_key(mq >> (3 * kHeavyLevel), kHeavyLevel));
+    is_heavy = e == nullptr || e->end - e->start < kHeavyBelow;
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned long long hm = __ballot(valid && is_heavy), lm = __ballot(valid && !is_heavy);
+  if (lane == 0) {
+    wave_heavy[wave] = (uint32_t)__builtin_popcountll(hm);
+    wave_light[wave] = (uint32_t)__builtin_popcountll(lm);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {   // thread 0: the heavy list, thread 1: the light one -- exclusive prefix over the waves, one atomic
+    uint32_t* per_wave = threadIdx.x == 0 ? wave_heavy : wave_light;
+    uint32_t total = 0;
+    for (int k = 0; k < kSplitBlock / 64; ++k) {
+      const uint32_t c = per_wave[k];
+      per_wave[k] = total;
+      total += c;
+    }
+    base_sh[threadIdx.x] = total ? atomicAdd(&counters[threadIdx.x == 0 ? kHeavyQueries : kLightQueries], total) : 0u;
+  }
+  __syncthreads();
+  if (valid) {
+    if (is_heavy) heavy[base_sh[0] + wave_heavy[wave] + (uint32_t)__builtin_popcountll(hm & below)] = qj;
+    else light[base_sh[1] + wave_light[wave] + (uint32_t)__builtin_popcountll(lm & below)] = qj;
+  }
+}
+
 // Exact k nearest neighbours of one kept point per wave; writes the neighbours' original indices (ascending
 // distance, ties by index) to nbr[slot * kMaxKnn + k] and the point itself to the output.
 __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     const double* __restrict__ spts, const uint32_t* __restrict__ sorted_idx, uint32_t n, double h, int knn,
-    const CellEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ queries,
+    const CellEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ light,
     const uint32_t* __restrict__ slot_of_index, uint32_t epoch, uint32_t* __restrict__ nbr,
     double* __restrict__ out_pts, unsigned long long* __restrict__ out_idx, double* __restrict__ soa, uint64_t soa_stride,
     uint32_t* counters, int debug) {
@@ -590,10 +649,23 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   // so does everyone when the scan was refused (a point beyond the search grid) or a device-wide scan timed out
   const uint32_t m = uniform_u32(counters[0]);
   if (uniform_u32(counters[kBeyondGrid]) == epoch || uniform_u32(counters[kScanTimeout]) == epoch) return;
-  const uint32_t per_xcd = (m + kXcds - 1) / kXcds;
-  const uint32_t slot_in_xcd = (blockIdx.x / kXcds) * (kSearchBlock / 64) + wave;
-  const uint32_t qrank = (blockIdx.x % kXcds) * per_xcd + slot_in_xcd;
-  if (slot_in_xcd >= per_xcd || qrank >= m) return;  // whole waves leave; nothing below synchronises across waves
+  // the queries of sparse neighbourhoods first (query_split_kernel), one per wave in dispatch order; then the others,
+  // every XCD one contiguous eighth of their list
+  const uint32_t n_heavy = uniform_u32(counters[kHeavyQueries]);
+  const uint32_t n_light = m - n_heavy;
+  const uint32_t w = blockIdx.x * (kSearchBlock / 64) + wave;     // this wave in dispatch order
+  const uint32_t head = (n_heavy + kXcds * (kSearchBlock / 64) - 1) / (kXcds * (kSearchBlock / 64)) * (kXcds * (kSearchBlock / 64));
+  uint32_t qj_pick;
+  if (w < head) {
+    if (w >= n_heavy) return;  // whole waves leave; nothing below synchronises across waves
+    qj_pick = heavy[w];
+  } else {
+    const uint32_t per_xcd = (n_light + kXcds - 1) / kXcds;
+    const uint32_t slot_in_xcd = ((blockIdx.x - head / (kSearchBlock / 64)) / kXcds) * (kSearchBlock / 64) + wave;
+    const uint32_t qrank = (blockIdx.x % kXcds) * per_xcd + slot_in_xcd;
+    if (slot_in_xcd >= per_xcd || qrank >= n_light) return;
+    qj_pick = light[qrank];
+  }
   // The pool is this wave's own: its lanes exchange entries through it, and a wave's LDS instructions execute in
   // order. Plain LDS pointers (ds_read / ds_write) with a wave-scope fence wherever one lane reads what another
   // wrote -- NOT volatile: that turns every access into a flat load with its own full wait.
@@ -607,7 +679,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   const double fine = h / (double)(1 << kFineShift);
-  const uint32_t qj = uniform_u32(queries[qrank]);
+  const uint32_t qj = uniform_u32(qj_pick);
   const double qx = uniform_f64(spts[4 * (size_t)qj]), qy = uniform_f64(spts[4 * (size_t)qj + 1]),
                qz = uniform_f64(spts[4 * (size_t)qj + 2]);
   const int K = knn < (int)n ? knn : (int)n;
@@ -1448,13 +1520,18 @@ hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a) {
   // ---- octree cells of all levels, the exact search (one wave per kept point; the grid covers every raw point,
   //      the waves beyond the kept count leave at once), covariances ----
   hipLaunchKernelGGL(cell_build_kernel, dim3(blocks_for(n, 256), kLevels), dim3(256), 0, s, codes_out, n, table, mask);
-  hipLaunchKernelGGL(knn_search_kernel, dim3(8 * blocks_for((n + 7) / 8, kSearchBlock / 64)), dim3(kSearchBlock), 0, s, spts,
-                     idx_out, n, a.voxel_size, a.knn, table, mask, queries, rank_i, a.epoch, nbr, a.out_pts, a.out_idx, a.soa,
+  // the sort is done: its input buffers hold the two query lists now
+  uint32_t* q_heavy = idx_in;
+  uint32_t* q_light = reinterpret_cast<uint32_t*>(codes_in);
+  hipLaunchKernelGGL(query_split_kernel, dim3(blocks_for(n, kSplitBlock)), dim3(kSplitBlock), 0, s, spts, n, a.voxel_size, table, mask, queries,
+                     a.epoch, q_heavy, q_light, a.counters);
+  hipLaunchKernelGGL(knn_search_kernel, dim3(8 * (blocks_for((n + 7) / 8, kSearchBlock / 64) + 2)), dim3(kSearchBlock), 0, s, spts,
+                     idx_out, n, a.voxel_size, a.knn, table, mask, q_heavy, q_light, rank_i, a.epoch, nbr, a.out_pts, a.out_idx, a.soa,
                      a.soa_stride, a.counters, a.debug);
   const int found = a.knn < (int)n ? a.knn : (int)n;
   hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(n, kCovBlock)), dim3(kCovBlock), 0, s, a.pts, nbr, found, a.out_covs, a.soa,
                      a.soa_stride, a.counters, a.epoch);
-  g_kernel_launches += 5;
+  g_kernel_launches += 6;
   return hipGetLastError();
 }
 
