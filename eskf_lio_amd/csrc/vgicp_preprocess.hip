@@ -578,8 +578,14 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 // durations: frame sweep 147 -> 136 us, 100k-point sweep 244 -> 216 us, profiles/r10_knn_leaf.txt), the others follow in
 // (nearly) Morton order -- a workgroup's 1 024 queries stay together, the workgroups' blocks land in the order their atomics do.
 // The order of the queries changes nothing in what the search writes: every query owns its output slot.
-constexpr int kHeavyLevel = 4;
-constexpr uint32_t kHeavyBelow = 4;
+#ifndef VGICP_HEAVY_BELOW
+#define VGICP_HEAVY_BELOW 4
+#endif
+#ifndef VGICP_HEAVY_LEVEL
+#define VGICP_HEAVY_LEVEL 4
+#endif
+constexpr int kHeavyLevel = VGICP_HEAVY_LEVEL;
+constexpr uint32_t kHeavyBelow = VGICP_HEAVY_BELOW;
 constexpr int kSplitBlock = 1024;  // one atomic per list and workgroup: same-address atomics cost ~20 ns apiece
 __global__ __launch_bounds__(kSplitBlock) void query_split_kernel(const double* __restrict__ spts, uint32_t n, double h,
                                                                  const CellEntry* __restrict__ table, uint32_t mask,
