@@ -329,10 +329,21 @@ __device__ __forceinline__ RunMin runmin_wave_scan(RunMin v, uint32_t lane) {
 // voxel's rank, its kept point (lowest original index of the run) and that point's sorted position -- writes the
 // query list (Morton order of the voxels) and the kept flag.  The scan's total is the number of kept points and of
 // octree cells over all levels (counters[0], [1]); no atomics on shared words ("a note on atomics").
+// The launch carries the octree's cell table along: the workgroups behind the scan's tiles are cell_build_kernel's
+// (they need the sorted codes only and fill the CUs the thirty-odd tiles of a sweep leave idle; as a launch of its own
+// the table cost 13 us between the scans and the search).
+__device__ __forceinline__ void cell_build_body(const unsigned long long* __restrict__ codes, uint32_t n, CellEntry* table,
+                                                uint32_t mask, uint32_t block_x, int level);
 __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
     const double* __restrict__ pts, const unsigned long long* __restrict__ codes, const uint32_t* __restrict__ idx,
     uint32_t n, double* __restrict__ sorted_pts, uint32_t* __restrict__ queries, uint32_t* __restrict__ keep_by_index,
-    uint32_t* counters, TileSlot* tiles, uint32_t epoch) {
+    uint32_t* counters, TileSlot* tiles, uint32_t epoch, uint32_t scan_tiles, CellEntry* table, uint32_t mask,
+    uint32_t cell_blocks_x) {
+  if (blockIdx.x >= scan_tiles) {  // (whole workgroups; before anything synchronises)
+    const uint32_t v = blockIdx.x - scan_tiles;
+    cell_build_body(codes, n, table, mask, v % cell_blocks_x, (int)(v / cell_blocks_x));
+    return;
+  }
   __shared__ uint32_t tile_sh;
   __shared__ RunMin wave_tot[kScanThreads / 64];
   __shared__ RunMin prefix_sh;
@@ -528,12 +539,11 @@ __device__ __forceinline__ CellEntry* claim_cell(CellEntry* table, uint32_t mask
     slot = (slot + 1) & mask;
   }
 }
-__global__ void cell_build_kernel(const unsigned long long* __restrict__ codes, uint32_t n, CellEntry* table,
-                                  uint32_t mask) {
-  // one thread per (point, level) -- blockIdx.y is the level: a point on a coarse boundary opens and closes a
-  // cell on every level, and one thread doing those two dozen atomic round trips in sequence set the pace
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int l = (int)blockIdx.y;
+__device__ __forceinline__ void cell_build_body(const unsigned long long* __restrict__ codes, uint32_t n, CellEntry* table,
+                                                uint32_t mask, uint32_t block_x, int l) {
+  // one thread per (point, level): a point on a coarse boundary opens and closes a cell on every level, and one
+  // thread doing those two dozen atomic round trips in sequence set the pace
+  const uint32_t j = block_x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned long long c = codes[j] >> (3 * l);
   const bool opens = j == 0 || c != (codes[j - 1] >> (3 * l));
@@ -1519,13 +1529,13 @@ hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a) {
   g_kernel_launches += merge_sort_launches(n);
 
   // ---- runs, kept points, query list (one launch); output slots in scan order (one launch) ----
-  hipLaunchKernelGGL(run_scan_kernel, dim3(blocks_for(n, kScanTile)), dim3(kScanThreads), 0, s, a.pts, codes_out, idx_out, n,
-                     spts, queries, keep_i, a.counters, tiles_a, a.epoch);
+  const uint32_t scan_tiles = blocks_for(n, kScanTile), cell_blocks_x = blocks_for(n, kScanThreads);
+  hipLaunchKernelGGL(run_scan_kernel, dim3(scan_tiles + cell_blocks_x * kLevels), dim3(kScanThreads), 0, s, a.pts, codes_out,
+                     idx_out, n, spts, queries, keep_i, a.counters, tiles_a, a.epoch, scan_tiles, table, mask, cell_blocks_x);
   hipLaunchKernelGGL(keep_scan_kernel, dim3(blocks_for(n, kScanTile)), dim3(kScanThreads), 0, s, keep_i, n, rank_i,
                      a.counters, tiles_b, a.epoch);
   // ---- octree cells of all levels, the exact search (one wave per kept point; the grid covers every raw point,
   //      the waves beyond the kept count leave at once), covariances ----
-  hipLaunchKernelGGL(cell_build_kernel, dim3(blocks_for(n, 256), kLevels), dim3(256), 0, s, codes_out, n, table, mask);
   // the sort is done: its input buffers hold the two query lists now
   uint32_t* q_heavy = idx_in;
   uint32_t* q_light = reinterpret_cast<uint32_t*>(codes_in);
@@ -1537,7 +1547,7 @@ hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a) {
   const int found = a.knn < (int)n ? a.knn : (int)n;
   hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(n, kCovBlock)), dim3(kCovBlock), 0, s, a.pts, nbr, found, a.out_covs, a.soa,
                      a.soa_stride, a.counters, a.epoch);
-  g_kernel_launches += 6;
+  g_kernel_launches += 5;
   return hipGetLastError();
 }
 
