@@ -15,7 +15,9 @@
 //      order), and in its total the number of kept points and of octree cells; a prefix sum over scan
 //      order gives every kept point its output slot (ascending index)
 //   3. a hash table of (level, cell) -> [start, end) over the sorted order is built for all levels:
-//      an octree whose nodes are contiguous runs of the sorted points
+//      an octree whose nodes are contiguous runs of the sorted points (by the workgroups behind the scan's tiles
+//      in the same launch); query_split_kernel then puts the queries of sparse neighbourhoods -- the expensive
+//      ones -- at the head of the search's launch
 //   4. ONE WAVE per kept point (control flow is uniform, lanes share the work): the k-list starts
 //      full with sorted-order neighbours of the query; the finest own cell with >= k points ("home")
 //      is measured first, and the k-th distance after it picks the level whose 27-cell block covers
@@ -329,7 +331,7 @@ __device__ __forceinline__ RunMin runmin_wave_scan(RunMin v, uint32_t lane) {
 // voxel's rank, its kept point (lowest original index of the run) and that point's sorted position -- writes the
 // query list (Morton order of the voxels) and the kept flag.  The scan's total is the number of kept points and of
 // octree cells over all levels (counters[0], [1]); no atomics on shared words ("a note on atomics").
-// The launch carries the octree's cell table along: the workgroups behind the scan's tiles are cell_build_kernel's
+// The launch carries the octree's cell table along: the workgroups behind the scan's tiles run cell_build_body
 // (they need the sorted codes only and fill the CUs the thirty-odd tiles of a sweep leave idle; as a launch of its own
 // the table cost 13 us between the scans and the search).
 __device__ __forceinline__ void cell_build_body(const unsigned long long* __restrict__ codes, uint32_t n, CellEntry* table,
