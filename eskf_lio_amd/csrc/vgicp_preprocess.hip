@@ -1399,9 +1399,21 @@ __host__ inline uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < 
 // much as the work it does, so the sort is rocPRIM's stable merge sort with 2 048-item blocks (512 threads x 4):
 // 100 000 points are 49 sorted blocks and six merge passes; hipCUB's radix-sort front end picks the same merge sort
 // with 1 024-item blocks and seven passes at this size (-22 us; 1 024 / 4 096 / 8 192-item blocks: -17 / -10 / +55 us).
+// Which block size rocPRIM's merge sort runs with.  Its cost at these sizes is the number of launches, and that steps at
+// powers of two of the block count (rocprofv3, sort launches of one preparation, us; profiles/r10_knn_leaf.txt):
+//   points           28k   33k   60k   65k   66k  100k  130k  150k  250k  300k
+//   2 048 per block  35.5  50.8  50.9  51.3  48.7  50.1  52.7  70.8 108.1 115.8
+//   4 096 per block  43.8  42.3  43.7  43.1  59.1  60.2  62.0  60.5  93.9 119.3
+// so sweeps of 32 769 - 65 536 and of 131 073 - 262 144 points take the larger blocks.
+inline bool sort_in_large_blocks(uint32_t n) { return (n > 32768u && n <= 65536u) || (n > 131072u && n <= 262144u); }
 inline hipError_t sort_codes(void* temp, size_t& temp_bytes, const unsigned long long* codes_in,
                              unsigned long long* codes_out, const uint32_t* idx_in, uint32_t* idx_out, uint32_t n,
                              hipStream_t s) {
+  if (sort_in_large_blocks(n)) {
+    using Large = rocprim::merge_sort_config<512, 1024, 4>;
+    return rocprim::merge_sort<Large>(temp, temp_bytes, codes_in, codes_out, idx_in, idx_out, (size_t)n,
+                                      rocprim::less<unsigned long long>(), s);
+  }
   using Config = rocprim::merge_sort_config<512, 512, 4>;
   return rocprim::merge_sort<Config>(temp, temp_bytes, codes_in, codes_out, idx_in, idx_out, (size_t)n,
                                      rocprim::less<unsigned long long>(), s);
@@ -1451,11 +1463,11 @@ size_t preprocess_cell_bytes(uint64_t entries) { return entries * sizeof(CellEnt
 size_t preprocess_tile_bytes() { return (size_t)kMaxScanTiles * (sizeof(TileSlot) + sizeof(unsigned long long)); }
 
 namespace {
-// launches of rocPRIM's merge sort (merge_sort_config<512, 512, 4>: 2 048-item blocks): one block sort and one
+// launches of rocPRIM's merge sort (2 048- or 4 096-item blocks, sort_in_large_blocks): one block sort and one
 // merge launch per doubling of the sorted run length
 uint32_t merge_sort_launches(uint32_t n) {
   uint32_t launches = 1;
-  for (uint64_t run = 2048; run < n; run <<= 1) ++launches;
+  for (uint64_t run = sort_in_large_blocks(n) ? 4096 : 2048; run < n; run <<= 1) ++launches;
   return launches;
 }
 }  // namespace
