@@ -1312,7 +1312,8 @@ __global__ __launch_bounds__(kBoundsBlock) void deskew_bounds_kernel(const doubl
 constexpr uint32_t kDeskewParts = 512;      // at most this many blocks share the scan (one load per thread: the loop is a chain)
 constexpr uint32_t kProloguePartsMax = 64;  // ... and this many when every workgroup of the prologue merges them for itself
 constexpr uint32_t kDeskewMaxStates = 4096; // LDS: 12 bytes per state; longer queues take the walk
-__global__ __launch_bounds__(256) void deskew_first_hit_kernel(const double* __restrict__ point_time, uint32_t n,
+constexpr int kFirstHitBlock = 1024;   // a block covers its ~1 000 points in ONE pass: the loop over passes is a chain of trips to memory (256 threads: 9.6 us per 60k-point sweep)
+__global__ __launch_bounds__(kFirstHitBlock) void deskew_first_hit_kernel(const double* __restrict__ point_time, uint32_t n,
                                                                const double* __restrict__ state_time, uint32_t states,
                                                                uint32_t per_block, uint32_t* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char deskew_lds[];
@@ -1509,7 +1510,7 @@ hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a) {
       if (parts > kProloguePartsMax) parts = kProloguePartsMax;
       const uint32_t per_block = blocks_for(n, parts);
       uint32_t* part = a.ends + a.states;
-      hipLaunchKernelGGL(deskew_first_hit_kernel, dim3(parts), dim3(256), (size_t)a.states * 12, s, a.point_time, n,
+      hipLaunchKernelGGL(deskew_first_hit_kernel, dim3(parts), dim3(kFirstHitBlock), (size_t)a.states * 12, s, a.point_time, n,
                          a.state_time, a.states, per_block, part);
       ++g_kernel_launches;
       pa.parts = parts;
@@ -1575,7 +1576,7 @@ hipError_t launch_deskew(hipStream_t s, double* pts, uint32_t n, const double* p
     if (parts > kDeskewParts) parts = kDeskewParts;
     const uint32_t per_block = blocks_for(n, parts);
     uint32_t* part = ends + states;
-    hipLaunchKernelGGL(deskew_first_hit_kernel, dim3(parts), dim3(256), (size_t)states * 12, s, point_time, n,
+    hipLaunchKernelGGL(deskew_first_hit_kernel, dim3(parts), dim3(kFirstHitBlock), (size_t)states * 12, s, point_time, n,
                        state_time, states, per_block, part);
     hipLaunchKernelGGL(deskew_merge_kernel, dim3(1), dim3(1024), (size_t)states * 4, s, part, parts, states, ends);
     g_kernel_launches += 2;
