@@ -264,6 +264,7 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
             return wall / frames * 1e3, poses, resident, len(lmap)
         dropin("deferred", True)                                       # warm-up
         ms_def, poses_def, res_def, vox_def = dropin("deferred", True)
+        dropin("eager", False)                                         # warm-up (first-use allocations: page-locked arena, table growth)
         ms_eag, poses_eag, res_eag, _ = dropin("eager", False)
         out["dropin_ms_per_frame"] = ms_def
         out["dropin_eager_ms_per_frame"] = ms_eag
