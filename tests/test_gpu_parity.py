@@ -1347,6 +1347,17 @@ def test_preprocess_full_size_sweep(gpu_ctx, oracle):
     _assert_preprocess_parity(gpu_ctx.preprocess(pts, 0.3, 30), oracle.preprocess(pts, 0.3, 30), pts)
 
 
+@pytest.mark.parametrize("n", [32_768, 32_769, 65_537])
+def test_preprocess_either_side_of_the_sort_block_switch(gpu_ctx, oracle, n):
+    """The preparation's one sort runs in 2 048-item blocks up to 32 768 points and from 65 537 on, in 4 096-item blocks
+    in between (vgicp_preprocess.hip, sort_in_large_blocks); a stable sort either way, so the prepared scan is the
+    oracle's bits on both sides of each switch.  (Also sizes at which the queries of sparse neighbourhoods, which start
+    first, and the others split into uneven lists.)"""
+    from eskf_lio_amd import synth
+    pts = synth.make_lidar_scan(n, seed=n % 1000, extent=30.0)
+    _assert_preprocess_parity(gpu_ctx.preprocess(pts, 0.3, 30), oracle.preprocess(pts, 0.3, 30), pts)
+
+
 def test_preprocess_other_voxel_sizes_and_dense_cells(gpu_ctx, oracle):
     from eskf_lio_amd import synth
     pts = synth.make_lidar_scan(15_000, seed=5, extent=10.0)       # many points per voxel
