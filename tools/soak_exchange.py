@@ -14,6 +14,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--load" in sys.argv:
+    import torch  # noqa: E402,F401  BEFORE libvgicp_hip.so is loaded: one HIP runtime per process
 from eskf_lio_amd import capi, synth  # noqa: E402
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 60.0
