@@ -27,9 +27,15 @@ would hold, src/main.cpp:68-70) — same sharding, same mailboxes (wired by plai
 the data path; `config.sharding.wiring` says so.  Under the launcher, rank 0 measures that in-process context too, after
 the per-rank contexts are closed, and reports it as `in_process` beside the launcher's own figure.
 
-The upload is measured honestly: the reference deep-copies a FRESH cloud every frame (src/Registration.cpp:11), so
-the timed loop rotates over freshly allocated host buffers the HIP runtime has never seen (total far above the host's
-last-level cache); `upload` reports the first pass (never-seen pages), later passes and the old same-buffer figure.
+The upload is measured the way the reference's caller behaves: every timed step gets a FRESH cloud (host memory the
+HIP runtime has never seen, src/Registration.cpp:11 deep-copies a fresh cloud per frame) and that cloud is FREED INSIDE
+THE TIMED LOOP right after the align, as src/Odometry.cpp:84-87 lets it die with the frame — with free(); a second
+loop beside it (`config.upload.unmapped_every_step`) munmaps every cloud instead, so that the pages go back to the
+kernel at every step whatever malloc's thresholds are.  (A cloud the runtime had registered would
+stall every queue of the process for ~20 ms at that free: vgicp_align therefore stages the scan with its own copy
+threads and lets one kernel read the staging memory; `config.upload` reports the step-time distribution, the rate
+reached against the link, and beside it one re-used buffer, a buffer the caller page-locked, and the runtime's
+in-place path whose buffers must never be freed.)
 
 `roofline` is measured live over the timed region: every align brackets its iteration launch(es) with a HIP
 event pair on the module's own stream (stats.device_seconds); `achieved` = ALGORITHMIC bytes per launch
@@ -73,7 +79,7 @@ if ROOT not in sys.path:
 
 from eskf_lio_amd import capi, synth  # noqa: E402
 
-_KEEP_ALIVE = []   # host buffers the HIP runtime has registered stay mapped until the process ends
+_KEEP_ALIVE = []   # host buffers the HIP runtime has REGISTERED (the in-place comparison legs only) stay mapped until the process ends
 from eskf_lio_amd.distributed import gather_bytes, shard_bounds, share_unique_id  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s achievable)
@@ -526,19 +532,96 @@ def main():
         gc.enable()
         return host_max(elapsed), dev_s, res, per_step
 
-    # ---- the upload, honestly: every timed step takes its scan from a host buffer the HIP runtime has never seen ----
-    # (the reference deep-copies a FRESH cloud per frame, src/Registration.cpp:11). As many distinct buffers as steps,
-    # up to 6 GB of host memory (500 steps x 9.6 MB = 4.8 GB at C2); beyond that the rotation wraps and later passes are
-    # cache-cold but not first-touch.
+    # ---- the upload, as the reference's caller lives it: a fresh cloud per step, freed inside the timed loop ----
+    # (src/Registration.cpp:11 deep-copies a FRESH cloud per frame; src/Odometry.cpp:84-87 lets it die with the frame).
+    # As many distinct clouds as steps (500 steps x 9.6 MB = 4.8 GB of host memory at C2), each in an
+    # anonymous mapping of its own that is unmapped right after its align: the pages go back to the kernel THEN,
+    # whatever malloc's thresholds are.
+    import mmap
     scan_bytes = 96 * n_local
-    n_cold = int(max(1, min(args.steps, 6e9 // max(1, scan_bytes))))
-    if args.resident:
-        n_cold = 0
-    cold = [(my_pts.copy(), my_covs.copy()) for _ in range(n_cold)]   # written once (by the copy), never read since
 
-    def step_cold(k):
-        p, c = cold[k % n_cold]
-        return align_host(p, c)
+    class FreshCloud:
+        """One scan in host memory of its own, written once and never read since.  how = "free": numpy arrays from
+        malloc, released with free() (what `delete` of the reference's cloud does).
+        how = "munmap": an anonymous mapping per array, unmapped by release() — the pages go back to the kernel at
+        that very moment, whatever malloc's thresholds are."""
+        def __init__(self, how):
+            self.how = how
+            if how == "munmap":
+                self.maps = [mmap.mmap(-1, max(1, a.nbytes), flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS) for a in (my_pts, my_covs)]
+                self.arrays = [np.frombuffer(m, dtype=np.float64, count=a.size).reshape(a.shape)
+                               for m, a in zip(self.maps, (my_pts, my_covs))]
+                for dst, src in zip(self.arrays, (my_pts, my_covs)):
+                    dst[...] = src
+            else:
+                self.maps = []
+                self.arrays = [my_pts.copy(), my_covs.copy()]
+
+        def release(self):
+            self.arrays = None
+            for m in self.maps:
+                m.close()
+            self.maps = []
+
+    if not args.resident and args.steps * scan_bytes > 32e9:
+        raise SystemExit(f"--steps {args.steps}: {args.steps * scan_bytes / 1e9:.0f} GB of fresh clouds; use at most {int(32e9 // scan_bytes)} steps")
+
+    # free() hands a cloud back to the ALLOCATOR.  The clouds of all steps exist before the loop starts (their production is
+    # not part of the path), next to each other on the heap: left alone, glibc merges them as they are freed and gives
+    # the whole block (4.8 GB at 500 steps) back to the kernel inside the free() of the last one -- a quarter of a second
+    # that no caller with one cloud alive at a time ever sees.  So glibc is told to keep what is freed
+    # (M_TRIM_THRESHOLD); the loop `unmapped_every_step` beside it is the one in which every cloud's pages DO go back
+    # to the kernel, at every step.
+    try:
+        import ctypes
+        _libc = ctypes.CDLL("libc.so.6")
+        mallopt_ok = bool(_libc.mallopt(-1, -1)) and bool(_libc.mallopt(-3, 32 << 20))  # M_TRIM_THRESHOLD = never, M_MMAP_THRESHOLD = 32 MB
+    except Exception:  # noqa: BLE001
+        mallopt_ok = False
+
+    def fresh_loop(how, steps, keep=False):
+        """steps aligns, each from its own fresh cloud, which is freed right after its align INSIDE the timed loop (unless
+        keep) -> timed(...) + (seconds inside vgicp_align per step, seconds inside the free per step)"""
+        clouds = [FreshCloud(how) for _ in range(steps)]
+        align_s, free_s, up_s, dev_each = np.zeros(steps), np.zeros(steps), np.zeros(steps), np.zeros(steps)
+
+        def step(k):
+            cl = clouds[k]
+            ns_a = ctx.counter(3)
+            t_a = time.perf_counter()
+            r = align_host(cl.arrays[0], cl.arrays[1])
+            t_b = time.perf_counter()
+            if not keep:
+                cl.release()
+                free_s[k] = time.perf_counter() - t_b
+            align_s[k] = t_b - t_a
+            up_s[k] = (ctx.counter(3) - ns_a) * 1e-9
+            dev_each[k] = r.device_seconds
+            return r
+        out = timed(step, steps)
+        if keep:
+            _KEEP_ALIVE.append(clouds)
+        worst = [{"step": int(k), "align_ms": float(align_s[k] * 1e3), "of_which_upload_host_ms": float(up_s[k] * 1e3),
+                  "persistent_launch_ms": float(dev_each[k] * 1e3), "free_ms": float(free_s[k] * 1e3)}
+                 for k in np.argsort(align_s)[::-1][:5]]
+        return out + (align_s, free_s, worst)
+
+    def loop_report(el, per_step, align_s, free_s, worst, steps):
+        return {
+            "slowest_aligns": worst,
+            "steps": int(steps),
+            "ms_per_step": el / steps * 1e3,
+            "step_ms_p50": float(np.percentile(per_step, 50) * 1e3),
+            "step_ms_p99": float(np.percentile(per_step, 99) * 1e3),
+            "step_ms_max": float(per_step.max() * 1e3),
+            "steps_above_1ms": int((per_step > 1e-3).sum()),
+            "align_ms_mean": float(align_s.mean() * 1e3),
+            "align_ms_p99": float(np.percentile(align_s, 99) * 1e3),
+            "align_ms_max": float(align_s.max() * 1e3),
+            "aligns_above_1ms": int((align_s > 1e-3).sum()),
+            "free_ms_mean": float(free_s.mean() * 1e3),
+            "free_ms_max": float(free_s.max() * 1e3),
+        }
 
     if args.resident:
         ctx.scan_upload(my_pts, my_covs)
@@ -550,62 +633,68 @@ def main():
     else:
         for _ in range(args.warmup):                               # warm-up on a buffer of its own
             res = align_host(my_pts, my_covs)
-        ns0 = ctx.counter(3)
-        elapsed, dev_s, res, per_step = timed(step_cold, args.steps)   # ---- the timed region ----
+        ns0, slow0 = ctx.counter(3), ctx.counter(capi.COUNTER_UPLOAD_SLOW)
+        elapsed, dev_s, res, per_step, align_s, free_s, worst = fresh_loop("free", args.steps)      # ---- the timed region ----
         ns_cold = ctx.counter(3) - ns0
-        first = per_step[:n_cold]
-        # the same buffers a second time (the runtime has seen the pages; the CPU caches have long lost them)
-        again = min(n_cold, 100)
-        ns0 = ctx.counter(3)
-        el_again, _, _, _ = timed(step_cold, again)
-        ns_again = ctx.counter(3) - ns0
+        upload_slow = ctx.counter(capi.COUNTER_UPLOAD_SLOW) - slow0
+        side = min(args.steps, 100)
+        # the same, every cloud in a mapping of its own that is UNMAPPED right after its align: the pages go back to the
+        # kernel at every step (the operating system charges ~0.8 ms per 9.6 MB for that, tools/probe_munmap.py) -- the
+        # loop in which a registered buffer would stall every queue of the process for ~20 ms per step
+        el_unmap, _, _, per_unmap, align_unmap, free_unmap, worst_unmap = fresh_loop("munmap", side)
         # one buffer over and over (what rounds 1-2 timed)
-        reused = min(args.steps, 100)
         ns0 = ctx.counter(3)
-        el_reused, _, _, _ = timed(lambda k: align_host(my_pts, my_covs), reused)
+        el_reused, _, _, _ = timed(lambda k: align_host(my_pts, my_covs), side)
         ns_reused = ctx.counter(3) - ns0
-        # ... and the same buffer page-locked once by the caller (vgicp_host_register: a pool of clouds)
+        # ... the same buffer page-locked once by the caller (vgicp_host_register: a pool of clouds): read in place
         ctx.host_register(my_pts)
         ctx.host_register(my_covs)
         for _ in range(3):
             align_host(my_pts, my_covs)
-        el_reg, _, _, _ = timed(lambda k: align_host(my_pts, my_covs), reused)
+        el_reg, _, _, _ = timed(lambda k: align_host(my_pts, my_covs), side)
         ctx.host_unregister(my_pts)
         ctx.host_unregister(my_covs)
-        # ... and with the scan copied through page-locked memory of the context instead of being registered in place:
-        # what a caller that FREES its 9.6 MB clouds per frame should ask for (a freed registered buffer stalls every
-        # queue of the process for ~20 ms; scans up to 4 MB take this path by default)
-        ctx.set_option(capi.OPTION_UPLOAD_STAGE_KB, 16384)
-        for _ in range(3):
-            step_cold(0)
-        el_staged, _, _, _ = timed(step_cold, again)
-        ctx.set_option(capi.OPTION_UPLOAD_STAGE_KB, 4096)
+        # ... and the runtime's in-place path (VGICP_OPTION_UPLOAD_STAGE_KB = 0: the runtime registers the caller's pages):
+        # last of the upload legs, its clouds are never freed (freeing one would stall every queue for ~20 ms)
+        ctx.set_option(capi.OPTION_UPLOAD_STAGE_KB, 0)
+        el_inplace, _, _, _, _, _, _ = fresh_loop("free", side, keep=True)
+        ctx.set_option(capi.OPTION_UPLOAD_STAGE_KB, 512 << 10)
+        upload_ms = ns_cold / 1e6 / args.steps
         upload_report = {
             "bytes_per_step": scan_bytes,
-            "buffers": n_cold,
-            "buffers_used_by_the_timed_steps": "every timed step read a freshly allocated, never-uploaded pageable host "
-                                               f"buffer ({n_cold} distinct buffers, {n_cold * scan_bytes / 1e6:.0f} MB in all"
-                                               + (")" if n_cold >= args.steps else f"; the rotation wrapped after {n_cold} steps)"),
-            "ms_per_step_cold": elapsed / args.steps * 1e3,
-            "ms_per_step_first_touch": float(first.mean() * 1e3),
-            "ms_per_step_second_pass": el_again / again * 1e3,
-            "ms_per_step_reused": el_reused / reused * 1e3,
-            "ms_per_step_registered": el_reg / reused * 1e3,
-            "ms_per_step_staged": el_staged / again * 1e3,
-            "host_threads": "2 (points on a helper thread and stream, covariances on the caller's)"
-                            if os.environ.get("VGICP_UPLOAD_THREADS", "2") != "1" else "1",
-            "upload_ms_cold": ns_cold / 1e6 / args.steps,
-            "upload_ms_second_pass": ns_again / 1e6 / again,
-            "upload_ms_reused": ns_reused / 1e6 / reused,
-            "what": "host side of the two hipMemcpyAsync from the caller's pageable buffers + the enqueue of the pack "
-                    "kernel, in front of the persistent launch; `value` is the cold figure.  The runtime REGISTERS such a "
-                    "buffer with the driver; a caller that frees it per frame pays ~20 ms when it is unmapped "
-                    "(profiles/r10_sync_stall.txt) and should take the staged path (`ms_per_step_staged`: "
-                    "VGICP_OPTION_UPLOAD_STAGE_KB / VGICP_UPLOAD_STAGE_LIMIT; the default for scans up to 4 MB)",
+            "clouds": f"{args.steps} distinct fresh clouds, one per timed step ({args.steps * scan_bytes / 1e6:.0f} MB in all): numpy "
+                      "arrays from malloc, written once, handed to vgicp_align, then FREED (free(), as `delete` of the "
+                      "reference's cloud does) inside the timed loop",
+            "how": f"staged: {os.environ.get('VGICP_UPLOAD_THREADS', '2')} host thread(s) (the caller's included, no HIP calls) copy "
+                   "the scan into page-locked memory of the context in units of 2048 points; ONE kernel launch reads the "
+                   "units over PCIe as they are published and packs them (pack_arena_kernel); the runtime never "
+                   "registers the caller's pages",
+            **loop_report(elapsed, per_step, align_s, free_s, worst, args.steps),
+            "allocator": "glibc keeps freed memory (mallopt: M_TRIM_THRESHOLD = never, M_MMAP_THRESHOLD = 32 MB)" if mallopt_ok else "glibc defaults (mallopt failed)",
+            "upload_ms": upload_ms,
+            "upload_GBps": scan_bytes / upload_ms / 1e6 if upload_ms > 0 else None,
+            "fraction_of_kernel_read_rate_54GBps": scan_bytes / upload_ms / 1e6 / 54.0 if upload_ms > 0 else None,
+            "fraction_of_pcie5_x16_63GBps": scan_bytes / upload_ms / 1e6 / 63.0 if upload_ms > 0 else None,
+            "link_rate_source": "54 GB/s: a kernel reading page-locked host memory on this node type, "
+                                "tools/micro/stage_crew_probe.hip (profiles/r12_stage_crew_probe.txt); 63 GB/s: PCIe 5.0 x16 payload",
+            "uploads_repeated_because_the_copy_threads_were_held_up": int(upload_slow),
+            "unmapped_every_step": {
+                **loop_report(el_unmap, per_unmap, align_unmap, free_unmap, worst_unmap, side),
+                "what": "the same loop with every cloud in an anonymous mapping of its own, munmap'ed right after its "
+                        "align inside the timed loop: the pages return to the KERNEL at every step.  free_ms is what the "
+                        "operating system charges for that (tools/probe_munmap.py: the same without any GPU work); "
+                        "align_ms_max / aligns_above_1ms show that no queue stalls (a buffer the runtime had registered "
+                        "costs ~20 ms at this point, profiles/r10_sync_stall.txt)"},
+            "ms_per_step_reused": el_reused / side * 1e3,
+            "upload_ms_reused": ns_reused / 1e6 / side,
+            "ms_per_step_registered": el_reg / side * 1e3,
+            "ms_per_step_in_place": el_inplace / side * 1e3,
+            "what": "upload_ms: host side of the staged upload (the copy threads' time; the pack launch runs beside "
+                    "them and ends a few microseconds after the last unit) in front of the persistent launch; `value` is "
+                    "ms_per_step.  ms_per_step_in_place: the runtime's pin-on-the-fly path (VGICP_OPTION_UPLOAD_STAGE_KB "
+                    "= 0) from fresh clouds that are never freed — freeing one takes every queue of the "
+                    "process off the device for ~20 ms (profiles/r10_sync_stall.txt), which is why it is not the default",
         }
-        # NOT freed here: unmapping a buffer the HIP runtime has registered takes every queue of the process off the device
-        # for ~20 ms (profiles/r10_sync_stall.txt) and would land in the legs that follow; they go with the process
-        _KEEP_ALIVE.append(cold)
         for _ in range(2):
             step_resident()
         elapsed_res, _, _, _ = timed(lambda k: step_resident(), args.steps)
@@ -681,7 +770,8 @@ def main():
             workload += "PROFILING MODE --resident: scan already in HBM (not the headline configuration)"
         elif world == 1 and not inproc:
             workload += ("each step = vgicp_align with the scan in host buffers: upload of the 96*N-byte scan + pack + "
-                         "20 rounds in one persistent launch; map resident")
+                         "20 rounds in one persistent launch; map resident; every step's cloud is fresh host memory and is "
+                         "freed inside the timed loop right after its align")
         else:
             workload += (f"ONE scan point-sharded over {eff_world} ranks (contiguous shards, replicated map); each step = "
                          f"every rank uploads its shard from host buffers and runs the sharded loop, one exchange of the "

@@ -59,7 +59,8 @@ class FrameStats(C.Structure):
 
 
 OPTION_STAGE_EVENTS = 1
-OPTION_UPLOAD_STAGE_KB = 2   # scans up to this many KiB go through page-locked memory of the context (vgicp_hip.h)
+OPTION_UPLOAD_STAGE_KB = 2   # scans up to this many KiB are staged through page-locked memory of the context; 0 = in place (vgicp_hip.h)
+COUNTER_UPLOAD_SLOW = 6
 
 
 class Stats(C.Structure):

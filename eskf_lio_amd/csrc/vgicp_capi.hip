@@ -328,11 +328,14 @@ bool wants_dense(const vgicp_ctx* ctx, uint32_t n_upper) {
 }
 int ensure_dense(vgicp_ctx* ctx) {
   if (ctx->dense_version == ctx->map_version && ctx->d_dense) return VGICP_OK;
-  if (ctx->voxels > ctx->dense_capacity) {
+  // ctx->voxels is stale while a deferred insertion (vgicp_map_insert_resident_async) is pending: the records it adds are
+  // in the table when the copy is made, before the host has read their count (insert_pending_upper bounds it)
+  const uint64_t may_hold = ctx->voxels + ctx->insert_pending_upper;
+  if (may_hold > ctx->dense_capacity) {
     if (ctx->d_dense) VG_HIP(ctx, hipFree(ctx->d_dense));
     ctx->d_dense = nullptr;
     ctx->dense_capacity = 0;
-    const uint64_t cap = ctx->voxels + ctx->voxels / 8;
+    const uint64_t cap = may_hold + may_hold / 8;
     VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_dense), cap * sizeof(VoxelRecord)));
     ctx->dense_capacity = cap;
   }
@@ -344,7 +347,7 @@ int ensure_dense(vgicp_ctx* ctx) {
     VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_dense_counts), (size_t)(nb + 1) * sizeof(uint32_t)));
     ctx->dense_counts_capacity = nb + 1;
   }
-  VG_HIP(ctx, launch_table_dense(ctx->stream, ctx->table, ctx->slots, ctx->d_dense, ctx->d_dense_counts));
+  VG_HIP(ctx, launch_table_dense(ctx->stream, ctx->table, ctx->slots, ctx->d_dense, ctx->dense_capacity, ctx->d_dense_counts));
   ctx->dense_version = ctx->map_version;
   return VGICP_OK;
 }
@@ -731,8 +734,8 @@ int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgi
   if (const char* ds = std::getenv("VGICP_DENSE_SLOTS")) ctx->dense_slots_threshold = std::strtoull(ds, nullptr, 10);
   if (const char* pm = std::getenv("VGICP_PREFETCH_MARGIN")) ctx->prefetch_margin = std::atof(pm);
   if (const char* sl = std::getenv("VGICP_SPIN_LIMIT")) ctx->persist_spin_limit = (uint32_t)std::strtoul(sl, nullptr, 10);
-  if (const char* ut = std::getenv("VGICP_UPLOAD_THREADS")) ctx->uploader_enabled = std::atoi(ut) != 1;
-  if (const char* ul = std::getenv("VGICP_UPLOAD_STAGE_LIMIT")) ctx->upload_stage_limit = std::min<size_t>((size_t)std::atoll(ul), 16u << 20);
+  if (const char* ut = std::getenv("VGICP_UPLOAD_THREADS")) ctx->upload_threads = std::max(1, std::min(16, std::atoi(ut)));
+  if (const char* ul = std::getenv("VGICP_UPLOAD_STAGE_LIMIT")) ctx->upload_stage_limit = (size_t)std::max(0ll, std::atoll(ul));
   {
     // the in-kernel exchange needs every workgroup resident: one 512-thread workgroup with the LARGEST dynamic LDS
     // a launch plan asks for (memo + parked points of a scan bigger than the grid: 150 KB) must fit a CU — checked
@@ -777,18 +780,13 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   if (ctx->multi) return vgicp_multi_api::destroy(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->uploader) {
-    {
-      std::lock_guard<std::mutex> lk(ctx->uploader->m);
-      ctx->uploader->quit = true;
-      ctx->uploader->cv.notify_all();
-    }
-    if (ctx->uploader->th.joinable()) ctx->uploader->th.join();
-    if (ctx->uploader->stream) { (void)hipStreamSynchronize(ctx->uploader->stream); (void)hipStreamDestroy(ctx->uploader->stream); }
-    if (ctx->uploader->ev) (void)hipEventDestroy(ctx->uploader->ev);
-    delete ctx->uploader;
-    ctx->uploader = nullptr;
+  if (ctx->crew) {
+    ctx->crew->stop();
+    delete ctx->crew;
+    ctx->crew = nullptr;
   }
+  if (ctx->h_upload) (void)hipHostFree(ctx->h_upload);
+  if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
   close_peers(ctx);
   if (ctx->d_mail) (void)hipFree(ctx->d_mail);
   if (ctx->d_mail_table) (void)hipFree(ctx->d_mail_table);
@@ -903,6 +901,7 @@ int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
       break;
     }
     case VGICP_COUNTER_SCAN_GENERATION: *value = ctx->scan_generation; break;
+    case VGICP_COUNTER_UPLOAD_SLOW: *value = ctx->upload_slow; break;
     default: return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown counter");
   }
   return VGICP_OK;
@@ -1161,7 +1160,7 @@ int vgicp_set_option(vgicp_ctx* ctx, int option, int value) {
       return VGICP_OK;
     case VGICP_OPTION_UPLOAD_STAGE_KB:
       if (value < 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "negative size");
-      ctx->upload_stage_limit = std::min<size_t>((size_t)value << 10, kArenaBytes);
+      ctx->upload_stage_limit = (size_t)value << 10;
       return VGICP_OK;
     default:
       return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown option");
@@ -1225,12 +1224,37 @@ int vgicp_map_export(vgicp_ctx* ctx, size_t capacity, int32_t* keys, double* mea
 
 namespace {
 // Copy the scan to the device and pack it into the SoA planes (reference: the deep copy of the cloud at
-// src/Registration.cpp:11, which here is the copy to the device).  The caller's buffers are ordinary pageable
-// memory (std::vector storage): hipMemcpyAsync pins such ranges on the fly and lets the DMA engine read them
-// in place — measured 46 GB/s for the 9.6 MB of a 100k-point scan (tools/probe_upload.py), against 26-31 GB/s
-// for staging them through a pinned buffer with 2-12 copy threads on the two-socket host of the GPU box — and
-// returns once the caller's memory has been read, so the buffers may be released on return.  The pack kernel
-// (and whatever the caller enqueues next) follows in stream order; nothing is waited for here.
+// src/Registration.cpp:11, which here is the copy to the device).  The caller's buffers are ordinary pageable memory
+// (std::vector storage) that the caller may free on return, as the reference frees its cloud every frame
+// (src/Odometry.cpp:84-87) — so the runtime must never get to register them (a freed registered range takes every
+// queue of the process off the device for ~20 ms).  The copy crew (vgicp_context.h) moves the scan into page-locked
+// staging memory of the context, this thread and `upload_threads - 1` helpers, unit by unit, while ONE kernel launch
+// reads the staged units over PCIe behind them and packs them: 9.6 MB in 0.19 - 0.20 ms, the link's rate, where the
+// runtime's in-place path took 0.27 - 0.6 ms and staging with copy commands 0.45 - 0.68 ms.  The pack kernel (and whatever
+// the caller enqueues next) runs in stream order; nothing on the DEVICE is waited for here, but the copy threads are:
+// the caller's buffers are free again on return.
+// Page-locked buffers (vgicp_host_register, hipHostMalloc) are read by the copy engine in place.  In place as well,
+// through the runtime's pin-on-the-fly path: scans larger than the stage limit (default 512 MB) and every scan with
+// the limit 0 (VGICP_OPTION_UPLOAD_STAGE_KB / VGICP_UPLOAD_STAGE_LIMIT / VGICP_STAGE_LIMIT=0) — for callers that keep
+// their buffers.
+constexpr uint32_t kPackSpinLimit = 400000;   // polls of a staged unit's flag (>= 1 us each) before the pack kernel gives up
+constexpr double kCrewSlowSeconds = 0.1;      // copy threads slower than this: the packing is repeated behind the launch
+
+int ensure_upload_stage(vgicp_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->upload_cap) return VGICP_OK;
+  if (ctx->upload_in_flight) { VG_HIP(ctx, hipEventSynchronize(ctx->ev_upload)); ctx->upload_in_flight = false; }
+  if (ctx->h_upload) VG_HIP(ctx, hipHostFree(ctx->h_upload));
+  ctx->h_upload = nullptr;
+  ctx->upload_cap = 0;
+  const size_t want = std::max<size_t>(bytes + bytes / 4, 4u << 20);
+  const size_t flag_bytes = (want / ((size_t)pack_arena_unit() * kScanPlanes * sizeof(double)) + 2) * 64;
+  VG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_upload), flag_bytes + want, 0));
+  std::memset(ctx->h_upload, 0, flag_bytes);   // "no upload yet" (a sequence number is never 0)
+  ctx->upload_cap = want;
+  ctx->upload_flag_bytes = flag_bytes;
+  return VGICP_OK;
+}
+
 int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const double* covs) {
   if (n > 0 && (!points || !covs)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL scan pointer");
   if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "scan too large");
@@ -1249,57 +1273,66 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
   const double t0 = now_seconds();
   double* aos_pts = ctx->d_scan_aos;
   double* aos_cov = ctx->d_scan_aos + 3 * ctx->scan_capacity;
-  if (ctx->uploader_enabled && n * 3 * sizeof(double) >= (512u << 10)) {
-    // the points on the helper thread and its stream, the covariances here; the pack kernel waits for both
-    if (!ctx->uploader) {
-      UploadHelper* u = new UploadHelper;
-      u->device = ctx->device;
-      if (hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&u->ev, hipEventDisableTiming) != hipSuccess) {
-        delete u;
-        ctx->uploader_enabled = false;
-      } else {
-        u->th = std::thread([u] { u->run(); });
-        ctx->uploader = u;
-      }
-    }
-  }
-  bool seen_before = false;
-  for (int k = 0; k < 1024 && !seen_before; ++k)
-    seen_before = ctx->seen_ptr[k] == static_cast<const void*>(covs) && ctx->seen_bytes[k] >= n * 9 * sizeof(double);
-  if (!seen_before) {
-    ctx->seen_ptr[ctx->seen_next & 1023u] = covs;
-    ctx->seen_bytes[ctx->seen_next & 1023u] = n * 9 * sizeof(double);
-    ++ctx->seen_next;
-  }
-  // a scan of up to 4 MB (42 k points: what a LiDAR sweep keeps) goes through the page-locked arena: the caller of the
-  // reference allocates and frees its clouds per frame, and a range the runtime registered stalls every queue of the
-  // process for ~20 ms when it is unmapped (above).  Larger scans go up directly, as measured in DESIGN.md 6.
+  if (++ctx->scan_seq == 0) ++ctx->scan_seq;
+  ctx->scan_sym_known = true;
+  const size_t bytes = n * kScanPlanes * sizeof(double);
   static const bool stage_off = std::getenv("VGICP_STAGE_LIMIT") && std::atoll(std::getenv("VGICP_STAGE_LIMIT")) == 0;
-  const size_t whole_bytes = ctx->upload_whole_hint ? ctx->upload_whole_hint : n * kScanPlanes * sizeof(double);
-  if (!stage_off && whole_bytes <= ctx->upload_stage_limit && n * kScanPlanes * sizeof(double) <= kArenaBytes &&
-      !is_pagelocked(points) && !is_pagelocked(covs)) {
-    arena_reset(ctx);
-    VG_RC(user_h2d(ctx, aos_pts, points, n * 3 * sizeof(double)));
-    VG_RC(user_h2d(ctx, aos_cov, covs, n * 9 * sizeof(double)));
-  } else if (ctx->uploader && ctx->uploader_enabled && !seen_before && n * 3 * sizeof(double) >= (512u << 10)) {
-    ctx->uploader->post(aos_pts, points, n * 3 * sizeof(double));
-    ++g_copy_ops;
-    const hipError_t e_cov = hipMemcpyAsync(aos_cov, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    const hipError_t e_pts = ctx->uploader->wait();   // always: the caller's buffer must not be in use on return
-    if (e_cov != hipSuccess) return fail_hip(ctx, e_cov, "hipMemcpyAsync(covariances)");
-    if (e_pts != hipSuccess) return fail_hip(ctx, e_pts, "hipMemcpyAsync(points, helper thread)");
-    VG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->uploader->ev, 0));
+  const size_t whole_bytes = ctx->upload_whole_hint ? ctx->upload_whole_hint : bytes;
+  const bool staged = !stage_off && whole_bytes <= ctx->upload_stage_limit && bytes > (256u << 10) &&
+                      !(is_pagelocked(points) && is_pagelocked(covs));
+  if (staged) {
+    const uint32_t unit = pack_arena_unit(), units = (uint32_t)((n + unit - 1) / unit);
+    const size_t pb = (n * 3 * sizeof(double) + 255 + 16) & ~size_t(255), cb = (n * 9 * sizeof(double) + 255 + 16) & ~size_t(255);
+    rc = ensure_upload_stage(ctx, pb + cb);
+    if (rc != VGICP_OK) return rc;
+    if (!ctx->ev_upload) VG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
+    // the kernel that read the staging memory last has long finished (every align ends in a synchronisation); make sure
+    if (ctx->upload_in_flight && hipEventQuery(ctx->ev_upload) != hipSuccess) VG_HIP(ctx, hipEventSynchronize(ctx->ev_upload));
+    ctx->upload_in_flight = false;
+    const bool want_helpers = ctx->upload_threads > 1 && bytes >= (2u << 20);
+    if (!ctx->crew) ctx->crew = new CopyCrew;
+    CopyCrew* crew = ctx->crew;
+    if (want_helpers && crew->th.empty()) crew->start(ctx->upload_threads - 1);
+    crew->pts = reinterpret_cast<const char*>(points);
+    crew->cov = reinterpret_cast<const char*>(covs);
+    crew->flags = reinterpret_cast<uint32_t*>(ctx->h_upload);
+    crew->apts = ctx->h_upload + ctx->upload_flag_bytes;
+    crew->acov = crew->apts + pb;
+    crew->n = (uint32_t)n;
+    crew->unit = unit;
+    crew->units = units;
+    crew->seq = ctx->scan_seq;
+    crew->copy = stage_copy;
+    const double t_post = now_seconds();
+    const uint32_t job = crew->post(want_helpers);
+    // the launch first (it starts reading as soon as unit 0 is published), then this thread copies too
+    // test aids: a pack kernel with little patience and a copy thread that is held up (the repeat below is then what counts)
+    static const uint32_t spin_limit = std::getenv("VGICP_PACK_SPIN_LIMIT") ? (uint32_t)std::strtoul(std::getenv("VGICP_PACK_SPIN_LIMIT"), nullptr, 10) : kPackSpinLimit;
+    static const long debug_delay_us = std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US") ? std::atol(std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US")) : 0;
+    const hipError_t e_launch = launch_pack_arena(ctx->stream, crew->apts, crew->acov, (uint32_t)n, crew->flags, ctx->scan_seq,
+                                                  spin_limit, aos_pts, aos_cov, ctx->d_scan, ctx->stride,
+                                                  ctx->d_ins_counters + 2);
+    if (debug_delay_us > 0 && !want_helpers) std::this_thread::sleep_for(std::chrono::microseconds(debug_delay_us));
+    crew->work(job);
+    crew->finish();   // always: the caller's buffers must not be in use on return
+    if (e_launch != hipSuccess) return fail_hip(ctx, e_launch, "launch_pack_arena");
+    if (now_seconds() - t_post > kCrewSlowSeconds) {
+      // the copy threads were held up for so long that a workgroup of the launch may have stopped waiting: everything
+      // is staged now, pack it again behind the launch (no flags to wait for)
+      ++ctx->upload_slow;
+      VG_HIP(ctx, launch_pack_arena(ctx->stream, crew->apts, crew->acov, (uint32_t)n, nullptr, ctx->scan_seq, 0, aos_pts,
+                                    aos_cov, ctx->d_scan, ctx->stride, ctx->d_ins_counters + 2));
+    }
+    VG_HIP(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
+    ctx->upload_in_flight = true;
   } else {
     VG_HIP(ctx, hipMemcpyAsync(aos_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     VG_HIP(ctx, hipMemcpyAsync(aos_cov, covs, n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, (uint32_t)n, ctx->d_scan, ctx->stride,
+                                 ctx->d_ins_counters + 2, ctx->scan_seq));
   }
-  if (++ctx->scan_seq == 0) ++ctx->scan_seq;
-  ctx->scan_sym_known = true;
-  VG_HIP(ctx, launch_pack_scan(ctx->stream, aos_pts, aos_cov, (uint32_t)n, ctx->d_scan, ctx->stride,
-                               ctx->d_ins_counters + 2, ctx->scan_seq));
-  ctx->upload_bytes += n * kScanPlanes * sizeof(double);
-  ctx->upload_seconds += now_seconds() - t0;  // host side of the two copies + the enqueue of the pack kernel
+  ctx->upload_bytes += bytes;
+  ctx->upload_seconds += now_seconds() - t0;  // host side: the staging copy (or the copy calls) + the enqueue of the pack kernel
   return VGICP_OK;
 }
 }  // namespace
@@ -2014,6 +2047,9 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     dk.ends = reinterpret_cast<uint32_t*>(base + pb + tb + sb);
   }
   VG_HIP(ctx, hipEventRecord(ctx->ev_state_table[slot], ctx->stream));   // behind the last copy out of this slot's pinned buffers
+  // a sweep too large to stage was handed to the runtime in place: its copies have to be over before the call returns,
+  // because the caller's buffers are free again on return whatever the size (the drop-in releases the capture times at once)
+  if (!staged) VG_HIP(ctx, hipEventSynchronize(ctx->ev_state_table[slot]));
   const double tr2 = trace ? now_seconds() : 0.0;
   rc = enqueue_prepare(ctx, d_pts, n, voxel_size, knn, extrinsic, dk, scratch, ctx->d_scan_aos,
                        ctx->d_scan_aos + 3 * ctx->scan_capacity, d_idx, ctx->d_scan, ctx->stride);

@@ -5,6 +5,8 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <limits>
@@ -69,51 +71,97 @@ constexpr int kPersistentCooldownAligns = 8;  // aligns on the per-launch loop a
 }  // namespace vgicp
 using namespace vgicp;
 
-// A second host thread for the scan upload. hipMemcpyAsync from pageable memory the runtime has never seen spends
-// as long again preparing the pages as the DMA then takes (tools/micro/h2d_cold_probe.hip: 9.6 MB cold 0.35 - 0.56 ms
-// on one thread, 0.27 - 0.28 ms with the two arrays on two threads and two streams; buffers seen before: 0.19 / 0.20
-// ms).  The helper copies the points while the caller's thread copies the covariances; the context's stream waits
-// for the helper's event before the pack kernel.
-struct UploadHelper {
-  std::thread th;
+// The host side of the scan upload (vgicp_align, vgicp_scan_upload): a crew of plain-memcpy threads.
+// The caller's scan lives in pageable memory that the caller frees right after the call (the reference deep-copies a
+// fresh cloud per frame, src/Registration.cpp:11).  Handing such a buffer to the runtime registers its pages with the
+// driver, and the free() then takes every queue of the process off the device for ~20 ms (profiles/r10_sync_stall.txt);
+// staging it through page-locked memory with copy COMMANDS cost 0.45 - 0.68 ms for 9.6 MB (25 commands of ~19 us).
+// So: the crew — the caller's own thread plus `helpers` threads that make no HIP call — copies the scan into page-locked
+// staging memory in units of pack_arena_unit() points and publishes every unit with a flag, and ONE kernel launch
+// (pack_arena_kernel) reads the staging memory over PCIe behind them.  Measured (tools/micro/stage_crew_probe.hip,
+// 2 x EPYC 9575F): one thread copies 9.6 MB from never-seen pages in 0.22 ms (43 GB/s), two in 0.13 - 0.15 ms; the kernel
+// gets 54 GB/s out of the link; copy + transfer + packing overlapped: 0.19 - 0.20 ms with ONE helper, the link's rate.
+// A helper spins for a short while after a job (the next frame's upload follows soon in a loop) and then sleeps.
+struct CopyCrew {
+  std::vector<std::thread> th;
   std::mutex m;
   std::condition_variable cv;
-  bool has_job = false, done = true, quit = false;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev = nullptr;
-  void* dst = nullptr;
-  const void* src = nullptr;
-  size_t bytes = 0;
-  hipError_t result = hipSuccess;
+  std::atomic<uint32_t> gen{0};        // the job the helpers were last woken for
+  std::atomic<uint64_t> next{0};       // job number << 32 | next unit to take: a thread that comes late to a job that is
+                                       // over finds another job's number here and leaves without touching anything
+  std::atomic<uint32_t> finished{0};
+  uint32_t job = 0;                    // jobs posted so far (the caller's thread only)
+  bool quit = false;
+  // the job (written before `next` is set, read only after a unit of THIS job was taken from it)
+  const char* pts = nullptr;
+  const char* cov = nullptr;
+  char* apts = nullptr;
+  char* acov = nullptr;
+  uint32_t* flags = nullptr;
+  uint32_t n = 0, unit = 0, units = 0, seq = 0;
+  void (*copy)(void*, const void*, size_t) = nullptr;
 
-  void run() {
-    (void)hipSetDevice(device);
-    std::unique_lock<std::mutex> lk(m);
+  void work(uint32_t my_job) {
     for (;;) {
-      cv.wait(lk, [&] { return has_job || quit; });
-      if (quit) return;
-      has_job = false;
-      lk.unlock();
-      hipError_t e = (hipMemcpyAsync)(dst, src, bytes, hipMemcpyHostToDevice, stream);
-      if (e == hipSuccess) e = hipEventRecord(ev, stream);
-      lk.lock();
-      result = e;
-      done = true;
-      cv.notify_all();
+      const uint64_t v = next.fetch_add(1, std::memory_order_acq_rel);
+      if ((uint32_t)(v >> 32) != my_job) return;
+      const uint32_t u = (uint32_t)v;
+      if (u >= units) return;
+      const size_t p0 = (size_t)u * unit, cnt = std::min<size_t>(unit, n - p0);
+      copy(apts + p0 * 24, pts + p0 * 24, cnt * 24);
+      copy(acov + p0 * 72, cov + p0 * 72, cnt * 72);
+      // the unit's bytes (streaming stores, fenced by `copy`) are globally visible before its flag
+      __atomic_store_n(flags + 16 * (size_t)u, seq, __ATOMIC_RELEASE);
+      finished.fetch_add(1, std::memory_order_release);
     }
   }
-  void post(void* d, const void* s, size_t n) {
-    std::lock_guard<std::mutex> lk(m);
-    dst = d; src = s; bytes = n;
-    done = false;
-    has_job = true;
-    cv.notify_all();
+  void run() {
+    uint32_t seen = gen.load(std::memory_order_acquire);
+    for (;;) {
+      bool have = false;
+      for (int spins = 0; spins < 40000 && !have; ++spins) {   // ~1 ms
+        have = gen.load(std::memory_order_acquire) != seen;
+        if (!have) __builtin_ia32_pause();
+      }
+      if (!have) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return quit || gen.load(std::memory_order_acquire) != seen; });
+        if (quit) return;
+      }
+      seen = gen.load(std::memory_order_acquire);
+      work(seen);
+    }
   }
-  hipError_t wait() {
-    std::unique_lock<std::mutex> lk(m);
-    cv.wait(lk, [&] { return done; });
-    return result;
+  void start(int helpers) {
+    for (int i = 0; i < helpers; ++i) th.emplace_back([this] { run(); });
+  }
+  // everything of the job is in place: open it (to the helpers too if asked); the caller then works on it itself
+  // (work(job)) and waits for the units others took (finish())
+  uint32_t post(bool wake_helpers) {
+    if (++job == 0) ++job;
+    finished.store(0, std::memory_order_relaxed);
+    next.store((uint64_t)job << 32, std::memory_order_release);
+    if (wake_helpers && !th.empty()) {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        gen.store(job, std::memory_order_release);
+      }
+      cv.notify_all();
+    }
+    return job;
+  }
+  void finish() const {
+    while (finished.load(std::memory_order_acquire) < units) __builtin_ia32_pause();
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      quit = true;
+    }
+    cv.notify_all();
+    for (auto& t : th)
+      if (t.joinable()) t.join();
+    th.clear();
   }
 };
 
@@ -182,13 +230,14 @@ struct vgicp_ctx {
   uint64_t upload_bytes = 0;
   double upload_seconds = 0.0;
   uint64_t prep_indefinite = 0;      // kept points of the last scan preparation with an indefinite covariance
-  UploadHelper* uploader = nullptr;  // created with the first large upload (VGICP_UPLOAD_THREADS=1 keeps one thread)
-  bool uploader_enabled = true;
-  // host buffers uploaded recently (address of the covariances, ring of 1 024): a buffer the runtime has seen before
-  // goes up fastest from ONE thread (9.6 MB: 0.19 ms against 0.33 ms with two), a new one from TWO (0.32 against 0.44)
-  const void* seen_ptr[1024] = {nullptr};
-  size_t seen_bytes[1024] = {0};
-  uint32_t seen_next = 0;
+  CopyCrew* crew = nullptr;          // the upload's copy threads, created with the first upload that wants a helper
+  int upload_threads = 2;            // threads that copy a scan into the staging memory, the caller's included (VGICP_UPLOAD_THREADS)
+  char* h_upload = nullptr;          // page-locked staging memory of the scan upload: [unit flags][points][covariances]
+  size_t upload_cap = 0;             // bytes behind the flags
+  size_t upload_flag_bytes = 0;      // one 64-byte line per unit the capacity can hold; never holds anything but flags
+  hipEvent_t ev_upload = nullptr;    // behind the kernel that read h_upload last (the next upload overwrites it)
+  bool upload_in_flight = false;
+  uint64_t upload_slow = 0;          // uploads whose copy threads took so long that the packing was repeated behind them
   // scan preparation without host round trips
   void* d_tiles = nullptr;           // tile slots of the two device-wide scans
   uint32_t* h_prep = nullptr;        // pinned: the counter block as a preparation left it (kCounterWords)
@@ -213,8 +262,10 @@ struct vgicp_ctx {
   // pin-on-the-fly path, whose registrations stall the whole process when the caller frees the buffer
   char* h_arena = nullptr;
   size_t arena_used = 0;
-  size_t upload_stage_limit = 4u << 20;   // scans up to this many bytes go through the arena (VGICP_UPLOAD_STAGE_LIMIT, VGICP_OPTION_UPLOAD_STAGE_KB)
-  size_t upload_whole_hint = 0;           // a sub-context's shard: the size of the caller's WHOLE scan decides, not the shard's
+  size_t upload_stage_limit = 512u << 20;   // scans up to this many bytes are staged by the copy crew; larger ones (and
+                                            // all of them with the limit 0) are handed to the runtime in place
+                                            // (VGICP_UPLOAD_STAGE_LIMIT, VGICP_OPTION_UPLOAD_STAGE_KB)
+  size_t upload_whole_hint = 0;             // a sub-context's shard: the size of the caller's WHOLE scan decides, not the shard's
   struct PendingOut { void* dst; const char* src; size_t bytes; };
   std::vector<PendingOut> pending_out;
   char* h_raw_stage[2] = {nullptr, nullptr};

@@ -178,11 +178,19 @@ hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosin
 // asym: one device word that receives seq when a covariance is not bitwise symmetric (PersistArgs::asym_dev)
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
                             uint32_t n, double* soa, uint64_t stride, uint32_t* asym, uint32_t seq);
+// The same packing straight out of page-locked HOST staging memory that host threads are still filling, unit by unit
+// (pack_arena_unit() points each; flags[16 * u] == seq publishes unit u; flags == nullptr: all there).  Also leaves the
+// AoS copy on the device.  See pack_arena_kernel.
+uint32_t pack_arena_unit();
+hipError_t launch_pack_arena(hipStream_t s, const void* arena_points, const void* arena_covs, uint32_t n,
+                             const uint32_t* flags, uint32_t seq, uint32_t spin_limit, double* aos_pts, double* aos_cov,
+                             double* soa, uint64_t stride, uint32_t* asym);
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots);
 // Pack the FULL records of `table` into `dense` in slot order (128 bytes each) and leave every record's index there in
 // the upper half of its spare word.  block_counts: scratch of table_dense_blocks(slots) + 1 words.
 uint32_t table_dense_blocks(uint64_t slots);
-hipError_t launch_table_dense(hipStream_t s, VoxelRecord* table, uint64_t slots, VoxelRecord* dense, uint32_t* block_counts);
+hipError_t launch_table_dense(hipStream_t s, VoxelRecord* table, uint64_t slots, VoxelRecord* dense, uint64_t dense_capacity,
+                              uint32_t* block_counts);
 // claimed: scratch of n words (upsert) / old_slots words (rehash): claim launch -> write launch
 hipError_t launch_upsert(hipStream_t s, VoxelRecord* table, uint32_t mask, uint32_t n,
                          const int32_t* keys, const double* means, const double* covs,

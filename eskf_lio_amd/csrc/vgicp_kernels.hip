@@ -1217,6 +1217,90 @@ __global__ void pack_scan_kernel(const double* __restrict__ pts, const double* _
   if (!same) *asym = seq;
 }
 
+// The same packing for a scan that is still ARRIVING in page-locked host memory: the upload of vgicp_align /
+// vgicp_scan_upload without the runtime's copy engine.  Host threads (plain memcpy, no HIP call: CopyCrew,
+// vgicp_context.h) fill `apts` (n x 24 B) and `acov` (n x 72 B) in units of `unit` points and publish each unit by
+// storing `seq` into flags[16 * u] (one 64-byte line per flag, written after the unit's bytes).  This ONE launch reads
+// the staging memory over PCIe itself — 16-byte loads of consecutive lanes, a block's 96 x kPackArenaBlock bytes
+// through LDS — while the threads are still copying the units behind: 9.6 MB arrive in 0.19 - 0.20 ms = 49 GB/s
+// (tools/micro/stage_crew_probe.hip: a kernel gets 54 GB/s out of the link; staging + copy commands + pack took 0.45 ms).
+// Every block also leaves the AoS copy on the device (map insertion and download read it) and reports an asymmetric
+// covariance like pack_scan_kernel.  flags == nullptr: everything is there already (no waiting).
+// A wait that exceeds spin_limit polls (each a PCIe round trip, >= 1 us) ends the block's workgroup: the host, which
+// knows how long its copy threads took, then repeats the packing without flags behind this launch.
+constexpr int kPackArenaBlock = 256;
+__global__ __launch_bounds__(kPackArenaBlock) void pack_arena_kernel(
+    const char* __restrict__ apts, const char* __restrict__ acov, uint32_t n, uint32_t unit, const uint32_t* flags,
+    uint32_t seq, uint32_t spin_limit, double* __restrict__ aos_pts, double* __restrict__ aos_cov,
+    double* __restrict__ soa, uint64_t stride, uint32_t* asym) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  constexpr uint32_t B = kPackArenaBlock;
+  __shared__ __attribute__((aligned(16))) double lds[12 * B];
+  __shared__ uint32_t ok;
+  const uint32_t t = threadIdx.x, blocks = (n + B - 1) / B;
+  uint32_t have_unit = 0xFFFFFFFFu;
+  for (uint32_t b = blockIdx.x; b < blocks; b += gridDim.x) {
+    const uint32_t p0 = b * B, cnt = min(B, n - p0);
+    if (flags != nullptr) {
+      const uint32_t u = p0 / unit;   // unit is a multiple of the block: a block never straddles two units
+      if (u != have_unit) {
+        if (t == 0) {
+          uint32_t good = 1;
+          for (uint32_t spins = 0; __hip_atomic_load(flags + 16 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq; ++spins) {
+            if (spins >= spin_limit) { good = 0; break; }
+            __builtin_amdgcn_s_sleep(20);
+          }
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+          ok = good;
+        }
+        __syncthreads();
+        if (!ok) return;   // uniform
+        have_unit = u;
+      }
+    }
+    const v4i* sp = reinterpret_cast<const v4i*>(apts + (size_t)p0 * 24);
+    const v4i* sc = reinterpret_cast<const v4i*>(acov + (size_t)p0 * 72);
+    v4i* lp = reinterpret_cast<v4i*>(lds);
+    v4i* lc = reinterpret_cast<v4i*>(lds + 3 * B);
+    // an odd count (the scan's last block only) leaves half a 16-byte chunk at the end of the points AND of the
+    // covariances: read whole (the staging areas are padded), stored to the device copy as 8 bytes
+    const uint32_t np = (cnt * 24 + 15) / 16, np_whole = (cnt * 24) / 16, nc = (cnt * 72 + 15) / 16, nc_whole = (cnt * 72) / 16;
+    v4i* dp = reinterpret_cast<v4i*>(aos_pts + 3 * (size_t)p0);
+    v4i* dc = reinterpret_cast<v4i*>(aos_cov + 9 * (size_t)p0);
+    for (uint32_t k = t; k < np; k += B) {
+      const v4i w = __builtin_nontemporal_load(sp + k);
+      lp[k] = w;
+      if (k < np_whole) dp[k] = w;
+    }
+    for (uint32_t k = t; k < nc; k += B) {
+      const v4i w = __builtin_nontemporal_load(sc + k);
+      lc[k] = w;
+      if (k < nc_whole) dc[k] = w;
+    }
+    __syncthreads();
+    if (t == 0 && np != np_whole) {
+      aos_pts[3 * (size_t)(p0 + cnt) - 1] = lds[3 * cnt - 1];
+      aos_cov[9 * (size_t)(p0 + cnt) - 1] = lds[3 * B + 9 * cnt - 1];
+    }
+    if (t < cnt) {
+      const size_t i = p0 + t;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) soa[k * stride + i] = lds[3 * t + k];
+      double c[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        c[k] = lds[3 * B + 9 * t + k];
+        soa[(3 + k) * stride + i] = c[k];
+      }
+      const bool same = __double_as_longlong(c[1]) == __double_as_longlong(c[3]) &&
+                        __double_as_longlong(c[2]) == __double_as_longlong(c[6]) &&
+                        __double_as_longlong(c[5]) == __double_as_longlong(c[7]);
+      if (!same) *asym = seq;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void table_clear_kernel(VoxelRecord* table, uint64_t slots) {
   // 8 threads per record, 16 B each
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1459,7 +1543,7 @@ __global__ __launch_bounds__(kDenseBlock) void dense_count_kernel(const VoxelRec
 }
 __global__ __launch_bounds__(kDenseBlock) void dense_write_kernel(VoxelRecord* table, uint64_t slots,
                                                                   const uint32_t* __restrict__ block_offsets,
-                                                                  VoxelRecord* __restrict__ dense) {
+                                                                  VoxelRecord* __restrict__ dense, uint64_t capacity) {
   __shared__ uint32_t wave_hits[kDenseBlock / 64];
   __shared__ uint32_t src[kDenseBlock];   // local slot numbers of the block's FULL records, in slot order
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1480,7 +1564,8 @@ __global__ __launch_bounds__(kDenseBlock) void dense_write_kernel(VoxelRecord* t
   }
   __syncthreads();
   // eight lanes per record, 16 bytes each: coalesced 128-byte lines both ways
-  for (uint32_t r = tid >> 3; r < total; r += kDenseBlock / 8) {
+  // never beyond the allocation (the host sizes it for every record a pending insertion may still add; this is the belt)
+  for (uint32_t r = tid >> 3; r < total && (uint64_t)base + r < capacity; r += kDenseBlock / 8) {
     const double2 piece = reinterpret_cast<const double2*>(table + ((uint64_t)blockIdx.x * kDenseBlock + src[r]))[tid & 7u];
     reinterpret_cast<double2*>(dense + base + r)[tid & 7u] = piece;
   }
@@ -1658,6 +1743,20 @@ hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const doubl
   return hipGetLastError();
 }
 
+uint32_t pack_arena_unit() { return 8u * kPackArenaBlock; }   // 2 048 points = 196 KB per unit
+hipError_t launch_pack_arena(hipStream_t s, const void* arena_points, const void* arena_covs, uint32_t n,
+                             const uint32_t* flags, uint32_t seq, uint32_t spin_limit, double* aos_pts, double* aos_cov,
+                             double* soa, uint64_t stride, uint32_t* asym) {
+  if (n == 0) return hipSuccess;
+  // few enough workgroups that the ones still waiting for their unit are a trickle of PCIe reads, enough of them that
+  // 3 MB of loads are in flight; small LDS and 256 threads so that they find room beside other contexts' launches
+  const uint32_t grid = std::min<uint32_t>(blocks_for(n, kPackArenaBlock), 128u);
+  ++g_kernel_launches; hipLaunchKernelGGL(pack_arena_kernel, dim3(grid), dim3(kPackArenaBlock), 0, s,
+                                          static_cast<const char*>(arena_points), static_cast<const char*>(arena_covs), n,
+                                          pack_arena_unit(), flags, seq, spin_limit, aos_pts, aos_cov, soa, stride, asym);
+  return hipGetLastError();
+}
+
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots) {
   ++g_kernel_launches; hipLaunchKernelGGL(table_clear_kernel, dim3(blocks_for(slots * 8, 256)), dim3(256), 0, s, table,
                      slots);
@@ -1666,11 +1765,12 @@ hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots)
 
 uint32_t table_dense_blocks(uint64_t slots) { return blocks_for(slots, kDenseBlock); }
 
-hipError_t launch_table_dense(hipStream_t s, VoxelRecord* table, uint64_t slots, VoxelRecord* dense, uint32_t* block_counts) {
+hipError_t launch_table_dense(hipStream_t s, VoxelRecord* table, uint64_t slots, VoxelRecord* dense, uint64_t dense_capacity,
+                              uint32_t* block_counts) {
   const uint32_t nb = table_dense_blocks(slots);
   ++g_kernel_launches; hipLaunchKernelGGL(dense_count_kernel, dim3(nb), dim3(kDenseBlock), 0, s, table, slots, block_counts);
   ++g_kernel_launches; hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nb, block_counts + nb);
-  ++g_kernel_launches; hipLaunchKernelGGL(dense_write_kernel, dim3(nb), dim3(kDenseBlock), 0, s, table, slots, block_counts, dense);
+  ++g_kernel_launches; hipLaunchKernelGGL(dense_write_kernel, dim3(nb), dim3(kDenseBlock), 0, s, table, slots, block_counts, dense, dense_capacity);
   return hipGetLastError();
 }
 

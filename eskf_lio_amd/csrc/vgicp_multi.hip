@@ -232,7 +232,12 @@ int align_shards(vgicp_ctx* parent, const double* points, const double* covs, co
   const double t0 = now_seconds();
   if (!params) return fail(parent, VGICP_ERR_BAD_ARGUMENT, "params is NULL");
   const bool host_loop_asked = (params->flags & (VGICP_FLAG_PROFILE | VGICP_FLAG_NO_PERSISTENT)) != 0 || params->max_iteration <= 0;
-  bool single = g->mailboxes && !host_loop_asked && g->cooldown == 0;
+  // the single launch needs the persistent kernel on EVERY device (VGICP_PERSISTENT=0, or a workgroup that does not fit a
+  // compute unit, leaves a sub-context on the launch-per-round loop): without it the host-summed loop is the path, not a
+  // fallback — nothing is counted, announced or re-wired, and no device waits for a peer that will never publish
+  bool all_persistent = true;
+  for (int r = 0; r < g->n; ++r) all_persistent = all_persistent && g->subs[(size_t)r]->persistent_enabled;
+  bool single = g->mailboxes && all_persistent && !host_loop_asked && g->cooldown == 0;
   if (g->cooldown > 0 && !host_loop_asked) --g->cooldown;
   if (single && points) {
     // no allocation between the launches: a sub-context that has to grow its scan buffers does so now, while nobody's
@@ -364,7 +369,7 @@ extern "C" int vgicp_create_multi(const int* device_ids, int n_devices, vgicp_ct
     sub->owner = g;
     // their uploads already run side by side (one thread per sub-context); a helper stream per sub-context on ONE
     // device would only make them share hardware queues with a neighbour's persistent launch
-    if (m > 1) sub->uploader_enabled = false;
+    if (m > 1) sub->upload_threads = 1;
     // ... and a workgroup of theirs plans with less than half a CU's LDS: launches of several queues that each need
     // WHOLE compute units were seen not to become resident side by side (4 and 8 queues, 150 KB per workgroup)
     if (m > 1) sub->persist_lds_budget = 64u * 1024u;
@@ -459,6 +464,7 @@ int get_counter(const vgicp_ctx* ctx, int which, uint64_t* value) {
     case VGICP_COUNTER_UPLOAD_BYTES: for (const vgicp_ctx* s : g->subs) v += s->upload_bytes; break;
     case VGICP_COUNTER_UPLOAD_NANOSECONDS: for (const vgicp_ctx* s : g->subs) v = std::max<uint64_t>(v, (uint64_t)(s->upload_seconds * 1e9)); break;
     case VGICP_COUNTER_SCAN_GENERATION: v = g->scan_generation; break;
+    case VGICP_COUNTER_UPLOAD_SLOW: for (const vgicp_ctx* s : g->subs) v += s->upload_slow; break;
     case VGICP_COUNTER_PREP_INDEFINITE: return sub_fail(const_cast<vgicp_ctx*>(ctx), g->subs[0], vgicp_get_counter(g->subs[0], which, value));
     default: return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown counter");
   }
@@ -665,14 +671,18 @@ int scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double* covs,
   if (g->n_total == 0 || (!points && !covs)) return VGICP_OK;
   if (capacity < g->n_total) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "capacity smaller than the resident scan");
   if (!points || !covs) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL output pointer");
-  if (g->resident == Resident::PreparedDealt) {   // device 0 still holds all of it
+  if (g->resident == Resident::PreparedDealt) {   // device 0 still holds all of it (its own shard is a prefix of the planes)
     int rc = vgicp_internal::settle_context(lead);
     if (rc != VGICP_OK) return sub_fail(ctx, lead, rc);
-    VG_HIP(ctx, hipSetDevice(lead->device));
-    VG_HIP(ctx, hipMemcpyAsync(points, lead->d_scan_aos, g->n_total * 3 * sizeof(double), hipMemcpyDeviceToHost, lead->stream));
-    VG_HIP(ctx, hipMemcpyAsync(covs, lead->d_scan_aos + 3 * lead->scan_capacity, g->n_total * 9 * sizeof(double), hipMemcpyDeviceToHost, lead->stream));
-    VG_HIP(ctx, hipStreamSynchronize(lead->stream));
-    return VGICP_OK;
+    // through the single-device entry point with the full count: its copies go through the context's page-locked arena
+    // (a copy straight into the caller's pageable memory would let the runtime register those pages: the ~20 ms stall
+    // when the caller frees them)
+    const uint32_t shard = lead->n;
+    lead->n = (uint32_t)g->n_total;
+    size_t got = 0;
+    rc = vgicp_scan_download(lead, capacity, points, covs, &got);
+    lead->n = shard;
+    return sub_fail(ctx, lead, rc);
   }
   return run_all(ctx, [&](int r) {
     const size_t lo = g->lo[(size_t)r], cnt = g->hi[(size_t)r] - lo;

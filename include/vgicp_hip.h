@@ -119,7 +119,9 @@ enum {
   VGICP_COUNTER_SCAN_GENERATION = 5   /* goes up whenever the RESIDENT scan is replaced (vgicp_align, vgicp_scan_upload,
                                          vgicp_scan_prepare*, vgicp_accumulate): a host object that remembers "my cloud is
                                          the resident scan" (the shim's CloudPreprocessor / ICP pair) checks it; no
-                                         synchronisation */
+                                         synchronisation */,
+  VGICP_COUNTER_UPLOAD_SLOW = 6       /* staged uploads whose copy threads were held up for so long (> 0.1 s) that the
+                                         packing was repeated behind the launch that reads the staging memory */
 };
 int vgicp_get_counter(const vgicp_ctx* ctx, int which, uint64_t* value);
 
@@ -169,6 +171,14 @@ int vgicp_map_export(vgicp_ctx* ctx, size_t capacity, int32_t* keys, double* mea
  * src/Registration.cpp:13,27), Utils::se3ToSE3 (src/Utils.cpp:40-63) and ICP::convergenceCheck
  * (src/Registration.cpp:37-50).  Inputs are not modified (the reference deep-copies the cloud,
  * src/Registration.cpp:11; here the scan is copied to the device instead).
+ * Lifetime of `points` / `covs`: free again on return — the reference frees its cloud every frame
+ * (src/Odometry.cpp:84-87), and the upload is built for exactly that caller: the scan is copied by this thread and one
+ * helper (VGICP_UPLOAD_THREADS in the environment = threads in all, default 2; they make no HIP call) into page-locked
+ * staging memory of the context, unit by unit, while ONE kernel launch reads the staged units over PCIe behind them
+ * and packs them — the runtime never registers the caller's pages (a registered range that is freed takes every queue
+ * of the process off the device for ~20 ms), and 9.6 MB reach the device in 0.19 - 0.20 ms, ~90 % of what a kernel gets
+ * out of the link.  Page-locked buffers (vgicp_host_register) are read in place.  VGICP_OPTION_UPLOAD_STAGE_KB sets
+ * the size up to which scans are staged (default 512 MB; 0 = hand every scan to the runtime in place).
  * With a communicator (below) every rank passes ITS shard of the scan and all ranks return the same
  * pose. */
 int vgicp_align(vgicp_ctx* ctx, size_t n, const double* points, const double* covs,
@@ -181,11 +191,10 @@ int vgicp_align_resident(vgicp_ctx* ctx, const double guess[16], const vgicp_par
                          double out_pose[16], vgicp_stats* stats);
 
 /* Optional, for callers that keep their clouds in buffers which live across frames (a pool): page-lock such a buffer
- * once and every upload out of it runs at the link's rate from the first time on (9.6 MB in 0.19 ms; a pageable
- * buffer the runtime has never seen takes 0.27 - 0.56 ms, tools/micro/h2d_cold_probe.hip).  The reference allocates
- * a fresh cloud per frame (src/Registration.cpp:11), for which there is nothing to register: that case is what the
- * two-thread upload inside vgicp_align is for, and the resident chain (vgicp_scan_prepare*) avoids the upload of the
- * covariances altogether.  Unregister before the buffer is freed. */
+ * once and the copy engine reads it in place, no CPU copy at all (9.6 MB in 0.19 ms).  The reference allocates a fresh
+ * cloud per frame (src/Registration.cpp:11), for which there is nothing to register: that case is what the staged
+ * upload inside vgicp_align is for, and the resident chain (vgicp_scan_prepare*) avoids the upload of the covariances
+ * altogether.  Unregister before the buffer is freed. */
 int vgicp_host_register(vgicp_ctx* ctx, const void* buffer, size_t bytes);
 int vgicp_host_unregister(vgicp_ctx* ctx, const void* buffer);
 
@@ -283,11 +292,11 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
  * buffers are free again at once, and the runtime never registers the caller's pages.  (A registered range that the
  * caller frees takes every queue of the process off the device for ~20 ms: the fate of a caller that allocates and
  * frees its clouds per frame, as the reference does.  For the same reason every synchronous entry point of this
- * header moves buffers of 0.5 - 16 MB -- and the scan of a vgicp_align up to 4 MB, VGICP_UPLOAD_STAGE_LIMIT -- through
- * a page-locked arena of the context; page-locked buffers, vgicp_host_register, go directly.)  A LARGER
- * sweep is read straight from `points` / `point_time`, which then must stay valid and unchanged until the next call
- * that synchronises (vgicp_align_resident, vgicp_scan_info, ...).  `states` and `extrinsic` are always copied before
- * the call returns.  At most 16 000 IMU states may fall inside one sweep (VGICP_ERR_BAD_ARGUMENT beyond; vgicp_deskew
+ * header moves buffers of 0.5 - 16 MB through a page-locked arena of the context, and vgicp_align stages its scan;
+ * page-locked buffers, vgicp_host_register, go directly.)  A LARGER
+ * sweep is handed to the runtime in place and the call waits for those copies (not for the kernels behind them), so
+ * `points` / `point_time` are free again on return whatever the size.  `states` and `extrinsic` are always copied
+ * before the call returns.  At most 16 000 IMU states may fall inside one sweep (VGICP_ERR_BAD_ARGUMENT beyond; vgicp_deskew
  * has no such limit). */
 int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time,
                              size_t num_states, const double* states, const double extrinsic[16],
@@ -313,10 +322,10 @@ typedef struct vgicp_frame_stats {
 } vgicp_frame_stats;
 int vgicp_get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset);
 #define VGICP_OPTION_STAGE_EVENTS 1
-/* value = KiB: scans of up to this size handed to vgicp_align / vgicp_scan_upload are copied through page-locked
- * memory of the context instead of being registered with the driver in place (default 4096 = 42 k points, at most
- * 16384; VGICP_UPLOAD_STAGE_LIMIT=bytes in the environment sets the default).  Raise it when scans of that size live
- * in buffers that are freed per frame: freeing a registered buffer stalls every queue of the process for ~20 ms. */
+/* value = KiB: scans of up to this size handed to vgicp_align / vgicp_scan_upload are staged through page-locked
+ * memory of the context by the copy threads (see vgicp_align; default 524288 = 512 MB;
+ * VGICP_UPLOAD_STAGE_LIMIT=bytes in the environment sets the default).  0: every scan is handed to the runtime in
+ * place, which registers the caller's pages with the driver — for callers that never free those buffers. */
 #define VGICP_OPTION_UPLOAD_STAGE_KB 2
 int vgicp_set_option(vgicp_ctx* ctx, int option, int value);
 
