@@ -808,6 +808,11 @@ int vgicp_destroy(vgicp_ctx* ctx) {
                      o == 8 ? "solver wave" : "first worker lane", (unsigned long long)h[o + 5], h[o] * k, h[o + 1] * k,
                      h[o + 2] * k, h[o + 3] * k);
       }
+      const double kf = 0.01 / (double)h[13];
+      std::fprintf(stderr, "[vgicp stamps] inside solve+broadcast (solver wave of workgroup 0): re-arm + totals through LDS to registers "
+                   "%.3f us, LDL^T %.3f us, exponential + compose + test %.3f us, pose to LDS (+ state, workgroup 0) %.3f us, the rest "
+                   "(barrier, pose read by every wave) %.3f us\n", h[24] * kf, h[25] * kf, h[26] * kf, h[27] * kf,
+                   (h[11] - h[24] - h[25] - h[26] - h[27]) * kf);
     }
     uint64_t wg[kExchangeRows];
     if (h[13] > 0 && hipMemcpy(wg, ctx->d_stamps + 32, sizeof wg, hipMemcpyDeviceToHost) == hipSuccess) {

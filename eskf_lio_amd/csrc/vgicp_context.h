@@ -5,6 +5,8 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -122,6 +124,9 @@ struct CopyCrew {
       for (int spins = 0; spins < 40000 && !have; ++spins) {   // ~1 ms
         have = gen.load(std::memory_order_acquire) != seen;
         if (!have) __builtin_ia32_pause();
+        // should the scheduler have put this thread on the CPU of one that has work to do (a wake-up lands on the
+        // waker's CPU): let it run.  Costs a fraction of a microsecond when nobody else wants this CPU.
+        if (!have && (spins & 1023) == 1023) sched_yield();
       }
       if (!have) {
         std::unique_lock<std::mutex> lk(m);
@@ -150,8 +155,14 @@ struct CopyCrew {
     }
     return job;
   }
+  // Wait for the units other threads took.  A helper that was woken for this job may sit on THIS thread's CPU (a
+  // wake-up lands on the waker's CPU) with a unit half copied: spinning here would keep it off the CPU for a whole
+  // scheduler slice (3 ms steps were measured); after a short spin the CPU is offered to whoever else wants it.
   void finish() const {
-    while (finished.load(std::memory_order_acquire) < units) __builtin_ia32_pause();
+    for (uint32_t spins = 0; finished.load(std::memory_order_acquire) < units; ++spins) {
+      if (spins < 512) __builtin_ia32_pause();
+      else sched_yield();
+    }
   }
   void stop() {
     {

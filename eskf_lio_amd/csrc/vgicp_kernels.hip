@@ -99,10 +99,15 @@ __device__ __forceinline__ void fold_swap(double (&v)[kSlots]) {
 // natural-order LDL^T, 1 / angle), where a last-bit difference is below the solve's own rounding.
 __device__ __forceinline__ double rcp_newton(double d) {
   double y = __builtin_amdgcn_rcp(d);
+#if defined(VGICP_RCP_CUBIC)   // developer A/B: one third-order step, 3 dependent operations instead of 4
+  const double e = fma(-d, y, 1.0);
+  return fma(y, fma(e, e, e), y);
+#else
   double e = fma(-d, y, 1.0);
   y = fma(y, e, y);
   e = fma(-d, y, 1.0);
   return fma(y, e, y);
+#endif
 }
 
 // Fallback of the 6x6 solve: vgicp_math.h's ldlt6_solve — Eigen's pivoted LDLT with pseudo-inverted D, the
@@ -203,7 +208,7 @@ __device__ __forceinline__ bool ldlt6_solve_spd(const double (&A)[21], const dou
 
 // se(3) exponential as vgicp_math.h's se3_exp (reference src/Utils.cpp:28-32,40-63) with the sine
 // and cosine of the one angle taken from a single sincos call.
-__device__ __forceinline__ void se3_exp_device(const double* xi, Pose& T) {
+__device__ __forceinline__ void se3_exp_angle(const double* xi, Pose& T) {
   const double* r = xi + 3;
   const double n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   const double angle = sqrt(n2);
@@ -236,6 +241,52 @@ __device__ __forceinline__ void se3_exp_device(const double* xi, Pose& T) {
   J[1] += f2 * k[2];  J[7] += -f2 * k[0];
   J[2] += -f2 * k[1]; J[5] += f2 * k[0];
   mat3_vec(J, xi, T.t);
+}
+
+// The same map for the steps Gauss-Newton actually takes (|phi| <= 0.5 rad), written in phi itself instead of
+// (angle, axis): with n2 = |phi|^2,
+//   A = sin a / a = 1 - n2 C,   B = (1 - cos a) / a^2,   C = (a - sin a) / a^3      (power series in n2)
+//   R = (1 - n2 B) I + B phi phi^T + A [phi]x              (= cos a I + (1 - cos a) k k^T + sin a [k]x, reference src/Utils.cpp:28-32)
+//   t = A rho + C phi (phi . rho) + B (phi x rho)          (= J_l(phi) rho, reference src/Utils.cpp:40-54)
+// No square root, no reciprocal, no normalisation and no sine / cosine on the round's serial chain: the two series in
+// Estrin form are 4 dependent operations deep after n2 (the angle-axis form: sqrt ~10, Taylor sincos 10, rcp 5, products
+// 4).  Truncation < 1e-17 relative at |phi| = 0.5; the results agree with the angle-axis form to rounding (~1e-16), not bit for bit.
+// The reference's branch "angle < 1e-6 -> t = rho" is kept: kSmallAngle2 is the smallest double whose square root rounds
+// to >= 1e-6 (tests/test_capi_cpu.py checks the constant against sqrt).
+constexpr double kSmallAngle2 = 0x1.19799812dea10p-40;   // 9.999999999999998e-13
+__device__ __forceinline__ void se3_exp_device(const double* xi, Pose& T) {
+  const double px = xi[0], py = xi[1], pz = xi[2], rx = xi[3], ry = xi[4], rz = xi[5];
+  const double n2 = rx * rx + ry * ry + rz * rz;
+#if defined(VGICP_EXP_ANGLE_AXIS)   // developer A/B (tools/ab_build.sh): the angle-axis form for every step
+  if (true) {
+#else
+  if (n2 > 0.25) {  // uniform on the solver wave
+#endif
+    se3_exp_angle(xi, T);
+    return;
+  }
+  const double z2 = n2 * n2, z4 = z2 * z2;
+  // B = sum (-1)^k n2^k / (2k + 2)!,  C = sum (-1)^k n2^k / (2k + 3)!,  k = 0 .. 7
+  const double b01 = fma(n2, -1.0 / 24.0, 0.5), b23 = fma(n2, -1.0 / 40320.0, 1.0 / 720.0);
+  const double b45 = fma(n2, -1.0 / 479001600.0, 1.0 / 3628800.0), b67 = fma(n2, -1.0 / 20922789888000.0, 1.0 / 87178291200.0);
+  const double c01 = fma(n2, -1.0 / 120.0, 1.0 / 6.0), c23 = fma(n2, -1.0 / 362880.0, 1.0 / 5040.0);
+  const double c45 = fma(n2, -1.0 / 6227020800.0, 1.0 / 39916800.0), c67 = fma(n2, -1.0 / 355687428096000.0, 1.0 / 1307674368000.0);
+  const double B = fma(z4, fma(z2, b67, b45), fma(z2, b23, b01));
+  const double C = fma(z4, fma(z2, c67, c45), fma(z2, c23, c01));
+  const double A = fma(-n2, C, 1.0), c = fma(-n2, B, 1.0);
+  const double bx = B * rx, by = B * ry, bz = B * rz, ax = A * rx, ay = A * ry, az = A * rz;
+  T.R[0] = fma(bx, rx, c); T.R[4] = fma(by, ry, c); T.R[8] = fma(bz, rz, c);
+  T.R[3] = fma(bx, ry, -az); T.R[1] = fma(bx, ry, az);
+  T.R[6] = fma(bx, rz, ay);  T.R[2] = fma(bx, rz, -ay);
+  T.R[7] = fma(by, rz, -ax); T.R[5] = fma(by, rz, ax);
+  if (n2 < kSmallAngle2) {
+    T.t[0] = px; T.t[1] = py; T.t[2] = pz;
+    return;
+  }
+  const double cd = C * (rx * px + ry * py + rz * pz);
+  T.t[0] = fma(A, px, fma(cd, rx, B * (ry * pz - rz * py)));
+  T.t[1] = fma(A, py, fma(cd, ry, B * (rz * px - rx * pz)));
+  T.t[2] = fma(A, pz, fma(cd, rz, B * (rx * py - ry * px)));
 }
 
 // Fixed-shape pairwise sum of N values: (first half) + (second half), recursively.  The order every fold of the
@@ -728,6 +779,17 @@ __device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, u
   return true;
 }
 
+// STAMPS builds only: a clock reading that cannot move across the values it is given (they pass through an empty asm)
+template <int N>
+__device__ __forceinline__ uint64_t pinned_clock(double (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(x[k]));
+  const uint64_t t = wall_clock64();
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(x[k]));
+  return t;
+}
+
 constexpr uint32_t kMemoMiss = 0xFFFFFFFFu;  // memo.w of a point whose voxel is not in the map
 constexpr uint32_t kMemoNone = 0xFFFFFFFEu;  // nothing looked up
 
@@ -829,6 +891,8 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
 
   uint64_t t_mark = STAMPS ? wall_clock64() : 0;
   uint64_t acc_body = 0, acc_l1 = 0, acc_l2 = 0, acc_solve = 0;
+  uint64_t fine[4] = {0, 0, 0, 0};   // STAMPS: inside "solve + broadcast": totals to registers, LDL^T, exp + compose, publication
+  bool conv_keep = false;            // wave 0: the last round's convergence verdict, for the final state
   int it = 0;
   bool gave_up = false;
   for (;;) {
@@ -1002,7 +1066,7 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
       const uint32_t lane = lane_here;
       // the buffers rotate with a round number that runs on from launch to launch (a.round0: rounds executed on
       // this context before): nothing has to be tidied up when a launch ends
-      const uint32_t buf = (a.round0 + (uint32_t)it) % 3u, rearm = (a.round0 + (uint32_t)it + 2u) % 3u;
+      const uint32_t buf = (a.round0 + (uint32_t)it) % 3u;
       double* rows = a.rows + (size_t)buf * kExchangeRows * kSlots;
       double* parts = a.parts + (size_t)buf * kFolders * kSlots;
       // ---- level 1: publish this workgroup's row (every re-arming store of mine has completed) ----
@@ -1040,29 +1104,18 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
           }
         }
         if (ok) ok = poll_and_sum<true>(a.mail[a.rank] + (size_t)mbuf * kMaxRanks * kSlots, lane, a.spin_limit, tot);
-        // re-arm the mailbox buffer everyone (on every rank) finished with a round ago; the running round
-        // number carries over from launch to launch, so there is no clean-up at the end of a launch
-        if (ok && blk == 0 && lane <= (uint32_t)kCountSlot) {
-          const uint32_t old = (a.mail_round0 + (uint32_t)it + 2u) % 3u;
-          for (uint32_t r = 0; r < a.world; ++r)
-            store_system_bits(a.mail[a.rank] + ((size_t)old * kMaxRanks + r) * kSlots + lane, kRowUnset);
-        }
+        // (the mailbox buffer everyone finished with a round ago is re-armed behind the round's last barrier, with the
+        // rows and parts)
       }
       if (STAMPS) { const uint64_t n = wall_clock64(); acc_l2 += n - t_mark; t_mark = n; }
       if (!ok) {
         if (lane == 0) stop_sh = 2;
       } else {
-        // re-arm what was consumed a round ago. In a launch's first round that is what the launch BEFORE published
-        // last: everyone has published this round, so everyone has left that launch and its reads behind. (Before
-        // the very first round of a context the buffer is unset already; storing "unset" again is harmless.)
-        if (lane <= (uint32_t)kCountSlot) {
-          store_through_bits(a.rows + ((size_t)rearm * kExchangeRows + my_row) * kSlots + lane, kRowUnset);
-          if (folder) store_through_bits(a.parts + ((size_t)rearm * kFolders + blk) * kSlots + lane, kRowUnset);
-        }
-        if (lane < kSlots) {
-          totals[lane] = lane <= (uint32_t)kCountSlot ? tot : 0.0;
-          if (blk == 0) a.log[(size_t)it * kSlots + lane] = lane <= (uint32_t)kCountSlot ? tot : 0.0;
-        }
+        // (what was consumed a round ago is re-armed, and the round's row of the log written, BEHIND the barrier below:
+        // a release fence — the one in front of the LDS hand-over here, the one inside __syncthreads — makes the wave
+        // wait for every store it has in flight, and a write-through store takes its time; this wave's part of the
+        // round is the one everybody waits for)
+        if (lane < kSlots) totals[lane] = lane <= (uint32_t)kCountSlot ? tot : 0.0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1071,30 +1124,51 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
         for (int k = 0; k < 21; ++k) A[k] = totals[k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) g[k] = -totals[21 + k];
+        uint64_t f0 = 0, f1 = 0, f2 = 0;
+        if (STAMPS) { f0 = pinned_clock(A); fine[0] += f0 - t_mark; }
         if (!ldlt6_solve_spd(A, g, xi)) ldlt6_solve_pivoted(totals, work, lane, xi);  // uniform branch
+        if (STAMPS) { f1 = pinned_clock(xi); fine[1] += f1 - f0; }
         Pose next, step;
         se3_exp_device(xi, step);
         pose_compose(step, total, next);
-        const bool conv = converged(step, cos_thr, tsq_thr);
+        conv_keep = converged(step, cos_thr, tsq_thr);
+        if (STAMPS) { f2 = pinned_clock(next.R); fine[2] += f2 - f1; }
         if (lane == 0) {
 #pragma unroll
           for (int k = 0; k < 9; ++k) pose_sh[k] = next.R[k];
 #pragma unroll
           for (int k = 0; k < 3; ++k) pose_sh[9 + k] = next.t[k];
-          stop_sh = (conv || (it + 1 >= max_it)) ? 1 : 0;
-          if (blk == 0) {  // the last increment, for the state the host reads
-#pragma unroll
-            for (int k = 0; k < 9; ++k) a.state->step[k] = step.R[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) a.state->step[9 + k] = step.t[k];
-            a.state->converged = conv ? 1 : 0;
-          }
+          stop_sh = (conv_keep || (it + 1 >= max_it)) ? 1 : 0;
         }
+        if (STAMPS) fine[3] += wall_clock64() - f2;
       }
     }
     __syncthreads();
     const int stop = stop_sh;
     if (stop == 2) { gave_up = true; break; }  // uniform: a workgroup never published (not all resident?)
+    if (wave == 0) {
+      // Off the round's critical path (the other waves are already transforming their points with the new pose): re-arm
+      // what was consumed a round ago.  In a launch's first round that is what the launch BEFORE published last:
+      // everyone has published this round, so everyone has left that launch and its reads behind.  (Before the very
+      // first round of a context the buffer is unset already; storing "unset" again is harmless.)  The stores are
+      // complete long before this wave publishes again (s_waitcnt vmcnt(0) in front of the publication).
+      uint32_t lane_here = tid & 63;
+      asm volatile("" : "+v"(lane_here));
+      const uint32_t rearm = (a.round0 + (uint32_t)it + 2u) % 3u;
+      if (lane_here <= (uint32_t)kCountSlot) {
+        store_through_bits(a.rows + ((size_t)rearm * kExchangeRows + my_row) * kSlots + lane_here, kRowUnset);
+        if (folder) store_through_bits(a.parts + ((size_t)rearm * kFolders + blk) * kSlots + lane_here, kRowUnset);
+      }
+      if (MULTI && blk == 0 && lane_here <= (uint32_t)kCountSlot) {
+        // ... and the mailbox buffer everyone (on every rank) finished with a round ago; the running round number
+        // carries over from launch to launch, so there is no clean-up at the end of a launch
+        const uint32_t old = (a.mail_round0 + (uint32_t)it + 2u) % 3u;
+        for (uint32_t r = 0; r < a.world; ++r)
+          store_system_bits(a.mail[a.rank] + ((size_t)old * kMaxRanks + r) * kSlots + lane_here, kRowUnset);
+      }
+      // the round's row of the log: still in LDS (written again only after the next round's barrier)
+      if (blk == 0 && lane_here < kSlots) a.log[(size_t)it * kSlots + lane_here] = totals[lane_here];
+    }
 #pragma unroll
     for (int k = 0; k < 9; ++k) total.R[k] = pose_sh[k];
 #pragma unroll
@@ -1143,6 +1217,7 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
         out->translation_sq_threshold = tsq_thr;
         out->max_iteration = max_it;
         out->iteration = it;
+        out->converged = conv_keep ? 1 : 0;   // (the last increment itself, AlignState::step, is not reported by this launch)
         out->done = 1;
         out->pad = 0;
         out->seq = a.seq;
@@ -1157,6 +1232,8 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
     atomicAdd((unsigned long long*)&a.stamps[o + 2], (unsigned long long)acc_l2);
     atomicAdd((unsigned long long*)&a.stamps[o + 3], (unsigned long long)acc_solve);
     atomicAdd((unsigned long long*)&a.stamps[o + 5], (unsigned long long)it);
+    if (tid == 0)
+      for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)&a.stamps[24 + k], (unsigned long long)fine[k]);
   }
 }
 

@@ -62,6 +62,8 @@ def load_library() -> C.CDLL:
     lib.host_preprocessor_downsample.argtypes = [vp, sz, dp, dp, dp, C.POINTER(sz)]
     lib.host_math_ldlt6_solve.argtypes = [dp, dp, dp]
     lib.host_math_ldlt6_solve.restype = None
+    lib.host_math_solve6_block3.argtypes = [dp, dp, dp]
+    lib.host_math_solve6_block3.restype = C.c_int
     lib.host_math_se3_exp.argtypes = [dp, dp]
     lib.host_math_se3_exp.restype = None
     _lib = lib
@@ -77,6 +79,16 @@ def math_ldlt6_solve(JTJ, b) -> np.ndarray:
     x = np.zeros(6)
     load_library().host_math_ldlt6_solve(_dp(low), _dp(rhs), _dp(x))
     return x
+
+
+def math_solve6_block3(JTJ, b):
+    """csrc/vgicp_math.h's solve6_spd_block3 (the kernels' fast path) compiled for the host -> (x, accepted)."""
+    A = np.asarray(JTJ, dtype=np.float64).reshape(6, 6)
+    low = np.ascontiguousarray([A[r, c] for r in range(6) for c in range(r + 1)], dtype=np.float64)
+    rhs = np.ascontiguousarray(b, dtype=np.float64).reshape(6)
+    x = np.zeros(6)
+    ok = load_library().host_math_solve6_block3(_dp(low), _dp(rhs), _dp(x))
+    return x, bool(ok)
 
 
 def math_se3_exp(xi) -> np.ndarray:

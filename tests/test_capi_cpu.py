@@ -260,3 +260,17 @@ def test_same_voxel_shortcut_implies_an_unchanged_key():
                         yes += 1
                         assert cand == true_key, (x, h, cand, true_key)
     assert yes > total // 10  # the shortcut does say yes for ordinary points
+
+
+def test_small_angle_threshold_of_the_series_exponential_is_the_references_branch():
+    """se3_exp_device tests n2 < kSmallAngle2 where the reference tests sqrt(n2) < 1e-6 (src/Utils.cpp:47): the constant
+    must be the smallest double whose (correctly rounded) square root reaches 1e-6."""
+    import math
+    import re
+    import struct
+    src = open(os.path.join(ROOT, "eskf_lio_amd", "csrc", "vgicp_kernels.hip")).read()
+    m = re.search(r"constexpr double kSmallAngle2 = (0x[0-9a-fA-F.]+p[-+]?\d+);", src)
+    assert m, "kSmallAngle2 not found"
+    t = float.fromhex(m.group(1))
+    below = struct.unpack("<d", struct.pack("<q", struct.unpack("<q", struct.pack("<d", t))[0] - 1))[0]
+    assert math.sqrt(t) >= 1e-6 and math.sqrt(below) < 1e-6
