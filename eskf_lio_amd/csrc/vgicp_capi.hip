@@ -1307,6 +1307,8 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
     crew->unit = unit;
     crew->units = units;
     crew->seq = ctx->scan_seq;
+    crew->size_a = 3 * sizeof(double);
+    crew->size_b = 9 * sizeof(double);
     crew->copy = stage_copy;
     const double t_post = now_seconds();
     const uint32_t job = crew->post(want_helpers);
@@ -1602,9 +1604,17 @@ struct DeskewOnDevice {
   bool ordered = false;
   uint32_t* ends = nullptr;
 };
+// The raw points of a preparation that are still to be copied into page-locked staging memory (scan_prepare_enqueue):
+// enqueue_prepare launches the kernels that read them, copies (this thread and the crew's helpers), and launches the rest.
+struct StagedPoints {
+  const double* points = nullptr;   // the caller's, n x 3
+  char* stage = nullptr;            // page-locked, n x 24 bytes (+ padding)
+  uint32_t* flags = nullptr;        // one 64-byte line per unit
+  hipEvent_t done = nullptr;        // recorded behind the last kernel that reads the staging memory
+};
 int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, int knn, const double* extrinsic16,
                     const DeskewOnDevice& dk, void* scratch, double* d_out_pts, double* d_out_covs,
-                    unsigned long long* d_out_idx, double* soa, uint64_t soa_stride) {
+                    unsigned long long* d_out_idx, double* soa, uint64_t soa_stride, const StagedPoints* staged = nullptr) {
   const uint64_t entries = preprocess_cell_entries_for((uint32_t)n);
   int rc = ensure_cells(ctx, preprocess_cell_bytes(entries));
   if (rc != VGICP_OK) return rc;
@@ -1638,7 +1648,55 @@ int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, 
   a.debug = debug;
   a.ev_after_prologue = ctx->stage_events ? ctx->ev_stage[6] : nullptr;
   if (ctx->stage_events) ctx->ev_stage_set[6] = true;
-  VG_HIP(ctx, launch_prepare(ctx->stream, a));
+  if (!staged) {
+    VG_HIP(ctx, launch_prepare(ctx->stream, a));
+  } else {
+    // the sweep's points go up without a copy command: the copy threads fill the staging memory unit by unit, the
+    // prologue (launched FIRST) reads the units over PCIe as they are published (see scan_upload_enqueue)
+    static const uint32_t spin_limit = std::getenv("VGICP_PACK_SPIN_LIMIT") ? (uint32_t)std::strtoul(std::getenv("VGICP_PACK_SPIN_LIMIT"), nullptr, 10) : kPackSpinLimit;
+    static const long debug_delay_us = std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US") ? std::atol(std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US")) : 0;
+    if (++ctx->scan_seq == 0) ++ctx->scan_seq;
+    const uint32_t unit = pack_arena_unit();
+    const bool want_helpers = ctx->upload_threads > 1 && n * 3 * sizeof(double) >= (1u << 20);
+    if (!ctx->crew) ctx->crew = new CopyCrew;
+    CopyCrew* crew = ctx->crew;
+    if (want_helpers && crew->th.empty()) crew->start(ctx->upload_threads - 1);
+    crew->pts = reinterpret_cast<const char*>(staged->points);
+    crew->cov = nullptr;
+    crew->apts = staged->stage;
+    crew->acov = nullptr;
+    crew->flags = staged->flags;
+    crew->n = (uint32_t)n;
+    crew->unit = unit;
+    crew->units = (uint32_t)((n + unit - 1) / unit);
+    crew->seq = ctx->scan_seq;
+    crew->size_a = 24;
+    crew->size_b = 0;
+    crew->copy = stage_copy;
+    a.src_points = staged->stage;
+    a.src_flags = staged->flags;
+    a.src_seq = ctx->scan_seq;
+    a.src_unit = unit;
+    a.src_spin = spin_limit;
+    const double t_post = now_seconds();
+    const uint32_t job = crew->post(want_helpers);
+    const hipError_t e_head = launch_prepare_head(ctx->stream, a);
+    if (debug_delay_us > 0 && !want_helpers) std::this_thread::sleep_for(std::chrono::microseconds(debug_delay_us));
+    crew->work(job);
+    crew->finish();   // always: the caller's buffer is free again on return
+    if (e_head != hipSuccess) return fail_hip(ctx, e_head, "launch_prepare_head");
+    if (now_seconds() - t_post > kCrewSlowSeconds) {
+      // the copy threads were held up so long that a workgroup of the prologue may have stopped waiting (and said so in
+      // the counter block under this epoch): everything is staged now — the head once more, nothing to wait for
+      ++ctx->upload_slow;
+      if (++ctx->prep_epoch == 0) ++ctx->prep_epoch;
+      a.epoch = ctx->prep_epoch;
+      a.src_flags = nullptr;
+      VG_HIP(ctx, launch_prepare_head(ctx->stream, a));
+    }
+    if (staged->done) VG_HIP(ctx, hipEventRecord(staged->done, ctx->stream));
+    VG_HIP(ctx, launch_prepare_tail(ctx->stream, a));
+  }
   VG_HIP(ctx, hipMemcpyAsync(ctx->h_prep, ctx->d_counters, (kCounterWords + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   if (ctx->insert_pending && !ctx->ins_copy_enqueued) {   // the deferred insertion's totals travel with this copy
     ctx->ins_copy_enqueued = true;
@@ -2002,38 +2060,45 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   const size_t raw_bytes = n * 3 * sizeof(double) + (with_deskew ? n * sizeof(double) : 0);
   static const size_t stage_limit = std::getenv("VGICP_STAGE_LIMIT") ? (size_t)std::atoll(std::getenv("VGICP_STAGE_LIMIT")) : (16u << 20);
   const bool staged = raw_bytes <= stage_limit;   // larger sweeps go up straight from the caller's memory
-  const double* src_points = points;
-  const double* src_time = point_time;
-  (void)src_points;
+  const bool walk = with_deskew && !(ordered && used <= kDeskewMaxStates);   // the serial bounds walk reads the times many times over: on the device
+  StagedPoints sp;
+  const double* time_src = nullptr;   // where the deskew's first kernel reads the capture times
   if (staged) {
-    if (ctx->raw_stage_cap[slot] < raw_bytes) {
+    // slot layout: [unit flags][points, padded][capture times]
+    const size_t pts_bytes = n * 3 * sizeof(double);
+    const size_t flag_bytes = ((n + pack_arena_unit() - 1) / pack_arena_unit() + 1) * 64;
+    const size_t pts_room = (pts_bytes + 16 + 255) & ~size_t(255);
+    if (ctx->raw_stage_cap[slot] < flag_bytes + pts_room + n * sizeof(double)) {
       if (ctx->h_raw_stage[slot]) VG_HIP(ctx, hipHostFree(ctx->h_raw_stage[slot]));
       ctx->h_raw_stage[slot] = nullptr;
       ctx->raw_stage_cap[slot] = 0;
-      const size_t cap = n * 4 * sizeof(double) + n * sizeof(double);   // room for the capture times whether or not this sweep has them, and a quarter more
+      const size_t cap = (flag_bytes + pts_room + n * sizeof(double)) * 5 / 4 + 4096;   // a quarter more
       VG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_raw_stage[slot]), cap, 0));
+      std::memset(ctx->h_raw_stage[slot], 0, cap);   // flags of "no sweep yet" (a sequence number is never 0)
       ctx->raw_stage_cap[slot] = cap;
     }
-    // in pieces, each piece on its way to the device while the CPU copies the next one: the device would otherwise
-    // idle for the whole host copy (the frame is device-bound; the stage span showed 45 us of it)
     char* stage = ctx->h_raw_stage[slot];
-    const size_t pts_bytes = n * 3 * sizeof(double), piece = 384u << 10;
-    for (size_t off = 0; off < pts_bytes; off += piece) {
-      const size_t len = std::min(piece, pts_bytes - off);
-      stage_copy(stage + off, reinterpret_cast<const char*>(points) + off, len);
-      VG_HIP(ctx, hipMemcpyAsync(reinterpret_cast<char*>(d_pts) + off, stage + off, len, hipMemcpyHostToDevice, ctx->stream));
-    }
+    // a flag only ever means "this unit of THIS sweep": the flag area moves with the sweep's size, so it is wiped
+    std::memset(stage, 0, flag_bytes);
+    sp.points = points;
+    sp.flags = reinterpret_cast<uint32_t*>(stage);
+    sp.stage = stage + flag_bytes;
+    sp.done = ctx->ev_state_table[slot];
     if (with_deskew) {
-      stage_copy(stage + pts_bytes, point_time, n * sizeof(double));
-      src_time = reinterpret_cast<const double*>(stage + pts_bytes);
+      // the capture times first (a sixth of the bytes): the deskew's bounds need nothing else, and its kernel reads them
+      // where they are staged
+      double* times_stage = reinterpret_cast<double*>(stage + flag_bytes + pts_room);
+      stage_copy(times_stage, point_time, n * sizeof(double));
+      time_src = times_stage;
+      if (walk) VG_HIP(ctx, hipMemcpyAsync(d_time, times_stage, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     }
   } else {
-    VG_HIP(ctx, hipMemcpyAsync(d_pts, src_points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VG_HIP(ctx, hipMemcpyAsync(d_pts, points, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (with_deskew) VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   }
   const double tr1 = trace ? now_seconds() : 0.0;
   DeskewOnDevice dk;
   if (with_deskew) {
-    VG_HIP(ctx, hipMemcpyAsync(d_time, src_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (ctx->state_table_cap[slot] < used * 13) {
       if (ctx->h_state_table[slot]) VG_HIP(ctx, hipHostFree(ctx->h_state_table[slot]));
       ctx->h_state_table[slot] = nullptr;
@@ -2044,20 +2109,23 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     }
     std::memcpy(ctx->h_state_table[slot], host.data(), used * 13 * sizeof(double));
     VG_HIP(ctx, hipMemcpyAsync(d_states, ctx->h_state_table[slot], used * 13 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    dk.point_time = d_time;
+    dk.point_time = (staged && !walk) ? time_src : d_time;
     dk.state_time = d_states;
     dk.poses = d_states + used;
     dk.states = (uint32_t)used;
     dk.ordered = ordered;
     dk.ends = reinterpret_cast<uint32_t*>(base + pb + tb + sb);
   }
-  VG_HIP(ctx, hipEventRecord(ctx->ev_state_table[slot], ctx->stream));   // behind the last copy out of this slot's pinned buffers
-  // a sweep too large to stage was handed to the runtime in place: its copies have to be over before the call returns,
-  // because the caller's buffers are free again on return whatever the size (the drop-in releases the capture times at once)
-  if (!staged) VG_HIP(ctx, hipEventSynchronize(ctx->ev_state_table[slot]));
+  if (!staged) {
+    VG_HIP(ctx, hipEventRecord(ctx->ev_state_table[slot], ctx->stream));   // behind the last copy out of this slot's pinned buffers
+    // a sweep too large to stage was handed to the runtime in place: its copies have to be over before the call returns,
+    // because the caller's buffers are free again on return whatever the size (the drop-in releases the capture times at once)
+    VG_HIP(ctx, hipEventSynchronize(ctx->ev_state_table[slot]));
+  }
   const double tr2 = trace ? now_seconds() : 0.0;
+  // (staged: the slot's event is recorded inside, behind the kernels that read the staging memory)
   rc = enqueue_prepare(ctx, d_pts, n, voxel_size, knn, extrinsic, dk, scratch, ctx->d_scan_aos,
-                       ctx->d_scan_aos + 3 * ctx->scan_capacity, d_idx, ctx->d_scan, ctx->stride);
+                       ctx->d_scan_aos + 3 * ctx->scan_capacity, d_idx, ctx->d_scan, ctx->stride, staged ? &sp : nullptr);
   if (rc != VGICP_OK) return rc;
   if (trace)
     std::fprintf(stderr, "[vgicp trace] prepare enqueue: staging + points copy %.3f ms, times + states copies %.3f ms, kernels %.3f ms\n",

@@ -101,6 +101,7 @@ struct CopyCrew {
   char* acov = nullptr;
   uint32_t* flags = nullptr;
   uint32_t n = 0, unit = 0, units = 0, seq = 0;
+  uint32_t size_a = 24, size_b = 72;   // bytes per point of the two arrays (size_b = 0: one array only)
   void (*copy)(void*, const void*, size_t) = nullptr;
 
   void work(uint32_t my_job) {
@@ -110,8 +111,8 @@ struct CopyCrew {
       const uint32_t u = (uint32_t)v;
       if (u >= units) return;
       const size_t p0 = (size_t)u * unit, cnt = std::min<size_t>(unit, n - p0);
-      copy(apts + p0 * 24, pts + p0 * 24, cnt * 24);
-      copy(acov + p0 * 72, cov + p0 * 72, cnt * 72);
+      copy(apts + p0 * size_a, pts + p0 * size_a, cnt * size_a);
+      if (size_b) copy(acov + p0 * size_b, cov + p0 * size_b, cnt * size_b);
       // the unit's bytes (streaming stores, fenced by `copy`) are globally visible before its flag
       __atomic_store_n(flags + 16 * (size_t)u, seq, __ATOMIC_RELEASE);
       finished.fetch_add(1, std::memory_order_release);

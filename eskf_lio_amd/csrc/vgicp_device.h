@@ -231,6 +231,7 @@ constexpr int kTicketA = 76;
 constexpr int kTicketB = 77;
 constexpr int kHeavyQueries = 78;
 constexpr int kLightQueries = 79;
+constexpr uint32_t kDeskewMaxStates = 4096;   // the parallel deskew bounds keep 12 bytes per state in LDS; longer (or unordered) queues take the serial walk
 constexpr uint32_t kPrepareMaxStates = 16000;  // IMU states that can own points of ONE sweep in the fused preparation (LDS)
 constexpr uint32_t kMaxScanTiles = 4096;  // x 2 048 points: scans up to 8 M points
 size_t preprocess_scratch_bytes(uint32_t n);
@@ -270,8 +271,22 @@ struct PrepareArgs {
   uint32_t epoch;
   int debug;
   hipEvent_t ev_after_prologue;  // optional: recorded behind the prologue (extrinsic + deskew + codes)
+  // The raw points may still be ARRIVING in page-locked host memory (the frame chain's upload without copy commands, as
+  // pack_arena_kernel does it for vgicp_align): src_points != nullptr = n x 24 bytes of staging memory that host threads
+  // fill in units of src_unit points (a multiple of 256), publishing unit u by storing src_seq into src_flags[16 * u];
+  // the prologue then reads its points from there (a unit's workgroups wait for its flag, at most src_spin polls; a
+  // wait that runs out is reported like a scan's: counters[kScanTimeout] = epoch) and writes them to `pts`.
+  // src_flags == nullptr with src_points set: everything is staged already.
+  const char* src_points;
+  const uint32_t* src_flags;
+  uint32_t src_seq, src_unit, src_spin;
 };
-hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a);
+hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a);        // = head + tail
+// head: the kernels that read the raw sweep (deskew bounds from the times, prologue); tail: everything behind them.
+// A host that stages the sweep itself launches the head, finishes staging and launches the tail, so that the device
+// reads the first units while the later ones are still being copied.
+hipError_t launch_prepare_head(hipStream_t s, const PrepareArgs& a);
+hipError_t launch_prepare_tail(hipStream_t s, const PrepareArgs& a);
 uint64_t preprocess_cell_entries_for(uint32_t n);  // from the number of points alone (no host round trip)
 // kernels enqueued by the launchers of this module since the counter was last reset (per host thread)
 extern thread_local uint64_t g_kernel_launches;

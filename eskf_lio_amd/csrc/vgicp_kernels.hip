@@ -94,19 +94,20 @@ __device__ __forceinline__ void fold_swap(double (&v)[kSlots]) {
   }
 }
 
-// 1 / d for a normal, finite d by v_rcp_f64 + two Newton steps (FMA): ~1 ulp, a third of the dependent
-// instructions of the correctly rounded division.  Only on the solver wave's serial chain (pivots of the
-// natural-order LDL^T, 1 / angle), where a last-bit difference is below the solve's own rounding.
+// 1 / d for a normal, finite d by v_rcp_f64 (good to 2^-24) + ONE third-order step y (1 + e + e^2), e = 1 - d y: three
+// dependent FMAs, error 2^-72 before the last rounding — the correctly rounded quotient for all of 4 M random
+// arguments (tools/micro/rcp_accuracy.hip), as the two Newton steps of rounds 1-4 were, with one instruction less on
+// the chain; a quarter of the dependent instructions of the IEEE division.
 __device__ __forceinline__ double rcp_newton(double d) {
-  double y = __builtin_amdgcn_rcp(d);
-#if defined(VGICP_RCP_CUBIC)   // developer A/B: one third-order step, 3 dependent operations instead of 4
+  const double y = __builtin_amdgcn_rcp(d);
+#if defined(VGICP_RCP_TWO_STEPS)   // developer A/B: two second-order steps (what rounds 1-4 shipped): 4 dependent operations
+  double e = fma(-d, y, 1.0);
+  const double y1 = fma(y, e, y);
+  e = fma(-d, y1, 1.0);
+  return fma(y1, e, y1);
+#else
   const double e = fma(-d, y, 1.0);
   return fma(y, fma(e, e, e), y);
-#else
-  double e = fma(-d, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-d, y, 1.0);
-  return fma(y, e, y);
 #endif
 }
 

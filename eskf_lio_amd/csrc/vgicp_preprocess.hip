@@ -147,12 +147,48 @@ struct PrologueArgs {
   uint32_t epoch;
   unsigned long long* table;  // CellEntry[entries] as 16-byte pairs
   unsigned long long entries;
+  const char* src;            // nullptr, or the raw points in page-locked HOST memory (PrepareArgs::src_points)
+  const uint32_t* src_flags;
+  uint32_t src_seq, src_unit, src_spin;
 };
 __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char prologue_lds[];
   uint32_t* ends_sh = reinterpret_cast<uint32_t*>(prologue_lds);
   __shared__ uint32_t last_found;
+  __shared__ __attribute__((aligned(16))) double staged[3 * 256];
+  __shared__ uint32_t staged_ok;
   const uint32_t tid = threadIdx.x;
+  if (a.src) {
+    // this block's 256 points out of the staging memory: wait for their unit (one lane polls over PCIe), then 16-byte
+    // loads of consecutive lanes (every 64-byte request of the link is used whole), handed out through LDS
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const uint32_t p0 = blockIdx.x * 256u;
+    if (a.src_flags && p0 < a.n) {
+      if (tid == 0) {
+        const uint32_t* flag = a.src_flags + 16 * (size_t)(p0 / a.src_unit);
+        uint32_t good = 1;
+        for (uint32_t spins = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.src_seq; ++spins) {
+          if (spins >= a.src_spin) { good = 0; break; }
+          __builtin_amdgcn_s_sleep(20);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        staged_ok = good;
+      }
+      __syncthreads();
+      if (!staged_ok) {   // uniform: the host's copy threads never delivered; reported like a scan that gave up
+        if (tid == 0) a.counters[kScanTimeout] = a.epoch;
+        return;
+      }
+    }
+    if (p0 < a.n) {
+      const uint32_t cnt = a.n - p0 < 256u ? a.n - p0 : 256u;
+      const v4i* sp = reinterpret_cast<const v4i*>(a.src + (size_t)p0 * 24);
+      v4i* lp = reinterpret_cast<v4i*>(staged);
+      const uint32_t chunks = (cnt * 24u + 15u) / 16u;   // an odd count: half a chunk more (the staging memory is padded)
+      for (uint32_t c = tid; c < chunks; c += 256u) lp[c] = __builtin_nontemporal_load(sp + c);
+    }
+    __syncthreads();
+  }
   if (a.states) {
     if (a.parts) {
       if (tid == 0) last_found = 0u;
@@ -195,8 +231,13 @@ __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
   }
   const uint32_t i = blockIdx.x * blockDim.x + tid;
   if (i >= a.n) return;
-  double x = a.pts[3 * (size_t)i], y = a.pts[3 * (size_t)i + 1], z = a.pts[3 * (size_t)i + 2];
-  bool moved = false;
+  double x, y, z;
+  bool moved = a.src != nullptr;   // points that came from the host are written to the device whether or not they move
+  if (a.src) {
+    x = staged[3 * tid]; y = staged[3 * tid + 1]; z = staged[3 * tid + 2];
+  } else {
+    x = a.pts[3 * (size_t)i]; y = a.pts[3 * (size_t)i + 1]; z = a.pts[3 * (size_t)i + 2];
+  }
   if (a.has_T) {
     double q[4];
 #pragma unroll
@@ -1311,7 +1352,6 @@ __global__ __launch_bounds__(kBoundsBlock) void deskew_bounds_kernel(const doubl
 // second small kernel takes the minimum over the blocks. 163 us -> two launches of a few us per 60k-point sweep.
 constexpr uint32_t kDeskewParts = 512;      // at most this many blocks share the scan (one load per thread: the loop is a chain)
 constexpr uint32_t kProloguePartsMax = 64;  // ... and this many when every workgroup of the prologue merges them for itself
-constexpr uint32_t kDeskewMaxStates = 4096; // LDS: 12 bytes per state; longer queues take the walk
 constexpr int kFirstHitBlock = 1024;   // a block covers its ~1 000 points in ONE pass: the loop over passes is a chain of trips to memory (256 threads: 9.6 us per 60k-point sweep)
 __global__ __launch_bounds__(kFirstHitBlock) void deskew_first_hit_kernel(const double* __restrict__ point_time, uint32_t n,
                                                                const double* __restrict__ state_time, uint32_t states,
@@ -1474,24 +1514,53 @@ uint32_t merge_sort_launches(uint32_t n) {
 }  // namespace
 
 hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a) {
+  const hipError_t e = launch_prepare_head(s, a);
+  return e != hipSuccess ? e : launch_prepare_tail(s, a);
+}
+
+namespace {
+struct PrepareBuffers {
+  unsigned long long *codes_in, *codes_out;
+  uint32_t *idx_in, *idx_out, *keep_i, *rank_i, *queries, *nbr;
+  double* spts;
+  CellEntry* table;
+  uint32_t mask;
+  TileSlot* tiles_a;
+  unsigned long long* tiles_b;
+  char* cub;
+  size_t cub_bytes;
+};
+PrepareBuffers prepare_buffers(const PrepareArgs& a) {
+  const Layout L = layout_for(a.n);
+  char* b = static_cast<char*>(a.scratch);
+  PrepareBuffers B;
+  B.codes_in = reinterpret_cast<unsigned long long*>(b + L.codes_in);
+  B.codes_out = reinterpret_cast<unsigned long long*>(b + L.codes_out);
+  B.idx_in = reinterpret_cast<uint32_t*>(b + L.idx_in);
+  B.idx_out = reinterpret_cast<uint32_t*>(b + L.idx_out);
+  B.spts = reinterpret_cast<double*>(b + L.spts);
+  B.keep_i = reinterpret_cast<uint32_t*>(b + L.keep_i);
+  B.rank_i = reinterpret_cast<uint32_t*>(b + L.rank_i);
+  B.queries = reinterpret_cast<uint32_t*>(b + L.queries);
+  B.nbr = reinterpret_cast<uint32_t*>(b + L.nbr);
+  B.table = static_cast<CellEntry*>(a.cell_table);
+  B.mask = (uint32_t)(a.table_entries - 1);
+  B.tiles_a = static_cast<TileSlot*>(a.tiles);
+  B.tiles_b = reinterpret_cast<unsigned long long*>(static_cast<char*>(a.tiles) + (size_t)kMaxScanTiles * sizeof(TileSlot));
+  B.cub = b + L.cub;
+  B.cub_bytes = L.cub_bytes;
+  return B;
+}
+}  // namespace
+
+hipError_t launch_prepare_head(hipStream_t s, const PrepareArgs& a) {
   const uint32_t n = a.n;
   if (n == 0) return hipSuccess;
   if ((uint64_t)blocks_for(n, kScanTile) > kMaxScanTiles) return hipErrorInvalidValue;
-  const Layout L = layout_for(n);
-  char* b = static_cast<char*>(a.scratch);
-  auto* codes_in = reinterpret_cast<unsigned long long*>(b + L.codes_in);
-  auto* codes_out = reinterpret_cast<unsigned long long*>(b + L.codes_out);
-  auto* idx_in = reinterpret_cast<uint32_t*>(b + L.idx_in);
-  auto* idx_out = reinterpret_cast<uint32_t*>(b + L.idx_out);
-  auto* spts = reinterpret_cast<double*>(b + L.spts);
-  auto* keep_i = reinterpret_cast<uint32_t*>(b + L.keep_i);
-  auto* rank_i = reinterpret_cast<uint32_t*>(b + L.rank_i);
-  auto* queries = reinterpret_cast<uint32_t*>(b + L.queries);
-  auto* nbr = reinterpret_cast<uint32_t*>(b + L.nbr);
-  auto* table = static_cast<CellEntry*>(a.cell_table);
-  const uint32_t mask = (uint32_t)(a.table_entries - 1);
-  auto* tiles_a = static_cast<TileSlot*>(a.tiles);
-  auto* tiles_b = reinterpret_cast<unsigned long long*>(static_cast<char*>(a.tiles) + (size_t)kMaxScanTiles * sizeof(TileSlot));
+  const PrepareBuffers B = prepare_buffers(a);
+  unsigned long long* codes_in = B.codes_in;
+  uint32_t *idx_in = B.idx_in, *keep_i = B.keep_i;
+  CellEntry* table = B.table;
 
   // ---- deskew bounds (times only), then the prologue: extrinsic + deskew + codes + clears ----
   PrologueArgs pa;
@@ -1530,16 +1599,35 @@ hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a) {
   pa.epoch = a.epoch;
   pa.table = reinterpret_cast<unsigned long long*>(table);
   pa.entries = a.table_entries;
+  pa.src = a.src_points;
+  pa.src_flags = a.src_flags;
+  pa.src_seq = a.src_seq;
+  pa.src_unit = a.src_unit ? a.src_unit : 256u;
+  pa.src_spin = a.src_spin;
   hipLaunchKernelGGL(sweep_prologue_kernel, dim3(blocks_for(n, 256)), dim3(256), (size_t)a.states * sizeof(uint32_t), s, pa);
   ++g_kernel_launches;
   if (a.ev_after_prologue) {
     const hipError_t ee = hipEventRecord(a.ev_after_prologue, s);
     if (ee != hipSuccess) return ee;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_prepare_tail(hipStream_t s, const PrepareArgs& a) {
+  const uint32_t n = a.n;
+  if (n == 0) return hipSuccess;
+  const PrepareBuffers B = prepare_buffers(a);
+  unsigned long long *codes_in = B.codes_in, *codes_out = B.codes_out;
+  uint32_t *idx_in = B.idx_in, *idx_out = B.idx_out, *keep_i = B.keep_i, *rank_i = B.rank_i, *queries = B.queries, *nbr = B.nbr;
+  double* spts = B.spts;
+  CellEntry* table = B.table;
+  const uint32_t mask = B.mask;
+  TileSlot* tiles_a = B.tiles_a;
+  unsigned long long* tiles_b = B.tiles_b;
 
   // ---- the one sort ----
-  size_t cub_bytes = L.cub_bytes;
-  hipError_t e = sort_codes(b + L.cub, cub_bytes, codes_in, codes_out, idx_in, idx_out, n, s);
+  size_t cub_bytes = B.cub_bytes;
+  hipError_t e = sort_codes(B.cub, cub_bytes, codes_in, codes_out, idx_in, idx_out, n, s);
   if (e != hipSuccess) return e;
   g_kernel_launches += merge_sort_launches(n);
 
