@@ -199,7 +199,10 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
         return np.ascontiguousarray(pts @ Tinv[:3, :3].T + Tinv[:3, 3])
     sweeps = [sweep(f) for f in range(frames + 1)]
 
-    def run(ctx, record=None):
+    def run(ctx, record=None, on_arrival=False):
+        """on_arrival: every sweep is handed over when it 'arrives' (vgicp_sweep_stage, right after the previous frame's
+        preparation was enqueued: where a lidar callback's thread would be copying beside the device's work) and prepared
+        from its ticket; else vgicp_scan_prepare_async copies it first."""
         ctx.map_reset(h, 400_000)
         ctx.scan_prepare_async(sweeps[0], tt, st, ext, h, knn)
         if record is not None:
@@ -207,10 +210,16 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
         ctx.map_insert_resident_async(np.eye(4), cap)
         ctx.map_size()
         pose, results = np.eye(4), []
+        ticket = ctx.sweep_stage(sweeps[1], tt) if on_arrival else 0
         ctx.frame_stats(reset=True)
         t0 = time.perf_counter()
         for f in range(1, frames + 1):
-            ctx.scan_prepare_async(sweeps[f], tt, st, ext, h, knn)
+            if on_arrival:
+                ctx.scan_prepare_staged_async(ticket, st, ext, h, knn)
+                if f < frames:
+                    ticket = ctx.sweep_stage(sweeps[f + 1], tt)
+            else:
+                ctx.scan_prepare_async(sweeps[f], tt, st, ext, h, knn)
             r = ctx.align_resident(pose, 30, 1e-6, 0.9999)
             pose = r.pose
             if record is not None:
@@ -229,8 +238,17 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
     with capi.Context(device) as ctx:
         run(ctx)                                                       # warm-up (allocations, code objects)
         wall, fs, results, _ = run(ctx)
+        run(ctx, on_arrival=True)
+        wall_arr, fs_arr, results_arr, _ = run(ctx, on_arrival=True)
         out.update({
             "ms_per_frame": wall / frames * 1e3,
+            "ms_per_frame_sweeps_staged_on_arrival": wall_arr / frames * 1e3,
+            "staged_on_arrival": {
+                "what": "the same frames with every sweep handed over when it arrives (vgicp_sweep_stage, called where a lidar "
+                        "callback's thread would run: beside the device's work on the frame before) and prepared from its "
+                        "ticket (vgicp_scan_prepare_staged_async): the frame's first stage starts from page-locked bytes",
+                "poses_bit_equal": bool(all(np.array_equal(a.pose, b.pose) for a, b in zip(results, results_arr))),
+                "copies_per_frame": fs_arr.copies / frames, "kernel_launches_per_frame": fs_arr.kernel_launches / frames},
             "kernel_launches_per_frame": fs.kernel_launches / frames,
             "kernel_launches_note": "counted by the library; rocPRIM's merge sort (the scan preparation's one sort) is counted "
                                     "as one block sort + one launch per doubling of the run length, rocprofv3 sees two more "
@@ -248,7 +266,7 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
         from eskf_lio_amd import host
         chain_poses = [r.pose for r in results]
 
-        def dropin(host_copy, device_resident):
+        def dropin(host_copy, device_resident, on_arrival=False):
             pre = host.CloudPreprocessor(h, ext, host_copy)
             icp = host.ICP(30, 1e-6, 0.9999)
             cfg = dict(translation_sq_threshold=-1.0, cosine_threshold=2.0, remove_distant_points=False,
@@ -258,10 +276,14 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
             fr.run(pre, icp, lmap, np.eye(4), first_frame=True)
             fr.end()
             pose, poses, resident, wall = np.eye(4), [], 0, 0.0
+            nxt = host.Frame(sweeps[1], tt, st)
+            if on_arrival:
+                nxt.stage(pre)
             for f in range(1, frames + 1):
-                fr = host.Frame(sweeps[f], tt, st)                 # the measurement object: built outside the timed part
+                fr = nxt                                           # the measurement object: built outside the timed part
+                nxt = host.Frame(sweeps[f + 1], tt, st) if f < frames else None
                 t0 = time.perf_counter()
-                fr.run(pre, icp, lmap, pose)
+                fr.run(pre, icp, lmap, pose, stage_next=nxt if on_arrival else None)
                 wall += time.perf_counter() - t0
                 got = fr.end()
                 pose = got["pose"]
@@ -272,7 +294,10 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
         ms_def, poses_def, res_def, vox_def = dropin("deferred", True)
         dropin("eager", False)                                         # warm-up (first-use allocations: page-locked arena, table growth)
         ms_eag, poses_eag, res_eag, _ = dropin("eager", False)
+        dropin("deferred", True, on_arrival=True)
+        ms_arr, poses_arr, res_arr, _ = dropin("deferred", True, on_arrival=True)
         out["dropin_ms_per_frame"] = ms_def
+        out["dropin_ms_per_frame_sweeps_staged_on_arrival"] = ms_arr
         out["dropin_eager_ms_per_frame"] = ms_eag
         out["dropin"] = {
             "what": "the frames above through ESKF_LIO::CloudPreprocessor::process / ICP::align / LocalMap::updateLocalMap "
@@ -284,6 +309,10 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
             "poses_bit_equal_to_the_abi_chain": bool(all(np.array_equal(a, b) for a, b in zip(poses_def, chain_poses))),
             "eager_pose_delta_max": float(max(np.abs(a - b).max() for a, b in zip(poses_eag, chain_poses))),
             "map_voxels": vox_def,
+            "staged_on_arrival": {"what": "CloudPreprocessor::stage(meas) called where the lidar callback would (here: right after the "
+                                          "previous frame's process()); process() then starts from the staged sweep",
+                                  "poses_bit_equal": bool(all(np.array_equal(a, b) for a, b in zip(poses_arr, chain_poses))),
+                                  "aligns_that_found_the_scan_resident": f"{res_arr} of {frames}"},
         }
     except Exception as e:  # noqa: BLE001 - a secondary record
         out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
@@ -352,6 +381,24 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
                    "pose_delta_max": pose_delta, "final_map_equal": map_equal,
                    "frames_checked": "prepared scan: frames 0, 1 and the last; align + map: every frame"},
     })
+    # what bounds a frame from below: the launches it still makes (each costs the host ~5 us to enqueue and the device
+    # ~2-4 us to start: MI355X_MICROARCH.md), and the bytes it has to move at the rates they can move at
+    kept_mean = float(np.mean(kept_points))
+    launches = out["kernel_launches_per_frame"]
+    raw_bytes = 32.0 * sweep_points
+    out["floor"] = {
+        "launches_per_frame": launches,
+        "launch_floor_us": launches * 5.0,
+        "launch_floor_what": "kernel launches per frame x ~5 us of host enqueue each (measured: tools/frame_gaps.sh, "
+                             "profiles/NOTES_dropped_experiments.md); the device-side start of a dependent launch is 2-4 us",
+        "pcie_bytes_per_frame": raw_bytes,
+        "pcie_floor_us": raw_bytes / 54e9 * 1e6,
+        "hbm_bytes_per_frame_order_of": 10e6,
+        "hbm_floor_us": 10e6 / 8e12 * 1e6,
+        "what": "a frame moves ~2 MB over PCIe (the raw sweep, 32 B per point) and of the order of 10 MB through HBM: "
+                "bytes are not what bounds it; the launches' fixed costs and the neighbour search's instruction count are",
+        "achieved_us": out["ms_per_frame"] * 1e3,
+    }
     if cpu:
         cpu_times["what"] = ("the oracle's stages on the last frame, OpenMP on all host cores: deskew (serial, as the "
                              "reference), down-sampling + BRUTE-FORCE 30-NN + covariances (the reference uses a KD-tree; "

@@ -33,7 +33,7 @@ EXPORTS = (
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
     "vgicp_accumulate", "vgicp_solve_step", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_scan_prepare", "vgicp_scan_download",
-    "vgicp_scan_prepare_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
+    "vgicp_scan_prepare_async", "vgicp_sweep_stage", "vgicp_scan_prepare_staged_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
     "vgicp_set_option", "vgicp_host_register", "vgicp_host_unregister",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
     "vgicp_peer_export", "vgicp_peer_connect", "vgicp_peer_disconnect",
@@ -113,6 +113,8 @@ def load_library() -> C.CDLL:
                                        C.POINTER(C.c_int64)]
     lib.vgicp_scan_download.argtypes = [vp, sz, dp, dp, C.POINTER(sz)]
     lib.vgicp_scan_prepare_async.argtypes = [vp, sz, dp, dp, sz, dp, dp, C.c_double, C.c_int]
+    lib.vgicp_sweep_stage.argtypes = [vp, sz, dp, dp, C.POINTER(C.c_uint64)]
+    lib.vgicp_scan_prepare_staged_async.argtypes = [vp, C.c_uint64, sz, dp, dp, C.c_double, C.c_int]
     lib.vgicp_scan_info.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
     lib.vgicp_map_insert_resident_async.argtypes = [vp, dp, sz]
     lib.vgicp_get_frame_stats.argtypes = [vp, C.POINTER(FrameStats), C.c_int]
@@ -474,6 +476,23 @@ class Context:
         self._check(self._lib.vgicp_scan_prepare_async(self._h, n, _dp(pts), _dp(t) if t.size else None, st.shape[0],
                                                        _dp(st) if st.size else None, _dp(ext) if ext is not None else None,
                                                        float(voxel_size), int(knn)))
+
+    def sweep_stage(self, points, point_time=None) -> int:
+        """vgicp_sweep_stage: a raw sweep copied into page-locked memory of the context when it arrives -> ticket."""
+        pts = _f64(points, 3)
+        t = np.ascontiguousarray(point_time, dtype=np.float64).reshape(-1) if point_time is not None else np.zeros(0)
+        if t.size and t.shape[0] != pts.shape[0]:
+            raise ValueError("one capture time per point")
+        ticket = C.c_uint64(0)
+        self._check(self._lib.vgicp_sweep_stage(self._h, pts.shape[0], _dp(pts), _dp(t) if t.size else None, C.byref(ticket)))
+        return int(ticket.value)
+
+    def scan_prepare_staged_async(self, ticket: int, states=None, extrinsic=None, voxel_size: float = 0.3, knn: int = 30):
+        """vgicp_scan_prepare_staged_async: vgicp_scan_prepare_async for a sweep staged by sweep_stage."""
+        st = _f64(states, 8) if states is not None and len(states) else np.zeros((0, 8))
+        ext = pose_to_abi(extrinsic) if extrinsic is not None else None
+        self._check(self._lib.vgicp_scan_prepare_staged_async(self._h, int(ticket), st.shape[0], _dp(st) if st.size else None,
+                                                              _dp(ext) if ext is not None else None, float(voxel_size), int(knn)))
 
     def scan_info(self):
         """(kept points, what the deskew reports, indefinite covariances) of the last preparation."""

@@ -787,6 +787,10 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   }
   if (ctx->h_upload) (void)hipHostFree(ctx->h_upload);
   if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+  for (auto& s : ctx->ahead) {
+    if (s.mem) (void)hipHostFree(s.mem);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
   close_peers(ctx);
   if (ctx->d_mail) (void)hipFree(ctx->d_mail);
   if (ctx->d_mail_table) (void)hipFree(ctx->d_mail_table);
@@ -1607,14 +1611,47 @@ struct DeskewOnDevice {
 // The raw points of a preparation that are still to be copied into page-locked staging memory (scan_prepare_enqueue):
 // enqueue_prepare launches the kernels that read them, copies (this thread and the crew's helpers), and launches the rest.
 struct StagedPoints {
-  const double* points = nullptr;   // the caller's, n x 3
+  const double* points = nullptr;   // the caller's, n x 3; nullptr: the staging memory holds them already (vgicp_sweep_stage)
   char* stage = nullptr;            // page-locked, n x 24 bytes (+ padding)
   uint32_t* flags = nullptr;        // one 64-byte line per unit
   hipEvent_t done = nullptr;        // recorded behind the last kernel that reads the staging memory
+  uint32_t job = 0, seq = 0;        // the copy crew's job (posted by scan_prepare_enqueue: a helper is copying already)
+  bool helpers = false;
+  double t_post = 0.0;
+  CopyCrew* open_with = nullptr;    // the job is open: whoever leaves early has to finish it (the caller's buffer is read)
+  ~StagedPoints() {
+    if (open_with) { open_with->work(job); open_with->finish(); }
+  }
 };
+// The copy of a sweep's points into `stage`, opened to the crew: the helpers (if any are awake or worth waking) start at
+// once, the caller joins through crew->work(job) when it has launched the kernels that read the staging memory.
+void post_sweep_copy(vgicp_ctx* ctx, size_t n, StagedPoints* sp) {
+  if (++ctx->scan_seq == 0) ++ctx->scan_seq;
+  sp->seq = ctx->scan_seq;
+  const uint32_t unit = pack_arena_unit();
+  sp->helpers = ctx->upload_threads > 1 && n * 3 * sizeof(double) >= (1u << 20);
+  if (!ctx->crew) ctx->crew = new CopyCrew;
+  CopyCrew* crew = ctx->crew;
+  if (sp->helpers && crew->th.empty()) crew->start(ctx->upload_threads - 1);
+  crew->pts = reinterpret_cast<const char*>(sp->points);
+  crew->cov = nullptr;
+  crew->apts = sp->stage;
+  crew->acov = nullptr;
+  crew->flags = sp->flags;
+  crew->n = (uint32_t)n;
+  crew->unit = unit;
+  crew->units = (uint32_t)((n + unit - 1) / unit);
+  crew->seq = sp->seq;
+  crew->size_a = 24;
+  crew->size_b = 0;
+  crew->copy = stage_copy;
+  sp->t_post = now_seconds();
+  sp->job = crew->post(sp->helpers);
+  sp->open_with = crew;
+}
 int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, int knn, const double* extrinsic16,
                     const DeskewOnDevice& dk, void* scratch, double* d_out_pts, double* d_out_covs,
-                    unsigned long long* d_out_idx, double* soa, uint64_t soa_stride, const StagedPoints* staged = nullptr) {
+                    unsigned long long* d_out_idx, double* soa, uint64_t soa_stride, StagedPoints* staged = nullptr) {
   const uint64_t entries = preprocess_cell_entries_for((uint32_t)n);
   int rc = ensure_cells(ctx, preprocess_cell_bytes(entries));
   if (rc != VGICP_OK) return rc;
@@ -1650,40 +1687,32 @@ int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, 
   if (ctx->stage_events) ctx->ev_stage_set[6] = true;
   if (!staged) {
     VG_HIP(ctx, launch_prepare(ctx->stream, a));
+  } else if (!staged->points) {
+    // staged ahead of time: the prologue reads the page-locked copy where it lies, nothing to wait for
+    a.src_points = staged->stage;
+    a.src_flags = nullptr;
+    VG_HIP(ctx, launch_prepare_head(ctx->stream, a));
+    if (staged->done) VG_HIP(ctx, hipEventRecord(staged->done, ctx->stream));
+    VG_HIP(ctx, launch_prepare_tail(ctx->stream, a));
   } else {
     // the sweep's points go up without a copy command: the copy threads fill the staging memory unit by unit, the
     // prologue (launched FIRST) reads the units over PCIe as they are published (see scan_upload_enqueue)
     static const uint32_t spin_limit = std::getenv("VGICP_PACK_SPIN_LIMIT") ? (uint32_t)std::strtoul(std::getenv("VGICP_PACK_SPIN_LIMIT"), nullptr, 10) : kPackSpinLimit;
     static const long debug_delay_us = std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US") ? std::atol(std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US")) : 0;
-    if (++ctx->scan_seq == 0) ++ctx->scan_seq;
-    const uint32_t unit = pack_arena_unit();
-    const bool want_helpers = ctx->upload_threads > 1 && n * 3 * sizeof(double) >= (1u << 20);
-    if (!ctx->crew) ctx->crew = new CopyCrew;
     CopyCrew* crew = ctx->crew;
-    if (want_helpers && crew->th.empty()) crew->start(ctx->upload_threads - 1);
-    crew->pts = reinterpret_cast<const char*>(staged->points);
-    crew->cov = nullptr;
-    crew->apts = staged->stage;
-    crew->acov = nullptr;
-    crew->flags = staged->flags;
-    crew->n = (uint32_t)n;
-    crew->unit = unit;
-    crew->units = (uint32_t)((n + unit - 1) / unit);
-    crew->seq = ctx->scan_seq;
-    crew->size_a = 24;
-    crew->size_b = 0;
-    crew->copy = stage_copy;
+    const bool want_helpers = staged->helpers;
+    const uint32_t job = staged->job;
+    const double t_post = staged->t_post;
     a.src_points = staged->stage;
     a.src_flags = staged->flags;
-    a.src_seq = ctx->scan_seq;
-    a.src_unit = unit;
+    a.src_seq = staged->seq;
+    a.src_unit = pack_arena_unit();
     a.src_spin = spin_limit;
-    const double t_post = now_seconds();
-    const uint32_t job = crew->post(want_helpers);
     const hipError_t e_head = launch_prepare_head(ctx->stream, a);
     if (debug_delay_us > 0 && !want_helpers) std::this_thread::sleep_for(std::chrono::microseconds(debug_delay_us));
     crew->work(job);
     crew->finish();   // always: the caller's buffer is free again on return
+    staged->open_with = nullptr;
     if (e_head != hipSuccess) return fail_hip(ctx, e_head, "launch_prepare_head");
     if (now_seconds() - t_post > kCrewSlowSeconds) {
       // the copy threads were held up so long that a workgroup of the prologue may have stopped waiting (and said so in
@@ -1996,8 +2025,11 @@ namespace {
 // CloudPreprocessor::process enqueued on the context's stream with the prepared scan left resident: upload of the
 // raw sweep, then launch_prepare writing the AoS scan AND the SoA planes the registration reads. Nothing is waited
 // for: the scan is `pending` (its size is on the device, ctx->n_upper bounds it).
+// ahead: the sweep was staged by vgicp_sweep_stage (points / point_time then point INTO that page-locked slot and nothing
+// is copied here; its `done` event is recorded behind the kernels that read it).
 int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, size_t num_states,
-                         const double* states, const double extrinsic[16], double voxel_size, int knn) {
+                         const double* states, const double extrinsic[16], double voxel_size, int knn,
+                         vgicp_ctx::AheadSlot* ahead = nullptr) {
   int rc = check_preprocess_args(ctx, n, voxel_size, knn);
   if (rc != VGICP_OK) return rc;
   if ((ctx->comm || ctx->peers_connected) && !ctx->owner) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the prepared scan is whole: not available on a communicator (shards)");
@@ -2059,11 +2091,19 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   }
   const size_t raw_bytes = n * 3 * sizeof(double) + (with_deskew ? n * sizeof(double) : 0);
   static const size_t stage_limit = std::getenv("VGICP_STAGE_LIMIT") ? (size_t)std::atoll(std::getenv("VGICP_STAGE_LIMIT")) : (16u << 20);
-  const bool staged = raw_bytes <= stage_limit;   // larger sweeps go up straight from the caller's memory
+  const bool staged = ahead != nullptr || raw_bytes <= stage_limit;   // larger sweeps go up straight from the caller's memory
   const bool walk = with_deskew && !(ordered && used <= kDeskewMaxStates);   // the serial bounds walk reads the times many times over: on the device
   StagedPoints sp;
   const double* time_src = nullptr;   // where the deskew's first kernel reads the capture times
-  if (staged) {
+  if (ahead) {
+    sp.points = nullptr;
+    sp.stage = const_cast<char*>(reinterpret_cast<const char*>(points));
+    sp.done = ahead->done;
+    if (with_deskew) {
+      time_src = point_time;
+      if (walk) VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+  } else if (staged) {
     // slot layout: [unit flags][points, padded][capture times]
     const size_t pts_bytes = n * 3 * sizeof(double);
     const size_t flag_bytes = ((n + pack_arena_unit() - 1) / pack_arena_unit() + 1) * 64;
@@ -2084,9 +2124,10 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     sp.flags = reinterpret_cast<uint32_t*>(stage);
     sp.stage = stage + flag_bytes;
     sp.done = ctx->ev_state_table[slot];
+    post_sweep_copy(ctx, n, &sp);   // a helper that is awake starts on the points now
     if (with_deskew) {
-      // the capture times first (a sixth of the bytes): the deskew's bounds need nothing else, and its kernel reads them
-      // where they are staged
+      // this thread: the capture times first (a sixth of the bytes): the deskew's bounds need nothing else, and its
+      // kernel reads them where they are staged
       double* times_stage = reinterpret_cast<double*>(stage + flag_bytes + pts_room);
       stage_copy(times_stage, point_time, n * sizeof(double));
       time_src = times_stage;
@@ -2127,6 +2168,7 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   rc = enqueue_prepare(ctx, d_pts, n, voxel_size, knn, extrinsic, dk, scratch, ctx->d_scan_aos,
                        ctx->d_scan_aos + 3 * ctx->scan_capacity, d_idx, ctx->d_scan, ctx->stride, staged ? &sp : nullptr);
   if (rc != VGICP_OK) return rc;
+  if (ahead) VG_HIP(ctx, hipEventRecord(ctx->ev_state_table[slot], ctx->stream));   // (the state table's pinned slot)
   if (trace)
     std::fprintf(stderr, "[vgicp trace] prepare enqueue: staging + points copy %.3f ms, times + states copies %.3f ms, kernels %.3f ms\n",
                  (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, (now_seconds() - tr2) * 1e3);
@@ -2148,6 +2190,76 @@ int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, con
   // nothing is settled here: a map insertion still pending from the previous frame has counters of its own and is
   // read at this frame's one synchronisation (the align); a scan that was prepared but never used is simply replaced
   return scan_prepare_enqueue(ctx, n, points, point_time, num_states, states, extrinsic, voxel_size, knn);
+}
+
+// A sweep copied into page-locked memory of the context WHEN IT ARRIVES (the lidar callback's thread, reference
+// include/ESKF_LIO/Subscriber.hpp:80-103; src/Odometry.cpp:43-48 pops the sweep long before :74 prepares it), so that
+// the preparation later starts from bytes the device can read at once.  Only plain CPU copies here, under a mutex
+// of its own: the one entry point another thread may call while the context's owner is inside a call.
+int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, uint64_t* ticket) {
+  if (!ctx || !ticket) return VGICP_ERR_BAD_ARGUMENT;
+  *ticket = 0;
+  if (ctx->multi) return vgicp_sweep_stage(vgicp_multi_api::first(ctx), n, points, point_time, ticket);
+  if (n == 0 || !points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
+  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "sweep too large");
+  vgicp_ctx::AheadSlot* slot = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
+    for (auto& s : ctx->ahead)
+      if (s.state == 0) { slot = &s; break; }
+    if (!slot)
+      for (auto& s : ctx->ahead)   // handed to the device two preparations ago: its readers have long finished
+        if (s.state == 2 && (!s.done || hipEventQuery(s.done) == hipSuccess)) { slot = &s; break; }
+    if (!slot) return fail(ctx, VGICP_ERR_NOT_READY, "three sweeps are staged ahead already: prepare one first");
+    slot->state = 3;
+  }
+  const size_t pts_room = (n * 3 * sizeof(double) + 16 + 255) & ~size_t(255);
+  const size_t need = pts_room + n * sizeof(double);
+  if (slot->cap < need) {
+    if (hipSetDevice(ctx->device) != hipSuccess) { slot->state = 0; return fail(ctx, VGICP_ERR_HIP, "hipSetDevice"); }
+    if (slot->mem) (void)hipHostFree(slot->mem);
+    slot->mem = nullptr;
+    slot->cap = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&slot->mem), need * 5 / 4 + 4096, 0) != hipSuccess) {
+      slot->state = 0;
+      return fail(ctx, VGICP_ERR_HIP, "hipHostMalloc(sweep staging)");
+    }
+    slot->cap = need * 5 / 4 + 4096;
+  }
+  stage_copy(slot->mem, points, n * 3 * sizeof(double));
+  if (point_time) stage_copy(slot->mem + pts_room, point_time, n * sizeof(double));
+  std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
+  slot->n = n;
+  slot->has_times = point_time != nullptr;
+  slot->ticket = ++ctx->ahead_tickets;
+  slot->state = 1;
+  *ticket = slot->ticket;
+  return VGICP_OK;
+}
+
+int vgicp_scan_prepare_staged_async(vgicp_ctx* ctx, uint64_t ticket, size_t num_states, const double* states,
+                                    const double extrinsic[16], double voxel_size, int knn) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) return vgicp_multi_api::scan_prepare(ctx, 0, nullptr, nullptr, num_states, states, extrinsic, voxel_size, knn, nullptr, nullptr, true, ticket);
+  vgicp_ctx::AheadSlot* slot = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
+    for (auto& s : ctx->ahead)
+      if (s.state == 1 && s.ticket == ticket) { slot = &s; break; }
+  }
+  if (!slot || ticket == 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "no sweep staged under this ticket (staged by vgicp_sweep_stage, used once)");
+  if (num_states > 0 && !slot->has_times) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the sweep was staged without capture times");
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  if (!slot->done) VG_HIP(ctx, hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+  const size_t pts_room = (slot->n * 3 * sizeof(double) + 16 + 255) & ~size_t(255);
+  const int rc = scan_prepare_enqueue(ctx, slot->n, reinterpret_cast<const double*>(slot->mem),
+                                      reinterpret_cast<const double*>(slot->mem + pts_room), num_states, states, extrinsic,
+                                      voxel_size, knn, slot);
+  std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
+  // whatever the outcome the ticket is used up; the slot is free again once the kernels that read it are through
+  // (an enqueue that failed before it launched anything left `done` as it was: an old, completed event)
+  slot->state = 2;
+  return rc;
 }
 
 int vgicp_scan_info(vgicp_ctx* ctx, size_t* kept, int64_t* deskewed, uint64_t* indefinite) {

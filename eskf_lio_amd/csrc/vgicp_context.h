@@ -280,6 +280,20 @@ struct vgicp_ctx {
   size_t upload_whole_hint = 0;             // a sub-context's shard: the size of the caller's WHOLE scan decides, not the shard's
   struct PendingOut { void* dst; const char* src; size_t bytes; };
   std::vector<PendingOut> pending_out;
+  // sweeps staged AHEAD of their preparation (vgicp_sweep_stage: the lidar callback's thread copies a sweep into
+  // page-locked memory when it arrives; vgicp_scan_prepare_staged_async consumes it by ticket).  Guarded by
+  // ahead_mutex: the one part of a context that another thread may enter while the owner thread is inside a call.
+  struct AheadSlot {
+    char* mem = nullptr;
+    size_t cap = 0, n = 0;
+    uint64_t ticket = 0;
+    bool has_times = false;
+    int state = 0;                 // 0 free, 1 staged, 2 handed to the device (`done` recorded behind its readers), 3 being filled
+    hipEvent_t done = nullptr;
+  };
+  AheadSlot ahead[3];
+  std::mutex ahead_mutex;
+  uint64_t ahead_tickets = 0;
   char* h_raw_stage[2] = {nullptr, nullptr};
   size_t raw_stage_cap[2] = {0, 0};
   double* h_state_table[2] = {nullptr, nullptr};
@@ -398,7 +412,7 @@ int align_resident(vgicp_ctx* ctx, const double guess[16], const vgicp_params* p
                    vgicp_stats* stats);
 int scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, size_t num_states,
                  const double* states, const double extrinsic[16], double voxel_size, int knn, size_t* kept,
-                 int64_t* deskewed, bool deferred);
+                 int64_t* deskewed, bool deferred, uint64_t ticket = 0);
 int scan_info(vgicp_ctx* ctx, size_t* kept, int64_t* deskewed, uint64_t* indefinite);
 int scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double* covs, size_t* n);
 int get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset);

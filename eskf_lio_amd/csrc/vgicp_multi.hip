@@ -624,13 +624,14 @@ int align_resident(vgicp_ctx* ctx, const double guess[16], const vgicp_params* p
 // to the other devices right before the align.
 int scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, size_t num_states,
                  const double* states, const double extrinsic[16], double voxel_size, int knn, size_t* kept,
-                 int64_t* deskewed, bool deferred) {
+                 int64_t* deskewed, bool deferred, uint64_t ticket) {
   vgicp_multi* g = ctx->multi;
   vgicp_ctx* lead = g->subs[0];
   ++g->scan_generation;
   g->resident = Resident::None;
   int rc;
-  if (deferred) rc = vgicp_scan_prepare_async(lead, n, points, point_time, num_states, states, extrinsic, voxel_size, knn);
+  if (ticket) rc = vgicp_scan_prepare_staged_async(lead, ticket, num_states, states, extrinsic, voxel_size, knn);
+  else if (deferred) rc = vgicp_scan_prepare_async(lead, n, points, point_time, num_states, states, extrinsic, voxel_size, knn);
   else rc = vgicp_scan_prepare(lead, n, points, point_time, num_states, states, extrinsic, voxel_size, knn, kept, deskewed);
   if (rc != VGICP_OK) return sub_fail(ctx, lead, rc);
   g->resident = Resident::PreparedWhole;

@@ -54,7 +54,9 @@ def load_library() -> C.CDLL:
     lib.host_preprocessor_create.argtypes = [C.c_double, dp, C.c_int]
     lib.host_frame_begin.restype = vp
     lib.host_frame_begin.argtypes = [sz, dp, dp, sz, dp]
-    lib.host_frame_run.argtypes = [vp, vp, vp, vp, dp, C.c_int, C.c_int]
+    lib.host_frame_run.argtypes = [vp, vp, vp, vp, dp, C.c_int, C.c_int, vp]
+    lib.host_frame_stage.argtypes = [vp, vp]
+    lib.host_frame_stage.restype = C.c_int
     lib.host_frame_end.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
                                    C.POINTER(sz), sz, dp, dp]
     lib.host_preprocessor_process.argtypes = [vp, sz, dp, dp, sz, dp, dp, dp, C.POINTER(sz)]
@@ -255,11 +257,20 @@ class Frame:
         self._h = self._lib.host_frame_begin(self._pts.shape[0], _dp(self._pts), _dp(self._t), self._st.shape[0],
                                              _dp(self._st))
 
+    def stage(self, preprocessor: "CloudPreprocessor") -> bool:
+        """CloudPreprocessor::stage on this frame's measurement: what a lidar callback does when the sweep arrives."""
+        rc = self._lib.host_frame_stage(self._h, preprocessor._h)
+        if rc < 0:
+            raise RuntimeError("CloudPreprocessor::stage failed")
+        return bool(rc)
+
     def run(self, preprocessor: "CloudPreprocessor", icp: "ICP", localMap: "LocalMap", guess, first_frame=False,
-            mutate: int = 0):
+            mutate: int = 0, stage_next: "Frame" = None):
+        """stage_next: a later Frame whose sweep 'arrives' during this one (staged right after this frame's process())."""
         g = capi.pose_to_abi(guess)
         _check(self._lib, self._lib.host_frame_run(self._h, preprocessor._h, icp._h, localMap._h, _dp(g),
-                                                   1 if first_frame else 0, int(mutate)))
+                                                   1 if first_frame else 0, int(mutate),
+                                                   stage_next._h if stage_next is not None else None))
 
     def end(self, want_cloud: bool = False):
         """-> dict(pose, iterations, used_resident, corr0, host_points[, points, covs])."""

@@ -235,12 +235,22 @@ HostFrame * host_frame_begin(
   return f;
 }
 
+// CloudPreprocessor::stage on the frame's measurement (what a lidar callback would do when the sweep arrives): 1 staged
+int host_frame_stage(HostFrame * f, const CloudPreprocessor * p)
+{
+  int staged = 0;
+  const int rc = guarded([&] {staged = p->stage(f->meas) ? 1 : 0;});
+  return rc == 0 ? staged : -1;
+}
+
 // mutate: 0 = the frame as the reference runs it; 1 = the caller edits the prepared cloud between process() and
 // align() (its FIRST point moves by 1 mm: a sampled element, so the stamp must notice); 2 = the caller resizes it.
 // first_frame: process({}, meas) + updateLocalMap(cloud, guess) without align (src/Odometry.cpp:60-61).
+// stage_next: a later frame whose sweep "arrives" while this one is being processed: staged (CloudPreprocessor::stage)
+// right after this frame's process(), where a lidar callback's thread would be copying beside the device's work.
 int host_frame_run(
   HostFrame * f, const CloudPreprocessor * p, ICP * icp, LocalMap * map, const double guess[16], int first_frame,
-  int mutate)
+  int mutate, HostFrame * stage_next)
 {
   return guarded(
     [&] {
@@ -252,6 +262,7 @@ int host_frame_run(
         return;
       }
       p->process(f->states, f->meas);
+      if (stage_next) {p->stage(stage_next->meas);}
       if (mutate) {ESKF_LIO::shim::materialize(map->context(), *f->meas->cloud);}   // an editor needs the data first
       if (mutate == 1 && !f->meas->cloud->points_.empty()) {f->meas->cloud->points_[0](0) += 1e-3;}
       if (mutate == 2 && f->meas->cloud->points_.size() > 1) {

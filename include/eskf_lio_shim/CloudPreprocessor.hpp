@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <deque>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "LocalMap.hpp"
@@ -62,6 +63,30 @@ struct CloudPreprocessorConfig
   double T_il[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 };
 
+namespace shim
+{
+// Sweeps handed to the device module when they ARRIVED (CloudPreprocessor::stage, called from the lidar callback's
+// thread): measurement object -> ticket of vgicp_sweep_stage.  process() looks its measurement up here.
+struct StagedSweep
+{
+  vgicp_ctx * ctx;
+  const void * meas;
+  const void * pointData;
+  size_t n;
+  uint64_t ticket;
+};
+inline std::mutex & stagedSweepsMutex()
+{
+  static std::mutex m;
+  return m;
+}
+inline std::vector<StagedSweep> & stagedSweeps()
+{
+  static std::vector<StagedSweep> v;
+  return v;
+}
+}  // namespace shim
+
 class CloudPreprocessor
 {
 public:
@@ -90,6 +115,26 @@ public:
   }
 #endif
 
+  // OPTIONAL, not in the reference: call it where the sweep arrives (the lidar callback, include/ESKF_LIO/Subscriber.hpp:
+  // 80-103, once cloud and pointTime are filled).  The raw sweep is copied into page-locked memory of the device module
+  // right away (CPU copies only; safe to call from the callback's thread while Odometry::run is inside process / align
+  // / updateLocalMap), and the process() that later gets this measurement starts from there instead of copying first:
+  // src/Odometry.cpp:43-48 pops a measurement long after it arrived.  The measurement must not be edited in between.
+  // Returns false (and does nothing) when three sweeps are staged already.
+  bool stage(const LidarMeasurementPtr & lidarMeas) const
+  {
+    const PointCloud & cloud = *lidarMeas->cloud;
+    const size_t n = cloud.points_.size();
+    if (n == 0 || lidarMeas->pointTime.size() != n) {return false;}
+    uint64_t ticket = 0;
+    const int rc = vgicp_sweep_stage(
+      ctx_, n, reinterpret_cast<const double *>(cloud.points_.data()), lidarMeas->pointTime.data(), &ticket);
+    if (rc != VGICP_OK) {return false;}
+    std::lock_guard<std::mutex> lk(shim::stagedSweepsMutex());
+    shim::stagedSweeps().push_back({ctx_, lidarMeas.get(), cloud.points_.data(), n, ticket});
+    return true;
+  }
+
   // reference src/CloudPreprocessor.cpp:8-23: extrinsic, deskew, down-sampling + covariances — here ONE enqueue
   // (vgicp_scan_prepare_async: 32 bytes per raw point go up, every step runs on the device) that leaves the
   // prepared scan resident, plus the host copy the configuration asks for.
@@ -106,9 +151,28 @@ public:
       for (int a = 0; a < 4; ++a) {packed[k++] = q[a];}
     }
     static_assert(sizeof(Vector3d) == 3 * sizeof(double), "points must be packed xyz triples");
-    const int rc = vgicp_scan_prepare_async(
-      ctx_, n, n ? reinterpret_cast<const double *>(cloud.points_.data()) : nullptr,
-      lidarMeas->pointTime.data(), states.size(), packed.data(), shim::poseData(T_il_), voxelSize_, knn_);
+    uint64_t ticket = 0;   // staged when it arrived (stage())?
+    {
+      std::lock_guard<std::mutex> lk(shim::stagedSweepsMutex());
+      auto & staged = shim::stagedSweeps();
+      for (size_t i = 0; i < staged.size(); ++i) {
+        if (staged[i].ctx == ctx_ && staged[i].meas == lidarMeas.get()) {
+          if (staged[i].pointData == cloud.points_.data() && staged[i].n == n) {ticket = staged[i].ticket;}
+          staged.erase(staged.begin() + static_cast<std::ptrdiff_t>(i));
+          break;
+        }
+      }
+    }
+    int rc = VGICP_ERR_BAD_ARGUMENT;
+    if (ticket) {
+      rc = vgicp_scan_prepare_staged_async(
+        ctx_, ticket, states.size(), packed.data(), shim::poseData(T_il_), voxelSize_, knn_);
+    }
+    if (!ticket) {
+      rc = vgicp_scan_prepare_async(
+        ctx_, n, n ? reinterpret_cast<const double *>(cloud.points_.data()) : nullptr,
+        lidarMeas->pointTime.data(), states.size(), packed.data(), shim::poseData(T_il_), voxelSize_, knn_);
+    }
     if (rc == VGICP_ERR_BAD_ARGUMENT && !states.empty() && n) {
       // where the reference's deskew would step off its state queue (undefined behaviour there)
       throw std::runtime_error(std::string("process: ") + vgicp_last_error(ctx_));

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGICP_ABI_VERSION 4
+#define VGICP_ABI_VERSION 5
 
 typedef struct vgicp_ctx vgicp_ctx;
 
@@ -302,6 +302,17 @@ int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, con
                              size_t num_states, const double* states, const double extrinsic[16],
                              double voxel_size, int knn);
 int vgicp_scan_info(vgicp_ctx* ctx, size_t* kept, int64_t* deskewed, uint64_t* indefinite);
+/* A sweep handed over WHEN IT ARRIVES: the reference's lidar callback (include/ESKF_LIO/Subscriber.hpp:80-103) builds
+ * the cloud and its capture times long before Odometry::run pops the measurement (src/Odometry.cpp:43-48) and prepares
+ * it (:74).  vgicp_sweep_stage copies the raw sweep (points n x 3, point_time n or NULL) into page-locked memory of the
+ * context with the CPU and returns a ticket; vgicp_scan_prepare_staged_async is vgicp_scan_prepare_async for that
+ * sweep: the device reads the staged bytes where they lie, the frame's first stage no longer waits for a host copy.
+ * vgicp_sweep_stage makes no device call and is the ONE entry point that another thread may call while the
+ * context's owner thread is inside a call (it has a mutex of its own); the buffers are free again on return.  At
+ * most three sweeps can be staged ahead (VGICP_ERR_NOT_READY beyond); a ticket is used once. */
+int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, uint64_t* ticket);
+int vgicp_scan_prepare_staged_async(vgicp_ctx* ctx, uint64_t ticket, size_t num_states, const double* states,
+                                    const double extrinsic[16], double voxel_size, int knn);
 int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel);
 
 /* What the calls of THIS HOST THREAD into the module (whatever the context) have cost the host since this context's

@@ -1000,6 +1000,71 @@ def test_async_frame_chain_has_one_sync_per_frame_and_the_same_bits(oracle):
         assert c.scan_info()[0] == len(oracle.preprocess(good, 0.3, 30)[2])
 
 
+def test_sweep_staged_on_arrival_prepares_to_the_same_bits(oracle):
+    """vgicp_sweep_stage + vgicp_scan_prepare_staged_async: a sweep handed over when it arrives (plain CPU copy into
+    page-locked memory, from ANOTHER thread while the owner thread aligns) and prepared later from its ticket gives the
+    prepared scan, pose and map of vgicp_scan_prepare_async bit for bit; a ticket works once; at most three sweeps
+    are staged ahead; a sweep staged without capture times cannot be deskewed."""
+    import threading
+    from eskf_lio_amd import capi, synth
+    st = synth.make_imu_states(48, seed=5)
+    ext = synth.se3_to_SE3([0.01, -0.02, 0.03, 0.002, -0.001, 0.003])
+    sweeps = [synth.make_lidar_scan(n, seed=40 + k) for k, n in enumerate((30_001, 8_000, 52_345))]
+    times = [synth.make_point_times(len(s), st[1, 0] + 1e-4, st[-3, 0] + 0.4 / 400.0, seed=7 + k) for k, s in enumerate(sweeps)]
+
+    def chain(ctx, staged):
+        ctx.map_reset(0.3, 200_000)
+        out = []
+        pose = np.eye(4)
+        for k, (sw, tt) in enumerate(zip(sweeps, times)):
+            if staged:
+                # the copy runs on another thread while this one is inside the library (here: a map query)
+                box = {}
+                th = threading.Thread(target=lambda: box.setdefault("t", ctx.sweep_stage(sw, tt)))
+                th.start()
+                ctx.map_size()
+                th.join()
+                ctx.scan_prepare_staged_async(box["t"], st, ext, 0.3, 30)
+                with pytest.raises(capi.VgicpError):
+                    ctx.scan_prepare_staged_async(box["t"], st, ext, 0.3, 30)      # a ticket is used once
+                ctx.scan_prepare_staged_async(ctx.sweep_stage(sw, tt), st, ext, 0.3, 30)   # (the same sweep again: fine)
+            else:
+                ctx.scan_prepare_async(sw, tt, st, ext, 0.3, 30)
+            if k:
+                r = ctx.align_resident(pose, 10, 1e-6, 0.9999)
+                pose = r.pose
+                out.append((r.pose, r.normal_eq))
+            out.append(ctx.scan_download())
+            ctx.map_insert_resident_async(pose, 20)
+        out.append(ctx.map_export())
+        return out
+    with capi.Context(0) as a, capi.Context(0) as b:
+        ra, rb = chain(a, False), chain(b, True)
+        for x, y in zip(ra, rb):
+            for u, v in zip(x, y):
+                assert np.array_equal(u, v)
+        # against the oracle chain: the prepared scan of the first sweep
+        moved, _ = oracle.transform(sweeps[0], np.tile(np.eye(3).reshape(9), (len(sweeps[0]), 1)), ext)
+        desk, _ = oracle.deskew(moved, times[0], st)
+        rp, rc, _ = oracle.preprocess(desk, 0.3, 30)
+        assert np.array_equal(rb[0][0], rp) and np.array_equal(rb[0][1], rc)
+        # three sweeps ahead at most; the fourth is refused until one has been prepared
+        tickets = [b.sweep_stage(sweeps[1], times[1]) for _ in range(3)]
+        with pytest.raises(capi.VgicpError) as e:
+            b.sweep_stage(sweeps[1], times[1])
+        assert e.value.code == capi.ERR_NOT_READY
+        b.scan_prepare_staged_async(tickets[0], st, ext, 0.3, 30)
+        assert b.scan_info()[0] == len(rb[2][0])                                  # the 8 000-point sweep's kept count
+        b.sweep_stage(sweeps[1], times[1])                                        # a slot is free again (its readers are through)
+        # without capture times: no deskew from that ticket, but a plain preparation
+        t_plain = a.sweep_stage(sweeps[1])
+        with pytest.raises(capi.VgicpError):
+            a.scan_prepare_staged_async(t_plain, st, ext, 0.3, 30)
+        t_plain = a.sweep_stage(sweeps[1])
+        a.scan_prepare_staged_async(t_plain, None, ext, 0.3, 30)
+        assert a.scan_info()[0] > 0
+
+
 def test_prepared_scan_of_a_sweep_larger_than_the_grid(oracle):
     """A raw sweep with more points than the persistent launch has point-carrying threads (150 000 > 256 x 448), prepared
     on the device and aligned WITHOUT waiting for the kept count: the launch plan is made from the raw count (the

@@ -332,6 +332,37 @@ def test_dropin_classes_ride_the_resident_chain(host_copy, device_resident):
     assert len(lmap) == voxels
 
 
+def test_dropin_sweeps_staged_on_arrival_give_the_same_poses():
+    """CloudPreprocessor::stage (the optional hook for the lidar callback): every frame's sweep is staged while the
+    frame before is being processed; process() picks the staged sweep up by its measurement object.  Poses, round counts
+    and the map are those of the chain that copies inside process()."""
+    from eskf_lio_amd import host
+    st, t, ext, raws = _frame_inputs()
+    want, voxels, _ = _abi_chain(st, t, ext, raws)
+    pre = host.CloudPreprocessor(0.3, ext, "deferred")
+    icp = host.ICP(30, 1e-6, 0.9999)
+    lmap = host.LocalMap(0.3, 20, dict(_NO_GATE, device_resident=True))
+    pose = np.eye(4)
+    frames = [host.Frame(raw, t, st) for raw in raws]
+    assert frames[0].stage(pre)
+    for f, fr in enumerate(frames):
+        nxt = frames[f + 1] if f + 1 < len(frames) else None
+        if f == 0:
+            fr.run(pre, icp, lmap, pose, first_frame=True)
+            if nxt is not None:
+                assert nxt.stage(pre)
+        else:
+            fr.run(pre, icp, lmap, pose, stage_next=nxt)
+        got = fr.end()
+        if f == 0:
+            continue
+        pose = got["pose"]
+        assert got["used_resident"] and got["iterations"] == want[f - 1][1] and got["corr0"] == want[f - 1][2]
+        if not os.environ.get("VGICP_DEVICES"):
+            assert np.array_equal(pose, want[f - 1][0])
+    assert len(lmap) == voxels
+
+
 def test_dropin_align_falls_back_when_the_cloud_changed():
     """A caller that edits or resizes the prepared cloud between process() and align() gets what it asked for: the
     stamp no longer matches, align() uploads the cloud as it is now, and the result is the registration of THAT cloud."""
