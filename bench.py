@@ -858,6 +858,7 @@ def main():
                               "rendezvous, vgicp_peer_export/_connect by hand, "
                               f"VGICP_PERSIST_GRID={os.environ.get('VGICP_PERSIST_GRID')}" if share_device else
                               "one rank per GPU, torch.distributed (nccl = RCCL) rendezvous, vgicp_comm_init",
+                    "peer_status": ctx.peer_status() or "wired: the kernels' own mailboxes carry the per-iteration merge",
                     **(exchange or {}),
                 },
                 "matches_per_iteration": float(res.corr_count.mean()),

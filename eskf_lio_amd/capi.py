@@ -33,7 +33,7 @@ EXPORTS = (
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
     "vgicp_accumulate", "vgicp_solve_step", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_scan_prepare", "vgicp_scan_download",
-    "vgicp_scan_prepare_async", "vgicp_sweep_stage", "vgicp_scan_prepare_staged_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
+    "vgicp_peer_status", "vgicp_scan_prepare_async", "vgicp_sweep_stage", "vgicp_scan_prepare_staged_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
     "vgicp_set_option", "vgicp_host_register", "vgicp_host_unregister",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
     "vgicp_peer_export", "vgicp_peer_connect", "vgicp_peer_disconnect",
@@ -114,6 +114,8 @@ def load_library() -> C.CDLL:
     lib.vgicp_scan_download.argtypes = [vp, sz, dp, dp, C.POINTER(sz)]
     lib.vgicp_scan_prepare_async.argtypes = [vp, sz, dp, dp, sz, dp, dp, C.c_double, C.c_int]
     lib.vgicp_sweep_stage.argtypes = [vp, sz, dp, dp, C.POINTER(C.c_uint64)]
+    lib.vgicp_peer_status.argtypes = [vp]
+    lib.vgicp_peer_status.restype = C.c_char_p
     lib.vgicp_scan_prepare_staged_async.argtypes = [vp, C.c_uint64, sz, dp, dp, C.c_double, C.c_int]
     lib.vgicp_scan_info.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
     lib.vgicp_map_insert_resident_async.argtypes = [vp, dp, sz]
@@ -476,6 +478,10 @@ class Context:
         self._check(self._lib.vgicp_scan_prepare_async(self._h, n, _dp(pts), _dp(t) if t.size else None, st.shape[0],
                                                        _dp(st) if st.size else None, _dp(ext) if ext is not None else None,
                                                        float(voxel_size), int(knn)))
+
+    def peer_status(self) -> str:
+        """vgicp_peer_status: "" while the kernels' own mailboxes carry the merge between devices, else why not."""
+        return self._lib.vgicp_peer_status(self._h).decode()
 
     def sweep_stage(self, points, point_time=None) -> int:
         """vgicp_sweep_stage: a raw sweep copied into page-locked memory of the context when it arrives -> ticket."""

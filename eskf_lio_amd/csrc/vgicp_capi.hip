@@ -2477,9 +2477,20 @@ int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128)
     if (!ctx->peers_connected && std::getenv("VGICP_VERBOSE"))
       std::fprintf(stderr, "[vgicp] rank %d: no device-initiated exchange (%s); using RCCL all-reduce per iteration\n", rank,
                    why.c_str());
+    ctx->peer_status = ctx->peers_connected ? std::string() : ("mailboxes not wired: " + (why.empty() ? std::string("unknown reason") : why));
     ctx->err.clear();
+  } else if (world_size > 1 && !ctx->peers_connected) {
+    ctx->peer_status = (want && want[0] == '0') ? "mailboxes not wired: VGICP_PEER_EXCHANGE=0" :
+                       world_size > kMaxRanks ? "mailboxes not wired: more than 16 ranks" : "mailboxes not wired: librccl has no ncclAllGather";
   }
   return VGICP_OK;
+}
+
+const char* vgicp_peer_status(const vgicp_ctx* ctx) {
+  if (!ctx) return "no context";
+  if (ctx->multi) return ctx->peer_status.c_str();
+  if (ctx->peers_connected && !ctx->peer_enabled) return "mailboxes wired, but a launch gave up waiting for a peer: one launch + one RCCL all-reduce per iteration since";
+  return ctx->peer_status.c_str();
 }
 
 int vgicp_comm_destroy(vgicp_ctx* ctx) {

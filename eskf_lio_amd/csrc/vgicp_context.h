@@ -185,6 +185,7 @@ struct vgicp_ctx {
   vgicp_multi* owner = nullptr;   // this context is one of a multi-device context's sub-contexts (rank = peer_rank)
   hipStream_t stream = nullptr;
   mutable std::string err;
+  std::string peer_status;   // "" while the device-initiated exchange is wired (or nothing to exchange); else why it is not (vgicp_peer_status)
   int cu_count = 0;
   uint64_t hbm_bytes = 0;
   std::string arch;

@@ -384,8 +384,12 @@ extern "C" int vgicp_create_multi(const int* device_ids, int n_devices, vgicp_ct
     if (!g->mailboxes && std::getenv("VGICP_VERBOSE"))
       std::fprintf(stderr, "[vgicp] multi-device context: no device-initiated exchange (%s); the devices' rows are added on the host\n",
                    g->subs[0]->err.c_str());
-    if (!g->mailboxes)
+    if (!g->mailboxes) {
+      parent->peer_status = "mailboxes not wired: " + g->subs[0]->err + " (the devices' rows are added on the host)";
       for (vgicp_ctx* sub : g->subs) { sub->world_size = n_devices; sub->peer_world = n_devices; sub->peers_connected = false; }
+    }
+  } else {
+    parent->peer_status = "mailboxes not wired: VGICP_MULTI_EXCHANGE=host";
   }
   for (int r = 0; r < n_devices; ++r) {   // ranks the sub-contexts report even without mailboxes
     g->subs[(size_t)r]->rank = r;

@@ -633,6 +633,11 @@ class DeviceBackend:
         self.cap = int(lm["max_num_points_per_voxel"])
         self.gate = (lm["translation_sq_threshold"], lm["cosine_threshold"])
         self.evict = (bool(lm["remove_distant_points"]), float(lm["distance_threshold"]), float(lm["removing_period"]))
+        # the reference's period is wall-clock time (omp_get_wtime, src/LocalMap.cpp:60,70); a replay that has to be
+        # repeatable counts map updates instead: local_map.remove_every_updates (10 s of sweeps at 10 Hz = 100)
+        self.evict_every = int(lm.get("remove_every_updates", 0))
+        self.updates_since_evict = 0
+        self.removed: List[int] = []
         self.last_evict = time.perf_counter()
         self.prev: Optional[np.ndarray] = None
         self.reg = config["registration"]
@@ -660,7 +665,11 @@ class DeviceBackend:
                 self.prev = transform.copy()
                 return
         self.ctx.map_insert_resident(transform, self.cap)
-        if self.evict[0] and time.perf_counter() - self.last_evict > self.evict[2]:
-            self.ctx.map_evict(transform[:3, 3], self.evict[1])
+        self.updates_since_evict += 1
+        due = (self.updates_since_evict >= self.evict_every) if self.evict_every else \
+            (time.perf_counter() - self.last_evict > self.evict[2])
+        if self.evict[0] and due:
+            self.removed.append(self.ctx.map_evict(transform[:3, 3], self.evict[1]))
             self.last_evict = time.perf_counter()
+            self.updates_since_evict = 0
         self.prev = transform.copy()

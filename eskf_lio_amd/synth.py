@@ -344,3 +344,164 @@ CONFIGS = {
     "C2": (100_000, 1_000_000),
     "C5": (1_000_000, 10_000_000),
 }
+
+
+# ---- a drive along a street seen by a 32-ring spinning LiDAR: the stand-in for BASELINE config C4 ----------------
+# (HILTI exp21 is a Hesai PandarXT-32 carried through a building site: config/hilti_config.yaml:20-26; the recording is
+# not available offline.)  32 rings x 2 000 azimuth steps at 10 Hz = 64 000 rays per sweep, every ray cast from the pose
+# the sensor has AT ITS OWN FIRING TIME into a world of axis-aligned boxes over a ground plane, returned in the LiDAR
+# frame as float32 with range noise: ~60 000 returns per sweep, motion-distorted like a real sweep.  The sensor drives
+# > 200 m in 30 s, so a local map with the reference's 100 m eviction radius grows, is evicted from, and rehashes.
+DRIVE_RINGS, DRIVE_AZIMUTHS = 32, 2000
+DRIVE_SENSOR_HEIGHT = 1.6
+
+
+def hilti_lidar_extrinsic() -> np.ndarray:
+    """sensors.lidar.extrinsics of config/hilti_config.yaml:20-25 as the 4x4 the reference builds from them
+    (include/ESKF_LIO/CloudPreprocessor.hpp:20-28): quaternion (x, y, z, w) = (0.7071068, -0.7071068, 0, 0), normalised."""
+    q = np.array([0.7071068, -0.7071068, 0.0, 0.0])
+    x, y, z, w = q / np.linalg.norm(q)
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = [-0.001, -0.00855, 0.055]
+    return T
+
+
+def drive_world(seed: int = SCAN_SEED, length: float = 290.0) -> np.ndarray:
+    """-> boxes [B, 6] (xmin, ymin, zmin, xmax, ymax, zmax), ground at z = -DRIVE_SENSOR_HEIGHT: buildings of varying
+    depth, height and setback on both sides of a street along +x, parked cars, poles, kiosks."""
+    g = -DRIVE_SENSOR_HEIGHT
+    boxes = []
+    idx = np.arange(4096, dtype=np.uint64)
+    u = [rand_unit(seed, 500 + k, idx) for k in range(10)]
+    for side in (1.0, -1.0):
+        x, k = -40.0, (0 if side > 0 else 2048)
+        while x < length:
+            w, gap = 8.0 + 14.0 * u[0][k], 1.5 + 4.5 * u[1][k]
+            setback, depth, height = 8.0 + 4.0 * u[2][k], 6.0 + 10.0 * u[3][k], 5.0 + 11.0 * u[4][k]
+            y0, y1 = sorted((side * setback, side * (setback + depth)))
+            boxes.append([x, y0, g, x + w, y1, g + height])
+            x += w + gap
+            k += 1
+    for j in range(int(length / 11.0) + 4):                   # parked cars, alternating sides, irregular spacing
+        side = 1.0 if j % 2 == 0 else -1.0
+        cx = -35.0 + 11.0 * j + 4.0 * u[5][j]
+        cy = side * (5.2 + 0.8 * u[6][j])
+        boxes.append([cx, cy - 0.9, g, cx + 4.2, cy + 0.9, g + 1.45 + 0.3 * u[7][j]])
+    for j in range(int(length / 23.0) + 3):                   # poles and kiosks
+        cx = -30.0 + 23.0 * j + 6.0 * u[8][j]
+        boxes.append([cx, 6.9, g, cx + 0.3, 7.2, g + 7.0])
+        boxes.append([cx + 9.0, -7.2, g, cx + 9.3, -6.9, g + 7.0])
+        if j % 3 == 1:
+            boxes.append([cx + 4.0, 6.2 + u[9][j], g, cx + 6.5, 7.9 + u[9][j], g + 2.6])
+    return np.ascontiguousarray(np.array(boxes, dtype=np.float64))
+
+
+def drive_pose(tau):
+    """Pose of the IMU in the world tau seconds after the end of the first sweep: at rest before, then accelerating to
+    7.5 m/s along the street with a lateral sway and small attitude oscillations.  -> (R [..., 3, 3], p [..., 3])."""
+    tau = np.asarray(tau, dtype=np.float64)
+    s = np.maximum(tau, 0.0)
+    v, T = 7.5, 2.0
+    p = np.stack([v * (s - T * (1.0 - np.exp(-s / T))), 1.2 * (1.0 - np.cos(0.35 * s)), 0.05 * (1.0 - np.cos(1.1 * s))], axis=-1)
+    yaw, pitch, roll = 0.12 * (1 - np.cos(0.3 * s)), 0.02 * (1 - np.cos(0.9 * s)), 0.015 * (1 - np.cos(0.7 * s))
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    R = np.empty(tau.shape + (3, 3))
+    R[..., 0, 0], R[..., 0, 1], R[..., 0, 2] = cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr
+    R[..., 1, 0], R[..., 1, 1], R[..., 1, 2] = sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr
+    R[..., 2, 0], R[..., 2, 1], R[..., 2, 2] = -sp, cp * sr, cp * cr
+    return R, p
+
+
+def _cast(origin, direction, boxes, max_range):
+    """Nearest hit of rays (origin [N, 3], unit direction [N, 3]) with the ground plane z = -DRIVE_SENSOR_HEIGHT and the
+    boxes; -> range [N], inf where nothing is hit within max_range.  The sensor drives between the two rows of boxes
+    (|y| < 3 m, boxes at |y| > 4 m), so a box is only tested against the rays that point to its side."""
+    n = origin.shape[0]
+    best = np.full(n, np.inf)
+    dz = direction[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = (-DRIVE_SENSOR_HEIGHT - origin[:, 2]) / dz
+    best = np.where((dz < 0.0) & (tg > 0.0), tg, best)
+    d = np.where(np.abs(direction) < 1e-12, 1e-12, direction)
+    inv = 1.0 / d
+    lo_x, hi_x = origin[:, 0].min() - max_range, origin[:, 0].max() + max_range
+    near = boxes[(boxes[:, 3] >= lo_x) & (boxes[:, 0] <= hi_x)]
+    for side in (1.0, -1.0):
+        rays = np.nonzero(direction[:, 1] * side > 0.0)[0]
+        o, iv, b_best = origin[rays], inv[rays], best[rays]
+        for b in near[(near[:, 1] if side > 0 else -near[:, 4]) > 3.0]:
+            t1 = (b[:3] - o) * iv
+            t2 = (b[3:] - o) * iv
+            tmin = np.minimum(t1, t2).max(axis=1)
+            tmax = np.maximum(t1, t2).min(axis=1)
+            b_best = np.where((tmax >= tmin) & (tmin > 0.0) & (tmin < b_best), tmin, b_best)
+        best[rays] = b_best
+    return np.where(best <= max_range, best, np.inf)
+
+
+def drive_truth(frames: int, sweep: float = 0.1):
+    """[(end time, 4x4 IMU pose)] of the drive's sweeps."""
+    out = []
+    for k in range(frames):
+        Re, pe = drive_pose(np.array(sweep * k))
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = Re, pe
+        out.append((STREAM_T0 + sweep * k, T))
+    return out
+
+
+def iter_drive_stream(frames: int = 300, seed: int = SCAN_SEED, imu_rate: float = 400.0, sweep: float = 0.1,
+                      max_range: float = 60.0, noise: float = 0.01, extrinsic=None):
+    """Yields (arrival time, ("imu", t, gyro, accel) | ("lidar", points float32-exact in the LiDAR frame, pointTime)) in
+    arrival order (a generator: 300 sweeps of 57 000 points are 0.5 GB).  extrinsic: LiDAR -> IMU (default:
+    hilti_lidar_extrinsic()).  Deterministic in its arguments."""
+    T_il = hilti_lidar_extrinsic() if extrinsic is None else np.asarray(extrinsic, dtype=np.float64)
+    boxes = drive_world(seed)
+    n_imu = int(round((0.02 + sweep * (frames - 1) + 0.0125) * imu_rate)) + 1
+    tau_imu = -0.0213 + np.arange(n_imu) / imu_rate
+    R, p0 = drive_pose(tau_imu)
+    d = 1e-5
+    Rm, _ = drive_pose(tau_imu - d)
+    Rp, _ = drive_pose(tau_imu + d)
+    dR = np.einsum("nji,njk->nik", Rm, Rp)
+    gyro = np.stack([dR[:, 2, 1] - dR[:, 1, 2], dR[:, 0, 2] - dR[:, 2, 0], dR[:, 1, 0] - dR[:, 0, 1]], axis=1) / (4 * d)
+    da = 1e-3                                                     # world acceleration by a central second difference
+    _, pm = drive_pose(tau_imu - da)
+    _, pp = drive_pose(tau_imu + da)
+    acc = (pp - 2.0 * p0 + pm) / (da * da)
+    accel = np.einsum("nji,nj->ni", R, acc - STREAM_GRAVITY)
+    # the firing pattern: azimuth column j fires all 32 rings at once (elevations -16 .. +15 degrees)
+    el = np.deg2rad(np.arange(DRIVE_RINGS, dtype=np.float64) - 16.0)
+    az = 2.0 * np.pi * np.arange(DRIVE_AZIMUTHS, dtype=np.float64) / DRIVE_AZIMUTHS
+    d_l = np.stack([np.cos(el)[None, :] * np.cos(az)[:, None], np.cos(el)[None, :] * np.sin(az)[:, None],
+                    np.broadcast_to(np.sin(el)[None, :], (DRIVE_AZIMUTHS, DRIVE_RINGS))], axis=-1)   # [A, 32, 3]
+    ray = np.arange(DRIVE_AZIMUTHS * DRIVE_RINGS, dtype=np.uint64)
+    next_imu = 0
+    for k in range(frames):
+        end = sweep * k
+        arrival = STREAM_T0 + end + 5e-4
+        while next_imu < n_imu and STREAM_T0 + tau_imu[next_imu] <= arrival:
+            t = STREAM_T0 + tau_imu[next_imu]
+            yield t, ("imu", t, gyro[next_imu].copy(), accel[next_imu].copy())
+            next_imu += 1
+        tau = end - sweep + sweep * (np.arange(DRIVE_AZIMUTHS) + 1.0) / DRIVE_AZIMUTHS     # column j fires at tau[j]
+        Rk, pk = drive_pose(tau)
+        Rw = np.einsum("aij,jk->aik", Rk, T_il[:3, :3])                                       # LiDAR -> world, per column
+        origin = np.einsum("aij,j->ai", Rk, T_il[:3, 3]) + pk
+        d_w = np.einsum("aij,arj->ari", Rw, d_l)
+        rng = _cast(np.repeat(origin, DRIVE_RINGS, axis=0), d_w.reshape(-1, 3), boxes, max_range)
+        keep = np.isfinite(rng) & (rng > 0.5)
+        eps = (rand_unit(seed + 31 * (k + 1), 520, ray) + rand_unit(seed + 31 * (k + 1), 521, ray) +
+               rand_unit(seed + 31 * (k + 1), 522, ray) + rand_unit(seed + 31 * (k + 1), 523, ray) - 2.0) * noise
+        local = d_l.reshape(-1, 3)[keep] * (rng[keep] + eps[keep])[:, None]
+        local = local.astype(np.float32).astype(np.float64)       # what a PointCloud2 carries
+        t_pts = np.repeat(STREAM_T0 + tau, DRIVE_RINGS)[keep]
+        yield arrival, ("lidar", np.ascontiguousarray(local), np.ascontiguousarray(t_pts))
+    while next_imu < n_imu:
+        t = STREAM_T0 + tau_imu[next_imu]
+        yield t, ("imu", t, gyro[next_imu].copy(), accel[next_imu].copy())
+        next_imu += 1

@@ -375,6 +375,10 @@ int vgicp_comm_destroy(vgicp_ctx* ctx);
 int vgicp_peer_export(vgicp_ctx* ctx, void* handle64);
 int vgicp_peer_connect(vgicp_ctx* ctx, int world_size, int rank, const void* handles);
 int vgicp_peer_disconnect(vgicp_ctx* ctx);
+/* "" while the device-initiated exchange carries the per-iteration merge (or there is nothing to merge: one device);
+ * otherwise why it does not — a peer mapping that was refused, VGICP_PEER_EXCHANGE=0, a launch that gave up waiting
+ * for a peer — and what is used instead.  For a multi-device context and for a communicator alike.  Never NULL. */
+const char* vgicp_peer_status(const vgicp_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,8 @@ def load() -> C.CDLL:
     lib.oracle_map_size.restype = sz
     lib.oracle_map_size.argtypes = [vp]
     lib.oracle_map_insert.argtypes = [vp, sz, dp, dp]
+    lib.oracle_map_evict.argtypes = [vp, dp, C.c_double]
+    lib.oracle_map_evict.restype = sz
     lib.oracle_map_export.restype = sz
     lib.oracle_map_export.argtypes = [vp, sz, ip, dp, dp, up]
     lib.oracle_voxel_index.argtypes = [C.c_double, sz, dp, ip]
@@ -131,6 +133,11 @@ class OracleMap:
     def insert(self, points, covs):
         points, covs = _f64(points, 3), _f64(covs, 9)
         self._lib.oracle_map_insert(self._h, points.shape[0], _dp(points), _dp(covs))
+
+    def evict(self, position, distance_threshold: float) -> int:
+        """LocalMap::updateLocalMap's eviction loop (src/LocalMap.cpp:60-72): -> voxels removed."""
+        pos = np.ascontiguousarray(position, dtype=np.float64).reshape(3)
+        return int(self._lib.oracle_map_evict(self._h, _dp(pos), float(distance_threshold)))
 
     def export(self):
         n = len(self)

@@ -461,6 +461,26 @@ void oracle_map_insert(oracle_map* map, size_t n, const double* points, const do
   }
 }
 
+// The eviction loop of LocalMap::updateLocalMap (reference src/LocalMap.cpp:60-72) with needsPointRemoval (:149-154):
+// every voxel whose centre (index + 0.5) * voxelSize is farther than distance_threshold from `position` is erased.
+// (voxelCenter - currentPos).norm(): Eigen's norm() is sqrt(squaredNorm()), the squares added left to right.
+size_t oracle_map_evict(oracle_map* map, const double position[3], double distance_threshold) {
+  size_t removed = 0;
+  for (auto it = map->grid.begin(); it != map->grid.end();) {
+    const double cx = ((double)it->first.i + 0.5) * map->voxel_size - position[0];
+    const double cy = ((double)it->first.j + 0.5) * map->voxel_size - position[1];
+    const double cz = ((double)it->first.k + 0.5) * map->voxel_size - position[2];
+    const double distance = std::sqrt(cx * cx + cy * cy + cz * cz);
+    if (distance > distance_threshold) {
+      it = map->grid.erase(it);
+      ++removed;
+    } else {
+      ++it;
+    }
+  }
+  return removed;
+}
+
 size_t oracle_map_export(const oracle_map* map, size_t capacity, int32_t* keys, double* means,
                          double* covs, uint64_t* counts) {
   size_t w = 0;

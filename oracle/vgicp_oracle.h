@@ -32,6 +32,9 @@ size_t oracle_map_size(const oracle_map* map);
 /* The insertion loop of LocalMap::updateLocalMap (LocalMap.cpp:47-58) with Voxel's constructor and
  * Voxel::addPoint (LocalMap.hpp:72-87): points are taken as already in the world frame. */
 void oracle_map_insert(oracle_map* map, size_t n, const double* points, const double* covs);
+/* reference src/LocalMap.cpp:60-72,149-154: erase every voxel whose centre is farther than distance_threshold from
+ * position; returns the number of voxels removed */
+size_t oracle_map_evict(oracle_map* map, const double position[3], double distance_threshold);
 
 /* Dump every voxel: keys n x 3 int32, means n x 3, covs n x 9, counts n (numPoints). Order is the
  * container's iteration order (unspecified). Returns the number of voxels written (<= capacity). */

@@ -27,6 +27,11 @@ class OracleBackend:
         self.voxel = config["cloud_preprocessor"]["voxel_size"]
         self.T_il = np.asarray(config["lidar_extrinsic"], dtype=np.float64)
         self.iterations = []
+        self.kept = []
+        # eviction (src/LocalMap.cpp:60-72) by a count of map updates instead of the reference's wall-clock period
+        self.evict = (bool(lm["remove_distant_points"]), float(lm["distance_threshold"]), int(lm.get("remove_every_updates", 0)))
+        self.updates_since_evict = 0
+        self.removed = []
 
     def preprocess(self, states, points, pointTime):
         eye = np.tile(np.eye(3).reshape(9), (len(points), 1))
@@ -35,6 +40,7 @@ class OracleBackend:
             pts, done = self.o.deskew(pts, pointTime, states)
             assert done >= 0, "IMU states do not bracket the sweep"
         p, c, _ = self.o.preprocess(pts, self.voxel, 30)
+        self.kept.append(len(p))
         return p, c
 
     def align(self, points, covs, guess):
@@ -52,4 +58,8 @@ class OracleBackend:
                 return
         wp, wc = self.o.transform(points, covs, transform)
         self.map.insert(wp, wc)
+        self.updates_since_evict += 1
+        if self.evict[0] and self.evict[2] and self.updates_since_evict >= self.evict[2]:
+            self.removed.append(self.map.evict(transform[:3, 3], self.evict[1]))
+            self.updates_since_evict = 0
         self.prev = transform.copy()

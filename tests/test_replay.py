@@ -359,3 +359,83 @@ def test_the_package_writer_agrees_with_the_hand_assembled_layout():
     assert mine[140:164] == hand[140:164] and mine[236:260] == hand[236:260]
     back = replay.decode_imu(mine)
     assert back.timestamp == m.timestamp and back.angularVelocity.tolist() == m.angularVelocity.tolist()
+
+
+# ---- the stand-in for BASELINE config C4 (HILTI exp21 through Odometry.cpp end to end) -----------------------------
+def _drive_config():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_drive_fixture", os.path.join(os.path.dirname(__file__), "golden", "make_drive_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.drive_config(), mod.lazy_events
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_street_drive_c4_surrogate(capsys):
+    """300 sweeps of ~57 000 points from a 32-ring spinning sensor that drives > 200 m down a street (synth.
+    iter_drive_stream; every ray cast from the pose at its own firing time), through Odometry::run's frame loop with the
+    HIP module behind every stage (vgicp_scan_prepare -> vgicp_align_resident -> vgicp_map_insert_resident ->
+    vgicp_map_evict every 100 updates), against the ORACLE-driven replay of the same stream (tests/golden/drive_c4.npz,
+    made once by tests/golden/make_drive_fixture.py: minutes of CPU): the trajectory (to rounding while no voxel
+    assignment has flipped between the two chains, to a fraction of the sensor noise after), the Gauss-Newton round
+    counts, the kept points, what every eviction removed, and the final map's voxel set.  The map grows from
+    nothing through several table sizes, is evicted from three times (tombstones, then rehashes under them), and the
+    registration runs on whatever the table looks like at that frame.  Prints the three stage timers the way
+    src/Odometry.cpp:98-109 does."""
+    fixture = os.path.join(os.path.dirname(__file__), "golden", "drive_c4.npz")
+    ref = np.load(fixture)
+    frames = int(ref["frames"])
+    assert frames >= 300
+    cfg, lazy_events = _drive_config()
+    backend = replay.DeviceBackend(cfg, 0)
+    odo = replay.Odometry(cfg, backend)
+    slots_seen = set()
+    orig_update = backend.update_map
+
+    def update_and_watch(points, covs, transform, initialize):
+        orig_update(points, covs, transform, initialize)
+        slots_seen.add(backend.ctx.map_size()[1])
+    backend.update_map = update_and_watch
+    traj = odo.run(lazy_events(frames))
+    with capsys.disabled():
+        print("\n[street drive, %d frames, GPU-driven]\n%s" % (len(traj), odo.report()))
+    assert len(traj) == frames
+    # The trajectory.  Closed loop, the two chains cannot stay bit-close for 300 frames: they differ by rounding (1e-13)
+    # until, in some frame, a point sits within that distance of a voxel face and the two sides bin it differently --
+    # one correspondence more or less moves the pose by ~1e-5 m, the next frame's deskew and map inherit that, and from
+    # there on the runs are two equally valid registrations of the same noisy sweeps (1 cm range noise): millimetres
+    # apart, both on the generating motion.  So: rounding-level agreement while no flip has happened (the first
+    # frames), then agreement to a fraction of the sensor noise, and the SAME accuracy against the truth.
+    truth = synth.drive_truth(frames)
+    dev = np.array([pose_error(T1, T0)[0] for (_, T1), T0 in zip(traj, ref["poses"])])
+    assert all(s1 == s0 for (s1, _), s0 in zip(traj, ref["stamps"]))
+    assert dev[:10].max() < 1e-9, dev[:10]
+    assert dev.max() < 0.02 and np.median(dev) < 0.006, (dev.max(), np.median(dev))
+    err_gpu = np.array([np.linalg.norm(T[:3, 3] - G[:3, 3]) for (_, T), (_, G) in zip(traj, truth)])
+    err_ref = np.array([np.linalg.norm(T[:3, 3] - G[:3, 3]) for T, (_, G) in zip(ref["poses"], truth)])
+    assert err_gpu.max() < 0.25 and abs(err_gpu.max() - err_ref.max()) < 0.02 and abs(err_gpu[-1] - err_ref[-1]) < 0.02
+    # rounds per frame: the same distribution (one frame of the fixture never converges: Gauss-Newton without damping
+    # cycles between two voxel assignments until max_iteration = 100 stops it -- the reference's behaviour)
+    it_gpu, it_ref = np.array(backend.iterations), ref["iterations"]
+    cap = cfg["registration"]["max_iteration"]
+    assert len(it_gpu) == len(it_ref) and np.array_equal(it_gpu[:10], it_ref[:10])
+    assert abs(np.mean(it_gpu[it_gpu < cap]) - np.mean(it_ref[it_ref < cap])) < 0.3 and (it_gpu >= cap).sum() <= 3
+    # kept points per frame: equal while the chains are bit-close, within half a per cent after
+    kept_gpu, kept_ref = np.array(backend.kept), ref["kept"]
+    assert len(kept_gpu) == len(kept_ref) and np.array_equal(kept_gpu[:10], kept_ref[:10])
+    assert (np.abs(kept_gpu - kept_ref) / kept_ref).max() < 0.005
+    # evictions fired, and removed what the oracle's loop removed (to the voxels the maps differ in)
+    assert len(backend.removed) == len(ref["removed"]) >= 2 and max(backend.removed) > 10_000
+    assert (np.abs(np.array(backend.removed) - ref["removed"]) / ref["removed"]).max() < 0.01
+    # the table grew through several sizes on the way, and tombstones were left behind by the evictions
+    assert len(slots_seen) >= 3, slots_seen
+    # the final map: the same voxels but for the fringe the flips decide
+    keys, means, covs, counts = backend.ctx.map_export()
+    a = {tuple(k) for k in keys.tolist()}
+    b = {tuple(k) for k in ref["map_keys"].tolist()}
+    assert len(a ^ b) < 0.02 * len(b), (len(a), len(b), len(a ^ b))
+    assert abs(int(counts.sum()) - int(ref["map_count_sum"])) < 0.01 * int(ref["map_count_sum"])
+    assert np.abs(means.mean(axis=0) - ref["map_mean_centroid"]).max() < 0.05
+    assert backend.ctx.counter(1) == 0      # no persistent launch gave up
+    backend.ctx.close()
