@@ -134,7 +134,7 @@ def load_library() -> C.CDLL:
     lib.vgicp_peer_disconnect.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("vgicp_last_error",):
+        if name not in ("vgicp_last_error", "vgicp_peer_status"):
             fn.restype = C.c_int
     _lib = lib
     return lib
