@@ -112,7 +112,8 @@ inline vgicp_ctx * defaultContext()
 // buffers' addresses and sizes, a hash over 64 evenly spaced elements (first and last included) and the library's
 // scan generation (VGICP_COUNTER_SCAN_GENERATION: anything else that replaced the resident scan voids it).  A
 // cloud that was resized, reallocated, or edited at a sampled element falls back to the upload path; an edit of
-// an unsampled element in place is NOT seen — callers that edit a prepared cloud in place call shim::forget(cloud).
+// an unsampled element in place is NOT seen — callers that edit a prepared cloud in place call shim::forget(cloud), or
+// run with VGICP_SHIM_FULL_HASH=1 (every byte of both buffers is hashed).
 struct ResidentStamp
 {
   vgicp_ctx * ctx = nullptr;
@@ -131,12 +132,37 @@ inline std::vector<ResidentStamp> & residentStamps()
 }
 inline uint64_t sampleHash(const PointCloud & cloud)
 {
+  // VGICP_SHIM_FULL_HASH=1: every byte of both buffers (a caller that edits prepared clouds in place and does not want to
+  // call shim::forget); default: 64 evenly spaced elements of each
+  static const bool full = [] {
+      const char * e = std::getenv("VGICP_SHIM_FULL_HASH");
+      return e && e[0] == '1';
+    }();
+  const size_t n = cloud.points_.size(), m = cloud.covariances_.size();
+  if (full) {
+    // four independent multiply-xorshift lanes over 8-byte words: runs at the speed the caches deliver the buffers
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    auto mixWords = [&h](const void * p, size_t bytes) {
+        const uint64_t * w = static_cast<const uint64_t *>(p);
+        const size_t words = bytes / 8;
+        size_t i = 0;
+        for (; i + 4 <= words; i += 4) {
+          for (int k = 0; k < 4; ++k) {
+            h[k] = (h[k] ^ w[i + k]) * 0x9FB21C651E98DF25ull;
+            h[k] ^= h[k] >> 29;
+          }
+        }
+        for (; i < words; ++i) {h[0] = (h[0] ^ w[i]) * 0x9FB21C651E98DF25ull; h[0] ^= h[0] >> 29;}
+      };
+    if (n) {mixWords(cloud.points_.data(), n * sizeof(Vector3d));}
+    if (m) {mixWords(cloud.covariances_.data(), m * sizeof(Matrix3d));}
+    return h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ (n * 0x100000001B3ull) ^ m;
+  }
   uint64_t h = 1469598103934665603ull;
   auto mix = [&h](const void * p, size_t bytes) {
       const unsigned char * b = static_cast<const unsigned char *>(p);
       for (size_t i = 0; i < bytes; ++i) {h = (h ^ b[i]) * 1099511628211ull;}
     };
-  const size_t n = cloud.points_.size(), m = cloud.covariances_.size();
   for (size_t k = 0; k < 64 && n; ++k) {mix(&cloud.points_[k * (n - 1) / 63], sizeof(Vector3d));}
   for (size_t k = 0; k < 64 && m; ++k) {mix(&cloud.covariances_[k * (m - 1) / 63], sizeof(Matrix3d));}
   return h;
