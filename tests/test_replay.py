@@ -372,7 +372,8 @@ def _drive_config():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
-def test_street_drive_c4_surrogate(capsys):
+@pytest.mark.parametrize("launch", ["one point per thread", "several points per thread + dense record copy"])
+def test_street_drive_c4_surrogate(capsys, monkeypatch, launch):
     """300 sweeps of ~57 000 points from a 32-ring spinning sensor that drives > 200 m down a street (synth.
     iter_drive_stream; every ray cast from the pose at its own firing time), through Odometry::run's frame loop with the
     HIP module behind every stage (vgicp_scan_prepare -> vgicp_align_resident -> vgicp_map_insert_resident ->
@@ -382,7 +383,15 @@ def test_street_drive_c4_surrogate(capsys):
     counts, the kept points, what every eviction removed, and the final map's voxel set.  The map grows from
     nothing through several table sizes, is evicted from three times (tombstones, then rehashes under them), and the
     registration runs on whatever the table looks like at that frame.  Prints the three stage timers the way
-    src/Odometry.cpp:98-109 does."""
+    src/Odometry.cpp:98-109 does.
+    Second parametrisation: the same drive with the persistent launch on 120 workgroups and the dense-copy threshold at
+    4 096 slots (VGICP_PERSIST_GRID, VGICP_DENSE_SLOTS: read when the context is created) — every align is then the
+    several-points-per-thread instantiation (57 000 raw points > 120 x 448) reading remembered voxel payloads from a dense
+    copy of the occupied records that is REBUILT EVERY FRAME, because every frame's insertion (and every eviction, and
+    every rehash) changes the map: the long-run exercise of that path that C5 (one map, never mutated) cannot give."""
+    if launch != "one point per thread":
+        monkeypatch.setenv("VGICP_PERSIST_GRID", "120")
+        monkeypatch.setenv("VGICP_DENSE_SLOTS", "4096")
     fixture = os.path.join(os.path.dirname(__file__), "golden", "drive_c4.npz")
     ref = np.load(fixture)
     frames = int(ref["frames"])
@@ -411,6 +420,8 @@ def test_street_drive_c4_surrogate(capsys):
     dev = np.array([pose_error(T1, T0)[0] for (_, T1), T0 in zip(traj, ref["poses"])])
     assert all(s1 == s0 for (s1, _), s0 in zip(traj, ref["stamps"]))
     assert dev[:10].max() < 1e-9, dev[:10]
+    if launch != "one point per thread":
+        assert backend.ctx.counter(0) >= frames - 1          # every align was ONE persistent launch
     assert dev.max() < 0.02 and np.median(dev) < 0.006, (dev.max(), np.median(dev))
     err_gpu = np.array([np.linalg.norm(T[:3, 3] - G[:3, 3]) for (_, T), (_, G) in zip(traj, truth)])
     err_ref = np.array([np.linalg.norm(T[:3, 3] - G[:3, 3]) for T, (_, G) in zip(ref["poses"], truth)])
