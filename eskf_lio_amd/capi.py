@@ -33,7 +33,7 @@ EXPORTS = (
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
     "vgicp_accumulate", "vgicp_solve_step", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_scan_prepare", "vgicp_scan_download",
-    "vgicp_peer_status", "vgicp_scan_prepare_async", "vgicp_sweep_stage", "vgicp_scan_prepare_staged_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
+    "vgicp_peer_status", "vgicp_scan_prepare_async", "vgicp_sweep_stage", "vgicp_sweep_stage_cloud2", "vgicp_scan_prepare_staged_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
     "vgicp_set_option", "vgicp_host_register", "vgicp_host_unregister",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
     "vgicp_peer_export", "vgicp_peer_connect", "vgicp_peer_disconnect",
@@ -114,6 +114,7 @@ def load_library() -> C.CDLL:
     lib.vgicp_scan_download.argtypes = [vp, sz, dp, dp, C.POINTER(sz)]
     lib.vgicp_scan_prepare_async.argtypes = [vp, sz, dp, dp, sz, dp, dp, C.c_double, C.c_int]
     lib.vgicp_sweep_stage.argtypes = [vp, sz, dp, dp, C.POINTER(C.c_uint64)]
+    lib.vgicp_sweep_stage_cloud2.argtypes = [vp, sz, vp, sz, sz, sz, sz, sz, C.POINTER(C.c_uint64)]
     lib.vgicp_peer_status.argtypes = [vp]
     lib.vgicp_peer_status.restype = C.c_char_p
     lib.vgicp_scan_prepare_staged_async.argtypes = [vp, C.c_uint64, sz, dp, dp, C.c_double, C.c_int]
@@ -491,6 +492,18 @@ class Context:
             raise ValueError("one capture time per point")
         ticket = C.c_uint64(0)
         self._check(self._lib.vgicp_sweep_stage(self._h, pts.shape[0], _dp(pts), _dp(t) if t.size else None, C.byref(ticket)))
+        return int(ticket.value)
+
+    def sweep_stage_cloud2(self, data, n: int, point_step: int, off_x: int, off_y: int, off_z: int, off_time=None) -> int:
+        """vgicp_sweep_stage_cloud2: the payload of a PointCloud2 (bytes / uint8 array, little-endian records) as it
+        arrives; the device widens the float32 coordinates -> ticket."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        if buf.size < n * point_step:
+            raise ValueError("payload shorter than n * point_step")
+        ticket = C.c_uint64(0)
+        self._check(self._lib.vgicp_sweep_stage_cloud2(self._h, int(n), buf.ctypes.data_as(C.c_void_p), int(point_step), int(off_x),
+                                                       int(off_y), int(off_z), (2 ** 64 - 1) if off_time is None else int(off_time),
+                                                       C.byref(ticket)))
         return int(ticket.value)
 
     def scan_prepare_staged_async(self, ticket: int, states=None, extrinsic=None, voxel_size: float = 0.3, knn: int = 30):

@@ -1615,6 +1615,7 @@ struct StagedPoints {
   char* stage = nullptr;            // page-locked, n x 24 bytes (+ padding)
   uint32_t* flags = nullptr;        // one 64-byte line per unit
   hipEvent_t done = nullptr;        // recorded behind the last kernel that reads the staging memory
+  uint32_t step = 0, off[3] = {0, 0, 0};   // staged ahead as sensor records (vgicp_sweep_stage_cloud2): PrepareArgs::src_step
   uint32_t job = 0, seq = 0;        // the copy crew's job (posted by scan_prepare_enqueue: a helper is copying already)
   bool helpers = false;
   double t_post = 0.0;
@@ -1691,6 +1692,8 @@ int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, 
     // staged ahead of time: the prologue reads the page-locked copy where it lies, nothing to wait for
     a.src_points = staged->stage;
     a.src_flags = nullptr;
+    a.src_step = staged->step;
+    for (int k = 0; k < 3; ++k) a.src_off[k] = staged->off[k];
     VG_HIP(ctx, launch_prepare_head(ctx->stream, a));
     if (staged->done) VG_HIP(ctx, hipEventRecord(staged->done, ctx->stream));
     VG_HIP(ctx, launch_prepare_tail(ctx->stream, a));
@@ -2099,6 +2102,8 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     sp.points = nullptr;
     sp.stage = const_cast<char*>(reinterpret_cast<const char*>(points));
     sp.done = ahead->done;
+    sp.step = ahead->step;
+    for (int k = 0; k < 3; ++k) sp.off[k] = ahead->off[k];
     if (with_deskew) {
       time_src = point_time;
       if (walk) VG_HIP(ctx, hipMemcpyAsync(d_time, point_time, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -2196,12 +2201,11 @@ int vgicp_scan_prepare_async(vgicp_ctx* ctx, size_t n, const double* points, con
 // include/ESKF_LIO/Subscriber.hpp:80-103; src/Odometry.cpp:43-48 pops the sweep long before :74 prepares it), so that
 // the preparation later starts from bytes the device can read at once.  Only plain CPU copies here, under a mutex
 // of its own: the one entry point another thread may call while the context's owner is inside a call.
-int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, uint64_t* ticket) {
-  if (!ctx || !ticket) return VGICP_ERR_BAD_ARGUMENT;
-  *ticket = 0;
-  if (ctx->multi) return vgicp_sweep_stage(vgicp_multi_api::first(ctx), n, points, point_time, ticket);
-  if (n == 0 || !points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
-  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "sweep too large");
+namespace {
+// data: n x 3 doubles (step == 0) or n sensor records of `step` bytes (float32 x y z at off[], a float64 capture time at
+// off_time, or none: SIZE_MAX).  times: n doubles for the first form (or nullptr).
+int stage_sweep_ahead(vgicp_ctx* ctx, size_t n, const void* data, const double* times, uint32_t step, const uint32_t off[3],
+                      size_t off_time, uint64_t* ticket) {
   vgicp_ctx::AheadSlot* slot = nullptr;
   {
     std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
@@ -2213,7 +2217,9 @@ int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const doub
     if (!slot) return fail(ctx, VGICP_ERR_NOT_READY, "three sweeps are staged ahead already: prepare one first");
     slot->state = 3;
   }
-  const size_t pts_room = (n * 3 * sizeof(double) + 16 + 255) & ~size_t(255);
+  const size_t rec = step ? step : 3 * sizeof(double);
+  const size_t pts_room = (n * rec + 16 + 255) & ~size_t(255);
+  const bool has_times = step ? off_time != SIZE_MAX : times != nullptr;
   const size_t need = pts_room + n * sizeof(double);
   if (slot->cap < need) {
     if (hipSetDevice(ctx->device) != hipSuccess) { slot->state = 0; return fail(ctx, VGICP_ERR_HIP, "hipSetDevice"); }
@@ -2226,15 +2232,52 @@ int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const doub
     }
     slot->cap = need * 5 / 4 + 4096;
   }
-  stage_copy(slot->mem, points, n * 3 * sizeof(double));
-  if (point_time) stage_copy(slot->mem + pts_room, point_time, n * sizeof(double));
+  stage_copy(slot->mem, data, n * rec);   // the records as they are: the device picks the floats out and widens them
+  double* t_dst = reinterpret_cast<double*>(slot->mem + pts_room);
+  if (step && has_times) {
+    // the capture times out of the records into an array of their own (the deskew's first kernel reads them contiguously)
+    const char* src = static_cast<const char*>(data) + off_time;
+    for (size_t i = 0; i < n; ++i) std::memcpy(t_dst + i, src + i * step, sizeof(double));
+  } else if (has_times) {
+    stage_copy(t_dst, times, n * sizeof(double));
+  }
   std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
   slot->n = n;
-  slot->has_times = point_time != nullptr;
+  slot->has_times = has_times;
+  slot->step = step;
+  for (int k = 0; k < 3; ++k) slot->off[k] = step ? off[k] : 0u;
+  slot->times_at = pts_room;
   slot->ticket = ++ctx->ahead_tickets;
   slot->state = 1;
   *ticket = slot->ticket;
   return VGICP_OK;
+}
+}  // namespace
+
+int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, uint64_t* ticket) {
+  if (!ctx || !ticket) return VGICP_ERR_BAD_ARGUMENT;
+  *ticket = 0;
+  if (ctx->multi) return vgicp_sweep_stage(vgicp_multi_api::first(ctx), n, points, point_time, ticket);
+  if (n == 0 || !points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
+  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "sweep too large");
+  const uint32_t none[3] = {0, 0, 0};
+  return stage_sweep_ahead(ctx, n, points, point_time, 0, none, SIZE_MAX, ticket);
+}
+
+int vgicp_sweep_stage_cloud2(vgicp_ctx* ctx, size_t n, const void* data, size_t point_step, size_t off_x, size_t off_y,
+                             size_t off_z, size_t off_time, uint64_t* ticket) {
+  if (!ctx || !ticket) return VGICP_ERR_BAD_ARGUMENT;
+  *ticket = 0;
+  if (ctx->multi) return vgicp_sweep_stage_cloud2(vgicp_multi_api::first(ctx), n, data, point_step, off_x, off_y, off_z, off_time, ticket);
+  if (n == 0 || !data) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
+  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "sweep too large");
+  if (point_step < 12 || point_step > 64 || point_step % 4 != 0)
+    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "point_step must be a multiple of 4 between 12 and 64 bytes");
+  for (size_t o : {off_x, off_y, off_z})
+    if (o % 4 != 0 || o + 4 > point_step) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "x / y / z must be float32 fields inside the record, 4-byte aligned");
+  if (off_time != SIZE_MAX && off_time + 8 > point_step) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the float64 capture time must lie inside the record");
+  const uint32_t off[3] = {(uint32_t)off_x, (uint32_t)off_y, (uint32_t)off_z};
+  return stage_sweep_ahead(ctx, n, data, nullptr, (uint32_t)point_step, off, off_time, ticket);
 }
 
 int vgicp_scan_prepare_staged_async(vgicp_ctx* ctx, uint64_t ticket, size_t num_states, const double* states,
@@ -2251,9 +2294,8 @@ int vgicp_scan_prepare_staged_async(vgicp_ctx* ctx, uint64_t ticket, size_t num_
   if (num_states > 0 && !slot->has_times) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the sweep was staged without capture times");
   VG_HIP(ctx, hipSetDevice(ctx->device));
   if (!slot->done) VG_HIP(ctx, hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
-  const size_t pts_room = (slot->n * 3 * sizeof(double) + 16 + 255) & ~size_t(255);
   const int rc = scan_prepare_enqueue(ctx, slot->n, reinterpret_cast<const double*>(slot->mem),
-                                      reinterpret_cast<const double*>(slot->mem + pts_room), num_states, states, extrinsic,
+                                      reinterpret_cast<const double*>(slot->mem + slot->times_at), num_states, states, extrinsic,
                                       voxel_size, knn, slot);
   std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
   // whatever the outcome the ticket is used up; the slot is free again once the kernels that read it are through

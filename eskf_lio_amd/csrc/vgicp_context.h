@@ -289,6 +289,8 @@ struct vgicp_ctx {
     size_t cap = 0, n = 0;
     uint64_t ticket = 0;
     bool has_times = false;
+    uint32_t step = 0, off[3] = {0, 0, 0};   // != 0: sensor records (vgicp_sweep_stage_cloud2), float32 x y z at these offsets
+    size_t times_at = 0;           // byte offset of the capture times (n doubles) inside mem
     int state = 0;                 // 0 free, 1 staged, 2 handed to the device (`done` recorded behind its readers), 3 being filled
     hipEvent_t done = nullptr;
   };

@@ -280,6 +280,10 @@ struct PrepareArgs {
   const char* src_points;
   const uint32_t* src_flags;
   uint32_t src_seq, src_unit, src_spin;
+  // src_step != 0: the staging memory holds the sensor's own records (a PointCloud2 payload, vgicp_sweep_stage_cloud2):
+  // src_step bytes per point (a multiple of 4, at most 64), float32 x, y, z at byte offsets src_off[0..2]; the prologue
+  // widens them (float -> double is exact).  src_step == 0: n x 3 doubles.
+  uint32_t src_step, src_off[3];
 };
 hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a);        // = head + tail
 // head: the kernels that read the raw sweep (deskew bounds from the times, prologue); tail: everything behind them.

@@ -150,12 +150,13 @@ struct PrologueArgs {
   const char* src;            // nullptr, or the raw points in page-locked HOST memory (PrepareArgs::src_points)
   const uint32_t* src_flags;
   uint32_t src_seq, src_unit, src_spin;
+  uint32_t src_step, src_off[3];   // != 0: the sensor's own records, float32 x y z at these byte offsets (PrepareArgs::src_step)
 };
 __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char prologue_lds[];
   uint32_t* ends_sh = reinterpret_cast<uint32_t*>(prologue_lds);
   __shared__ uint32_t last_found;
-  __shared__ __attribute__((aligned(16))) double staged[3 * 256];
+  __shared__ __attribute__((aligned(16))) double staged[256 * 64 / 8];   // 256 points of 24 bytes (doubles) or of up to 64 (sensor records)
   __shared__ uint32_t staged_ok;
   const uint32_t tid = threadIdx.x;
   if (a.src) {
@@ -182,9 +183,10 @@ __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
     }
     if (p0 < a.n) {
       const uint32_t cnt = a.n - p0 < 256u ? a.n - p0 : 256u;
-      const v4i* sp = reinterpret_cast<const v4i*>(a.src + (size_t)p0 * 24);
+      const uint32_t step = a.src_step ? a.src_step : 24u;
+      const v4i* sp = reinterpret_cast<const v4i*>(a.src + (size_t)p0 * step);   // p0 * step is a multiple of 16 (p0 of 256, step of 4)
       v4i* lp = reinterpret_cast<v4i*>(staged);
-      const uint32_t chunks = (cnt * 24u + 15u) / 16u;   // an odd count: half a chunk more (the staging memory is padded)
+      const uint32_t chunks = (cnt * step + 15u) / 16u;   // a last chunk may reach past the points (the staging memory is padded)
       for (uint32_t c = tid; c < chunks; c += 256u) lp[c] = __builtin_nontemporal_load(sp + c);
     }
     __syncthreads();
@@ -233,7 +235,12 @@ __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
   if (i >= a.n) return;
   double x, y, z;
   bool moved = a.src != nullptr;   // points that came from the host are written to the device whether or not they move
-  if (a.src) {
+  if (a.src && a.src_step) {
+    const char* rec = reinterpret_cast<const char*>(staged) + tid * a.src_step;
+    x = (double)*reinterpret_cast<const float*>(rec + a.src_off[0]);
+    y = (double)*reinterpret_cast<const float*>(rec + a.src_off[1]);
+    z = (double)*reinterpret_cast<const float*>(rec + a.src_off[2]);
+  } else if (a.src) {
     x = staged[3 * tid]; y = staged[3 * tid + 1]; z = staged[3 * tid + 2];
   } else {
     x = a.pts[3 * (size_t)i]; y = a.pts[3 * (size_t)i + 1]; z = a.pts[3 * (size_t)i + 2];
@@ -1604,6 +1611,8 @@ hipError_t launch_prepare_head(hipStream_t s, const PrepareArgs& a) {
   pa.src_seq = a.src_seq;
   pa.src_unit = a.src_unit ? a.src_unit : 256u;
   pa.src_spin = a.src_spin;
+  pa.src_step = a.src_step;
+  for (int c = 0; c < 3; ++c) pa.src_off[c] = a.src_off[c];
   hipLaunchKernelGGL(sweep_prologue_kernel, dim3(blocks_for(n, 256)), dim3(256), (size_t)a.states * sizeof(uint32_t), s, pa);
   ++g_kernel_launches;
   if (a.ev_after_prologue) {

@@ -181,6 +181,30 @@ def decode_pointcloud2(blob: bytes) -> LidarMeasurement:
     return LidarMeasurement(np.ascontiguousarray(pts), np.ascontiguousarray(t))
 
 
+def pointcloud2_payload(blob: bytes):
+    """sensor_msgs/PointCloud2 -> (payload uint8 array, n, point_step, off_x, off_y, off_z, off_timestamp): what
+    vgicp_sweep_stage_cloud2 takes -- the records stay as the sensor wrote them, the DEVICE widens the float32
+    coordinates (Subscriber.hpp:89-97 does it on the host, one point at a time).  Little-endian messages only."""
+    r = _CdrReader(blob)
+    r.header()
+    height, width = r.scalar("I"), r.scalar("I")
+    fields = {}
+    for _ in range(r.scalar("I")):
+        name = r.string()
+        offset, datatype, count = r.scalar("I"), r.scalar("B"), r.scalar("I")
+        fields[name] = (offset, datatype, count)
+    if bool(r.scalar("B")):
+        raise ValueError("big-endian PointCloud2: decode_pointcloud2 converts it on the host")
+    point_step, _row_step = r.scalar("I"), r.scalar("I")
+    data = r.array("u1", r.scalar("I"))
+    for name, want in (("x", _FLOAT32), ("y", _FLOAT32), ("z", _FLOAT32), ("timestamp", _FLOAT64)):
+        if name not in fields or fields[name][1] != want:
+            raise ValueError(f"PointCloud2 has no field '{name}' of the expected type")
+    n = height * width
+    payload = np.frombuffer(data, dtype=np.uint8, count=n * point_step)
+    return payload, n, point_step, fields["x"][0], fields["y"][0], fields["z"][0], fields["timestamp"][0]
+
+
 def encode_pointcloud2(points: np.ndarray, point_time: np.ndarray, frame_id: str = "PandarXT-32") -> bytes:
     """The layout of the Hesai driver's cloud as far as the reference reads it: x y z float32 at 0/4/8,
     intensity float32 at 12 (unused), timestamp float64 at 16, ring uint16 at 24 (unused), 32-byte points."""

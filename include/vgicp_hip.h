@@ -313,6 +313,15 @@ int vgicp_scan_info(vgicp_ctx* ctx, size_t* kept, int64_t* deskewed, uint64_t* i
 int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, uint64_t* ticket);
 int vgicp_scan_prepare_staged_async(vgicp_ctx* ctx, uint64_t ticket, size_t num_states, const double* states,
                                     const double extrinsic[16], double voxel_size, int knn);
+/* The same for the sensor's WIRE format: the payload of a sensor_msgs/PointCloud2 as it arrives (little-endian), n =
+ * height x width records of point_step bytes (a multiple of 4, 12 .. 64), float32 x / y / z at byte offsets off_x /
+ * off_y / off_z and a float64 capture time at off_time (SIZE_MAX: none) -- the four fields the reference's callback
+ * reads one point at a time and widens on the host (include/ESKF_LIO/Subscriber.hpp:89-97).  Here the records are
+ * copied as they are and the DEVICE picks the floats out and widens them (float -> double is exact: the prepared scan
+ * is bit-identical to the one made from the widened cloud); the host's loop over the points is gone.  Prepared with
+ * vgicp_scan_prepare_staged_async like any staged sweep. */
+int vgicp_sweep_stage_cloud2(vgicp_ctx* ctx, size_t n, const void* data, size_t point_step, size_t off_x, size_t off_y,
+                             size_t off_z, size_t off_time, uint64_t* ticket);
 int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel);
 
 /* What the calls of THIS HOST THREAD into the module (whatever the context) have cost the host since this context's

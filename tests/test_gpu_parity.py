@@ -1065,6 +1065,55 @@ def test_sweep_staged_on_arrival_prepares_to_the_same_bits(oracle):
         assert a.scan_info()[0] > 0
 
 
+def test_wire_format_sweep_is_widened_on_the_device(oracle):
+    """vgicp_sweep_stage_cloud2: the payload of a PointCloud2 handed over as the sensor wrote it (float32 x y z and a
+    float64 timestamp inside records of point_step bytes, other fields and padding around them); the device picks the
+    floats out and widens them.  float -> double is exact, so the prepared scan is bit-identical to the one made from the
+    cloud the reference's callback builds on the host (include/ESKF_LIO/Subscriber.hpp:89-97) -- and to the oracle's."""
+    from eskf_lio_amd import capi, replay, synth
+    st = synth.make_imu_states(48, seed=5)
+    ext = synth.se3_to_SE3([0.01, -0.02, 0.03, 0.002, -0.001, 0.003])
+    rng = np.random.default_rng(3)
+    for n, step, offs in ((30_001, 32, (0, 4, 8, 16)), (12_345, 28, (16, 20, 24, 0)), (257, 64, (40, 4, 52, 24)), (70_000, 20, (0, 4, 8, 12))):
+        pts = synth.make_lidar_scan(n, seed=60 + step).astype(np.float32).astype(np.float64)
+        tt = synth.make_point_times(n, st[1, 0] + 1e-4, st[-3, 0] + 0.4 / 400.0, seed=step)
+        raw = rng.integers(0, 256, size=(n, step), dtype=np.uint8)              # whatever else the records carry
+        for c in range(3):
+            raw[:, offs[c]:offs[c] + 4] = pts[:, c].astype("<f4").view(np.uint8).reshape(n, 4)
+        raw[:, offs[3]:offs[3] + 8] = tt.astype("<f8").view(np.uint8).reshape(n, 8)
+        with capi.Context(0) as a, capi.Context(0) as b:
+            for c in (a, b):
+                c.map_reset(0.3, 1000)
+            a.scan_prepare_staged_async(a.sweep_stage(pts, tt), st, ext, 0.3, 30)
+            b.scan_prepare_staged_async(b.sweep_stage_cloud2(raw, n, step, offs[0], offs[1], offs[2], offs[3]), st, ext, 0.3, 30)
+            pa, ca = a.scan_download()
+            pb, cb = b.scan_download()
+            assert a.scan_info() == b.scan_info() and np.array_equal(pa, pb) and np.array_equal(ca, cb), (n, step)
+            if n == 12_345:
+                moved, _ = oracle.transform(pts, np.tile(np.eye(3).reshape(9), (n, 1)), ext)
+                desk, _ = oracle.deskew(moved, tt, st)
+                rp, rc, _ = oracle.preprocess(desk, 0.3, 30)
+                assert np.array_equal(pb, rp) and np.array_equal(cb, rc)
+            # no capture times in the record: no deskew from that ticket
+            t2 = b.sweep_stage_cloud2(raw, n, step, offs[0], offs[1], offs[2], None)
+            with pytest.raises(capi.VgicpError):
+                b.scan_prepare_staged_async(t2, st, ext, 0.3, 30)
+    # a whole message, as the replay harness reads it off a bag
+    pts = synth.make_lidar_scan(5_000, seed=9).astype(np.float32).astype(np.float64)
+    tt = synth.make_point_times(5_000, 100.0, 100.1, seed=9)
+    payload, n, step, ox, oy, oz, ot = replay.pointcloud2_payload(replay.encode_pointcloud2(pts, tt))
+    host = replay.decode_pointcloud2(replay.encode_pointcloud2(pts, tt))
+    with capi.Context(0) as a, capi.Context(0) as b:
+        a.scan_prepare_staged_async(a.sweep_stage(host.points, host.pointTime), None, None, 0.3, 30)
+        b.scan_prepare_staged_async(b.sweep_stage_cloud2(payload, n, step, ox, oy, oz, ot), None, None, 0.3, 30)
+        for x, y in zip(a.scan_download(), b.scan_download()):
+            assert np.array_equal(x, y)
+    with capi.Context(0) as c:
+        for bad in ((8, 0, 4, 8), (68, 0, 4, 8), (30, 0, 4, 8), (32, 2, 4, 8), (32, 0, 4, 30)):
+            with pytest.raises(capi.VgicpError):
+                c.sweep_stage_cloud2(np.zeros(64 * 100, dtype=np.uint8), 64, bad[0], bad[1], bad[2], bad[3], None)
+
+
 def test_prepared_scan_of_a_sweep_larger_than_the_grid(oracle):
     """A raw sweep with more points than the persistent launch has point-carrying threads (150 000 > 256 x 448), prepared
     on the device and aligned WITHOUT waiting for the kept count: the launch plan is made from the raw count (the
