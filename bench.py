@@ -266,11 +266,12 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
         from eskf_lio_amd import host
         chain_poses = [r.pose for r in results]
 
-        def dropin(host_copy, device_resident, on_arrival=False):
+        def dropin(host_copy, device_resident, on_arrival=False, keep_raw_points=True):
             pre = host.CloudPreprocessor(h, ext, host_copy)
             icp = host.ICP(30, 1e-6, 0.9999)
             cfg = dict(translation_sq_threshold=-1.0, cosine_threshold=2.0, remove_distant_points=False,
-                       distance_threshold=1e9, removing_period=1e9, device_resident=device_resident)
+                       distance_threshold=1e9, removing_period=1e9, device_resident=device_resident,
+                       keep_raw_points=keep_raw_points)
             lmap = host.LocalMap(h, cap, cfg)
             fr = host.Frame(sweeps[0], tt, st)
             fr.run(pre, icp, lmap, np.eye(4), first_frame=True)
@@ -283,29 +284,36 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
                 fr = nxt                                           # the measurement object: built outside the timed part
                 nxt = host.Frame(sweeps[f + 1], tt, st) if f < frames else None
                 t0 = time.perf_counter()
-                fr.run(pre, icp, lmap, pose, stage_next=nxt if on_arrival else None)
+                fr.run(pre, icp, lmap, pose, stage_next=nxt if on_arrival else None, move_cloud=True)   # std::move, as src/Odometry.cpp:86
                 wall += time.perf_counter() - t0
                 got = fr.end()
                 pose = got["pose"]
                 poses.append(pose)
                 resident += int(got["used_resident"])
-            return wall / frames * 1e3, poses, resident, len(lmap)
+            voxels = len(lmap)
+            return wall / frames * 1e3, poses, resident, voxels
         dropin("deferred", True)                                       # warm-up
         ms_def, poses_def, res_def, vox_def = dropin("deferred", True)
+        dropin("eager", True)                                          # warm-up
+        ms_eag, poses_eag, res_eag, _ = dropin("eager", True)          # THE CLASSES' DEFAULTS since round 5
         dropin("eager", False)                                         # warm-up (first-use allocations: page-locked arena, table growth)
-        ms_eag, poses_eag, res_eag, _ = dropin("eager", False)
+        ms_host, poses_host, res_host, _ = dropin("eager", False)      # host-authoritative map (the defaults of rounds 1-4)
         dropin("deferred", True, on_arrival=True)
         ms_arr, poses_arr, res_arr, _ = dropin("deferred", True, on_arrival=True)
         out["dropin_ms_per_frame"] = ms_def
         out["dropin_ms_per_frame_sweeps_staged_on_arrival"] = ms_arr
         out["dropin_eager_ms_per_frame"] = ms_eag
+        out["dropin_host_authoritative_ms_per_frame"] = ms_host
         out["dropin"] = {
             "what": "the frames above through ESKF_LIO::CloudPreprocessor::process / ICP::align / LocalMap::updateLocalMap "
                     "(C++ shim, called as src/Odometry.cpp:73-87 does); dropin_ms_per_frame: LocalMapConfig::deviceResident + "
                     "CloudPreprocessorConfig::HostCopy::Deferred (the scan never returns to the host); dropin_eager: the "
-                    "classes' defaults (host map, host copy of the prepared scan)",
+                    "classes' DEFAULTS since round 5 (host copy of the prepared scan as the reference leaves it; the grid the "
+                    "registration reads on the device; a host-side shadow grid, kept by a worker thread, holds every raw point "
+                    "for save()); dropin_host_authoritative: the defaults of rounds 1-4 (host map authoritative, device mirror fed batches)",
             "ratio_to_the_abi_chain": ms_def / out["ms_per_frame"],
-            "aligns_that_found_the_scan_resident": f"{res_def} of {frames} (deferred), {res_eag} of {frames} (eager)",
+            "aligns_that_found_the_scan_resident": f"{res_def} of {frames} (deferred), {res_eag} of {frames} (defaults), {res_host} of {frames} (host-authoritative)",
+            "host_authoritative_pose_delta_max": float(max(np.abs(a - b).max() for a, b in zip(poses_host, chain_poses))),
             "poses_bit_equal_to_the_abi_chain": bool(all(np.array_equal(a, b) for a, b in zip(poses_def, chain_poses))),
             "eager_pose_delta_max": float(max(np.abs(a - b).max() for a, b in zip(poses_eag, chain_poses))),
             "map_voxels": vox_def,

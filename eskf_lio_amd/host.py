@@ -34,7 +34,7 @@ def load_library() -> C.CDLL:
     lib.host_last_error.restype = C.c_char_p
     lib.host_localmap_create_config.restype = vp
     lib.host_localmap_create_config.argtypes = [C.c_double, sz, C.c_double, C.c_double, C.c_int, C.c_double,
-                                                C.c_double, C.c_int]
+                                                C.c_double, C.c_int, C.c_int]
     lib.host_localmap_create.restype = vp
     lib.host_localmap_create.argtypes = [C.c_double, sz]
     lib.host_localmap_destroy.argtypes = [vp]
@@ -54,7 +54,7 @@ def load_library() -> C.CDLL:
     lib.host_preprocessor_create.argtypes = [C.c_double, dp, C.c_int]
     lib.host_frame_begin.restype = vp
     lib.host_frame_begin.argtypes = [sz, dp, dp, sz, dp]
-    lib.host_frame_run.argtypes = [vp, vp, vp, vp, dp, C.c_int, C.c_int, vp]
+    lib.host_frame_run.argtypes = [vp, vp, vp, vp, dp, C.c_int, C.c_int, vp, C.c_int]
     lib.host_frame_stage.argtypes = [vp, vp]
     lib.host_frame_stage.restype = C.c_int
     lib.host_frame_end.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
@@ -110,7 +110,8 @@ def _check(lib, rc):
 
 
 class LocalMap:
-    """ESKF_LIO::LocalMap: host-authoritative voxel grid + device mirror."""
+    """ESKF_LIO::LocalMap.  config: the YAML keys + device_resident (default True: the grid the registration reads lives
+    on the device) + keep_raw_points (default True: a host-side shadow grid keeps every raw point for save())."""
 
     def __init__(self, voxelSize: float, maxNumPointsPerVoxel: int, config: Optional[dict] = None):
         self._lib = load_library()
@@ -121,7 +122,7 @@ class LocalMap:
                 float(voxelSize), int(maxNumPointsPerVoxel), float(config["translation_sq_threshold"]),
                 float(config["cosine_threshold"]), int(bool(config["remove_distant_points"])),
                 float(config["distance_threshold"]), float(config["removing_period"]),
-                int(bool(config.get("device_resident", False))))
+                int(bool(config.get("device_resident", True))), int(bool(config.get("keep_raw_points", True))))
         if not self._h:
             raise RuntimeError(self._lib.host_last_error().decode())
 
@@ -265,12 +266,13 @@ class Frame:
         return bool(rc)
 
     def run(self, preprocessor: "CloudPreprocessor", icp: "ICP", localMap: "LocalMap", guess, first_frame=False,
-            mutate: int = 0, stage_next: "Frame" = None):
-        """stage_next: a later Frame whose sweep 'arrives' during this one (staged right after this frame's process())."""
+            mutate: int = 0, stage_next: "Frame" = None, move_cloud: bool = False):
+        """stage_next: a later Frame whose sweep 'arrives' during this one (staged right after this frame's process()).
+        move_cloud: hand the cloud to updateLocalMap as src/Odometry.cpp:86 does (std::move: end() then has no cloud)."""
         g = capi.pose_to_abi(guess)
         _check(self._lib, self._lib.host_frame_run(self._h, preprocessor._h, icp._h, localMap._h, _dp(g),
                                                    1 if first_frame else 0, int(mutate),
-                                                   stage_next._h if stage_next is not None else None))
+                                                   stage_next._h if stage_next is not None else None, int(bool(move_cloud))))
 
     def end(self, want_cloud: bool = False):
         """-> dict(pose, iterations, used_resident, corr0, host_points[, points, covs])."""

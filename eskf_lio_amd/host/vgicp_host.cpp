@@ -58,7 +58,7 @@ const char * host_last_error(void) {return g_error.c_str();}
 LocalMap * host_localmap_create_config(
   double voxel_size, size_t max_points_per_voxel, double translation_sq_threshold,
   double cosine_threshold, int remove_distant_points, double distance_threshold,
-  double remove_period, int device_resident)
+  double remove_period, int device_resident, int keep_raw_points)
 {
   LocalMap * out = nullptr;
   guarded(
@@ -72,6 +72,7 @@ LocalMap * host_localmap_create_config(
       c.distanceThreshold = distance_threshold;
       c.removePeriod = remove_period;
       c.deviceResident = device_resident != 0;
+      c.keepRawPoints = keep_raw_points != 0;
       out = new LocalMap(c);
     });
   return out;
@@ -250,7 +251,7 @@ int host_frame_stage(HostFrame * f, const CloudPreprocessor * p)
 // right after this frame's process(), where a lidar callback's thread would be copying beside the device's work.
 int host_frame_run(
   HostFrame * f, const CloudPreprocessor * p, ICP * icp, LocalMap * map, const double guess[16], int first_frame,
-  int mutate, HostFrame * stage_next)
+  int mutate, HostFrame * stage_next, int move_cloud)
 {
   return guarded(
     [&] {
@@ -273,7 +274,9 @@ int host_frame_run(
       f->usedResident = icp->lastUsedResidentScan();
       f->iterations = icp->lastStats().iterations;
       f->corr0 = icp->lastStats().correspondenceCounts.empty() ? 0 : icp->lastStats().correspondenceCounts[0];
-      map->updateLocalMap(f->meas->cloud, f->pose);
+      // move_cloud: as src/Odometry.cpp:86 hands it over (std::move: the map becomes the cloud's only owner);
+      // else a copy of the pointer stays with the frame so that host_frame_end can return the cloud
+      if (move_cloud) {map->updateLocalMap(std::move(f->meas->cloud), f->pose);} else {map->updateLocalMap(f->meas->cloud, f->pose);}
     });
 }
 
@@ -289,6 +292,10 @@ int host_frame_end(
       if (iterations) {*iterations = f->iterations;}
       if (used_resident) {*used_resident = f->usedResident ? 1 : 0;}
       if (corr0) {*corr0 = f->corr0;}
+      if (!f->meas->cloud) {                         // moved into the map (host_frame_run with move_cloud)
+        if (host_points) {*host_points = 0;}
+        return;
+      }
       const auto & cloud = *f->meas->cloud;
       if (host_points) {*host_points = cloud.points_.size();}
       if (points && covs && cloud.covariances_.size() == cloud.points_.size() && cloud.points_.size() <= capacity) {

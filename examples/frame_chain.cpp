@@ -7,7 +7,7 @@
 //          localMap.updateLocalMap(lidarMeas->cloud, T);
 //      — with the grid on the device (LocalMapConfig::deviceResident) and the host copy of the prepared scan
 //      deferred (CloudPreprocessorConfig::HostCopy::Deferred): the three classes pass the scan along ON the device;
-//   A2. the same classes with their safe defaults: host-authoritative map, eager host copy (the host cloud holds
+//   A2. the same classes with the host-authoritative map of rounds 1-4 (LocalMap(voxelSize, maxNumPointsPerVoxel)), eager host copy (the host cloud holds
 //      the prepared scan after process(), as in the reference);
 //   B. straight on the C ABI with the scan resident on the GPU from the raw sweep to the map update:
 //          vgicp_scan_prepare(...); vgicp_align_resident(...); vgicp_map_insert_resident(...);
@@ -133,7 +133,7 @@ int main(int argc, char ** argv)
     mc.voxelSize = voxel; mc.maxNumPointsPerVoxel = 20; mc.translationSquaredThreshold = -1.0; mc.cosineThreshold = 2.0;
     mc.removeDistantPoints = false; mc.deviceResident = true;
     LocalMap localMap(mc);
-    // chain A2 owns a context of its own: the classes with their defaults
+    // chain A2 owns a context of its own: the classes with the host-authoritative map
     vgicp_ctx * ctxA2 = nullptr;
     shim::check(nullptr, vgicp_create(0, &ctxA2), "vgicp_create");
     CloudPreprocessorConfig pc2;
@@ -208,7 +208,7 @@ int main(int argc, char ** argv)
       if (std::getenv("FRAME_CHAIN_VERBOSE")) {
         std::printf("  [chain A] frame %d: %.3f ms\n", f, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
       }
-      // ---- A2: the same classes with their defaults (host map, eager host copy) ----
+      // ---- A2: the same classes with the host-authoritative map and the eager host copy ----
       const auto a20 = std::chrono::steady_clock::now();
       if (f == 0) {
         preprocessor2.process({}, meas2);
@@ -278,7 +278,7 @@ int main(int argc, char ** argv)
         classesMs / residentFrames, residentAligns, frames - 1);
       std::printf("  of which process() %.3f ms (enqueue only), align() %.3f ms (the frame's one synchronisation), updateLocalMap() %.3f ms (enqueue only)\n",
         stageMs[0] / residentFrames, stageMs[1] / residentFrames, stageMs[2] / residentFrames);
-      std::printf("drop-in classes with their defaults (host map, eager host copy): %.3f ms per frame\n", classesEagerMs / residentFrames);
+      std::printf("drop-in classes with the host-authoritative map (eager host copy): %.3f ms per frame\n", classesEagerMs / residentFrames);
       if (residentAligns != frames - 1) {++bad;}
     }
     if (residentFrames) {

@@ -773,14 +773,30 @@ def test_host_mirror_device_resident_map(c1_inputs, oracle, tmp_path):
     assert np.array_equal(icp.correspondence_counts, ref.corr_count)
     dt, dr = pose_error(T, ref.pose)
     assert dt <= TIGHT_POSE_TOL and dr <= TIGHT_POSE_TOL
+    # save(): with the shadow grid (keep_raw_points, the default) every stored raw point, exactly what the
+    # host-authoritative map writes from the same updates (src/LocalMap.cpp:156-167) ...
     lmap.save(str(tmp_path / "m.pcd"), str(tmp_path / "t.json"))
-    assert f"POINTS {len(omap)}" in open(tmp_path / "m.pcd").read()
+    hmap = host.LocalMap(0.3, 20, dict(cfg, device_resident=False))
+    bare = host.LocalMap(0.3, 20, dict(cfg, keep_raw_points=False))
+    rng = np.random.default_rng(33)
+    for T in (np.eye(4), synth.se3_to_SE3([0.2, 0.1, 0.0, 0.0, 0.0, 0.02]), synth.se3_to_SE3([0.4, 0.2, 0.0, 0.0, 0.0, 0.04])):
+        p = vmap.means[rng.choice(50_000, 8_000)] + rng.normal(scale=0.02, size=(8_000, 3))
+        c = covs[rng.choice(5_000, 8_000)]
+        hmap.updateLocalMap(p, c, T)
+        bare.updateLocalMap(p, c, T)
+    hmap.save(str(tmp_path / "h.pcd"), str(tmp_path / "ht.json"))
+    got, want = open(tmp_path / "m.pcd").read().splitlines(), open(tmp_path / "h.pcd").read().splitlines()
+    assert got[:11] == want[:11] and sorted(got[11:]) == sorted(want[11:]) and len(got) - 11 > len(omap)
+    assert open(tmp_path / "t.json").read() == open(tmp_path / "ht.json").read()
+    # ... and one point per voxel (its mean) when the raw points are not kept
+    bare.save(str(tmp_path / "b.pcd"), str(tmp_path / "bt.json"))
+    assert f"POINTS {len(omap)}" in open(tmp_path / "b.pcd").read()
 
 
 def test_host_mirror_motion_gate_and_eviction(oracle, tmp_path):
     from eskf_lio_amd import host, synth
     cfg = dict(translation_sq_threshold=1e-2, cosine_threshold=0.985, remove_distant_points=True,
-               distance_threshold=5.0, removing_period=0.0)
+               distance_threshold=5.0, removing_period=0.0, device_resident=False)
     lmap = host.LocalMap(0.3, 1000, cfg)
     rng = np.random.default_rng(2)
     near = rng.uniform(-2, 2, size=(500, 3))
