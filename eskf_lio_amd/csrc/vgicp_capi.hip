@@ -13,6 +13,8 @@
 namespace vgicp {
 thread_local uint64_t g_copy_ops = 0, g_sync_ops = 0;
 thread_local std::string g_create_error;
+thread_local std::string g_stage_error;
+thread_local const vgicp_ctx* g_stage_error_ctx = nullptr;
 }  // namespace vgicp
 
 namespace {
@@ -873,11 +875,13 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   for (auto& e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev_prof) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (g_stage_error_ctx == ctx) g_stage_error_ctx = nullptr;
   delete ctx;
   return VGICP_OK;
 }
 
 const char* vgicp_last_error(const vgicp_ctx* ctx) {
+  if (ctx && g_stage_error_ctx == ctx) return g_stage_error.c_str();   // this thread's last failure was a vgicp_sweep_stage*
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
@@ -2214,7 +2218,7 @@ int stage_sweep_ahead(vgicp_ctx* ctx, size_t n, const void* data, const double* 
     if (!slot)
       for (auto& s : ctx->ahead)   // handed to the device two preparations ago: its readers have long finished
         if (s.state == 2 && (!s.done || hipEventQuery(s.done) == hipSuccess)) { slot = &s; break; }
-    if (!slot) return fail(ctx, VGICP_ERR_NOT_READY, "three sweeps are staged ahead already: prepare one first");
+    if (!slot) return fail_stage(ctx, VGICP_ERR_NOT_READY, "three sweeps are staged ahead already: prepare one first");
     slot->state = 3;
   }
   const size_t rec = step ? step : 3 * sizeof(double);
@@ -2222,13 +2226,13 @@ int stage_sweep_ahead(vgicp_ctx* ctx, size_t n, const void* data, const double* 
   const bool has_times = step ? off_time != SIZE_MAX : times != nullptr;
   const size_t need = pts_room + n * sizeof(double);
   if (slot->cap < need) {
-    if (hipSetDevice(ctx->device) != hipSuccess) { slot->state = 0; return fail(ctx, VGICP_ERR_HIP, "hipSetDevice"); }
+    if (hipSetDevice(ctx->device) != hipSuccess) { slot->state = 0; return fail_stage(ctx, VGICP_ERR_HIP, "hipSetDevice"); }
     if (slot->mem) (void)hipHostFree(slot->mem);
     slot->mem = nullptr;
     slot->cap = 0;
     if (hipHostMalloc(reinterpret_cast<void**>(&slot->mem), need * 5 / 4 + 4096, 0) != hipSuccess) {
       slot->state = 0;
-      return fail(ctx, VGICP_ERR_HIP, "hipHostMalloc(sweep staging)");
+      return fail_stage(ctx, VGICP_ERR_HIP, "hipHostMalloc(sweep staging)");
     }
     slot->cap = need * 5 / 4 + 4096;
   }
@@ -2257,9 +2261,13 @@ int stage_sweep_ahead(vgicp_ctx* ctx, size_t n, const void* data, const double* 
 int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, uint64_t* ticket) {
   if (!ctx || !ticket) return VGICP_ERR_BAD_ARGUMENT;
   *ticket = 0;
-  if (ctx->multi) return vgicp_sweep_stage(vgicp_multi_api::first(ctx), n, points, point_time, ticket);
-  if (n == 0 || !points) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
-  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "sweep too large");
+  if (ctx->multi) {
+    const int rc = vgicp_sweep_stage(vgicp_multi_api::first(ctx), n, points, point_time, ticket);
+    if (rc != VGICP_OK) g_stage_error_ctx = ctx;
+    return rc;
+  }
+  if (n == 0 || !points) return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
+  if (n > 0xFFFFFFFFull) return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "sweep too large");
   const uint32_t none[3] = {0, 0, 0};
   return stage_sweep_ahead(ctx, n, points, point_time, 0, none, SIZE_MAX, ticket);
 }
@@ -2268,14 +2276,18 @@ int vgicp_sweep_stage_cloud2(vgicp_ctx* ctx, size_t n, const void* data, size_t 
                              size_t off_z, size_t off_time, uint64_t* ticket) {
   if (!ctx || !ticket) return VGICP_ERR_BAD_ARGUMENT;
   *ticket = 0;
-  if (ctx->multi) return vgicp_sweep_stage_cloud2(vgicp_multi_api::first(ctx), n, data, point_step, off_x, off_y, off_z, off_time, ticket);
-  if (n == 0 || !data) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
-  if (n > 0xFFFFFFFFull) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "sweep too large");
+  if (ctx->multi) {
+    const int rc = vgicp_sweep_stage_cloud2(vgicp_multi_api::first(ctx), n, data, point_step, off_x, off_y, off_z, off_time, ticket);
+    if (rc != VGICP_OK) g_stage_error_ctx = ctx;
+    return rc;
+  }
+  if (n == 0 || !data) return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
+  if (n > 0xFFFFFFFFull) return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "sweep too large");
   if (point_step < 12 || point_step > 64 || point_step % 4 != 0)
-    return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "point_step must be a multiple of 4 between 12 and 64 bytes");
+    return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "point_step must be a multiple of 4 between 12 and 64 bytes");
   for (size_t o : {off_x, off_y, off_z})
-    if (o % 4 != 0 || o + 4 > point_step) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "x / y / z must be float32 fields inside the record, 4-byte aligned");
-  if (off_time != SIZE_MAX && off_time + 8 > point_step) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the float64 capture time must lie inside the record");
+    if (o % 4 != 0 || o + 4 > point_step) return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "x / y / z must be float32 fields inside the record, 4-byte aligned");
+  if (off_time != SIZE_MAX && off_time + 8 > point_step) return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "the float64 capture time must lie inside the record");
   const uint32_t off[3] = {(uint32_t)off_x, (uint32_t)off_y, (uint32_t)off_z};
   return stage_sweep_ahead(ctx, n, data, nullptr, (uint32_t)point_step, off, off_time, ticket);
 }

@@ -54,6 +54,10 @@ constexpr int kNcclSum = 0;
 constexpr int kNcclChar = 0;   // ncclInt8
 
 extern thread_local std::string g_create_error;
+// what vgicp_sweep_stage* report: those may run on another thread than the context's owner (who writes ctx->err), so
+// their text lives with the calling thread; vgicp_last_error(ctx) returns it to that thread until it fails elsewhere
+extern thread_local std::string g_stage_error;
+extern thread_local const vgicp_ctx* g_stage_error_ctx;
 
 inline double now_seconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -348,7 +352,17 @@ struct vgicp_ctx {
 // ---- helpers shared by the two translation units ----
 namespace vgicp {
 inline int fail(const vgicp_ctx* ctx, int code, const std::string& text) {
-  if (ctx) ctx->err = text; else g_create_error = text;
+  if (ctx) {
+    ctx->err = text;
+    if (g_stage_error_ctx == ctx) g_stage_error_ctx = nullptr;
+  } else {
+    g_create_error = text;
+  }
+  return code;
+}
+inline int fail_stage(const vgicp_ctx* ctx, int code, const std::string& text) {
+  g_stage_error = text;
+  g_stage_error_ctx = ctx;
   return code;
 }
 inline int fail_hip(const vgicp_ctx* ctx, hipError_t e, const char* what) {

@@ -185,65 +185,6 @@ VG_HD void ldlt6_solve(const double* lower21, const double* b, double* x, double
 }
 constexpr int kLdltWork = 48;
 
-// Fast path of the 6x6 solve for symmetric POSITIVE DEFINITE normal equations: elimination by 3x3 BLOCKS with
-// adjugates, scaled so that only two reciprocals are needed and only one of them sits on the dependent chain.
-//   A = [P Q^T; Q S],  adj = adj(P), d = det(P):      S' = d S - Q adj Q^T   (= d x the Schur complement)
-//   x2 = adj(S') (d b2 - Q adj b1) / det(S'),          x1 = adj (b1 - Q^T x2) / d
-// The chain is ~27 dependent operations (cofactors 2, Q adj 3, (Q adj) Q^T 3, S' 1, cofactors 2, determinant 3,
-// reciprocal, 1, Q^T x2 3, adj 3, 1) where the scalar-pivot LDL^T has ~50 (six reciprocals one after the other): on the
-// solver wave of a round a dependent fp64 operation costs its full latency, nothing else.  For a positive definite
-// matrix every order of elimination is stable; x agrees with the pivoted LDL^T to ~cond(A) * 1e-16, not bit for bit.
-// Magnitudes: det(S') ~ |P|^9 |S|^3 — 1e150 for the largest sums a 10^6-point scan produces, far inside the range.
-// Returns false (x undefined) unless both blocks are safely positive definite: leading minors positive and the
-// determinants not below 1e-10 x the product of the diagonals (Hadamard's bound) — singular, indefinite, non-finite
-// and all-zero systems ("no correspondences") go to the pivoted, Eigen-faithful ldlt6_solve above.
-// A: packed lower triangle (tri6); b: right-hand side; rcp: reciprocal of a positive normal double.
-template <typename Rcp>
-VG_HD bool solve6_spd_block3(const double* A, const double* b, double* x, Rcp rcp) {
-  const double p00 = A[0], p10 = A[1], p11 = A[2], p20 = A[3], p21 = A[4], p22 = A[5];
-  const double q00 = A[6], q01 = A[7], q02 = A[8], q10 = A[10], q11 = A[11], q12 = A[12], q20 = A[15], q21 = A[16], q22 = A[17];
-  const double s00 = A[9], s10 = A[13], s11 = A[14], s20 = A[18], s21 = A[19], s22 = A[20];
-  // adj(P) (symmetric) and det(P)
-  const double a00 = p11 * p22 - p21 * p21, a10 = p21 * p20 - p10 * p22, a20 = p10 * p21 - p11 * p20;
-  const double a11 = p00 * p22 - p20 * p20, a21 = p10 * p20 - p00 * p21, a22 = p00 * p11 - p10 * p10;
-  const double d = p00 * a00 + p10 * a10 + p20 * a20;
-  bool ok = (p00 > 0.0) && (a22 > 0.0) && (d > 1e-10 * (p00 * p11 * p22)) && (d < 1.0e100);
-  const double id = rcp(d);                                  // off the chain: needed last
-  // M = Q adj
-  const double m00 = q00 * a00 + q01 * a10 + q02 * a20, m01 = q00 * a10 + q01 * a11 + q02 * a21, m02 = q00 * a20 + q01 * a21 + q02 * a22;
-  const double m10 = q10 * a00 + q11 * a10 + q12 * a20, m11 = q10 * a10 + q11 * a11 + q12 * a21, m12 = q10 * a20 + q11 * a21 + q12 * a22;
-  const double m20 = q20 * a00 + q21 * a10 + q22 * a20, m21 = q20 * a10 + q21 * a11 + q22 * a21, m22 = q20 * a20 + q21 * a21 + q22 * a22;
-  // S' = d S - M Q^T (lower triangle)
-  const double t00 = d * s00 - (m00 * q00 + m01 * q01 + m02 * q02);
-  const double t10 = d * s10 - (m10 * q00 + m11 * q01 + m12 * q02);
-  const double t11 = d * s11 - (m10 * q10 + m11 * q11 + m12 * q12);
-  const double t20 = d * s20 - (m20 * q00 + m21 * q01 + m22 * q02);
-  const double t21 = d * s21 - (m20 * q10 + m21 * q11 + m22 * q12);
-  const double t22 = d * s22 - (m20 * q20 + m21 * q21 + m22 * q22);
-  // r2' = d b2 - M b1   (M b1 = Q adj b1)
-  const double r0 = d * b[3] - (m00 * b[0] + m01 * b[1] + m02 * b[2]);
-  const double r1 = d * b[4] - (m10 * b[0] + m11 * b[1] + m12 * b[2]);
-  const double r2 = d * b[5] - (m20 * b[0] + m21 * b[1] + m22 * b[2]);
-  // adj(S'), det(S')
-  const double c00 = t11 * t22 - t21 * t21, c10 = t21 * t20 - t10 * t22, c20 = t10 * t21 - t11 * t20;
-  const double c11 = t00 * t22 - t20 * t20, c21 = t10 * t20 - t00 * t21, c22 = t00 * t11 - t10 * t10;
-  const double e = t00 * c00 + t10 * c10 + t20 * c20;
-  ok = ok && (t00 > 0.0) && (c22 > 0.0) && (e > 1e-10 * (t00 * t11 * t22)) && (e < 1.0e300) && (e > 1.0e-290);
-  const double ie = rcp(e);
-  const double x3 = (c00 * r0 + c10 * r1 + c20 * r2) * ie;
-  const double x4 = (c10 * r0 + c11 * r1 + c21 * r2) * ie;
-  const double x5 = (c20 * r0 + c21 * r1 + c22 * r2) * ie;
-  // x1 = adj (b1 - Q^T x2) / d
-  const double u0 = b[0] - (q00 * x3 + q10 * x4 + q20 * x5);
-  const double u1 = b[1] - (q01 * x3 + q11 * x4 + q21 * x5);
-  const double u2 = b[2] - (q02 * x3 + q12 * x4 + q22 * x5);
-  x[0] = (a00 * u0 + a10 * u1 + a20 * u2) * id;
-  x[1] = (a10 * u0 + a11 * u1 + a21 * u2) * id;
-  x[2] = (a20 * u0 + a21 * u1 + a22 * u2) * id;
-  x[3] = x3; x[4] = x4; x[5] = x5;
-  return ok;
-}
-
 // Rotation vector -> rotation matrix, AngleAxis(|r|, r/|r|) with r left as is when |r| == 0.
 VG_HD void rodrigues(const double* r, double* R) {
   const double n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];

@@ -1268,14 +1268,20 @@ __global__ __launch_bounds__(kCovBlock) void cov_kernel(const double* __restrict
   double cov[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   if (found >= 3) {
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // eight neighbours at a time: their indices, then their points, are requested together (one thread per point
+    // sixteen neighbours at a time: their indices, then their points, are requested together (one thread per point
     // is less than a wave per SIMD -- nothing else hides a load, and one neighbour after the other was 60
-    // dependent round trips); the sums stay in ascending-distance order
-    constexpr int kChunk = 8;
+    // dependent round trips; 8 / 16 / 32 at a time: 19.6 / 18.9 / 20.2 us per 60 000-point sweep); the sums stay in
+    // ascending-distance order.  (The rest of the kernel is the Jacobi sweeps' chain of fp64 divisions and roots:
+    // half-filled waves -- twice as many -- take 26 us, not less.)
+    constexpr int kChunk = 16;
     const uint4* row = reinterpret_cast<const uint4*>(nbr + (size_t)o * kMaxKnn);
     for (int k0 = 0; k0 < found; k0 += kChunk) {
-      const uint4 ja = row[k0 / 4], jb = row[k0 / 4 + 1];
-      const uint32_t j[kChunk] = {ja.x, ja.y, ja.z, ja.w, jb.x, jb.y, jb.z, jb.w};
+      uint32_t j[kChunk];
+#pragma unroll
+      for (int q = 0; q < kChunk / 4; ++q) {
+        const uint4 jq = k0 + 4 * q < kMaxKnn ? row[k0 / 4 + q] : make_uint4(0u, 0u, 0u, 0u);
+        j[4 * q] = jq.x; j[4 * q + 1] = jq.y; j[4 * q + 2] = jq.z; j[4 * q + 3] = jq.w;
+      }
       double px[kChunk], py[kChunk], pz[kChunk];
 #pragma unroll
       for (int u = 0; u < kChunk; ++u) {

@@ -64,8 +64,6 @@ def load_library() -> C.CDLL:
     lib.host_preprocessor_downsample.argtypes = [vp, sz, dp, dp, dp, C.POINTER(sz)]
     lib.host_math_ldlt6_solve.argtypes = [dp, dp, dp]
     lib.host_math_ldlt6_solve.restype = None
-    lib.host_math_solve6_block3.argtypes = [dp, dp, dp]
-    lib.host_math_solve6_block3.restype = C.c_int
     lib.host_math_se3_exp.argtypes = [dp, dp]
     lib.host_math_se3_exp.restype = None
     _lib = lib
@@ -73,7 +71,7 @@ def load_library() -> C.CDLL:
 
 
 def math_ldlt6_solve(JTJ, b) -> np.ndarray:
-    """csrc/vgicp_math.h's pivoted LDLT (the kernels' fallback solve) compiled for the host: A x = b with A a
+    """csrc/vgicp_math.h's pivoted LDLT (the kernels' solve) compiled for the host: A x = b with A a
     6x6 (row, col) array of which the lower triangle is read."""
     A = np.asarray(JTJ, dtype=np.float64).reshape(6, 6)
     low = np.ascontiguousarray([A[r, c] for r in range(6) for c in range(r + 1)], dtype=np.float64)
@@ -81,16 +79,6 @@ def math_ldlt6_solve(JTJ, b) -> np.ndarray:
     x = np.zeros(6)
     load_library().host_math_ldlt6_solve(_dp(low), _dp(rhs), _dp(x))
     return x
-
-
-def math_solve6_block3(JTJ, b):
-    """csrc/vgicp_math.h's solve6_spd_block3 (the kernels' fast path) compiled for the host -> (x, accepted)."""
-    A = np.asarray(JTJ, dtype=np.float64).reshape(6, 6)
-    low = np.ascontiguousarray([A[r, c] for r in range(6) for c in range(r + 1)], dtype=np.float64)
-    rhs = np.ascontiguousarray(b, dtype=np.float64).reshape(6)
-    x = np.zeros(6)
-    ok = load_library().host_math_solve6_block3(_dp(low), _dp(rhs), _dp(x))
-    return x, bool(ok)
 
 
 def math_se3_exp(xi) -> np.ndarray:

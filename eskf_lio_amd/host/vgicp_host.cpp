@@ -369,13 +369,6 @@ void host_math_ldlt6_solve(const double * lower21, const double * b, double * x)
   vgicp::ldlt6_solve(lower21, b, x, work);
 }
 
-// The fast path of the kernels' solve (block elimination of a positive definite system), compiled for the host with an
-// exact division where the device uses v_rcp_f64 + Newton steps: returns 1 when the system passed the safety test.
-int host_math_solve6_block3(const double * lower21, const double * b, double * x)
-{
-  return vgicp::solve6_spd_block3(lower21, b, x, [](double v) {return 1.0 / v;}) ? 1 : 0;
-}
-
 // Utils::se3ToSE3 as the module's host math states it -> column-major 4x4.
 void host_math_se3_exp(const double * xi, double * out16)
 {

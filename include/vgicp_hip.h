@@ -98,7 +98,8 @@ int vgicp_create(int device_id, vgicp_ctx** out);
 int vgicp_create_multi(const int* device_ids, int n_devices, vgicp_ctx** out);
 int vgicp_destroy(vgicp_ctx* ctx);
 /* Text of the last failure on this context (never NULL; "" when none). ctx may be NULL for
- * failures of vgicp_create itself. */
+ * failures of vgicp_create itself.  A failure of vgicp_sweep_stage / vgicp_sweep_stage_cloud2 (which another thread
+ * than the context's owner may call) is kept with the thread that made the call and returned to that thread. */
 const char* vgicp_last_error(const vgicp_ctx* ctx);
 /* name[0..name_len) receives the device's gcnArchName; cu_count its compute units. */
 int vgicp_device_info(const vgicp_ctx* ctx, char* name, size_t name_len, int32_t* cu_count,

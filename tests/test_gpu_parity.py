@@ -1069,6 +1069,23 @@ def test_sweep_staged_on_arrival_prepares_to_the_same_bits(oracle):
         with pytest.raises(capi.VgicpError) as e:
             b.sweep_stage(sweeps[1], times[1])
         assert e.value.code == capi.ERR_NOT_READY
+        assert "three sweeps" in b.last_error()
+        # a staging call made on ANOTHER thread keeps its failure text with that thread: the owner's text is untouched
+        import threading
+        seen = {}
+        def other_thread():
+            try:
+                b.sweep_stage(sweeps[1], times[1])
+            except capi.VgicpError as err:
+                seen["code"], seen["text"] = err.code, b.last_error()
+        with pytest.raises(capi.VgicpError):
+            b.scan_prepare_staged_async(10 ** 9, st, ext, 0.3, 30)                # an unknown ticket: the owner's failure
+        owner_text = b.last_error()
+        th = threading.Thread(target=other_thread)
+        th.start()
+        th.join()
+        assert seen["code"] == capi.ERR_NOT_READY and "three sweeps" in seen["text"]
+        assert b.last_error() == owner_text and "three sweeps" not in owner_text
         b.scan_prepare_staged_async(tickets[0], st, ext, 0.3, 30)
         assert b.scan_info()[0] == len(rb[2][0])                                  # the 8 000-point sweep's kept count
         b.sweep_stage(sweeps[1], times[1])                                        # a slot is free again (its readers are through)
