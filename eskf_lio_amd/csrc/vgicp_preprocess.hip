@@ -756,6 +756,9 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
   uint32_t batches = 0, pops = 0, spills = 0, inserts = 0;
+#ifdef VGICP_PREP_TRACE
+  uint32_t opens = 0, home_batches = 0;
+#endif
   const unsigned long long list_lanes = K >= 64 ? ~0ull : (1ull << K) - 1ull;
 
   // squared distance to sorted point j and, from the same record, its original index
@@ -792,6 +795,59 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   // points of the sorted order around the query (w0 .. w0 + K - 1, inside home when there is one) are real points
   // and usually near ones. The search skips the points it has measured here when it meets them again
   // (sorted positions skip_start .. skip_start + skip_count - 1).
+#ifndef VGICP_KNN_SEEDS_ONLY
+  // The opening window: up to 64 consecutive points of the sorted order around the query (inside home when there is
+  // one), one per lane.  All of them are ranked against each other at once -- every lane counts the keys below its
+  // own, the keys read one after the other from this wave's (still empty) pool: one LDS broadcast read, one compare
+  // and one add per key -- and the K lowest are the list.  (Rounds 2-5 ranked K seeds with three v_readlane per key
+  // and inserted the rest of home one candidate at a time: 38 insertions of ~16 instructions per query.)
+  const uint32_t span_lo = has_home ? home_start : 0u, span_hi = has_home ? home_end : n;
+  const uint32_t W = span_hi - span_lo < 64u ? span_hi - span_lo : 64u;   // >= K: home holds K points, and K <= n
+  uint32_t w0 = qj > W / 2 ? qj - W / 2 : 0;
+  if (w0 < span_lo) w0 = span_lo;
+  if (w0 + W > span_hi) w0 = span_hi - W;
+  uint32_t skip_start = w0, skip_count = W;
+  double ld = INFINITY;
+  uint32_t li = 0xFFFFFFFFu;
+  {
+    const bool mine = (uint32_t)lane < W;
+    uint32_t id = 0xFFFFFFFFu;
+    double d = INFINITY;
+    if (mine) d = dist2(w0 + (uint32_t)lane, id);
+    if (!(d < INFINITY)) d = INFINITY;  // a NaN / infinite point is a placeholder that everything finite displaces
+    // squared distances are non-negative: their bit patterns order as unsigned integers
+    const unsigned long long key = (unsigned long long)__double_as_longlong(d);
+    pk[lane] = key;
+    ps[lane] = id;
+    wave_sync();
+    uint32_t rank = 0;
+#pragma unroll 16
+    for (int s = 0; s < 64; ++s) rank += pk[s] < key ? 1u : 0u;
+    // equal distances (rare) give equal ranks: found out by two lanes claiming one slot, settled by the index
+    if (mine) pe[rank] = (uint32_t)lane;
+    wave_sync();
+    const bool clash = mine && pe[rank] != (uint32_t)lane;
+    if (__ballot(clash)) {
+      rank = 0;
+      for (int s = 0; s < 64; ++s) {
+        const unsigned long long ks = pk[s];
+        const uint32_t is = ps[s];
+        rank += ((ks < key) | ((ks == key) & (is < id))) ? 1u : 0u;
+      }
+    }
+    wave_sync();   // every lane has read all keys: the slots can be rewritten in rank order
+    if (mine) {
+      pk[rank] = key;
+      ps[rank] = id;
+    }
+    wave_sync();
+    if (lane < K) {
+      ld = __longlong_as_double((long long)pk[lane]);
+      li = ps[lane];
+    }
+    wave_sync();
+  }
+#else
   const uint32_t half = (uint32_t)K / 2;
   uint32_t w0 = qj > half ? qj - half : 0;
   if (has_home) {
@@ -828,6 +884,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     }
     wave_sync();
   }
+#endif
   double kth = readlane_f64(ld, K - 1);
   uint32_t kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
   double bound = kth;
@@ -882,6 +939,19 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   };
   if (has_home) {
     // the rest of home, then home as a whole is what the search skips; all K are now within home's diagonal
+#ifndef VGICP_KNN_SEEDS_ONLY
+    const uint32_t rest = (home_end - home_start) - skip_count;   // home's points outside the opening window
+    for (uint32_t base = 0; base < rest; base += 64u) {
+      const uint32_t t = base + (uint32_t)lane;
+      const bool valid = t < rest;
+      uint32_t j = home_start + t;
+      if (j >= skip_start) j += skip_count;
+      uint32_t id = 0xFFFFFFFFu;
+      double d = INFINITY;
+      if (valid) d = dist2(j, id);
+      offer(valid, d, id, j);
+    }
+#else
     for (uint32_t base = home_start; base < home_end; base += 64u) {
       const uint32_t j = base + (uint32_t)lane;
       const bool valid = j < home_end;
@@ -890,6 +960,10 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       if (valid) d = dist2(j, id);
       offer(valid, d, id, j);
     }
+#endif
+#ifdef VGICP_PREP_TRACE
+    home_batches = batches;
+#endif
     skip_start = home_start;
     skip_count = home_end - home_start;
     bound = fmin(bound, kth);
@@ -1039,6 +1113,9 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       const unsigned long long mk = key & kKeyMask;
             bool measure = l == 0 || end - start <= kLeafPoints;
       if (!measure) {  // one lane per cell two levels down (one level above the finest)
+#ifdef VGICP_PREP_TRACE
+        ++opens;
+#endif
         const int step = l >= 2 ? 2 : 1;
         const int fan = 1 << (3 * step);
         const unsigned long long cm = (mk << (3 * step)) | (unsigned long long)lane;
@@ -1103,7 +1180,8 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
     {
       // the 10-bit field: cells taken (1), insertions (2), points in the query's own level-5 / level-4 cell (4 / 6), the
       // finest level whose own cell holds K points (5)
-      const uint32_t trace_field = VGICP_PREP_TRACE == 2 ? inserts
+      const uint32_t trace_field = VGICP_PREP_TRACE == 2 ? inserts : VGICP_PREP_TRACE == 7 ? batches : VGICP_PREP_TRACE == 8 ? opens
+                                 : VGICP_PREP_TRACE == 9 ? home_batches
                                  : VGICP_PREP_TRACE == 4 ? (uint32_t)__builtin_amdgcn_readlane((int)(own_end - own_start), 5)
                                  : VGICP_PREP_TRACE == 6 ? (uint32_t)__builtin_amdgcn_readlane((int)(own_end - own_start), 4)
                                  : VGICP_PREP_TRACE == 5 ? (enough ? (uint32_t)home_level : 15u) : pops;

@@ -236,7 +236,7 @@ def test_multi_device_sub_contexts_short_of_hardware_queues_still_return_the_rig
     """The same four sub-contexts with the runtime's default queue count: launches that share a hardware queue cannot
     run side by side, their in-kernel waits give up (bounded), and the context finishes every align on the host-summed
     loop — slower, never wrong."""
-    d, err = _worker(4, {"VGICP_SPIN_LIMIT": "400"})
+    d, err = _worker(4, {"VGICP_SPIN_LIMIT": "400", "GPU_MAX_HW_QUEUES": "4"})
     assert d["world_size"] == 4 and d["counts_equal"] and d["pose_delta"] <= MULTI_POSE_TOL
     assert d["big_counts_equal"] and d["big_pose_delta"] <= MULTI_POSE_TOL
     if d["fallbacks"]:
