@@ -54,6 +54,38 @@ __attribute__((target("avx2"))) void stage_copy_avx2(char* dst, const char* src,
   _mm_sfence();
   if (i < bytes) std::memcpy(dst + i, src + i, bytes - i);
 }
+// earliest / latest capture time and "is any NaN" of a sweep, as the plain loops  e = t < e ? t : e;  l = t > l ? t : l
+// give them (a NaN never replaces anything; a NaN in t[0] stays): vminpd / vmaxpd return their SECOND operand when the
+// comparison fails, which is exactly that.  One dependent chain of 60 000 vminsd is 27 us per sweep; eight lanes: 4 us.
+__attribute__((target("avx2"))) void time_range_avx2(const double* t, size_t n, double* earliest, double* latest, bool* any_nan) {
+  __m256d mn0 = _mm256_set1_pd(t[0]), mn1 = mn0, mx0 = mn0, mx1 = mn0;
+  __m256d un = _mm256_cmp_pd(mn0, mn0, _CMP_UNORD_Q);
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const __m256d a = _mm256_loadu_pd(t + i), b = _mm256_loadu_pd(t + i + 4);
+    mn0 = _mm256_min_pd(a, mn0);
+    mn1 = _mm256_min_pd(b, mn1);
+    mx0 = _mm256_max_pd(a, mx0);
+    mx1 = _mm256_max_pd(b, mx1);
+    un = _mm256_or_pd(un, _mm256_or_pd(_mm256_cmp_pd(a, a, _CMP_UNORD_Q), _mm256_cmp_pd(b, b, _CMP_UNORD_Q)));
+  }
+  double lo[8], hi[8];
+  _mm256_storeu_pd(lo, mn0); _mm256_storeu_pd(lo + 4, mn1);
+  _mm256_storeu_pd(hi, mx0); _mm256_storeu_pd(hi + 4, mx1);
+  double e = lo[0], l = hi[0];
+  for (int k = 1; k < 8; ++k) { e = lo[k] < e ? lo[k] : e; l = hi[k] > l ? hi[k] : l; }
+  bool nan = _mm256_movemask_pd(un) != 0;
+  for (; i < n; ++i) { e = t[i] < e ? t[i] : e; l = t[i] > l ? t[i] : l; nan |= !(t[i] == t[i]); }
+  *earliest = e; *latest = l; *any_nan = nan;
+}
+void time_range(const double* t, size_t n, double* earliest, double* latest, bool* any_nan) {
+  static const bool wide = __builtin_cpu_supports("avx2");
+  if (wide && n >= 16) { time_range_avx2(t, n, earliest, latest, any_nan); return; }
+  double e = t[0], l = t[0];
+  bool nan = !(t[0] == t[0]);
+  for (size_t i = 1; i < n; ++i) { e = t[i] < e ? t[i] : e; l = t[i] > l ? t[i] : l; nan |= !(t[i] == t[i]); }
+  *earliest = e; *latest = l; *any_nan = nan;
+}
 void stage_copy(void* dst, const void* src, size_t bytes) {
   static const bool streaming = __builtin_cpu_supports("avx2") &&
                                 !(std::getenv("VGICP_STAGE_COPY") && std::strcmp(std::getenv("VGICP_STAGE_COPY"), "memcpy") == 0);
@@ -1610,6 +1642,7 @@ struct DeskewOnDevice {
   const double* poses = nullptr;
   uint32_t states = 0;
   bool ordered = false;
+  uint32_t max_hits = 0;   // deskew_table: the largest hit count of any point (ordered queues)
   uint32_t* ends = nullptr;
 };
 // The raw points of a preparation that are still to be copied into page-locked staging memory (scan_prepare_enqueue):
@@ -1630,7 +1663,7 @@ struct StagedPoints {
 };
 // The copy of a sweep's points into `stage`, opened to the crew: the helpers (if any are awake or worth waking) start at
 // once, the caller joins through crew->work(job) when it has launched the kernels that read the staging memory.
-void post_sweep_copy(vgicp_ctx* ctx, size_t n, StagedPoints* sp) {
+void post_sweep_copy(vgicp_ctx* ctx, size_t n, StagedPoints* sp, const double* times = nullptr, double* times_stage = nullptr) {
   if (++ctx->scan_seq == 0) ++ctx->scan_seq;
   sp->seq = ctx->scan_seq;
   const uint32_t unit = pack_arena_unit();
@@ -1639,16 +1672,16 @@ void post_sweep_copy(vgicp_ctx* ctx, size_t n, StagedPoints* sp) {
   CopyCrew* crew = ctx->crew;
   if (sp->helpers && crew->th.empty()) crew->start(ctx->upload_threads - 1);
   crew->pts = reinterpret_cast<const char*>(sp->points);
-  crew->cov = nullptr;
+  crew->cov = reinterpret_cast<const char*>(times);           // a unit's capture times travel with its points (or nullptr)
   crew->apts = sp->stage;
-  crew->acov = nullptr;
+  crew->acov = reinterpret_cast<char*>(times_stage);
   crew->flags = sp->flags;
   crew->n = (uint32_t)n;
   crew->unit = unit;
   crew->units = (uint32_t)((n + unit - 1) / unit);
   crew->seq = sp->seq;
   crew->size_a = 24;
-  crew->size_b = 0;
+  crew->size_b = times ? 8 : 0;
   crew->copy = stage_copy;
   sp->t_post = now_seconds();
   sp->job = crew->post(sp->helpers);
@@ -1675,6 +1708,8 @@ int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, 
   a.poses = dk.poses;
   a.states = dk.states;
   a.ordered_states = dk.ordered;
+  a.max_hits_known = dk.ordered;
+  a.max_hits = dk.max_hits;
   a.ends = dk.ends;
   a.scratch = scratch;
   a.cell_table = ctx->d_cells;
@@ -1941,7 +1976,7 @@ namespace {
 // [state times | 12 doubles per state] for the states that can own points; false where the reference would
 // step off its deque (no state at or before the last point's time, or none after it).
 bool deskew_table(size_t n, const double* point_time, size_t num_states, const double* states,
-                  std::vector<double>& host, size_t& used, bool& ordered) {
+                  std::vector<double>& host, size_t& used, bool& ordered, uint32_t* max_hits = nullptr) {
   const double t_end = point_time[n - 1];
   long before = (long)num_states - 1;
   while (before >= 0 && states[8 * before] > t_end) --before;
@@ -1958,8 +1993,9 @@ bool deskew_table(size_t n, const double* point_time, size_t num_states, const d
   // The reference walks ALL states (its deque is never trimmed, so it grows by 400 entries per second). A
   // state whose timestamp is not above the smallest capture time can never take a point (the walk's
   // test "pointTime < timestamp" fails for whichever point it looks at), so leading ones are skipped here.
-  double earliest = point_time[0];
-  for (size_t i = 1; i < n; ++i) earliest = point_time[i] < earliest ? point_time[i] : earliest;
+  double earliest, latest;
+  bool any_nan;
+  time_range(point_time, n, &earliest, &latest, &any_nan);
   size_t first = 0;
   while (first + 1 < (size_t)before + 2 && states[8 * first] <= earliest) ++first;
   states += 8 * first;
@@ -1977,6 +2013,16 @@ bool deskew_table(size_t n, const double* point_time, size_t num_states, const d
   ordered = true;  // finite, non-decreasing state times: the device finds the segment bounds in parallel
   for (size_t s = 0; s < used; ++s)
     if (!(host[s] - host[s] == 0.0) || (s && host[s] < host[s - 1])) ordered = false;
+  if (max_hits) {
+    // the largest number of states that any point is a "hit" for (!(t < timestamp), nested for ordered timestamps):
+    // the count of the latest capture time -- every state when a time is NaN (a hit for all of them).  The states from
+    // this number on own no point (the walk finds no hit for them and keeps its bound): what the prologue needs to know
+    // about the WHOLE sweep, so that nothing on the device has to wait for all of it.
+    size_t hits = 0;
+    if (any_nan) hits = used;
+    else while (hits < used && !(latest < host[hits])) ++hits;
+    *max_hits = (uint32_t)hits;
+  }
   return true;
 }
 }  // namespace
@@ -2064,7 +2110,12 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   std::vector<double> host;
   size_t used = 0;
   bool ordered = false;
-  if (with_deskew && !deskew_table(n, point_time, num_states, states, host, used, ordered)) {
+  uint32_t max_hits = 0;
+  static const bool trace_table = std::getenv("VGICP_TRACE_PREPARE") != nullptr;
+  const double tt0 = trace_table ? now_seconds() : 0.0;
+  const bool table_ok = !with_deskew || deskew_table(n, point_time, num_states, states, host, used, ordered, &max_hits);
+  if (trace_table) std::fprintf(stderr, "[vgicp trace] deskew_table %.3f ms\n", (now_seconds() - tt0) * 1e3);
+  if (!table_ok) {
     ctx->prep_deskewed = -1;
     return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "the IMU states do not bracket the end of the sweep");
   }
@@ -2133,11 +2184,16 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     sp.flags = reinterpret_cast<uint32_t*>(stage);
     sp.stage = stage + flag_bytes;
     sp.done = ctx->ev_state_table[slot];
-    post_sweep_copy(ctx, n, &sp);   // a helper that is awake starts on the points now
-    if (with_deskew) {
+    double* times_stage = reinterpret_cast<double*>(stage + flag_bytes + pts_room);
+    // the prologue finds the deskew's segments itself and reads a workgroup's capture times behind the wait for its
+    // unit: they are staged unit by unit with the points, by whoever copies the unit
+    const bool times_by_unit = with_deskew && !walk && prepare_bounds_fused((uint32_t)n, (uint32_t)used, ordered);
+    post_sweep_copy(ctx, n, &sp, times_by_unit ? point_time : nullptr, times_by_unit ? times_stage : nullptr);   // a helper that is awake starts now
+    if (times_by_unit) {
+      time_src = times_stage;
+    } else if (with_deskew) {
       // this thread: the capture times first (a sixth of the bytes): the deskew's bounds need nothing else, and its
       // kernel reads them where they are staged
-      double* times_stage = reinterpret_cast<double*>(stage + flag_bytes + pts_room);
       stage_copy(times_stage, point_time, n * sizeof(double));
       time_src = times_stage;
       if (walk) VG_HIP(ctx, hipMemcpyAsync(d_time, times_stage, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -2164,6 +2220,7 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
     dk.poses = d_states + used;
     dk.states = (uint32_t)used;
     dk.ordered = ordered;
+    dk.max_hits = max_hits;
     dk.ends = reinterpret_cast<uint32_t*>(base + pb + tb + sb);
   }
   if (!staged) {

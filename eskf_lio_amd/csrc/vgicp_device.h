@@ -222,6 +222,7 @@ size_t map_insert_scratch_bytes(uint32_t n);
 //   [74] what the deskew reports (leading points moved)   [75] = epoch when a device-wide scan gave up waiting
 //   [76], [77] tile tickets of the two single-launch scans
 //   [78], [79] queries of the neighbour search that start first (sparse neighbourhood) / after them
+//   [80] workgroup ticket of the prologue (zero between launches: the workgroup that draws the last one clears it)
 constexpr int kCounterWords = 96;
 constexpr int kIndefiniteCounter = 72;
 constexpr int kBeyondGrid = 73;
@@ -231,6 +232,11 @@ constexpr int kTicketA = 76;
 constexpr int kTicketB = 77;
 constexpr int kHeavyQueries = 78;
 constexpr int kLightQueries = 79;
+constexpr int kTicketP = 80;
+// the prologue finds the deskew's segments itself (no launch for the bounds) for ordered state queues up to this many
+// states (8 bytes of LDS each) and sweeps up to this many workgroups of 256 points (a look-back slot each)
+constexpr uint32_t kFusedBoundsStatesMax = 4096;
+constexpr uint32_t kFusedBoundsBlocksMax = 4096;
 constexpr uint32_t kDeskewMaxStates = 4096;   // the parallel deskew bounds keep 12 bytes per state in LDS; longer (or unordered) queues take the serial walk
 constexpr uint32_t kPrepareMaxStates = 16000;  // IMU states that can own points of ONE sweep in the fused preparation (LDS)
 constexpr uint32_t kMaxScanTiles = 4096;  // x 2 048 points: scans up to 8 M points
@@ -257,6 +263,8 @@ struct PrepareArgs {
   const double* poses;           // device, 12 doubles per state
   uint32_t states;               // 0 = no deskew
   bool ordered_states;
+  bool max_hits_known;           // max_hits below is set (the host has walked the capture times)
+  uint32_t max_hits;             // the largest number of states whose timestamp is not above a point's capture time (all: a NaN time)
   uint32_t* ends;                // device scratch, deskew_scratch_words(states)
   void* scratch;                 // preprocess_scratch_bytes(n)
   void* cell_table;              // preprocess_cell_bytes(preprocess_cell_entries_for(n))
@@ -291,6 +299,10 @@ hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a);        // = head
 // reads the first units while the later ones are still being copied.
 hipError_t launch_prepare_head(hipStream_t s, const PrepareArgs& a);
 hipError_t launch_prepare_tail(hipStream_t s, const PrepareArgs& a);
+// true: the head finds the deskew's segments inside the prologue (PrepareArgs::max_hits must be known), and a workgroup
+// reads the capture times of ITS points only, behind the wait for their unit: a host that stages the sweep itself may
+// then stage the times unit by unit with the points instead of before the launch
+bool prepare_bounds_fused(uint32_t n, uint32_t states, bool ordered_states);
 uint64_t preprocess_cell_entries_for(uint32_t n);  // from the number of points alone (no host round trip)
 // kernels enqueued by the launchers of this module since the counter was last reset (per host thread)
 extern thread_local uint64_t g_kernel_launches;

@@ -119,6 +119,24 @@ __device__ __forceinline__ bool beyond_grid(double v, double fine) {
   return c < -(double)kCoordOffset || c > (double)(kCoordMax - kCoordOffset);  // false for NaN / infinity
 }
 
+// write-through stores / loads for words that workgroups of ONE launch hand to each other (MI355X_MICROARCH.md)
+typedef __attribute__((address_space(1))) unsigned long long pg64;
+typedef __attribute__((address_space(1))) unsigned int pg32;
+__device__ __forceinline__ void st_through64(void* p, unsigned long long v) {
+  __hip_atomic_store((pg64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_through32(void* p, uint32_t v) {
+  __hip_atomic_store((pg32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_through64(const void* p) {
+  return __hip_atomic_load((pg64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_through32(const void* p) {
+  return __hip_atomic_load((pg32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr uint32_t kLookBackSpinLimit = 1u << 22;
+
 // First kernel of a preparation, one thread per raw point (CloudPreprocessor::process, src/CloudPreprocessor.cpp:8-23,
 // up to the point where the neighbour search starts):
 //   extrinsic   Open3D PointCloud::Transform on points: p <- (T [p;1]).xyz / w              (:14)
@@ -151,19 +169,51 @@ struct PrologueArgs {
   const uint32_t* src_flags;
   uint32_t src_seq, src_unit, src_spin;
   uint32_t src_step, src_off[3];   // != 0: the sensor's own records, float32 x y z at these byte offsets (PrepareArgs::src_step)
+  // fused != 0: the segment of every point is found HERE, without a launch for the bounds (see the kernel)
+  uint32_t fused, max_hits;
+  const double* point_time;
+  const double* state_time;
+  unsigned long long* slots;       // [kFusedBoundsBlocksMax] (epoch << 32 | largest count of a workgroup)
 };
+// The deskew's segments without a kernel of their own (ordered state times).  Let a(j) = the number of states whose
+// timestamp is not above point j's capture time ("hits": !(t_j < ts_s); they nest because the timestamps ascend).  The
+// reference's walk gives point i to the first state s with i < ends[s], ends[s] = the first j with a(j) > s — that is
+// s = M(i) = max of a(j) over j <= i, a running maximum; and the states from A = max over ALL points on have no hit
+// at all, keep the last bound found and move nothing: a point with M(i) = A stays as it is.  A comes from the host
+// (deskew_table walks the capture times anyway: the count for the latest time, every state if a time is NaN).  So a
+// workgroup needs its own points' counts (binary search in LDS), their running maximum (wave scan) and the largest
+// count of every workgroup BEFORE it: each publishes that one number at once, tagged with the call's epoch, and reads
+// the earlier ones (look-back over slots, no chain: nobody waits for more than one publication).  Workgroup numbers
+// are drawn from a ticket, so a workgroup only ever waits for workgroups that started before it.
 __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char prologue_lds[];
   uint32_t* ends_sh = reinterpret_cast<uint32_t*>(prologue_lds);
   __shared__ uint32_t last_found;
   __shared__ __attribute__((aligned(16))) double staged[256 * 64 / 8];   // 256 points of 24 bytes (doubles) or of up to 64 (sensor records)
   __shared__ uint32_t staged_ok;
+  __shared__ uint32_t bid_sh, wave_max_sh[4], before_sh, first_stay_sh, gave_up_sh;
   const uint32_t tid = threadIdx.x;
+  uint32_t bid = blockIdx.x;
+  uint32_t run_max = 0, block_max = 0;   // fused: running maximum of the counts up to this thread's point (inside the workgroup), the workgroup's largest
+  if (a.fused) {
+    if (tid == 0) {
+      const uint32_t ticket = atomicAdd(&a.counters[kTicketP], 1u);
+      if (ticket == gridDim.x - 1) st_through32(&a.counters[kTicketP], 0u);   // all handed out: zero for the next launch
+      bid_sh = ticket;
+      before_sh = 0u;
+      first_stay_sh = 0xFFFFFFFFu;
+      gave_up_sh = 0u;
+    }
+    double* ts = reinterpret_cast<double*>(prologue_lds);
+    for (uint32_t s = tid; s < a.states; s += blockDim.x) ts[s] = a.state_time[s];
+    __syncthreads();
+    bid = bid_sh;
+  }
   if (a.src) {
     // this block's 256 points out of the staging memory: wait for their unit (one lane polls over PCIe), then 16-byte
     // loads of consecutive lanes (every 64-byte request of the link is used whole), handed out through LDS
     typedef int v4i __attribute__((ext_vector_type(4)));
-    const uint32_t p0 = blockIdx.x * 256u;
+    const uint32_t p0 = bid * 256u;
     if (a.src_flags && p0 < a.n) {
       if (tid == 0) {
         const uint32_t* flag = a.src_flags + 16 * (size_t)(p0 / a.src_unit);
@@ -177,7 +227,11 @@ __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
       }
       __syncthreads();
       if (!staged_ok) {   // uniform: the host's copy threads never delivered; reported like a scan that gave up
-        if (tid == 0) a.counters[kScanTimeout] = a.epoch;
+        if (tid == 0) {
+          a.counters[kScanTimeout] = a.epoch;
+          // (the workgroups behind this one look back at its slot: tell them not to wait)
+          if (a.fused) st_through64(&a.slots[bid], ((unsigned long long)a.epoch << 32) | 0xFFFFFFFFull);
+        }
         return;
       }
     }
@@ -191,7 +245,67 @@ __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
     }
     __syncthreads();
   }
-  if (a.states) {
+  if (a.fused) {
+    // (behind the wait for this workgroup's unit: the capture times may be staged with the points)
+    double* ts = reinterpret_cast<double*>(prologue_lds);
+    const uint32_t i0 = bid * 256u + tid;
+    uint32_t cnt = 0;
+    if (i0 < a.n) {
+      const double t = a.point_time[i0];
+      uint32_t hi = a.states;   // NaN is a hit for every state, like in the walk
+      while (cnt < hi) {
+        const uint32_t mid = (cnt + hi) >> 1;
+        if (!(t < ts[mid])) cnt = mid + 1; else hi = mid;
+      }
+    }
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    run_max = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)run_max, o, 64);
+      if (lane >= (uint32_t)o) run_max = v > run_max ? v : run_max;
+    }
+    if (lane == 63u) wave_max_sh[wave] = run_max;
+    __syncthreads();
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      const uint32_t v = wave_max_sh[k];
+      block_max = v > block_max ? v : block_max;
+      if (k < wave) carry = v > carry ? v : carry;
+    }
+    run_max = carry > run_max ? carry : run_max;
+    if (tid == 0) st_through64(&a.slots[bid], ((unsigned long long)a.epoch << 32) | block_max);
+    uint32_t before = 0;
+    bool gave_up = false;
+    for (uint32_t b = tid; b < bid; b += blockDim.x) {
+      unsigned long long v = ld_through64(&a.slots[b]);
+      for (uint32_t spins = 0; (uint32_t)(v >> 32) != a.epoch; ++spins) {
+        if (spins >= kLookBackSpinLimit) { gave_up = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+        v = ld_through64(&a.slots[b]);
+      }
+      const uint32_t c = (uint32_t)v;
+      if (c == 0xFFFFFFFFu) { gave_up = true; break; }   // that workgroup gave up waiting for its unit
+      before = c > before ? c : before;
+    }
+    if (before) atomicMax(&before_sh, before);
+    if (gave_up) gave_up_sh = 1u;
+    __syncthreads();
+    if (gave_up_sh) {   // uniform; reported like a scan that gave up (the preparation is refused)
+      if (tid == 0) a.counters[kScanTimeout] = a.epoch;
+      return;
+    }
+    run_max = before_sh > run_max ? before_sh : run_max;
+    // what the deskew reports: the points that a state moved = the first point whose running maximum is A
+    if (before_sh < a.max_hits && block_max >= a.max_hits) {   // uniform: the one workgroup in which A is reached (A > 0)
+      const uint32_t i0 = bid * 256u + tid;
+      if (i0 < a.n && run_max >= a.max_hits) atomicMin(&first_stay_sh, i0);
+      __syncthreads();
+      if (tid == 0) a.counters[kDeskewedCounter] = first_stay_sh;
+    }
+    if (a.max_hits == 0u && bid == 0u && tid == 0) a.counters[kDeskewedCounter] = 0u;
+  } else if (a.states) {
     if (a.parts) {
       if (tid == 0) last_found = 0u;
       for (uint32_t s = tid; s < a.states; s += blockDim.x) ends_sh[s] = 0xFFFFFFFFu;
@@ -216,13 +330,13 @@ __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
       __syncthreads();
     }
   }
-  if (blockIdx.x == 0 && tid == 0) {
+  if (bid == 0 && tid == 0) {
     a.counters[kTicketA] = 0u;
     a.counters[kTicketB] = 0u;
     a.counters[kHeavyQueries] = 0u;
     a.counters[kLightQueries] = 0u;
     a.counters[kIndefiniteCounter] = 0u;
-    a.counters[kDeskewedCounter] = a.states ? ends_sh[a.states - 1] : 0u;
+    if (!a.fused) a.counters[kDeskewedCounter] = a.states ? ends_sh[a.states - 1] : 0u;
   }
   // the cell table: key = empty, bounds 0 (16-byte entries, two 8-byte words each)
   {
@@ -231,7 +345,7 @@ __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
     for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + tid; e < a.entries; e += total)
       t2[e] = make_ulonglong2(kEmptyCell, 0ull);
   }
-  const uint32_t i = blockIdx.x * blockDim.x + tid;
+  const uint32_t i = bid * blockDim.x + tid;
   if (i >= a.n) return;
   double x, y, z;
   bool moved = a.src != nullptr;   // points that came from the host are written to the device whether or not they move
@@ -255,12 +369,12 @@ __global__ __launch_bounds__(256) void sweep_prologue_kernel(PrologueArgs a) {
     moved = true;
   }
   if (a.states) {
-    uint32_t lo = 0, hi = a.states;  // first s with i < ends[s]
+    uint32_t lo = run_max, hi = a.fused ? lo : a.states;  // first s with i < ends[s] (fused: the running maximum IS that state)
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
       if (i < ends_sh[mid]) hi = mid; else lo = mid + 1;
     }
-    if (lo < a.states) {  // (after the last segment: left as it is)
+    if (lo < (a.fused ? a.max_hits : a.states)) {  // (after the last segment: left as it is)
       const double* T = a.poses + 12 * (size_t)lo;
       const double rx = T[0] * x + T[3] * y + T[6] * z;
       const double ry = T[1] * x + T[4] * y + T[7] * z;
@@ -322,21 +436,6 @@ struct TileSlot {  // 32 bytes
   uint32_t pad[3];
 };
 static_assert(sizeof(TileSlot) == 32, "tile slot layout");
-
-typedef __attribute__((address_space(1))) unsigned long long pg64;
-typedef __attribute__((address_space(1))) unsigned int pg32;
-__device__ __forceinline__ void st_through64(void* p, unsigned long long v) {
-  __hip_atomic_store((pg64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_through32(void* p, uint32_t v) {
-  __hip_atomic_store((pg32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long ld_through64(const void* p) {
-  return __hip_atomic_load((pg64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t ld_through32(const void* p) {
-  return __hip_atomic_load((pg32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __device__ __forceinline__ RunMin runmin_identity() {
   RunMin r;
@@ -1592,7 +1691,9 @@ uint64_t preprocess_cell_entries(uint32_t cells) { return pow2_at_least((uint64_
 // the scan looks like.
 uint64_t preprocess_cell_entries_for(uint32_t n) { return pow2_at_least((uint64_t)(n ? n : 1) * 32 + 64); }
 size_t preprocess_cell_bytes(uint64_t entries) { return entries * sizeof(CellEntry); }
-size_t preprocess_tile_bytes() { return (size_t)kMaxScanTiles * (sizeof(TileSlot) + sizeof(unsigned long long)); }
+size_t preprocess_tile_bytes() {   // tile slots of the two scans + the prologue's look-back slots
+  return (size_t)kMaxScanTiles * (sizeof(TileSlot) + sizeof(unsigned long long)) + (size_t)kFusedBoundsBlocksMax * sizeof(unsigned long long);
+}
 
 namespace {
 // launches of rocPRIM's merge sort (2 048- or 4 096-item blocks, sort_in_large_blocks): one block sort and one
@@ -1644,6 +1745,10 @@ PrepareBuffers prepare_buffers(const PrepareArgs& a) {
 }
 }  // namespace
 
+bool prepare_bounds_fused(uint32_t n, uint32_t states, bool ordered_states) {
+  return states != 0 && ordered_states && states <= kFusedBoundsStatesMax && blocks_for(n, 256) <= kFusedBoundsBlocksMax;
+}
+
 hipError_t launch_prepare_head(hipStream_t s, const PrepareArgs& a) {
   const uint32_t n = a.n;
   if (n == 0) return hipSuccess;
@@ -1663,7 +1768,15 @@ hipError_t launch_prepare_head(hipStream_t s, const PrepareArgs& a) {
   pa.states = a.states;
   pa.ends = a.ends;
   pa.poses = a.poses;
-  if (a.states) {
+  const bool fused = a.max_hits_known && prepare_bounds_fused(n, a.states, a.ordered_states);
+  if (fused) {
+    pa.fused = 1u;
+    pa.max_hits = a.max_hits;
+    pa.point_time = a.point_time;
+    pa.state_time = a.state_time;
+    pa.slots = reinterpret_cast<unsigned long long*>(static_cast<char*>(a.tiles) +
+                                                     (size_t)kMaxScanTiles * (sizeof(TileSlot) + sizeof(unsigned long long)));
+  } else if (a.states) {
     if (a.ordered_states && a.states <= kDeskewMaxStates) {
       // few blocks: every workgroup of the prologue merges their first hits for itself
       uint32_t parts = blocks_for(n, 1024);
@@ -1697,7 +1810,8 @@ hipError_t launch_prepare_head(hipStream_t s, const PrepareArgs& a) {
   pa.src_spin = a.src_spin;
   pa.src_step = a.src_step;
   for (int c = 0; c < 3; ++c) pa.src_off[c] = a.src_off[c];
-  hipLaunchKernelGGL(sweep_prologue_kernel, dim3(blocks_for(n, 256)), dim3(256), (size_t)a.states * sizeof(uint32_t), s, pa);
+  hipLaunchKernelGGL(sweep_prologue_kernel, dim3(blocks_for(n, 256)), dim3(256),
+                     (size_t)a.states * (fused ? sizeof(double) : sizeof(uint32_t)), s, pa);
   ++g_kernel_launches;
   if (a.ev_after_prologue) {
     const hipError_t ee = hipEventRecord(a.ev_after_prologue, s);

@@ -1788,6 +1788,52 @@ def test_deskew_edge_cases(gpu_ctx, oracle):
     assert done == rdone and np.array_equal(gp, rp)
 
 
+def test_prepare_chain_finds_the_deskew_segments_of_awkward_sweeps(oracle):
+    """The scan preparation finds the deskew's segments inside its first kernel (a running maximum of per-point hit
+    counts, the sweep-wide maximum from the host; reference src/CloudPreprocessor.cpp:25-74): capture times that go
+    backwards, repeat a state's timestamp, are NaN, all lie before the first state, jitter across workgroup
+    boundaries; sweeps of one workgroup and of hundreds; staged by the copy threads and staged on arrival — the
+    prepared scan and the number of points moved equal the oracle's chain, and the stand-alone deskew's."""
+    from eskf_lio_amd import capi, synth
+    rng = np.random.default_rng(77)
+    st = synth.make_imu_states(12, seed=4)
+    cases = []
+    for n in (200, 300, 5_000, 70_000):
+        t = synth.make_point_times(n, st[1, 0] + 1e-4, st[-3, 0] + 1e-3, seed=4)
+        pts = synth.make_lidar_scan(n, seed=4 + n, extent=20.0)
+        back = t.copy()
+        back[n // 3:2 * n // 3] = back[n // 3:2 * n // 3][::-1]
+        back[n // 6] = st[4, 0]
+        wild = rng.permutation(np.concatenate([t[:n - 50], np.repeat(st[6, 0], 30), np.full(20, np.nan)]))
+        wild[-1] = st[-3, 0] + 1e-3
+        early = np.full(n, st[0, 0] - 1e-3)
+        early[-1] = st[5, 0] + 1e-4
+        jitter = t + rng.normal(size=n) * 2e-3
+        jitter[-1] = st[-3, 0] + 1e-3
+        nan_first = t.copy()
+        nan_first[0] = np.nan
+        for name, times in (("plain", t), ("back", back), ("wild", wild), ("early", early), ("jitter", jitter), ("nan_first", nan_first)):
+            cases.append((f"{name}/{n}", pts, times))
+    ext = synth.se3_to_SE3([0.02, -0.01, 0.03, 0.01, -0.02, 0.005])
+    with capi.Context(0) as ctx:
+        for name, pts, times in cases:
+            moved, _ = oracle.transform(pts, np.tile(np.eye(3).reshape(9), (len(pts), 1)), ext)
+            desk, rdone = oracle.deskew(moved, times, st)
+            rp, rc, _ = oracle.preprocess(desk, 0.3, 30)
+            kept, done = ctx.scan_prepare(pts, times, st, ext, 0.3, 30)
+            gp, gc = ctx.scan_download()
+            assert done == rdone, (name, done, rdone)
+            assert kept == len(rp) and np.array_equal(gp, rp, equal_nan=True) and np.array_equal(gc, rc, equal_nan=True), name
+            # staged on arrival: the prologue reads times and points where the ticket left them
+            ticket = ctx.sweep_stage(pts, times)
+            ctx.scan_prepare_staged_async(ticket, st, ext, 0.3, 30)
+            gp2, gc2 = ctx.scan_download()
+            assert ctx.scan_info()[:2] == (kept, done), name
+            assert np.array_equal(gp2, rp, equal_nan=True) and np.array_equal(gc2, rc, equal_nan=True), name
+            # the stand-alone deskew (its own kernels) agrees on the count
+            assert ctx.deskew(moved, times, st)[1] == rdone, name
+
+
 def test_host_mirror_cloud_preprocessor_process(oracle):
     """CloudPreprocessor::process through the C++ mirror: LiDAR->IMU extrinsic, deskew, scan preparation
     (reference src/CloudPreprocessor.cpp:8-23) against the same chain of oracle calls."""
