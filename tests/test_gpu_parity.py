@@ -521,6 +521,20 @@ def test_staged_upload_survives_copy_threads_that_are_held_up(c1_inputs):
         omap.insert(vmap.means, vmap.covs)
         ref = omap.align(pts, covs, g, 4, 1e-6, 2.0)
         assert np.array_equal(ref.corr_count, slow.corr_count) and np.abs(ref.pose - slow.pose).max() < 1e-11
+        # the same for a raw sweep: the preparation's first kernel gives up waiting for its units (and tells the
+        # workgroups that look back at its slot), the host launches it once more when everything is staged
+        st = synth.make_imu_states(48, seed=9)
+        t = synth.make_point_times(9_000, st[1, 0] + 1e-4, st[-3, 0] + 1e-3, seed=9)
+        raw = synth.make_lidar_scan(9_000, seed=41)
+        ext = synth.se3_to_SE3([0.01, -0.02, 0.03, 0.002, -0.001, 0.003])
+        with capi.Context(0) as ctx:
+            kept, moved = ctx.scan_prepare(raw, t, st, ext, 0.3, 30)
+            gp, gc = ctx.scan_download()
+            assert ctx.counter(capi.COUNTER_UPLOAD_SLOW) == 1
+        mv, _ = oracle.transform(raw, np.tile(np.eye(3).reshape(9), (len(raw), 1)), ext)
+        desk, rdone = oracle.deskew(mv, t, st)
+        rp, rc, _ = oracle.preprocess(desk, 0.3, 30)
+        assert moved == rdone and kept == len(rp) and np.array_equal(gp, rp) and np.array_equal(gc, rc)
         print("ok")
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, VGICP_PACK_SPIN_LIMIT="1", VGICP_DEBUG_UPLOAD_DELAY_US="150000", VGICP_UPLOAD_THREADS="1")
