@@ -95,6 +95,7 @@ struct CopyCrew {
   std::atomic<uint32_t> gen{0};        // the job the helpers were last woken for
   std::atomic<uint64_t> next{0};       // job number << 32 | next unit to take: a thread that comes late to a job that is
                                        // over finds another job's number here and leaves without touching anything
+                                       // (work() takes units by compare-and-swap for that reason)
   std::atomic<uint32_t> finished{0};
   uint32_t job = 0;                    // jobs posted so far (the caller's thread only)
   bool quit = false;
@@ -110,10 +111,15 @@ struct CopyCrew {
 
   void work(uint32_t my_job) {
     for (;;) {
-      const uint64_t v = next.fetch_add(1, std::memory_order_acq_rel);
-      if ((uint32_t)(v >> 32) != my_job) return;
+      // a unit is taken by compare-and-swap, never by a blind increment: a thread that comes late to a job that is over
+      // must leave the NEXT job's counter alone (an increment would take one of its units away from everybody:
+      // finish() would wait for it for ever — seen once per ~200 000 uploads as a soak that never returned)
+      uint64_t v = next.load(std::memory_order_acquire);
+      for (;;) {
+        if ((uint32_t)(v >> 32) != my_job || (uint32_t)v >= units) return;
+        if (next.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire)) break;
+      }
       const uint32_t u = (uint32_t)v;
-      if (u >= units) return;
       const size_t p0 = (size_t)u * unit, cnt = std::min<size_t>(unit, n - p0);
       copy(apts + p0 * size_a, pts + p0 * size_a, cnt * size_a);
       if (size_b) copy(acov + p0 * size_b, cov + p0 * size_b, cnt * size_b);

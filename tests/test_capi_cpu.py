@@ -226,6 +226,23 @@ def test_shim_native_types_branch_meets_a_compiler(tmp_path):
     assert "ESKF_LIO::ICP::align" in syms and "vgicp_align" in syms and "vgicp_map_upsert" in syms
 
 
+def test_copy_crew_survives_helpers_that_come_late(tmp_path):
+    """The threads that copy a scan into page-locked memory take units of a job from one atomic word (job number and
+    next unit).  A helper that was woken for a job which the caller has meanwhile finished alone finds the NEXT job's
+    word there: it must leave without taking anything (compare-and-swap on the job number) — a blind increment took a
+    unit away from everybody and the upload never finished (round 5: a soak that hung once per ~200 000 uploads;
+    this stress reproduced it within a few thousand jobs).  tests/native/crew_stress.cpp: 150 000 tiny jobs, every
+    third one not announced to the helpers; every unit published once, every byte copied, no job stuck."""
+    exe = tmp_path / "crew_stress"
+    out = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                          "-I" + os.path.join(ROOT, "eskf_lio_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
+                          os.path.join(ROOT, "tests", "native", "crew_stress.cpp")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    for helpers in ("1", "3"):
+        run = subprocess.run([str(exe), "150000", helpers], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0 and "ok 150000 jobs" in run.stdout, run.stdout[-500:] + run.stderr[-500:]
+
+
 def test_same_voxel_shortcut_implies_an_unchanged_key():
     """The persistent launch asks "is the point still inside last round's voxel?" before it makes a key
     (`same_voxel_coord`, eskf_lio_amd/csrc/vgicp_device_fn.h): r = fma(-k, h, x); yes iff 0 <= r and h - r > 2^-20 h.
