@@ -890,10 +890,10 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   // sorted order costs more insertions than the best-first search needs; 64: 270 us, 128 / 256: 250 us, no cap: 308 us)
   const bool has_home = enough != 0 && home_end - home_start <= kHomePoints;
 
-  // The k-list: lane l < K holds the l-th nearest so far, by (distance, index). It starts FULL: K consecutive
-  // points of the sorted order around the query (w0 .. w0 + K - 1, inside home when there is one) are real points
-  // and usually near ones. The search skips the points it has measured here when it meets them again
-  // (sorted positions skip_start .. skip_start + skip_count - 1).
+  // The k-list: lane l < K holds the l-th nearest so far, by (distance, index). It starts FULL, from consecutive points
+  // of the sorted order around the query (inside home when there is one): real points and usually near ones. The
+  // search skips the points it has measured here when it meets them again (sorted positions skip_start ..
+  // skip_start + skip_count - 1).  (-DVGICP_KNN_SEEDS_ONLY keeps the opening of rounds 2-5 for A/B runs: K seeds.)
 #ifndef VGICP_KNN_SEEDS_ONLY
   // The opening window: up to 64 consecutive points of the sorted order around the query (inside home when there is
   // one), one per lane.  All of them are ranked against each other at once -- every lane counts the keys below its
