@@ -105,7 +105,8 @@ struct CopyCrew {
   char* apts = nullptr;
   char* acov = nullptr;
   uint32_t* flags = nullptr;
-  uint32_t n = 0, unit = 0, units = 0, seq = 0;
+  uint32_t n = 0, unit = 0, seq = 0;
+  std::atomic<uint32_t> units{0};      // read BEFORE a unit is taken (by a thread that may have come late to an older job): atomic
   uint32_t size_a = 24, size_b = 72;   // bytes per point of the two arrays (size_b = 0: one array only)
   void (*copy)(void*, const void*, size_t) = nullptr;
 
@@ -116,7 +117,7 @@ struct CopyCrew {
       // finish() would wait for it for ever — seen once per ~200 000 uploads as a soak that never returned)
       uint64_t v = next.load(std::memory_order_acquire);
       for (;;) {
-        if ((uint32_t)(v >> 32) != my_job || (uint32_t)v >= units) return;
+        if ((uint32_t)(v >> 32) != my_job || (uint32_t)v >= units.load(std::memory_order_relaxed)) return;
         if (next.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire)) break;
       }
       const uint32_t u = (uint32_t)v;
@@ -170,7 +171,7 @@ struct CopyCrew {
   // wake-up lands on the waker's CPU) with a unit half copied: spinning here would keep it off the CPU for a whole
   // scheduler slice (3 ms steps were measured); after a short spin the CPU is offered to whoever else wants it.
   void finish() const {
-    for (uint32_t spins = 0; finished.load(std::memory_order_acquire) < units; ++spins) {
+    for (uint32_t spins = 0; finished.load(std::memory_order_acquire) < units.load(std::memory_order_relaxed); ++spins) {
       if (spins < 512) __builtin_ia32_pause();
       else sched_yield();
     }

@@ -241,6 +241,16 @@ def test_copy_crew_survives_helpers_that_come_late(tmp_path):
     for helpers in ("1", "3"):
         run = subprocess.run([str(exe), "150000", helpers], capture_output=True, text=True, timeout=300)
         assert run.returncode == 0 and "ok 150000 jobs" in run.stdout, run.stdout[-500:] + run.stderr[-500:]
+    # the same under ThreadSanitizer (the sanitizers run on the CPU build only): no data race between the caller's set-up
+    # of the next job and a helper still looking at the last one
+    tsan = tmp_path / "crew_stress_tsan"
+    out = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__",
+                          "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "eskf_lio_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                          "-o", str(tsan), os.path.join(ROOT, "tests", "native", "crew_stress.cpp")], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for this compiler: " + out.stderr[-200:])
+    run = subprocess.run([str(tsan), "20000", "2"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "ok 20000 jobs" in run.stdout and "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
 
 
 def test_same_voxel_shortcut_implies_an_unchanged_key():
