@@ -253,6 +253,28 @@ def test_copy_crew_survives_helpers_that_come_late(tmp_path):
     assert run.returncode == 0 and "ok 20000 jobs" in run.stdout and "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
 
 
+def test_shadow_grid_of_the_dropin_map_on_the_cpu(tmp_path):
+    """The drop-in LocalMap's defaults keep the grid on the device and a host-side SHADOW of it (a worker thread) for
+    save() (include/eskf_lio_shim/LocalMap.hpp; reference src/LocalMap.cpp:10-76,156-167).  tests/native/shadow_stress.cpp
+    stubs the C ABI (every call succeeds, nothing happens), so what runs is the class's host side alone: 120 frames with
+    insertion and eviction through the worker thread against a host-authoritative map on the caller's thread — save()
+    writes the same points; and the same under ThreadSanitizer."""
+    src = os.path.join(ROOT, "tests", "native", "shadow_stress.cpp")
+    exe = tmp_path / "shadow_stress"
+    out = subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", str(exe), src],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    run = subprocess.run([str(exe), "120", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "ok 120 frames" in run.stdout, run.stdout[-800:] + run.stderr[-800:]
+    tsan = tmp_path / "shadow_stress_tsan"
+    out = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include"),
+                          "-o", str(tsan), src], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for this compiler: " + out.stderr[-200:])
+    run = subprocess.run([str(tsan), "40", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "ok 40 frames" in run.stdout and "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
+
+
 def test_same_voxel_shortcut_implies_an_unchanged_key():
     """The persistent launch asks "is the point still inside last round's voxel?" before it makes a key
     (`same_voxel_coord`, eskf_lio_amd/csrc/vgicp_device_fn.h): r = fma(-k, h, x); yes iff 0 <= r and h - r > 2^-20 h.
