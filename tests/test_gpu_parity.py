@@ -1848,6 +1848,30 @@ def test_prepare_chain_finds_the_deskew_segments_of_awkward_sweeps(oracle):
             assert ctx.deskew(moved, times, st)[1] == rdone, name
 
 
+def test_prepare_chain_of_large_sweeps_matches_the_stand_alone_calls():
+    """Sweeps too large to stage go up straight from the caller's memory: 700 000 points (the prologue still finds the
+    deskew's segments itself, the capture times on the device) and 1 200 000 (more workgroups than look-back slots: the
+    bounds get their own launch, as before round 5).  Both against extrinsic (numpy, Open3D's operation order) +
+    vgicp_deskew + vgicp_preprocess, which run their own kernels: the same kept points, covariances and moved count."""
+    from eskf_lio_amd import capi, synth
+    st = synth.make_imu_states(48, seed=9)
+    ext = synth.se3_to_SE3([0.01, -0.02, 0.03, 0.002, -0.001, 0.003])
+    with capi.Context(0) as a, capi.Context(0) as b:
+        for n in (700_000, 1_200_000):
+            t = synth.make_point_times(n, st[1, 0] + 1e-4, st[-3, 0] + 1e-3, seed=9)
+            t = t + np.random.default_rng(1).normal(size=n) * 1e-3
+            t[-1] = st[-3, 0] + 1e-3
+            raw = synth.make_lidar_scan(n, seed=41, extent=60.0)
+            kept, moved = a.scan_prepare(raw, t, st, ext, 0.3, 30)
+            gp, gc = a.scan_download()
+            q = np.empty((n, 4))
+            for r in range(4):
+                q[:, r] = ext[r, 0] * raw[:, 0] + ext[r, 1] * raw[:, 1] + ext[r, 2] * raw[:, 2] + ext[r, 3]
+            dp, done = b.deskew(q[:, :3] / q[:, 3:4], t, st)
+            kp, kc, _ = b.preprocess(dp, 0.3, 30)
+            assert moved == done and kept == len(kp) and np.array_equal(gp, kp) and np.array_equal(gc, kc), n
+
+
 def test_host_mirror_cloud_preprocessor_process(oracle):
     """CloudPreprocessor::process through the C++ mirror: LiDAR->IMU extrinsic, deskew, scan preparation
     (reference src/CloudPreprocessor.cpp:8-23) against the same chain of oracle calls."""
