@@ -1872,6 +1872,24 @@ def test_prepare_chain_of_large_sweeps_matches_the_stand_alone_calls():
             assert moved == done and kept == len(kp) and np.array_equal(gp, kp) and np.array_equal(gc, kc), n
 
 
+def test_prepare_chain_across_state_queue_lengths():
+    """4 ... 6 000 IMU states inside one sweep: the prologue finds the segments itself up to 4 096 states (8 bytes of LDS
+    each), longer queues take the serial bounds walk — the same prepared scan and moved count as vgicp_deskew +
+    vgicp_preprocess either way."""
+    from eskf_lio_amd import capi, synth
+    n = 20_000
+    raw = synth.make_lidar_scan(n, seed=41, extent=30.0)
+    with capi.Context(0) as a, capi.Context(0) as b:
+        for states in (4, 300, 3000, 4096, 4100, 6000):
+            st = synth.make_imu_states(states, seed=states)
+            t = synth.make_point_times(n, st[1, 0] + 1e-6, st[-3, 0] + 1e-6, seed=9)
+            kept, moved = a.scan_prepare(raw, t, st, None, 0.3, 30)
+            gp, gc = a.scan_download()
+            dp, done = b.deskew(raw, t, st)
+            kp, kc, _ = b.preprocess(dp, 0.3, 30)
+            assert moved == done and kept == len(kp) and np.array_equal(gp, kp) and np.array_equal(gc, kc), states
+
+
 def test_host_mirror_cloud_preprocessor_process(oracle):
     """CloudPreprocessor::process through the C++ mirror: LiDAR->IMU extrinsic, deskew, scan preparation
     (reference src/CloudPreprocessor.cpp:8-23) against the same chain of oracle calls."""
