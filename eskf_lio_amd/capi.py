@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VGICP_LIB_PATH: a developer's A/B aid (two builds of the module timed in one session on one box)
 LIB_PATH = os.environ.get("VGICP_LIB_PATH") or os.path.join(_HERE, "lib", "libvgicp_hip.so")
 
-OK, ERR_BAD_ARGUMENT, ERR_HIP, ERR_RCCL, ERR_TABLE_FULL, ERR_DEGENERATE, ERR_NO_DEVICE, ERR_NOT_READY = range(8)
+OK, ERR_BAD_ARGUMENT, ERR_HIP, ERR_RCCL, ERR_TABLE_FULL, ERR_DEGENERATE, ERR_NO_DEVICE, ERR_NOT_READY, ERR_TIMEOUT = range(9)
 FLAG_PROFILE = 1
 FLAG_NO_PERSISTENT = 2
 SOLVE_FORCE_PIVOTED = 1
@@ -33,7 +33,7 @@ EXPORTS = (
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
     "vgicp_accumulate", "vgicp_solve_step", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_scan_prepare", "vgicp_scan_download",
-    "vgicp_peer_status", "vgicp_scan_prepare_async", "vgicp_sweep_stage", "vgicp_sweep_stage_cloud2", "vgicp_scan_prepare_staged_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
+    "vgicp_peer_status", "vgicp_scan_prepare_async", "vgicp_sweep_stage", "vgicp_sweep_stage_cloud2", "vgicp_sweep_unstage", "vgicp_scan_prepare_staged_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
     "vgicp_set_option", "vgicp_host_register", "vgicp_host_unregister",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
     "vgicp_peer_export", "vgicp_peer_connect", "vgicp_peer_disconnect",
@@ -115,6 +115,7 @@ def load_library() -> C.CDLL:
     lib.vgicp_scan_prepare_async.argtypes = [vp, sz, dp, dp, sz, dp, dp, C.c_double, C.c_int]
     lib.vgicp_sweep_stage.argtypes = [vp, sz, dp, dp, C.POINTER(C.c_uint64)]
     lib.vgicp_sweep_stage_cloud2.argtypes = [vp, sz, vp, sz, sz, sz, sz, sz, C.POINTER(C.c_uint64)]
+    lib.vgicp_sweep_unstage.argtypes = [vp, C.c_uint64]
     lib.vgicp_peer_status.argtypes = [vp]
     lib.vgicp_peer_status.restype = C.c_char_p
     lib.vgicp_scan_prepare_staged_async.argtypes = [vp, C.c_uint64, sz, dp, dp, C.c_double, C.c_int]
@@ -493,6 +494,10 @@ class Context:
         ticket = C.c_uint64(0)
         self._check(self._lib.vgicp_sweep_stage(self._h, pts.shape[0], _dp(pts), _dp(t) if t.size else None, C.byref(ticket)))
         return int(ticket.value)
+
+    def sweep_unstage(self, ticket: int) -> None:
+        """vgicp_sweep_unstage: drop a staged sweep that will not be prepared (its slot is free again)."""
+        self._check(self._lib.vgicp_sweep_unstage(self._h, C.c_uint64(int(ticket))))
 
     def sweep_stage_cloud2(self, data, n: int, point_step: int, off_x: int, off_y: int, off_z: int, off_time=None) -> int:
         """vgicp_sweep_stage_cloud2: the payload of a PointCloud2 (bytes / uint8 array, little-endian records) as it

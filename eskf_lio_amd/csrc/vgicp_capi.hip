@@ -14,7 +14,8 @@ namespace vgicp {
 thread_local uint64_t g_copy_ops = 0, g_sync_ops = 0;
 thread_local std::string g_create_error;
 thread_local std::string g_stage_error;
-thread_local const vgicp_ctx* g_stage_error_ctx = nullptr;
+thread_local uint64_t g_stage_error_ctx = 0;
+std::atomic<uint64_t> g_context_ids{0};
 }  // namespace vgicp
 
 namespace {
@@ -171,6 +172,7 @@ int alloc_table(vgicp_ctx* ctx, uint64_t slots, VoxelRecord** out) {
   return VGICP_OK;
 }
 
+int reserve_dense(vgicp_ctx* ctx);
 // Keep load (FULL + TOMB + incoming) <= 1/2 at all times; size new tables for load <= 1/4.
 int ensure_table(vgicp_ctx* ctx, uint64_t incoming) {
   const uint64_t used = ctx->voxels + ctx->tombstones + incoming + ctx->insert_pending_upper;
@@ -198,7 +200,7 @@ int ensure_table(vgicp_ctx* ctx, uint64_t incoming) {
   ctx->slots = slots;
   ctx->tombstones = 0;
   ++ctx->map_version;
-  return VGICP_OK;
+  return reserve_dense(ctx);   // the dense copy's storage follows the table's size here, never inside an align
 }
 
 int ensure_scan(vgicp_ctx* ctx, size_t n) {
@@ -360,27 +362,38 @@ bool wants_dense(const vgicp_ctx* ctx, uint32_t n_upper) {
   return ctx->table && ctx->dense_slots_threshold != 0 && ctx->slots >= ctx->dense_slots_threshold && ctx->voxels > 0 &&
          (uint64_t)n_upper > (uint64_t)ctx->persist_grid * 448u;
 }
-int ensure_dense(vgicp_ctx* ctx) {
-  if (ctx->dense_version == ctx->map_version && ctx->d_dense) return VGICP_OK;
-  // ctx->voxels is stale while a deferred insertion (vgicp_map_insert_resident_async) is pending: the records it adds are
-  // in the table when the copy is made, before the host has read their count (insert_pending_upper bounds it)
-  const uint64_t may_hold = ctx->voxels + ctx->insert_pending_upper;
-  if (may_hold > ctx->dense_capacity) {
-    if (ctx->d_dense) VG_HIP(ctx, hipFree(ctx->d_dense));
+// Storage of the dense copy: sized when the TABLE is (re)allocated (vgicp_map_reset, a growing upsert / insertion) —
+// never inside an align.  The table keeps FULL + tombstones + incoming <= slots / 2, so slots / 2 records always suffice.
+int reserve_dense(vgicp_ctx* ctx) {
+  if (!ctx->table || ctx->dense_slots_threshold == 0 || ctx->slots < ctx->dense_slots_threshold) return VGICP_OK;
+  const uint64_t cap = ctx->slots / 2;
+  if (cap > ctx->dense_capacity) {
+    if (ctx->d_dense) { VG_HIP(ctx, hipStreamSynchronize(ctx->stream)); VG_HIP(ctx, hipFree(ctx->d_dense)); }
     ctx->d_dense = nullptr;
     ctx->dense_capacity = 0;
-    const uint64_t cap = may_hold + may_hold / 8;
+    ctx->dense_version = 0;
     VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_dense), cap * sizeof(VoxelRecord)));
     ctx->dense_capacity = cap;
   }
   const uint32_t nb = table_dense_blocks(ctx->slots);
   if (nb + 1 > ctx->dense_counts_capacity) {
-    if (ctx->d_dense_counts) VG_HIP(ctx, hipFree(ctx->d_dense_counts));
+    if (ctx->d_dense_counts) { VG_HIP(ctx, hipStreamSynchronize(ctx->stream)); VG_HIP(ctx, hipFree(ctx->d_dense_counts)); }
     ctx->d_dense_counts = nullptr;
     ctx->dense_counts_capacity = 0;
     VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_dense_counts), (size_t)(nb + 1) * sizeof(uint32_t)));
     ctx->dense_counts_capacity = nb + 1;
   }
+  return VGICP_OK;
+}
+// The align's part: rebuild the copy (three launches, no allocation) when the map changed since the last align.
+// *usable = false when there is no storage for it (the threshold was lowered after the table was made): the launch then
+// simply reads the table.
+int ensure_dense(vgicp_ctx* ctx, bool* usable) {
+  *usable = false;
+  const uint32_t nb = table_dense_blocks(ctx->slots);
+  if (!ctx->d_dense || ctx->dense_capacity < ctx->slots / 2 || nb + 1 > ctx->dense_counts_capacity) return VGICP_OK;
+  *usable = true;
+  if (ctx->dense_version == ctx->map_version) return VGICP_OK;
   VG_HIP(ctx, launch_table_dense(ctx->stream, ctx->table, ctx->slots, ctx->d_dense, ctx->dense_capacity, ctx->d_dense_counts));
   ctx->dense_version = ctx->map_version;
   return VGICP_OK;
@@ -402,13 +415,14 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.n_dev = ctx->scan_pending ? ctx->d_counters : nullptr;  // ... and the kept count is read from the device
   a.asym_dev = ctx->scan_sym_known ? ctx->d_ins_counters + 2 : nullptr;  // word 2 of that block: the symmetry verdict
   a.scan_seq = ctx->scan_seq;
-  if (std::getenv("VGICP_NO_SYM")) a.asym_dev = nullptr;  // developer A/B: always read all twelve planes
+  if (ctx->dev.no_sym) a.asym_dev = nullptr;  // developer A/B: always read all twelve planes
   a.mask = (uint32_t)(ctx->slots - 1);
   a.table = ctx->table;
   if (wants_dense(ctx, ctx->n)) {
-    const int rc_dense = ensure_dense(ctx);   // a no-op unless the map changed since the last align
+    bool usable = false;
+    const int rc_dense = ensure_dense(ctx, &usable);   // a no-op unless the map changed since the last align; never allocates
     if (rc_dense != VGICP_OK) return rc_dense;
-    a.dense = ctx->d_dense;
+    if (usable) a.dense = ctx->d_dense;
   }
   a.voxel_size = ctx->voxel_size;
   a.rows = ctx->d_rows_persist;
@@ -427,8 +441,8 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
   a.translation_sq_threshold = params->translation_sq_threshold;
   a.max_iteration = max_it;
   persistent_lds_plan(ctx->n, grid, &a.memo_points, &a.stash_points, &a.stash_bytes, ctx->persist_lds_budget);
-  if (std::getenv("VGICP_NO_STASH")) a.stash_points = a.stash_bytes = 0;
-  if (std::getenv("VGICP_NO_MEMO")) a.memo_points = 0;
+  if (ctx->dev.no_stash) a.stash_points = a.stash_bytes = 0;
+  if (ctx->dev.no_memo) a.memo_points = 0;
   a.prefetch_margin = (a.memo_points == 0 && a.stash_points == 0 && ctx->n <= grid * 448u) ? ctx->prefetch_margin : 0.0;
   a.stamps = ctx->d_stamps;
   const bool multi = ctx->peers_connected && ctx->peer_world > 1;
@@ -484,7 +498,7 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
     // loop for this align and the next few, then try the single launch again.
     ++ctx->persistent_fallbacks;
     if (ctx->owner && multi) {
-      if (std::getenv("VGICP_VERBOSE"))
+      if (ctx->dev.verbose)
         std::fprintf(stderr, "[vgicp] rank %d of %d: persistent launch did not commit (echo %s, outcome %u, a workgroup gave up: %s, "
                      "rounds reported %d, %u points)\n", ctx->peer_rank, ctx->peer_world, result->seq == a.seq ? "yes" : "no",
                      result->outcome, someone_gave_up ? "yes" : "no", result->iteration, ctx->n);
@@ -494,7 +508,7 @@ int run_align_persistent(vgicp_ctx* ctx, const double* guess, const vgicp_params
       return rc_reset != VGICP_OK ? rc_reset : vgicp_internal::kNeedGroupLoop;
     }
     ctx->persistent_cooldown = kPersistentCooldownAligns;
-    if (ctx->persistent_fallbacks == 1 || std::getenv("VGICP_VERBOSE"))
+    if (ctx->persistent_fallbacks == 1 || ctx->dev.verbose)
       std::fprintf(stderr, "[vgicp] persistent align launch gave up waiting for a workgroup%s (fallback #%llu): using one "
                    "launch per iteration for the next %d aligns\n", multi ? " or a peer GPU" : "",
                    (unsigned long long)ctx->persistent_fallbacks, kPersistentCooldownAligns);
@@ -715,6 +729,7 @@ int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgi
     return fail(nullptr, VGICP_ERR_NO_DEVICE,
                 std::string("device is ") + prop.gcnArchName + ", this module is built for gfx950 only");
   vgicp_ctx* ctx = new vgicp_ctx;
+  ctx->id = ++g_context_ids;
   ctx->device = device_id;
   ctx->cu_count = prop.multiProcessorCount;
   ctx->hbm_bytes = prop.totalGlobalMem;
@@ -770,6 +785,15 @@ int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgi
   if (const char* sl = std::getenv("VGICP_SPIN_LIMIT")) ctx->persist_spin_limit = (uint32_t)std::strtoul(sl, nullptr, 10);
   if (const char* ut = std::getenv("VGICP_UPLOAD_THREADS")) ctx->upload_threads = std::max(1, std::min(16, std::atoi(ut)));
   if (const char* ul = std::getenv("VGICP_UPLOAD_STAGE_LIMIT")) ctx->upload_stage_limit = (size_t)std::max(0ll, std::atoll(ul));
+  // developer / test switches: read here, once; no entry point looks at the environment again
+  ctx->dev.no_sym = std::getenv("VGICP_NO_SYM") != nullptr;       // A/B: always read all twelve planes
+  ctx->dev.no_stash = std::getenv("VGICP_NO_STASH") != nullptr;
+  ctx->dev.no_memo = std::getenv("VGICP_NO_MEMO") != nullptr;
+  ctx->dev.verbose = std::getenv("VGICP_VERBOSE") != nullptr;
+  ctx->dev.insert_sort = std::getenv("VGICP_INSERT_SORT") != nullptr;
+  if (const char* dp = std::getenv("VGICP_DEBUG_PREP")) ctx->dev.debug_prep = std::atoi(dp);
+  if (const char* ps = std::getenv("VGICP_PACK_SPIN_LIMIT")) ctx->dev.pack_spin_limit = (uint32_t)std::strtoul(ps, nullptr, 10);
+  if (const char* dd = std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US")) ctx->dev.debug_upload_delay_us = std::atol(dd);
   {
     // the in-kernel exchange needs every workgroup resident: one 512-thread workgroup with the LARGEST dynamic LDS
     // a launch plan asks for (memo + parked points of a scan bigger than the grid: 150 KB) must fit a CU — checked
@@ -814,12 +838,14 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   if (ctx->multi) return vgicp_multi_api::destroy(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  bool crew_lost = false;   // a copy thread that never came back may still write the staging memory: both are leaked then
   if (ctx->crew) {
+    crew_lost = ctx->crew->broken;
     ctx->crew->stop();
-    delete ctx->crew;
+    if (!crew_lost) delete ctx->crew;
     ctx->crew = nullptr;
   }
-  if (ctx->h_upload) (void)hipHostFree(ctx->h_upload);
+  if (ctx->h_upload && !crew_lost) (void)hipHostFree(ctx->h_upload);
   if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
   for (auto& s : ctx->ahead) {
     if (s.mem) (void)hipHostFree(s.mem);
@@ -883,7 +909,7 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipHostFree(ctx->h_ins_counters);
   for (int k = 0; k < 2; ++k) {
     if (ctx->h_state_table[k]) (void)hipHostFree(ctx->h_state_table[k]);
-    if (ctx->h_raw_stage[k]) (void)hipHostFree(ctx->h_raw_stage[k]);
+    if (ctx->h_raw_stage[k] && !crew_lost) (void)hipHostFree(ctx->h_raw_stage[k]);
     if (k == 0 && ctx->h_arena) (void)hipHostFree(ctx->h_arena);
     if (ctx->ev_state_table[k]) (void)hipEventDestroy(ctx->ev_state_table[k]);
   }
@@ -907,13 +933,13 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   for (auto& e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev_prof) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  if (g_stage_error_ctx == ctx) g_stage_error_ctx = nullptr;
+  if (g_stage_error_ctx == ctx->id) g_stage_error_ctx = 0;
   delete ctx;
   return VGICP_OK;
 }
 
 const char* vgicp_last_error(const vgicp_ctx* ctx) {
-  if (ctx && g_stage_error_ctx == ctx) return g_stage_error.c_str();   // this thread's last failure was a vgicp_sweep_stage*
+  if (ctx && g_stage_error_ctx == ctx->id) return g_stage_error.c_str();   // this thread's last failure was a vgicp_sweep_stage*
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
@@ -969,6 +995,8 @@ int vgicp_map_reset(vgicp_ctx* ctx, double voxel_size, size_t capacity_hint) {
   int rc = alloc_table(ctx, slots, &ctx->table);
   if (rc != VGICP_OK) return rc;
   ctx->slots = slots;
+  rc = reserve_dense(ctx);
+  if (rc != VGICP_OK) return rc;
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VGICP_OK;
 }
@@ -1088,7 +1116,7 @@ namespace {
 // most (map voxel / scan voxel + 1)^3 of them, and when that is a handful the insertion goes without its sort
 // (launch_map_insert, short_lists).  Any other resident scan (uploaded as it came) keeps the sort.
 bool insertion_lists_stay_short(const vgicp_ctx* ctx) {
-  if (!(ctx->prep_voxel > 0.0) || std::getenv("VGICP_INSERT_SORT")) return false;
+  if (!(ctx->prep_voxel > 0.0) || ctx->dev.insert_sort) return false;
   const double per_axis = std::ceil(ctx->voxel_size / ctx->prep_voxel) + 1.0;
   return per_axis * per_axis * per_axis <= 64.0;
 }
@@ -1285,6 +1313,22 @@ namespace {
 constexpr uint32_t kPackSpinLimit = 400000;   // polls of a staged unit's flag (>= 1 us each) before the pack kernel gives up
 constexpr double kCrewSlowSeconds = 0.1;      // copy threads slower than this: the packing is repeated behind the launch
 
+// CopyCrew::finish() ran into its deadline: a helper thread took a unit of the upload and never delivered it.  The kernel
+// that waits for that unit's flag gives up by itself (kPackSpinLimit); the scan is not resident; the context copies
+// alone from now on.  The one thing that cannot be taken back is that helper's pointer into the caller's buffer.
+int crew_gave_up(vgicp_ctx* ctx) {
+  ctx->scan_ready = false;
+  ctx->upload_threads = 1;
+  (void)hipStreamSynchronize(ctx->stream);
+  // that thread may still write the staging memory it was copying into: later uploads get memory of their own
+  ctx->h_upload = nullptr;
+  ctx->upload_cap = ctx->upload_flag_bytes = 0;
+  for (int k = 0; k < 2; ++k) { ctx->h_raw_stage[k] = nullptr; ctx->raw_stage_cap[k] = 0; }
+  return fail(ctx, VGICP_ERR_TIMEOUT,
+              "a copy thread of the scan upload did not deliver its unit within 10 s (dead or never scheduled): the scan is "
+              "not resident, this context stages alone from now on; that thread may still read the caller's buffer");
+}
+
 int ensure_upload_stage(vgicp_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->upload_cap) return VGICP_OK;
   if (ctx->upload_in_flight) { VG_HIP(ctx, hipEventSynchronize(ctx->ev_upload)); ctx->upload_in_flight = false; }
@@ -1354,15 +1398,16 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
     const uint32_t job = crew->post(want_helpers);
     // the launch first (it starts reading as soon as unit 0 is published), then this thread copies too
     // test aids: a pack kernel with little patience and a copy thread that is held up (the repeat below is then what counts)
-    static const uint32_t spin_limit = std::getenv("VGICP_PACK_SPIN_LIMIT") ? (uint32_t)std::strtoul(std::getenv("VGICP_PACK_SPIN_LIMIT"), nullptr, 10) : kPackSpinLimit;
-    static const long debug_delay_us = std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US") ? std::atol(std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US")) : 0;
+    const uint32_t spin_limit = ctx->dev.pack_spin_limit ? ctx->dev.pack_spin_limit : kPackSpinLimit;
+    const long debug_delay_us = ctx->dev.debug_upload_delay_us;
     const hipError_t e_launch = launch_pack_arena(ctx->stream, crew->apts, crew->acov, (uint32_t)n, crew->flags, ctx->scan_seq,
                                                   spin_limit, aos_pts, aos_cov, ctx->d_scan, ctx->stride,
                                                   ctx->d_ins_counters + 2);
     if (debug_delay_us > 0 && !want_helpers) std::this_thread::sleep_for(std::chrono::microseconds(debug_delay_us));
     crew->work(job);
-    crew->finish();   // always: the caller's buffers must not be in use on return
+    const bool crew_done = crew->finish();   // always: the caller's buffers must not be in use on return
     if (e_launch != hipSuccess) return fail_hip(ctx, e_launch, "launch_pack_arena");
+    if (!crew_done) return crew_gave_up(ctx);
     if (now_seconds() - t_post > kCrewSlowSeconds) {
       // the copy threads were held up for so long that a workgroup of the launch may have stopped waiting: everything
       // is staged now, pack it again behind the launch (no flags to wait for)
@@ -1658,7 +1703,7 @@ struct StagedPoints {
   double t_post = 0.0;
   CopyCrew* open_with = nullptr;    // the job is open: whoever leaves early has to finish it (the caller's buffer is read)
   ~StagedPoints() {
-    if (open_with) { open_with->work(job); open_with->finish(); }
+    if (open_with) { open_with->work(job); (void)open_with->finish(); }
   }
 };
 // The copy of a sweep's points into `stage`, opened to the crew: the helpers (if any are awake or worth waking) start at
@@ -1693,7 +1738,7 @@ int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, 
   const uint64_t entries = preprocess_cell_entries_for((uint32_t)n);
   int rc = ensure_cells(ctx, preprocess_cell_bytes(entries));
   if (rc != VGICP_OK) return rc;
-  const int debug = std::getenv("VGICP_DEBUG_PREP") ? std::atoi(std::getenv("VGICP_DEBUG_PREP")) : 0;
+  const int debug = ctx->dev.debug_prep;
   if (debug) VG_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 72 * sizeof(uint32_t), ctx->stream));
   if (++ctx->prep_epoch == 0) ++ctx->prep_epoch;
   PrepareArgs a;
@@ -1739,8 +1784,8 @@ int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, 
   } else {
     // the sweep's points go up without a copy command: the copy threads fill the staging memory unit by unit, the
     // prologue (launched FIRST) reads the units over PCIe as they are published (see scan_upload_enqueue)
-    static const uint32_t spin_limit = std::getenv("VGICP_PACK_SPIN_LIMIT") ? (uint32_t)std::strtoul(std::getenv("VGICP_PACK_SPIN_LIMIT"), nullptr, 10) : kPackSpinLimit;
-    static const long debug_delay_us = std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US") ? std::atol(std::getenv("VGICP_DEBUG_UPLOAD_DELAY_US")) : 0;
+    const uint32_t spin_limit = ctx->dev.pack_spin_limit ? ctx->dev.pack_spin_limit : kPackSpinLimit;
+    const long debug_delay_us = ctx->dev.debug_upload_delay_us;
     CopyCrew* crew = ctx->crew;
     const bool want_helpers = staged->helpers;
     const uint32_t job = staged->job;
@@ -1753,9 +1798,10 @@ int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, 
     const hipError_t e_head = launch_prepare_head(ctx->stream, a);
     if (debug_delay_us > 0 && !want_helpers) std::this_thread::sleep_for(std::chrono::microseconds(debug_delay_us));
     crew->work(job);
-    crew->finish();   // always: the caller's buffer is free again on return
+    const bool crew_done = crew->finish();   // always: the caller's buffer is free again on return
     staged->open_with = nullptr;
     if (e_head != hipSuccess) return fail_hip(ctx, e_head, "launch_prepare_head");
+    if (!crew_done) return crew_gave_up(ctx);
     if (now_seconds() - t_post > kCrewSlowSeconds) {
       // the copy threads were held up so long that a workgroup of the prologue may have stopped waiting (and said so in
       // the counter block under this epoch): everything is staged now — the head once more, nothing to wait for
@@ -1787,8 +1833,8 @@ int resolve_prepare(vgicp_ctx* ctx, uint32_t* kept) {
   *kept = h[0];
   ctx->prep_indefinite = h[kIndefiniteCounter];
   ctx->prep_deskewed = (int64_t)h[kDeskewedCounter];
-  if (std::getenv("VGICP_DEBUG_PREP")) {
-    const int debug = std::atoi(std::getenv("VGICP_DEBUG_PREP"));
+  if (ctx->dev.debug_prep) {
+    const int debug = ctx->dev.debug_prep;
     if (debug >= 2) {
       std::fprintf(stderr, "[vgicp prep] queries by cells taken (buckets of 8):");
       for (int i = 0; i < 32; ++i) std::fprintf(stderr, " %u", h[8 + i]);
@@ -2271,13 +2317,22 @@ int stage_sweep_ahead(vgicp_ctx* ctx, size_t n, const void* data, const double* 
   {
     std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
     for (auto& s : ctx->ahead)
-      if (s.state == 0) { slot = &s; break; }
-    if (!slot)
-      for (auto& s : ctx->ahead)   // handed to the device two preparations ago: its readers have long finished
-        if (s.state == 2 && (!s.done || hipEventQuery(s.done) == hipSuccess)) { slot = &s; break; }
-    if (!slot) return fail_stage(ctx, VGICP_ERR_NOT_READY, "three sweeps are staged ahead already: prepare one first");
-    slot->state = 3;
+      if (s.state == 0) { slot = &s; slot->state = 3; break; }
   }
+  for (int k = 0; k < 3 && !slot; ++k) {
+    // handed to the device two preparations ago: its readers have long finished.  The event is asked OUTSIDE the mutex
+    // (the slot is reserved meanwhile), so the owner thread never waits for a runtime call made by this one.
+    vgicp_ctx::AheadSlot* cand = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
+      if (ctx->ahead[k].state == 2) { cand = &ctx->ahead[k]; cand->state = 3; }
+    }
+    if (!cand) continue;
+    if (!cand->done || hipEventQuery(cand->done) == hipSuccess) { slot = cand; break; }
+    std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
+    cand->state = 2;
+  }
+  if (!slot) return fail_stage(ctx, VGICP_ERR_NOT_READY, "three sweeps are staged ahead already: prepare one (or vgicp_sweep_unstage it) first");
   const size_t rec = step ? step : 3 * sizeof(double);
   const size_t pts_room = (n * rec + 16 + 255) & ~size_t(255);
   const bool has_times = step ? off_time != SIZE_MAX : times != nullptr;
@@ -2320,7 +2375,7 @@ int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const doub
   *ticket = 0;
   if (ctx->multi) {
     const int rc = vgicp_sweep_stage(vgicp_multi_api::first(ctx), n, points, point_time, ticket);
-    if (rc != VGICP_OK) g_stage_error_ctx = ctx;
+    if (rc != VGICP_OK) g_stage_error_ctx = ctx->id;
     return rc;
   }
   if (n == 0 || !points) return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
@@ -2335,7 +2390,7 @@ int vgicp_sweep_stage_cloud2(vgicp_ctx* ctx, size_t n, const void* data, size_t 
   *ticket = 0;
   if (ctx->multi) {
     const int rc = vgicp_sweep_stage_cloud2(vgicp_multi_api::first(ctx), n, data, point_step, off_x, off_y, off_z, off_time, ticket);
-    if (rc != VGICP_OK) g_stage_error_ctx = ctx;
+    if (rc != VGICP_OK) g_stage_error_ctx = ctx->id;
     return rc;
   }
   if (n == 0 || !data) return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "empty sweep");
@@ -2347,6 +2402,23 @@ int vgicp_sweep_stage_cloud2(vgicp_ctx* ctx, size_t n, const void* data, size_t 
   if (off_time != SIZE_MAX && off_time + 8 > point_step) return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "the float64 capture time must lie inside the record");
   const uint32_t off[3] = {(uint32_t)off_x, (uint32_t)off_y, (uint32_t)off_z};
   return stage_sweep_ahead(ctx, n, data, nullptr, (uint32_t)point_step, off, off_time, ticket);
+}
+
+int vgicp_sweep_unstage(vgicp_ctx* ctx, uint64_t ticket) {
+  if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi) {
+    const int rc = vgicp_sweep_unstage(vgicp_multi_api::first(ctx), ticket);
+    if (rc != VGICP_OK) g_stage_error_ctx = ctx->id;
+    return rc;
+  }
+  std::lock_guard<std::mutex> lk(ctx->ahead_mutex);
+  for (auto& s : ctx->ahead)
+    if (ticket != 0 && s.state == 1 && s.ticket == ticket) {
+      s.state = 0;   // staged, never handed to the device: nothing reads it
+      s.ticket = 0;
+      return VGICP_OK;
+    }
+  return fail_stage(ctx, VGICP_ERR_BAD_ARGUMENT, "no sweep staged under this ticket (used, dropped already, or never given out)");
 }
 
 int vgicp_scan_prepare_staged_async(vgicp_ctx* ctx, uint64_t ticket, size_t num_states, const double* states,
@@ -2585,7 +2657,7 @@ int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128)
       }
       (void)hipFree(d_all);
     }
-    if (!ctx->peers_connected && std::getenv("VGICP_VERBOSE"))
+    if (!ctx->peers_connected && ctx->dev.verbose)
       std::fprintf(stderr, "[vgicp] rank %d: no device-initiated exchange (%s); using RCCL all-reduce per iteration\n", rank,
                    why.c_str());
     ctx->peer_status = ctx->peers_connected ? std::string() : ("mailboxes not wired: " + (why.empty() ? std::string("unknown reason") : why));
@@ -2599,7 +2671,7 @@ int vgicp_comm_init(vgicp_ctx* ctx, int world_size, int rank, const void* id128)
 
 const char* vgicp_peer_status(const vgicp_ctx* ctx) {
   if (!ctx) return "no context";
-  if (ctx->multi) return ctx->peer_status.c_str();
+  if (ctx->multi) return vgicp_multi_api::peer_status(ctx);
   if (ctx->peers_connected && !ctx->peer_enabled) return "mailboxes wired, but a launch gave up waiting for a peer: one launch + one RCCL all-reduce per iteration since";
   return ctx->peer_status.c_str();
 }
@@ -2633,7 +2705,7 @@ namespace vgicp_internal {
 int settle_context(vgicp_ctx* ctx) { return settle(ctx); }
 
 bool insertion_lists_stay_short_for(const vgicp_ctx* ctx, double prep_voxel) {
-  if (!(prep_voxel > 0.0) || std::getenv("VGICP_INSERT_SORT")) return false;
+  if (!(prep_voxel > 0.0) || ctx->dev.insert_sort) return false;
   const double per_axis = std::ceil(ctx->voxel_size / prep_voxel) + 1.0;
   return per_axis * per_axis * per_axis <= 64.0;
 }
@@ -2643,7 +2715,7 @@ bool insertion_lists_stay_short_for(const vgicp_ctx* ctx, double prep_voxel) {
 // neighbour's persistent kernel is already running and waiting for this sub-context's), so the multi-device context
 // grows every sub-context's buffers in a phase of its own before anybody launches.
 bool align_needs_allocation(const vgicp_ctx* ctx, size_t n, int max_it) {
-  if (wants_dense(ctx, (uint32_t)n) && (ctx->dense_version != ctx->map_version || !ctx->d_dense)) return true;
+  // (the dense copy's storage is made when the table is: reserve_dense; an align only rebuilds its contents)
   return !ctx->d_scan || n > ctx->scan_capacity || max_it > ctx->log_capacity || ctx->log_capacity == 0;
 }
 int reserve_for_align(vgicp_ctx* ctx, size_t n, int max_it) {
@@ -2656,11 +2728,6 @@ int reserve_for_align(vgicp_ctx* ctx, size_t n, int max_it) {
     if (rc != VGICP_OK) return rc;
     ctx->scan_ready = false;   // whatever was resident went with the old buffers
     ctx->n = 0;
-  }
-  if (wants_dense(ctx, (uint32_t)n)) {
-    rc = ensure_dense(ctx);
-    if (rc != VGICP_OK) return rc;
-    VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   return ensure_log(ctx, std::max(max_it, 1));
 }

@@ -57,7 +57,10 @@ extern thread_local std::string g_create_error;
 // what vgicp_sweep_stage* report: those may run on another thread than the context's owner (who writes ctx->err), so
 // their text lives with the calling thread; vgicp_last_error(ctx) returns it to that thread until it fails elsewhere
 extern thread_local std::string g_stage_error;
-extern thread_local const vgicp_ctx* g_stage_error_ctx;
+// ... identified by the context's creation number, not by its address: a context destroyed on one thread and another
+// allocated at the same address must not inherit a stale text that a third thread still keeps
+extern thread_local uint64_t g_stage_error_ctx;
+extern std::atomic<uint64_t> g_context_ids;
 
 inline double now_seconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -93,13 +96,19 @@ struct CopyCrew {
   std::mutex m;
   std::condition_variable cv;
   std::atomic<uint32_t> gen{0};        // the job the helpers were last woken for
-  std::atomic<uint64_t> next{0};       // job number << 32 | next unit to take: a thread that comes late to a job that is
-                                       // over finds another job's number here and leaves without touching anything
-                                       // (work() takes units by compare-and-swap for that reason)
-  std::atomic<uint32_t> finished{0};
+  // job number << 32 | next unit to take.  A job is OPEN from post() to finish(): finish() closes it (unit word ~0)
+  // BEFORE the caller may write a field of the next job, so a thread that comes late to a job that is over can never
+  // take a unit with the next job's fields half written (round 5's advisor reproduced exactly that with a unit count
+  // that varies from job to job: its bounds check read the NEXT job's larger count, its compare-and-swap on the OLD
+  // job's exhausted ticket succeeded).  A unit is taken by compare-and-swap, so a closed ticket is left alone.
+  std::atomic<uint64_t> next{0};
+  // job number << 32 | units of that job completed: a completion that lands after its job was given up (deadline) finds
+  // another job's number here and is dropped instead of being counted for the job that follows
+  std::atomic<uint64_t> finished{0};
   uint32_t job = 0;                    // jobs posted so far (the caller's thread only)
   bool quit = false;
-  // the job (written before `next` is set, read only after a unit of THIS job was taken from it)
+  bool broken = false;                 // a helper missed finish()'s deadline: no helper is woken again (caller's thread only)
+  // the job (written while no job is open, read only after a unit of THIS job was taken)
   const char* pts = nullptr;
   const char* cov = nullptr;
   char* apts = nullptr;
@@ -109,24 +118,33 @@ struct CopyCrew {
   std::atomic<uint32_t> units{0};      // read BEFORE a unit is taken (by a thread that may have come late to an older job): atomic
   uint32_t size_a = 24, size_b = 72;   // bytes per point of the two arrays (size_b = 0: one array only)
   void (*copy)(void*, const void*, size_t) = nullptr;
+  static constexpr uint32_t kClosed = 0xFFFFFFFFu;
 
   void work(uint32_t my_job) {
     for (;;) {
-      // a unit is taken by compare-and-swap, never by a blind increment: a thread that comes late to a job that is over
-      // must leave the NEXT job's counter alone (an increment would take one of its units away from everybody:
-      // finish() would wait for it for ever — seen once per ~200 000 uploads as a soak that never returned)
       uint64_t v = next.load(std::memory_order_acquire);
       for (;;) {
+        // closed (~0) or exhausted or another job's ticket: nothing to take.  The count may belong to a LATER job only
+        // when this ticket is closed already, and then the compare-and-swap below cannot succeed.
         if ((uint32_t)(v >> 32) != my_job || (uint32_t)v >= units.load(std::memory_order_relaxed)) return;
         if (next.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire)) break;
       }
       const uint32_t u = (uint32_t)v;
+      // the job was open when the unit was taken and stays open until the unit is delivered — unless finish() gives
+      // up on this thread: everything it touches from here on is what the job was THEN, never a later job's fields
+      const char *j_pts = pts, *j_cov = cov;
+      char *j_apts = apts, *j_acov = acov;
+      uint32_t* j_flags = flags;
+      const uint32_t j_seq = seq, j_size_a = size_a, j_size_b = size_b;
       const size_t p0 = (size_t)u * unit, cnt = std::min<size_t>(unit, n - p0);
-      copy(apts + p0 * size_a, pts + p0 * size_a, cnt * size_a);
-      if (size_b) copy(acov + p0 * size_b, cov + p0 * size_b, cnt * size_b);
+      void (*j_copy)(void*, const void*, size_t) = copy;
+      j_copy(j_apts + p0 * j_size_a, j_pts + p0 * j_size_a, cnt * j_size_a);
+      if (j_size_b) j_copy(j_acov + p0 * j_size_b, j_cov + p0 * j_size_b, cnt * j_size_b);
       // the unit's bytes (streaming stores, fenced by `copy`) are globally visible before its flag
-      __atomic_store_n(flags + 16 * (size_t)u, seq, __ATOMIC_RELEASE);
-      finished.fetch_add(1, std::memory_order_release);
+      __atomic_store_n(j_flags + 16 * (size_t)u, j_seq, __ATOMIC_RELEASE);
+      uint64_t f = finished.load(std::memory_order_relaxed);
+      while ((uint32_t)(f >> 32) == my_job &&
+             !finished.compare_exchange_weak(f, f + 1, std::memory_order_release, std::memory_order_relaxed)) {}
     }
   }
   void run() {
@@ -156,9 +174,9 @@ struct CopyCrew {
   // (work(job)) and waits for the units others took (finish())
   uint32_t post(bool wake_helpers) {
     if (++job == 0) ++job;
-    finished.store(0, std::memory_order_relaxed);
+    finished.store((uint64_t)job << 32, std::memory_order_relaxed);
     next.store((uint64_t)job << 32, std::memory_order_release);
-    if (wake_helpers && !th.empty()) {
+    if (wake_helpers && !broken && !th.empty()) {
       {
         std::lock_guard<std::mutex> lk(m);
         gen.store(job, std::memory_order_release);
@@ -167,14 +185,29 @@ struct CopyCrew {
     }
     return job;
   }
-  // Wait for the units other threads took.  A helper that was woken for this job may sit on THIS thread's CPU (a
-  // wake-up lands on the waker's CPU) with a unit half copied: spinning here would keep it off the CPU for a whole
-  // scheduler slice (3 ms steps were measured); after a short spin the CPU is offered to whoever else wants it.
-  void finish() const {
-    for (uint32_t spins = 0; finished.load(std::memory_order_acquire) < units.load(std::memory_order_relaxed); ++spins) {
-      if (spins < 512) __builtin_ia32_pause();
-      else sched_yield();
+  // Wait for the units other threads took, then CLOSE the job.  A helper that was woken for this job may sit on THIS
+  // thread's CPU (a wake-up lands on the waker's CPU) with a unit half copied: spinning here would keep it off the CPU
+  // for a whole scheduler slice (3 ms steps were measured); after a short spin the CPU is offered to whoever else wants
+  // it.  Bounded: a helper that has not delivered its unit `deadline_seconds` after the caller ran out of work (it died,
+  // or the machine is not scheduling it) makes this return false — the job is closed, the crew never wakes a helper
+  // again (`broken`), and the caller reports the failure; the late helper's completion is dropped by its job number.
+  // (What cannot be taken back is the helper's pointer into the caller's buffer: the entry point says so in its error.)
+  bool finish(double deadline_seconds = 10.0) {
+    const uint32_t want = units.load(std::memory_order_relaxed);
+    bool ok = true;
+    double t0 = 0.0;
+    for (uint32_t spins = 0; (uint32_t)finished.load(std::memory_order_acquire) < want; ++spins) {
+      if (spins < 512) { __builtin_ia32_pause(); continue; }
+      sched_yield();
+      if ((spins & 255u) == 0) {
+        const double t = now_seconds();
+        if (t0 == 0.0) t0 = t;
+        else if (t - t0 > deadline_seconds) { ok = false; broken = true; break; }
+      }
     }
+    next.store(((uint64_t)job << 32) | kClosed, std::memory_order_release);
+    if (!ok) finished.store(0, std::memory_order_relaxed);   // job 0 is never posted: late completions go nowhere
+    return ok;
   }
   void stop() {
     {
@@ -183,7 +216,10 @@ struct CopyCrew {
     }
     cv.notify_all();
     for (auto& t : th)
-      if (t.joinable()) t.join();
+      if (t.joinable()) {
+        if (broken) t.detach();   // one of them never came back: nobody may wait for it (the owner leaks this object)
+        else t.join();
+      }
     th.clear();
   }
 };
@@ -191,6 +227,7 @@ struct CopyCrew {
 struct vgicp_multi;  // vgicp_multi.hip: the sub-contexts of an in-process multi-device context
 
 struct vgicp_ctx {
+  uint64_t id = 0;                // creation number (never 0, never reused)
   int device = -1;
   vgicp_multi* multi = nullptr;   // this handle IS a multi-device context: every entry point forwards to vgicp_multi.hip
   vgicp_multi* owner = nullptr;   // this context is one of a multi-device context's sub-contexts (rank = peer_rank)
@@ -254,6 +291,13 @@ struct vgicp_ctx {
   uint64_t upload_bytes = 0;
   double upload_seconds = 0.0;
   uint64_t prep_indefinite = 0;      // kept points of the last scan preparation with an indefinite covariance
+  // developer / test switches of the environment, read ONCE when the context is created (never inside a call)
+  struct DevSwitches {
+    bool no_sym = false, no_stash = false, no_memo = false, verbose = false, insert_sort = false;
+    int debug_prep = 0;
+    uint32_t pack_spin_limit = 0;     // 0 = the module's default
+    long debug_upload_delay_us = 0;
+  } dev;
   CopyCrew* crew = nullptr;          // the upload's copy threads, created with the first upload that wants a helper
   int upload_threads = 2;            // threads that copy a scan into the staging memory, the caller's included (VGICP_UPLOAD_THREADS)
   char* h_upload = nullptr;          // page-locked staging memory of the scan upload: [unit flags][points][covariances]
@@ -361,7 +405,7 @@ namespace vgicp {
 inline int fail(const vgicp_ctx* ctx, int code, const std::string& text) {
   if (ctx) {
     ctx->err = text;
-    if (g_stage_error_ctx == ctx) g_stage_error_ctx = nullptr;
+    if (g_stage_error_ctx == ctx->id) g_stage_error_ctx = 0;
   } else {
     g_create_error = text;
   }
@@ -369,7 +413,7 @@ inline int fail(const vgicp_ctx* ctx, int code, const std::string& text) {
 }
 inline int fail_stage(const vgicp_ctx* ctx, int code, const std::string& text) {
   g_stage_error = text;
-  g_stage_error_ctx = ctx;
+  g_stage_error_ctx = ctx ? ctx->id : 0;
   return code;
 }
 inline int fail_hip(const vgicp_ctx* ctx, hipError_t e, const char* what) {
@@ -442,5 +486,6 @@ int scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double* covs,
 int get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset);
 int set_option(vgicp_ctx* ctx, int option, int value);
 vgicp_ctx* first(const vgicp_ctx* ctx);  // sub-context 0: the hooks that work on one device
+const char* peer_status(const vgicp_ctx* ctx);
 void scan_replaced(vgicp_ctx* ctx);
 }  // namespace vgicp_multi_api

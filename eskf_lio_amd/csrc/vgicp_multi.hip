@@ -102,6 +102,9 @@ struct vgicp_multi {
   bool mailboxes = false;         // the device-initiated exchange is wired
   int cooldown = 0;               // aligns left on the host-summed loop after an in-kernel wait gave up
   uint64_t launches = 0, fallbacks = 0;
+  bool verbose = false;           // VGICP_VERBOSE, read when the context is created
+  mutable std::string status_text;   // vgicp_peer_status: composed when asked for
+  std::string last_fallback;      // why the last align that left the mailboxes did
   // the resident scan
   Resident resident = Resident::None;
   size_t n_total = 0;
@@ -206,7 +209,8 @@ void note_fallback(vgicp_ctx* parent, const char* why) {
   vgicp_multi* g = parent->multi;
   ++g->fallbacks;
   g->cooldown = kGroupCooldownAligns;
-  if (g->fallbacks == 1 || std::getenv("VGICP_VERBOSE"))
+  g->last_fallback = why;
+  if (g->fallbacks == 1 || g->verbose)
     std::fprintf(stderr, "[vgicp] multi-device align: %s (fallback #%llu): this align and the next %d run one launch per round with "
                  "the devices' rows added on the host\n", why, (unsigned long long)g->fallbacks, kGroupCooldownAligns);
 }
@@ -307,7 +311,10 @@ int align_shards(vgicp_ctx* parent, const double* points, const double* covs, co
     // thread returned): re-arm all mailboxes from scratch and run this align with the rows added on the host.
     note_fallback(parent, "an in-kernel wait for another device (or for a workgroup) gave up");
     const int rc = vgicp_internal::wire_mailboxes(g->subs.data(), g->n);
-    if (rc != VGICP_OK) g->mailboxes = false;
+    if (rc != VGICP_OK) {
+      g->mailboxes = false;
+      parent->peer_status = "mailboxes could not be re-armed after a launch gave up: " + g->subs[0]->err + " (the devices' rows are added on the host)";
+    }
   } else if (points) {
     const int rc = upload_shards(parent, points, covs);
     if (rc != VGICP_OK) return rc;
@@ -377,11 +384,12 @@ extern "C" int vgicp_create_multi(const int* device_ids, int n_devices, vgicp_ct
     if (hipSetDevice(dev) != hipSuccess || hipEventCreateWithFlags(&g->ev_gather[(size_t)r], hipEventDisableTiming) != hipSuccess)
       return bail(VGICP_ERR_HIP, "hipEventCreate failed");
   }
+  g->verbose = std::getenv("VGICP_VERBOSE") != nullptr;
   const char* how = std::getenv("VGICP_MULTI_EXCHANGE");   // "host": never use the mailboxes (developer / test aid)
   if (!(how && how[0] == 'h')) {
     const int rc = vgicp_internal::wire_mailboxes(g->subs.data(), n_devices);
     g->mailboxes = rc == VGICP_OK;
-    if (!g->mailboxes && std::getenv("VGICP_VERBOSE"))
+    if (!g->mailboxes && g->verbose)
       std::fprintf(stderr, "[vgicp] multi-device context: no device-initiated exchange (%s); the devices' rows are added on the host\n",
                    g->subs[0]->err.c_str());
     if (!g->mailboxes) {
@@ -412,6 +420,25 @@ extern "C" int vgicp_create_multi(const int* device_ids, int n_devices, vgicp_ct
 namespace vgicp_multi_api {
 
 vgicp_ctx* first(const vgicp_ctx* ctx) { return ctx->multi->subs[0]; }
+
+// What carries the per-round merge of the NEXT align, derived from the same three facts align_shards decides by: "" only
+// while the kernels' own mailboxes do.
+const char* peer_status(const vgicp_ctx* ctx) {
+  const vgicp_multi* g = ctx->multi;
+  if (!g->mailboxes) return ctx->peer_status.c_str();
+  for (int r = 0; r < g->n; ++r)
+    if (!g->subs[(size_t)r]->persistent_enabled) {
+      g->status_text = "mailboxes wired, but device rank " + std::to_string(r) + " cannot run the single persistent launch "
+                       "(VGICP_PERSISTENT=0 or its workgroup does not fit a compute unit): one launch per round, the devices' rows added on the host";
+      return g->status_text.c_str();
+    }
+  if (g->cooldown > 0) {
+    g->status_text = "mailboxes wired, but " + g->last_fallback + " (fallback #" + std::to_string(g->fallbacks) + "): the next " +
+                     std::to_string(g->cooldown) + " aligns run one launch per round with the devices' rows added on the host";
+    return g->status_text.c_str();
+  }
+  return "";
+}
 
 void scan_replaced(vgicp_ctx* ctx) {   // a hook put its own scan on device 0: nothing is resident as far as the caller goes
   ++ctx->multi->scan_generation;

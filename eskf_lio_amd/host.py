@@ -51,7 +51,7 @@ def load_library() -> C.CDLL:
     lib.host_icp_align.argtypes = [vp, sz, dp, dp, vp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_uint64), sz]
     lib.host_preprocessor_create.restype = vp
-    lib.host_preprocessor_create.argtypes = [C.c_double, dp, C.c_int]
+    lib.host_preprocessor_create.argtypes = [C.c_double, dp, C.c_int, C.c_int]
     lib.host_frame_begin.restype = vp
     lib.host_frame_begin.argtypes = [sz, dp, dp, sz, dp]
     lib.host_frame_run.argtypes = [vp, vp, vp, vp, dp, C.c_int, C.c_int, vp, C.c_int]
@@ -194,13 +194,15 @@ class CloudPreprocessor:
     """ESKF_LIO::CloudPreprocessor's scan-preparation half (include/eskf_lio_shim/CloudPreprocessor.hpp;
     reference include/ESKF_LIO/CloudPreprocessor.hpp:35-36, src/CloudPreprocessor.cpp:76-127)."""
 
-    def __init__(self, voxel_size: float, T_il=None, host_copy: Optional[str] = None):
+    def __init__(self, voxel_size: float, T_il=None, host_copy: Optional[str] = None, resident_check: str = "full"):
         """host_copy: "eager" (process() leaves the prepared scan in the host cloud, as the reference does),
-        "deferred" (it stays on the device until somebody materialises it), None = the shim's default."""
+        "deferred" (it stays on the device until somebody materialises it), None = the shim's default.
+        resident_check: "full" (default: every byte of the host cloud is hashed before the resident scan is trusted) or
+        "sampled" (CloudPreprocessorConfig::residentCheck = Sampled)."""
         self._lib = load_library()
         t = capi.pose_to_abi(np.eye(4) if T_il is None else T_il)
         mode = {None: -1, "eager": 0, "deferred": 1}[host_copy]
-        self._h = self._lib.host_preprocessor_create(float(voxel_size), _dp(t), mode)
+        self._h = self._lib.host_preprocessor_create(float(voxel_size), _dp(t), mode, 1 if resident_check == "sampled" else 0)
         if not self._h:
             raise RuntimeError(self._lib.host_last_error().decode())
 

@@ -187,8 +187,9 @@ int host_icp_align(
 }
 
 // CloudPreprocessor(config) — cloud_preprocessor.voxel_size, sensors.lidar.extrinsics as a 4x4;
-// host_copy: 0 = eager (the host cloud holds the prepared scan after process()), 1 = deferred, -1 = the default
-CloudPreprocessor * host_preprocessor_create(double voxel_size, const double T_il[16], int host_copy)
+// host_copy: 0 = eager (the host cloud holds the prepared scan after process()), 1 = deferred, -1 = the default;
+// sampled_check != 0: CloudPreprocessorConfig::residentCheck = Sampled (the default hashes every byte)
+CloudPreprocessor * host_preprocessor_create(double voxel_size, const double T_il[16], int host_copy, int sampled_check)
 {
   CloudPreprocessor * out = nullptr;
   guarded(
@@ -198,6 +199,7 @@ CloudPreprocessor * host_preprocessor_create(double voxel_size, const double T_i
       if (T_il) {std::memcpy(c.T_il, T_il, sizeof c.T_il);}
       if (host_copy == 0) {c.hostCopy = ESKF_LIO::CloudPreprocessorConfig::HostCopy::Eager;}
       if (host_copy == 1) {c.hostCopy = ESKF_LIO::CloudPreprocessorConfig::HostCopy::Deferred;}
+      if (sampled_check) {c.residentCheck = ESKF_LIO::shim::ResidentCheck::Sampled;}
       out = new CloudPreprocessor(c);
     });
   return out;
@@ -245,7 +247,9 @@ int host_frame_stage(HostFrame * f, const CloudPreprocessor * p)
 }
 
 // mutate: 0 = the frame as the reference runs it; 1 = the caller edits the prepared cloud between process() and
-// align() (its FIRST point moves by 1 mm: a sampled element, so the stamp must notice); 2 = the caller resizes it.
+// align() (its FIRST point moves by 1 mm: an element even the sampled check looks at); 2 = the caller resizes it;
+// 3 = the caller edits an element the SAMPLED check never looks at (point 1 of thousands: the default check, which
+// hashes every byte, must notice; ResidentCheck::Sampled does not — the documented price of that mode).
 // first_frame: process({}, meas) + updateLocalMap(cloud, guess) without align (src/Odometry.cpp:60-61).
 // stage_next: a later frame whose sweep "arrives" while this one is being processed: staged (CloudPreprocessor::stage)
 // right after this frame's process(), where a lidar callback's thread would be copying beside the device's work.
@@ -266,6 +270,7 @@ int host_frame_run(
       if (stage_next) {p->stage(stage_next->meas);}
       if (mutate) {ESKF_LIO::shim::materialize(map->context(), *f->meas->cloud);}   // an editor needs the data first
       if (mutate == 1 && !f->meas->cloud->points_.empty()) {f->meas->cloud->points_[0](0) += 1e-3;}
+      if (mutate == 3 && f->meas->cloud->points_.size() > 200) {f->meas->cloud->points_[1](0) += 1e-3;}
       if (mutate == 2 && f->meas->cloud->points_.size() > 1) {
         f->meas->cloud->points_.pop_back();
         f->meas->cloud->covariances_.pop_back();

@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <deque>
+#include <memory>
 #include <string>
 #include <mutex>
 #include <vector>
@@ -53,6 +54,11 @@ struct CloudPreprocessorConfig
   // YAML file) selects Deferred without touching the caller.
   enum class HostCopy {Eager, Deferred};
   HostCopy hostCopy = defaultHostCopy();
+  // how ICP::align / LocalMap::updateLocalMap later recognise "this host cloud is still the scan process() left on the
+  // device" (LocalMap.hpp, shim::ResidentCheck): FullHash (default) sees an in-place edit of ANY element and falls back
+  // to uploading the cloud, as the reference reads the host cloud every time; Sampled (~0.1 ms per frame cheaper) sees
+  // resizes, reallocations and edits of 64 sampled elements only
+  shim::ResidentCheck residentCheck = shim::ResidentCheck::FullHash;
   static HostCopy defaultHostCopy()
   {
     const char * env = std::getenv("VGICP_HOST_COPY");
@@ -70,11 +76,23 @@ namespace shim
 struct StagedSweep
 {
   vgicp_ctx * ctx;
-  const void * meas;
-  const void * pointData;
+  std::weak_ptr<const void> meas;   // the measurement object, watched: an entry whose measurement has died is dropped
+  const void * pointData;           // (and its slot in the module released) instead of meeting a new one at its address
   size_t n;
   uint64_t ticket;
 };
+// under stagedSweepsMutex(): forget the sweeps whose measurement no longer exists (dropped unprocessed by the caller)
+inline void dropDeadSweeps(std::vector<StagedSweep> & staged)
+{
+  for (size_t i = 0; i < staged.size(); ) {
+    if (staged[i].meas.expired()) {
+      (void)vgicp_sweep_unstage(staged[i].ctx, staged[i].ticket);
+      staged.erase(staged.begin() + static_cast<std::ptrdiff_t>(i));
+    } else {
+      ++i;
+    }
+  }
+}
 inline std::mutex & stagedSweepsMutex()
 {
   static std::mutex m;
@@ -92,7 +110,7 @@ class CloudPreprocessor
 public:
   explicit CloudPreprocessor(const CloudPreprocessorConfig & config, vgicp_ctx * ctx = nullptr)
   : voxelSize_(config.voxelSize), knn_(config.knn), T_il_(shim::poseFromData(config.T_il)),
-    hostCopy_(config.hostCopy), ctx_(ctx ? ctx : shim::defaultContext())
+    hostCopy_(config.hostCopy), residentCheck_(config.residentCheck), ctx_(ctx ? ctx : shim::defaultContext())
   {
   }
 
@@ -112,6 +130,10 @@ public:
       hostCopy_ = (mode == "deferred") ? CloudPreprocessorConfig::HostCopy::Deferred :
         CloudPreprocessorConfig::HostCopy::Eager;
     }
+    if (config["cloud_preprocessor"]["resident_check"].IsDefined()) {   // optional key, not in the reference's file
+      residentCheck_ = config["cloud_preprocessor"]["resident_check"].as<std::string>() == "sampled" ?
+        shim::ResidentCheck::Sampled : shim::ResidentCheck::FullHash;
+    }
   }
 #endif
 
@@ -127,11 +149,15 @@ public:
     const size_t n = cloud.points_.size();
     if (n == 0 || lidarMeas->pointTime.size() != n) {return false;}
     uint64_t ticket = 0;
+    {
+      std::lock_guard<std::mutex> lk(shim::stagedSweepsMutex());
+      shim::dropDeadSweeps(shim::stagedSweeps());   // measurements the caller discarded give their slots back first
+    }
     const int rc = vgicp_sweep_stage(
       ctx_, n, reinterpret_cast<const double *>(cloud.points_.data()), lidarMeas->pointTime.data(), &ticket);
     if (rc != VGICP_OK) {return false;}
     std::lock_guard<std::mutex> lk(shim::stagedSweepsMutex());
-    shim::stagedSweeps().push_back({ctx_, lidarMeas.get(), cloud.points_.data(), n, ticket});
+    shim::stagedSweeps().push_back({ctx_, std::weak_ptr<const void>(lidarMeas), cloud.points_.data(), n, ticket});
     return true;
   }
 
@@ -155,9 +181,14 @@ public:
     {
       std::lock_guard<std::mutex> lk(shim::stagedSweepsMutex());
       auto & staged = shim::stagedSweeps();
+      shim::dropDeadSweeps(staged);
       for (size_t i = 0; i < staged.size(); ++i) {
-        if (staged[i].ctx == ctx_ && staged[i].meas == lidarMeas.get()) {
-          if (staged[i].pointData == cloud.points_.data() && staged[i].n == n) {ticket = staged[i].ticket;}
+        if (staged[i].ctx == ctx_ && staged[i].meas.lock().get() == static_cast<const void *>(lidarMeas.get())) {
+          if (staged[i].pointData == cloud.points_.data() && staged[i].n == n) {
+            ticket = staged[i].ticket;
+          } else {
+            (void)vgicp_sweep_unstage(ctx_, staged[i].ticket);   // the cloud was replaced since: the staged bytes are stale
+          }
           staged.erase(staged.begin() + static_cast<std::ptrdiff_t>(i));
           break;
         }
@@ -182,7 +213,7 @@ public:
     lidarMeas->pointTime.shrink_to_fit();
     if (hostCopy_ == CloudPreprocessorConfig::HostCopy::Deferred) {
       cloud.covariances_.clear();
-      shim::stampResident(ctx_, cloud, 0, false);   // the host keeps the raw sweep; the prepared scan is on the device
+      shim::stampResident(ctx_, cloud, 0, false, residentCheck_);   // the host keeps the raw sweep; the prepared scan is on the device
       return;
     }
     size_t kept = 0;
@@ -195,7 +226,7 @@ public:
           ctx_, kept, reinterpret_cast<double *>(cloud.points_.data()),
           reinterpret_cast<double *>(cloud.covariances_.data()), &kept), "vgicp_scan_download");
     }
-    shim::stampResident(ctx_, cloud, kept, true);
+    shim::stampResident(ctx_, cloud, kept, true, residentCheck_);
   }
 
   void voxelDownsampleAndEstimateCovariances(PointCloud & cloud) const
@@ -255,6 +286,7 @@ private:
   int knn_;
   Isometry3d T_il_;
   CloudPreprocessorConfig::HostCopy hostCopy_ = CloudPreprocessorConfig::HostCopy::Eager;
+  shim::ResidentCheck residentCheck_ = shim::ResidentCheck::FullHash;
   vgicp_ctx * ctx_;
 };
 }  // namespace ESKF_LIO

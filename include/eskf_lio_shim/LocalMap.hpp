@@ -123,9 +123,15 @@ inline vgicp_ctx * defaultContext()
 // and work on the resident scan instead of uploading the cloud again.  The stamp is the cloud's address, its
 // buffers' addresses and sizes, a hash over 64 evenly spaced elements (first and last included) and the library's
 // scan generation (VGICP_COUNTER_SCAN_GENERATION: anything else that replaced the resident scan voids it).  A
-// cloud that was resized, reallocated, or edited at a sampled element falls back to the upload path; an edit of
-// an unsampled element in place is NOT seen — callers that edit a prepared cloud in place call shim::forget(cloud), or
-// run with VGICP_SHIM_FULL_HASH=1 (every byte of both buffers is hashed).
+// cloud that was resized, reallocated or edited in place — ANY byte of either buffer: by default every byte is hashed
+// (ResidentCheck::FullHash, ~25 GB/s out of the caches: 0.05 - 0.1 ms per check of a 27 000-point prepared cloud) —
+// falls back to the upload path, which is what the reference does with every cloud (src/Registration.cpp:11,
+// src/LocalMap.cpp:45-58 always read the host cloud).  ResidentCheck::Sampled hashes 64 evenly spaced elements of each
+// buffer instead (first and last included): ~1 us, but an edit of an UNSAMPLED element in place is not seen — only for
+// callers that never edit a prepared cloud in place, or call shim::forget(cloud) when they do.  Chosen through the
+// configuration structs (CloudPreprocessorConfig / RegistrationConfig / LocalMapConfig ::residentCheck, YAML key
+// cloud_preprocessor.resident_check: sampled), never through the environment; a stamp remembers how it was made.
+enum class ResidentCheck {FullHash, Sampled};
 struct ResidentStamp
 {
   vgicp_ctx * ctx = nullptr;
@@ -134,6 +140,7 @@ struct ResidentStamp
   const void * covData = nullptr;
   size_t pointCount = 0, covCount = 0;
   uint64_t hash = 0, generation = 0;
+  bool sampled = false;      // the hash covers 64 elements of each buffer only (ResidentCheck::Sampled)
   size_t kept = 0;           // points of the resident scan, when known (0 while the preparation has not reported)
   bool hostIsCurrent = false;  // the host buffers hold the prepared scan (false: the raw sweep, the scan is on the device only)
 };
@@ -142,14 +149,9 @@ inline std::vector<ResidentStamp> & residentStamps()
   static std::vector<ResidentStamp> stamps;
   return stamps;
 }
-inline uint64_t sampleHash(const PointCloud & cloud)
+inline uint64_t sampleHash(const PointCloud & cloud, bool sampled)
 {
-  // VGICP_SHIM_FULL_HASH=1: every byte of both buffers (a caller that edits prepared clouds in place and does not want to
-  // call shim::forget); default: 64 evenly spaced elements of each
-  static const bool full = [] {
-      const char * e = std::getenv("VGICP_SHIM_FULL_HASH");
-      return e && e[0] == '1';
-    }();
+  const bool full = !sampled;
   const size_t n = cloud.points_.size(), m = cloud.covariances_.size();
   if (full) {
     // four independent multiply-xorshift lanes over 8-byte words: runs at the speed the caches deliver the buffers
@@ -192,7 +194,9 @@ inline ResidentStamp * findStamp(vgicp_ctx * ctx)
   }
   return nullptr;
 }
-inline void stampResident(vgicp_ctx * ctx, const PointCloud & cloud, size_t kept, bool hostIsCurrent)
+inline void stampResident(
+  vgicp_ctx * ctx, const PointCloud & cloud, size_t kept, bool hostIsCurrent,
+  ResidentCheck how = ResidentCheck::FullHash)
 {
   ResidentStamp * st = findStamp(ctx);
   if (!st) {
@@ -205,7 +209,8 @@ inline void stampResident(vgicp_ctx * ctx, const PointCloud & cloud, size_t kept
   st->covData = cloud.covariances_.data();
   st->pointCount = cloud.points_.size();
   st->covCount = cloud.covariances_.size();
-  st->hash = sampleHash(cloud);
+  st->sampled = how == ResidentCheck::Sampled;
+  st->hash = sampleHash(cloud, st->sampled);
   st->generation = scanGeneration(ctx);
   st->kept = kept;
   st->hostIsCurrent = hostIsCurrent;
@@ -220,7 +225,7 @@ inline ResidentStamp * residentStampOf(vgicp_ctx * ctx, const PointCloud & cloud
   {
     return nullptr;
   }
-  if (st->generation != scanGeneration(ctx) || st->hash != sampleHash(cloud)) {return nullptr;}
+  if (st->generation != scanGeneration(ctx) || st->hash != sampleHash(cloud, st->sampled)) {return nullptr;}
   return st;
 }
 inline void forget(vgicp_ctx * ctx)
@@ -249,7 +254,7 @@ inline void materialize(vgicp_ctx * ctx, PointCloud & cloud)
         ctx, n, reinterpret_cast<double *>(cloud.points_.data()),
         reinterpret_cast<double *>(cloud.covariances_.data()), &n), "vgicp_scan_download");
   }
-  stampResident(ctx, cloud, n, true);
+  stampResident(ctx, cloud, n, true, st->sampled ? ResidentCheck::Sampled : ResidentCheck::FullHash);
 }
 }  // namespace shim
 
@@ -463,7 +468,10 @@ public:
       }
       if (keepRawPoints_ && shadowComplete_) {
         ShadowOp op;
-        op.cloud = std::move(cloud);
+        // the worker thread reads the cloud later: it gets the caller's object only when nobody else can reach it
+        // (src/Odometry.cpp:86 moves its pointer in), else a copy — a caller that keeps its pointer may edit or resize
+        // the cloud as soon as this call returns
+        if (cloud.use_count() == 1) {op.cloud = std::move(cloud);} else {op.cloud = std::make_shared<PointCloud>(*cloud);}
         op.transformFirst = false;
         op.insert = true;
         op.evict = evicted;

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGICP_ABI_VERSION 5
+#define VGICP_ABI_VERSION 6
 
 typedef struct vgicp_ctx vgicp_ctx;
 
@@ -42,7 +42,8 @@ enum {
   VGICP_ERR_TABLE_FULL = 4,   /* the device voxel table could not grow */
   VGICP_ERR_DEGENERATE = 5,   /* the solved pose is not finite (singular normal equations) */
   VGICP_ERR_NO_DEVICE = 6,    /* no usable gfx950 device */
-  VGICP_ERR_NOT_READY = 7     /* align before a map / scan exists */
+  VGICP_ERR_NOT_READY = 7,    /* align before a map / scan exists */
+  VGICP_ERR_TIMEOUT = 8       /* a bounded host-side wait ran out (a copy thread of the upload that never delivered) */
 };
 
 /* Replaces the three YAML keys ICP's constructor reads (include/ESKF_LIO/Registration.hpp:23-28,
@@ -308,10 +309,17 @@ int vgicp_scan_info(vgicp_ctx* ctx, size_t* kept, int64_t* deskewed, uint64_t* i
  * it (:74).  vgicp_sweep_stage copies the raw sweep (points n x 3, point_time n or NULL) into page-locked memory of the
  * context with the CPU and returns a ticket; vgicp_scan_prepare_staged_async is vgicp_scan_prepare_async for that
  * sweep: the device reads the staged bytes where they lie, the frame's first stage no longer waits for a host copy.
- * vgicp_sweep_stage makes no device call and is the ONE entry point that another thread may call while the
- * context's owner thread is inside a call (it has a mutex of its own); the buffers are free again on return.  At
- * most three sweeps can be staged ahead (VGICP_ERR_NOT_READY beyond); a ticket is used once. */
+ * vgicp_sweep_stage / _cloud2 / vgicp_sweep_unstage are the entry points that another thread may call while the
+ * context's owner thread is inside a call (they have a mutex of their own); the buffers are free again on return.
+ * They launch nothing and copy with the CPU, but they are not free of runtime calls: a slot that has to grow is
+ * re-allocated (hipSetDevice + hipHostFree + hipHostMalloc — hipHostFree may wait for work in flight on the device:
+ * once per slot and sweep size, three slots), and a slot whose last preparation may still be reading it is asked for
+ * with hipEventQuery (outside the mutex).  At most three sweeps can be staged ahead (VGICP_ERR_NOT_READY beyond); a
+ * ticket is used once — by vgicp_scan_prepare_staged_async, or by vgicp_sweep_unstage for a sweep that is dropped
+ * unprepared (a measurement the caller discards: src/Odometry.cpp:43-48 may pop several and keep one), which frees its
+ * slot; a ticket that is never used either way keeps its slot for the life of the context. */
 int vgicp_sweep_stage(vgicp_ctx* ctx, size_t n, const double* points, const double* point_time, uint64_t* ticket);
+int vgicp_sweep_unstage(vgicp_ctx* ctx, uint64_t ticket);
 int vgicp_scan_prepare_staged_async(vgicp_ctx* ctx, uint64_t ticket, size_t num_states, const double* states,
                                     const double extrinsic[16], double voxel_size, int knn);
 /* The same for the sensor's WIRE format: the payload of a sensor_msgs/PointCloud2 as it arrives (little-endian), n =

@@ -30,12 +30,12 @@ def test_library_exports_every_declared_symbol():
     from eskf_lio_amd import capi
     lib = capi.load_library()
     declared = header_symbols()
-    assert len(declared) == 43 and set(declared) == set(capi.EXPORTS)
+    assert len(declared) == 44 and set(declared) == set(capi.EXPORTS)
     out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True,
                          check=True).stdout
     exported = set(re.findall(r" T (vgicp_[a-z_0-9]+)", out))
     assert set(declared) <= exported
-    assert lib.vgicp_abi_version() == 5
+    assert lib.vgicp_abi_version() == 6
 
 
 def test_library_is_a_gfx950_code_object_without_torch_or_oracle():
@@ -231,16 +231,20 @@ def test_copy_crew_survives_helpers_that_come_late(tmp_path):
     next unit).  A helper that was woken for a job which the caller has meanwhile finished alone finds the NEXT job's
     word there: it must leave without taking anything (compare-and-swap on the job number) — a blind increment took a
     unit away from everybody and the upload never finished (round 5: a soak that hung once per ~200 000 uploads;
-    this stress reproduced it within a few thousand jobs).  tests/native/crew_stress.cpp: 150 000 tiny jobs, every
-    third one not announced to the helpers; every unit published once, every byte copied, no job stuck."""
+    this stress reproduced it within a few thousand jobs).  tests/native/crew_stress.cpp: 150 000 tiny jobs whose SHAPE
+    changes from job to job (round 5's advisor: a late helper checked its old ticket against the next job's larger unit
+    count — jobs are closed by finish() now), every third one not announced to the helpers; every unit published once,
+    every byte copied, no job stuck.  Then a helper that never returns from its copy: finish() reports it within its
+    deadline (the module returns VGICP_ERR_TIMEOUT), the crew goes on alone, the late completion is dropped."""
     exe = tmp_path / "crew_stress"
     out = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                           "-I" + os.path.join(ROOT, "eskf_lio_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
                           os.path.join(ROOT, "tests", "native", "crew_stress.cpp")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
     for helpers in ("1", "3"):
-        run = subprocess.run([str(exe), "150000", helpers], capture_output=True, text=True, timeout=300)
+        run = subprocess.run([str(exe), "150000", helpers, "1"], capture_output=True, text=True, timeout=300)
         assert run.returncode == 0 and "ok 150000 jobs" in run.stdout, run.stdout[-500:] + run.stderr[-500:]
+        assert "stuck helper: reported, crew went on alone, late completion dropped" in run.stdout, run.stdout[-500:]
     # the same under ThreadSanitizer (the sanitizers run on the CPU build only): no data race between the caller's set-up
     # of the next job and a helper still looking at the last one
     tsan = tmp_path / "crew_stress_tsan"
@@ -249,7 +253,7 @@ def test_copy_crew_survives_helpers_that_come_late(tmp_path):
                           "-o", str(tsan), os.path.join(ROOT, "tests", "native", "crew_stress.cpp")], capture_output=True, text=True)
     if out.returncode != 0:
         pytest.skip("no ThreadSanitizer runtime for this compiler: " + out.stderr[-200:])
-    run = subprocess.run([str(tsan), "20000", "2"], capture_output=True, text=True, timeout=600)
+    run = subprocess.run([str(tsan), "20000", "2", "1"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "ok 20000 jobs" in run.stdout and "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
 
 

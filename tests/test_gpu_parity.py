@@ -1110,6 +1110,25 @@ def test_sweep_staged_on_arrival_prepares_to_the_same_bits(oracle):
         t_plain = a.sweep_stage(sweeps[1])
         a.scan_prepare_staged_async(t_plain, None, ext, 0.3, 30)
         assert a.scan_info()[0] > 0
+    # a staged sweep that is DROPPED unprepared (vgicp_sweep_unstage, ABI 6): its slot is free again at once, its ticket
+    # is void; before that call three forgotten tickets took staging away from the context for good
+    with capi.Context(0) as c:
+        c.map_reset(0.3, 0)
+        tickets = [c.sweep_stage(sweeps[1], times[1]) for _ in range(3)]
+        with pytest.raises(capi.VgicpError):
+            c.sweep_stage(sweeps[1], times[1])
+        c.sweep_unstage(tickets[1])
+        with pytest.raises(capi.VgicpError):
+            c.sweep_unstage(tickets[1])                                           # used once
+        with pytest.raises(capi.VgicpError):
+            c.scan_prepare_staged_async(tickets[1], st, ext, 0.3, 30)             # ... and void for the preparation too
+        t_new = c.sweep_stage(sweeps[0], times[0])                                # the freed slot
+        c.scan_prepare_staged_async(t_new, st, ext, 0.3, 30)
+        gp, gc = c.scan_download()
+        assert np.array_equal(gp, rb[0][0]) and np.array_equal(gc, rb[0][1])
+        for tk in (tickets[0], tickets[2]):
+            c.sweep_unstage(tk)
+        assert len([c.sweep_stage(sweeps[1], times[1]) for _ in range(2)]) == 2
 
 
 def test_wire_format_sweep_is_widened_on_the_device(oracle):

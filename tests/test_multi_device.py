@@ -365,11 +365,14 @@ def test_dropin_sweeps_staged_on_arrival_give_the_same_poses():
 
 def test_dropin_align_falls_back_when_the_cloud_changed():
     """A caller that edits or resizes the prepared cloud between process() and align() gets what it asked for: the
-    stamp no longer matches, align() uploads the cloud as it is now, and the result is the registration of THAT cloud."""
+    stamp no longer matches, align() uploads the cloud as it is now, and the result is the registration of THAT cloud —
+    by DEFAULT for an edit of any element (mutate 3: point 1 of thousands, which a 64-sample stamp never looks at: the
+    classes hash every byte unless CloudPreprocessorConfig::residentCheck says Sampled), as the reference always reads
+    the host cloud (src/Registration.cpp:11, src/LocalMap.cpp:45-58)."""
     from eskf_lio_amd import host
     st, t, ext, raws = _frame_inputs(frames=2)
     for host_copy in ("eager", "deferred"):
-        for mutate in (1, 2):
+        for mutate in (1, 2, 3):
             pre = host.CloudPreprocessor(0.3, ext, host_copy)
             icp = host.ICP(30, 1e-6, 0.9999)
             lmap = host.LocalMap(0.3, 20, dict(_NO_GATE, device_resident=True))
@@ -381,6 +384,10 @@ def test_dropin_align_falls_back_when_the_cloud_changed():
             if mutate == 1:
                 gp = gp.copy()
                 gp[0, 0] += 1e-3
+            elif mutate == 3:
+                assert gp.shape[0] > 200
+                gp = gp.copy()
+                gp[1, 0] += 1e-3
             else:
                 gp, gc = gp[:-1], gc[:-1]
             want = host.ICP(30, 1e-6, 0.9999)
@@ -390,6 +397,17 @@ def test_dropin_align_falls_back_when_the_cloud_changed():
             got = fr.end()
             assert not got["used_resident"]
             assert got["iterations"] == want.iterations and np.array_equal(got["pose"], want_pose)
+    # the opt-in: a 64-sample stamp sees the edit of a sampled element (and a resize), not that of an unsampled one
+    for mutate, seen in ((1, True), (3, False)):
+        pre = host.CloudPreprocessor(0.3, ext, "eager", resident_check="sampled")
+        icp = host.ICP(30, 1e-6, 0.9999)
+        lmap = host.LocalMap(0.3, 20, dict(_NO_GATE, device_resident=True))
+        fr = host.Frame(raws[0], t, st)
+        fr.run(pre, icp, lmap, np.eye(4), first_frame=True)
+        fr.end()
+        fr = host.Frame(raws[1], t, st)
+        fr.run(pre, icp, lmap, np.eye(4), mutate=mutate)
+        assert fr.end()["used_resident"] == (not seen)
 
 
 @pytest.mark.parametrize("world", [2, 4])
