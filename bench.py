@@ -720,16 +720,22 @@ def main():
             "clouds": f"{args.steps} distinct fresh clouds, one per timed step ({args.steps * scan_bytes / 1e6:.0f} MB in all): numpy "
                       "arrays from malloc, written once, handed to vgicp_align, then FREED (free(), as `delete` of the "
                       "reference's cloud does) inside the timed loop",
-            "how": f"staged: {os.environ.get('VGICP_UPLOAD_THREADS', '2')} host thread(s) (the caller's included, no HIP calls) copy "
-                   "the scan into page-locked memory of the context in units of 2048 points; ONE kernel launch reads the "
-                   "units over PCIe as they are published and packs them (pack_arena_kernel); the runtime never "
+            "how": f"staged: {os.environ.get('VGICP_UPLOAD_THREADS', '3')} host thread(s) (the caller's included, no HIP calls) copy "
+                   "the scan into page-locked memory of the context in units of 2048 points — a unit whose covariances "
+                   "are all bitwise symmetric as six doubles per covariance (72 instead of 96 bytes per point cross the "
+                   "link; mirrored on the device, the resident scan is the caller's bit for bit); ONE kernel launch reads "
+                   "the units over PCIe as they are published and packs them (pack_arena_kernel); the runtime never "
                    "registers the caller's pages",
             **loop_report(elapsed, per_step, align_s, free_s, worst, args.steps),
             "allocator": "glibc keeps freed memory (mallopt: M_TRIM_THRESHOLD = never, M_MMAP_THRESHOLD = 32 MB)" if mallopt_ok else "glibc defaults (mallopt failed)",
             "upload_ms": upload_ms,
             "upload_GBps": scan_bytes / upload_ms / 1e6 if upload_ms > 0 else None,
-            "fraction_of_kernel_read_rate_54GBps": scan_bytes / upload_ms / 1e6 / 54.0 if upload_ms > 0 else None,
-            "fraction_of_pcie5_x16_63GBps": scan_bytes / upload_ms / 1e6 / 63.0 if upload_ms > 0 else None,
+            "bytes_over_the_link_per_step": 72 * n_local,
+            "bytes_over_the_link": "72 per point (24 + six doubles of a bitwise symmetric covariance; VGICP_UPLOAD_COMPACT=0 sends 96): "
+                                   "what upload_ms and the two fractions below are priced on since round 6 — upload_ms is the HOST side "
+                                   "(the copy threads), the link's own share is ms_per_step - persistent launch - host tail",
+            "fraction_of_kernel_read_rate_54GBps": 72 * n_local / upload_ms / 1e6 / 54.0 if upload_ms > 0 else None,
+            "fraction_of_pcie5_x16_63GBps": 72 * n_local / upload_ms / 1e6 / 63.0 if upload_ms > 0 else None,
             "link_rate_source": "54 GB/s: a kernel reading page-locked host memory on this node type, "
                                 "tools/micro/stage_crew_probe.hip (profiles/r12_stage_crew_probe.txt); 63 GB/s: PCIe 5.0 x16 payload",
             "uploads_repeated_because_the_copy_threads_were_held_up": int(upload_slow),

@@ -93,6 +93,47 @@ void stage_copy(void* dst, const void* src, size_t bytes) {
   if (streaming && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0) stage_copy_avx2(static_cast<char*>(dst), static_cast<const char*>(src), bytes);
   else std::memcpy(dst, src, bytes);
 }
+// A unit of covariances (cnt x 9 doubles, column-major) into the staging memory of the scan upload: when every one of
+// them is bitwise symmetric — c10 == c01, c20 == c02, c21 == c12; every covariance the reference makes is — only the six
+// entries c00 c10 c20 c11 c21 c22 are written (48 instead of 72 bytes per point cross the link; pack_arena_kernel
+// mirrors them), else the unit is copied whole.  Returns the form for the unit's flag line.
+__attribute__((target("avx2"))) bool cov_unit_compact_avx2(char* dst, const char* src, size_t cnt) {
+  const double* s = reinterpret_cast<const double*>(src);
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(src);
+  double* d = reinterpret_cast<double*>(dst);
+  uint64_t bad = 0;
+  size_t i = 0;
+  // two points per turn: 18 doubles in, 12 out = three aligned 32-byte streaming stores (dst is 64-byte aligned and a
+  // pair's 96 bytes keep it 32-byte aligned).  No shuffles: every output vector is two or three overlapping unaligned
+  // loads blended (the load ports have room; cross-lane permutes were the bottleneck of a first version), and the
+  // symmetry test is scalar on the same cache lines.
+  // in: A0 .. A8 at s[0..8], B0 .. B8 at s[9..17]; out: A0 A1 A2 A4 | A5 A8 B0 B1 | B2 B4 B5 B8
+  for (; i + 2 <= cnt; i += 2, s += 18, w += 18, d += 12) {
+    const __m256d o0 = _mm256_blend_pd(_mm256_loadu_pd(s), _mm256_loadu_pd(s + 1), 0x8);
+    const __m256d o1 = _mm256_blend_pd(_mm256_loadu_pd(s + 7), _mm256_loadu_pd(s + 5), 0x1);
+    const __m256d o2 = _mm256_blend_pd(_mm256_blend_pd(_mm256_loadu_pd(s + 11), _mm256_loadu_pd(s + 12), 0x6), _mm256_loadu_pd(s + 14), 0x8);
+    bad |= (w[1] ^ w[3]) | (w[2] ^ w[6]) | (w[5] ^ w[7]) | (w[10] ^ w[12]) | (w[11] ^ w[15]) | (w[14] ^ w[16]);
+    _mm256_stream_pd(d, o0);
+    _mm256_stream_pd(d + 4, o1);
+    _mm256_stream_pd(d + 8, o2);
+  }
+  if (i < cnt) {   // an odd count: the unit's (the scan's) last point
+    bad |= (w[1] ^ w[3]) | (w[2] ^ w[6]) | (w[5] ^ w[7]);
+    const uint64_t o[6] = {w[0], w[1], w[2], w[4], w[5], w[8]};
+    std::memcpy(d, o, sizeof o);
+  }
+  _mm_sfence();
+  return bad == 0;
+}
+uint32_t stage_cov_unit(void* dst, const void* src, size_t cnt) {
+  static const bool wide = __builtin_cpu_supports("avx2");
+  static const bool off = std::getenv("VGICP_UPLOAD_COMPACT") && std::getenv("VGICP_UPLOAD_COMPACT")[0] == '0';   // A/B aid
+  if (wide && !off && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0 &&
+      cov_unit_compact_avx2(static_cast<char*>(dst), static_cast<const char*>(src), cnt))
+    return kArenaCompact;
+  stage_copy(dst, src, cnt * 9 * sizeof(double));   // one asymmetric covariance (or no AVX2): the unit as it is
+  return kArenaFull;
+}
 void arena_reset(vgicp_ctx* ctx) {
   ctx->arena_used = 0;
   ctx->pending_out.clear();
@@ -914,6 +955,7 @@ int vgicp_destroy(vgicp_ctx* ctx) {
     if (ctx->ev_state_table[k]) (void)hipEventDestroy(ctx->ev_state_table[k]);
   }
   for (auto& e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev_pipe) if (e) (void)hipEventDestroy(e);
   (void)hipFree(ctx->d_stage);
   (void)hipFree(ctx->d_cells);
   (void)hipFree(ctx->d_scan);
@@ -1394,13 +1436,14 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
     crew->size_a = 3 * sizeof(double);
     crew->size_b = 9 * sizeof(double);
     crew->copy = stage_copy;
+    crew->copy_b_form = stage_cov_unit;
     const double t_post = now_seconds();
     const uint32_t job = crew->post(want_helpers);
     // the launch first (it starts reading as soon as unit 0 is published), then this thread copies too
     // test aids: a pack kernel with little patience and a copy thread that is held up (the repeat below is then what counts)
     const uint32_t spin_limit = ctx->dev.pack_spin_limit ? ctx->dev.pack_spin_limit : kPackSpinLimit;
     const long debug_delay_us = ctx->dev.debug_upload_delay_us;
-    const hipError_t e_launch = launch_pack_arena(ctx->stream, crew->apts, crew->acov, (uint32_t)n, crew->flags, ctx->scan_seq,
+    const hipError_t e_launch = launch_pack_arena(ctx->stream, crew->apts, crew->acov, (uint32_t)n, crew->flags, true, ctx->scan_seq,
                                                   spin_limit, aos_pts, aos_cov, ctx->d_scan, ctx->stride,
                                                   ctx->d_ins_counters + 2);
     if (debug_delay_us > 0 && !want_helpers) std::this_thread::sleep_for(std::chrono::microseconds(debug_delay_us));
@@ -1412,7 +1455,7 @@ int scan_upload_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const do
       // the copy threads were held up for so long that a workgroup of the launch may have stopped waiting: everything
       // is staged now, pack it again behind the launch (no flags to wait for)
       ++ctx->upload_slow;
-      VG_HIP(ctx, launch_pack_arena(ctx->stream, crew->apts, crew->acov, (uint32_t)n, nullptr, ctx->scan_seq, 0, aos_pts,
+      VG_HIP(ctx, launch_pack_arena(ctx->stream, crew->apts, crew->acov, (uint32_t)n, crew->flags, false, ctx->scan_seq, 0, aos_pts,
                                     aos_cov, ctx->d_scan, ctx->stride, ctx->d_ins_counters + 2));
     }
     VG_HIP(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
@@ -1728,6 +1771,7 @@ void post_sweep_copy(vgicp_ctx* ctx, size_t n, StagedPoints* sp, const double* t
   crew->size_a = 24;
   crew->size_b = times ? 8 : 0;
   crew->copy = stage_copy;
+  crew->copy_b_form = nullptr;
   sp->t_post = now_seconds();
   sp->job = crew->post(sp->helpers);
   sp->open_with = crew;
@@ -2498,8 +2542,47 @@ int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double*
   if (!points || !covs) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "NULL output pointer");
   VG_HIP(ctx, hipSetDevice(ctx->device));
   arena_reset(ctx);
-  VG_RC(user_d2h(ctx, points, ctx->d_scan_aos, (size_t)ctx->n * 3 * sizeof(double)));
-  VG_RC(user_d2h(ctx, covs, ctx->d_scan_aos + 3 * ctx->scan_capacity, (size_t)ctx->n * 9 * sizeof(double)));
+  const size_t pb = (size_t)ctx->n * 3 * sizeof(double), cb = (size_t)ctx->n * 9 * sizeof(double);
+  if (pb + cb > kArenaMin && pb + cb <= kArenaBytes && !is_pagelocked(points) && !is_pagelocked(covs)) {
+    // the drop-in's eager host copy (CloudPreprocessor::process, every frame): the DMA engine moves piece k + 1 into
+    // the page-locked arena while this thread copies piece k out to the caller — the two halves of the staged copy
+    // overlap instead of following each other (2.6 MB: one synchronisation + one 2.6 MB memcpy less on the frame's path)
+    char* stage = arena_take(ctx, pb + cb);
+    if (stage) {
+      constexpr size_t kPiece = 384u << 10;
+      constexpr int kEvents = 8;
+      for (int k = 0; k < kEvents; ++k)
+        if (!ctx->ev_pipe[k]) VG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pipe[k], hipEventDisableTiming));
+      struct Piece { char* dst; const char* src; size_t bytes; };
+      std::vector<Piece> pieces;
+      const char* dev_p = reinterpret_cast<const char*>(ctx->d_scan_aos);
+      const char* dev_c = reinterpret_cast<const char*>(ctx->d_scan_aos + 3 * ctx->scan_capacity);
+      for (size_t off = 0; off < pb; off += kPiece) pieces.push_back({reinterpret_cast<char*>(points) + off, dev_p + off, std::min(kPiece, pb - off)});
+      for (size_t off = 0; off < cb; off += kPiece) pieces.push_back({reinterpret_cast<char*>(covs) + off, dev_c + off, std::min(kPiece, cb - off)});
+      size_t enq = 0, done = 0, at = 0;
+      std::vector<size_t> where(pieces.size());
+      while (done < pieces.size()) {
+        for (; enq < pieces.size() && enq < done + (size_t)kEvents; ++enq) {   // at most kEvents pieces in flight
+          where[enq] = at;
+          VG_HIP(ctx, hipMemcpyAsync(stage + at, pieces[enq].src, pieces[enq].bytes, hipMemcpyDeviceToHost, ctx->stream));
+          VG_HIP(ctx, hipEventRecord(ctx->ev_pipe[enq % kEvents], ctx->stream));
+          at += (pieces[enq].bytes + 255) & ~size_t(255);
+        }
+        // polled, not slept on: a piece is 15 us of DMA, and an event wait that goes to sleep costs more than that
+        for (;;) {
+          const hipError_t q = hipEventQuery(ctx->ev_pipe[done % kEvents]);
+          if (q == hipSuccess) break;
+          if (q != hipErrorNotReady) return fail_hip(ctx, q, "hipEventQuery(download piece)");
+          __builtin_ia32_pause();
+        }
+        std::memcpy(pieces[done].dst, stage + where[done], pieces[done].bytes);
+        ++done;
+      }
+      return VGICP_OK;
+    }
+  }
+  VG_RC(user_d2h(ctx, points, ctx->d_scan_aos, pb));
+  VG_RC(user_d2h(ctx, covs, ctx->d_scan_aos + 3 * ctx->scan_capacity, cb));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   user_copies_finish(ctx);
   return VGICP_OK;

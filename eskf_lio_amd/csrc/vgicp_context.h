@@ -118,6 +118,10 @@ struct CopyCrew {
   std::atomic<uint32_t> units{0};      // read BEFORE a unit is taken (by a thread that may have come late to an older job): atomic
   uint32_t size_a = 24, size_b = 72;   // bytes per point of the two arrays (size_b = 0: one array only)
   void (*copy)(void*, const void*, size_t) = nullptr;
+  // optional: the second array's units are written by this instead (dst = the unit's place, cnt points of size_b bytes
+  // in src); what it returns is stored into the unit's flag line (word 1) before the flag: the form the unit was
+  // staged in (the covariances of a scan upload: compact when all of a unit's are bitwise symmetric)
+  uint32_t (*copy_b_form)(void*, const void*, size_t) = nullptr;
   static constexpr uint32_t kClosed = 0xFFFFFFFFu;
 
   void work(uint32_t my_job) {
@@ -138,8 +142,11 @@ struct CopyCrew {
       const uint32_t j_seq = seq, j_size_a = size_a, j_size_b = size_b;
       const size_t p0 = (size_t)u * unit, cnt = std::min<size_t>(unit, n - p0);
       void (*j_copy)(void*, const void*, size_t) = copy;
+      uint32_t (*j_copy_b_form)(void*, const void*, size_t) = copy_b_form;
       j_copy(j_apts + p0 * j_size_a, j_pts + p0 * j_size_a, cnt * j_size_a);
-      if (j_size_b) j_copy(j_acov + p0 * j_size_b, j_cov + p0 * j_size_b, cnt * j_size_b);
+      if (j_size_b && j_copy_b_form)
+        __atomic_store_n(j_flags + 16 * (size_t)u + 1, j_copy_b_form(j_acov + p0 * j_size_b, j_cov + p0 * j_size_b, cnt), __ATOMIC_RELAXED);
+      else if (j_size_b) j_copy(j_acov + p0 * j_size_b, j_cov + p0 * j_size_b, cnt * j_size_b);
       // the unit's bytes (streaming stores, fenced by `copy`) are globally visible before its flag
       __atomic_store_n(j_flags + 16 * (size_t)u, j_seq, __ATOMIC_RELEASE);
       uint64_t f = finished.load(std::memory_order_relaxed);
@@ -283,7 +290,8 @@ struct vgicp_ctx {
   double* d_parts_persist = nullptr; // [3][kFolders][kSlots]
   void* h_exchange_image = nullptr;  // pinned: what the two buffers hold between launches
   bool persistent_enabled = true;    // cleared by VGICP_PERSISTENT=0 or when a workgroup does not fit a CU
-  double prefetch_margin = 0.03;     // see PersistArgs::prefetch_margin; VGICP_PREFETCH_MARGIN overrides (0 = off)
+  double prefetch_margin = 0.015;    // see PersistArgs::prefetch_margin; VGICP_PREFETCH_MARGIN overrides (0 = off).  Round 6: 0.03 -> 0.015
+                                     // once the workgroups that are no folders stopped polling early (C2: 0 7.18, 0.01 6.41, 0.015 6.34, 0.02 6.35, 0.03 6.52, 0.04 6.66 us per round)
   uint32_t persist_spin_limit = 50000;  // polls (>= ~1 us each) before an in-kernel wait gives up
   int persistent_cooldown = 0;       // aligns left on the per-launch loop after an in-kernel wait timed out
   uint64_t persistent_launches = 0;  // diagnostics (vgicp_get_counter)
@@ -299,7 +307,10 @@ struct vgicp_ctx {
     long debug_upload_delay_us = 0;
   } dev;
   CopyCrew* crew = nullptr;          // the upload's copy threads, created with the first upload that wants a helper
-  int upload_threads = 2;            // threads that copy a scan into the staging memory, the caller's included (VGICP_UPLOAD_THREADS)
+  int upload_threads = 3;            // threads that copy a scan into the staging memory, the caller's included (VGICP_UPLOAD_THREADS).
+                                     // Round 6: 2 -> 3 — with symmetric covariances crossing the link as six doubles the HOST copy out of
+                                     // never-seen pages became the limit at two threads (C2 from fresh clouds: 2 threads 0.366 ms per align
+                                     // with or without the compaction, 3 threads 0.321, 4 threads 0.316 - 0.321)
   char* h_upload = nullptr;          // page-locked staging memory of the scan upload: [unit flags][points][covariances]
   size_t upload_cap = 0;             // bytes behind the flags
   size_t upload_flag_bytes = 0;      // one 64-byte line per unit the capacity can hold; never holds anything but flags
@@ -336,6 +347,7 @@ struct vgicp_ctx {
   size_t upload_whole_hint = 0;             // a sub-context's shard: the size of the caller's WHOLE scan decides, not the shard's
   struct PendingOut { void* dst; const char* src; size_t bytes; };
   std::vector<PendingOut> pending_out;
+  hipEvent_t ev_pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // vgicp_scan_download's pieces
   // sweeps staged AHEAD of their preparation (vgicp_sweep_stage: the lidar callback's thread copies a sweep into
   // page-locked memory when it arrives; vgicp_scan_prepare_staged_async consumes it by ticket).  Guarded by
   // ahead_mutex: the one part of a context that another thread may enter while the owner thread is inside a call.

@@ -179,11 +179,13 @@ hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosin
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
                             uint32_t n, double* soa, uint64_t stride, uint32_t* asym, uint32_t seq);
 // The same packing straight out of page-locked HOST staging memory that host threads are still filling, unit by unit
-// (pack_arena_unit() points each; flags[16 * u] == seq publishes unit u; flags == nullptr: all there).  Also leaves the
-// AoS copy on the device.  See pack_arena_kernel.
+// (pack_arena_unit() points each; flags[16 * u] == seq publishes unit u, flags[16 * u + 1] says in which form its
+// covariances were staged; wait == false: all there).  Also leaves the AoS copy on the device.  See pack_arena_kernel.
 uint32_t pack_arena_unit();
+constexpr uint32_t kArenaFull = 2u;      // a unit's covariances as the caller holds them: 72 bytes per point
+constexpr uint32_t kArenaCompact = 1u;   // all of them bitwise symmetric: c00 c10 c20 c11 c21 c22, 48 bytes per point
 hipError_t launch_pack_arena(hipStream_t s, const void* arena_points, const void* arena_covs, uint32_t n,
-                             const uint32_t* flags, uint32_t seq, uint32_t spin_limit, double* aos_pts, double* aos_cov,
+                             const uint32_t* flags, bool wait, uint32_t seq, uint32_t spin_limit, double* aos_pts, double* aos_cov,
                              double* soa, uint64_t stride, uint32_t* asym);
 hipError_t launch_table_clear(hipStream_t s, VoxelRecord* table, uint64_t slots);
 // Pack the FULL records of `table` into `dense` in slot order (128 bytes each) and leave every record's index there in

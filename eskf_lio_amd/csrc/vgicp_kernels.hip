@@ -754,29 +754,48 @@ __device__ __forceinline__ unsigned long long publishable(double v) {
 // the sum of their words as the pairwise tree over ascending rows (tree_sum<16>, as the folds of iterate_kernel
 // do; rows that belong to no workgroup hold +0.0 for good).  All 64 lanes of the wave call it; false when
 // spin_limit polls did not suffice.  The 16 loads are in flight together (one address, immediate offsets).
+#ifndef VGICP_L2_DELAY
+#define VGICP_L2_DELAY 64      // s_sleep units (64 clocks each) a workgroup that is no folder waits before its first poll of the parts
+#endif
+// Lanes <= kCountSlot (lane = slot) end with the sum over the 16 consecutive rows at src, as the pairwise tree over
+// ascending rows (tree_sum<16>, as the folds of iterate_kernel do; rows that belong to no workgroup hold +0.0 for
+// good).  All 64 lanes of the wave call it; false when spin_limit polls did not suffice.
+// The two halves of the wave share the work (round 6): lane l < 32 polls rows 0..7 of slot l, lane l + 32 rows 8..15, and
+// tree_sum<16> IS tree_sum<8>(first half) + tree_sum<8>(second half), so one half-swap gives the same bits with half the
+// registers and half the loads per lane.  ONE poll of the eight words is in flight: two, three or four of them, issued a
+// fraction of a memory round trip apart so that a word which lands just after a poll has passed need not wait a whole
+// round trip for the next, made every round SLOWER (C2 +0.3 / +0.9 / +1.5 us: the polls of 256 workgroups queue at the
+// memory side, profiles/NOTES_dropped_experiments.md) — which is what led to VGICP_L2_DELAY: poll LESS.
 template <bool SYSTEM>
 __device__ __forceinline__ bool poll_and_sum(const double* src, uint32_t lane, uint32_t spin_limit, double& sum) {
-  const bool active = lane <= (uint32_t)kCountSlot;
-  const double* mine = src + (active ? lane : 0u);
-  unsigned long long w[kFolders];
+  constexpr int H = kFolders / 2;
+  const uint32_t slot = lane & 31u, half = lane >> 5;
+  const bool active = slot <= (uint32_t)kCountSlot;
+  const double* mine = src + (size_t)half * H * kSlots + (active ? slot : 0u);
+  unsigned long long w[H];
 #pragma unroll
-  for (int k = 0; k < kFolders; ++k)
+  for (int k = 0; k < H; ++k)
     w[k] = active ? (SYSTEM ? load_system_bits(mine + k * kSlots) : load_through_bits(mine + k * kSlots)) : 0ull;
   for (uint32_t spins = 0;; ++spins) {
     bool missing = false;
 #pragma unroll
-    for (int k = 0; k < kFolders; ++k) missing = missing || (w[k] == kRowUnset);
+    for (int k = 0; k < H; ++k) missing = missing || (w[k] == kRowUnset);
     if (!__any(missing)) break;
     if (spins >= spin_limit) return false;
     __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-    for (int k = 0; k < kFolders; ++k)
+    for (int k = 0; k < H; ++k)
       if (w[k] == kRowUnset) w[k] = SYSTEM ? load_system_bits(mine + k * kSlots) : load_through_bits(mine + k * kSlots);
   }
-  double x[kFolders];
+  double x[H];
 #pragma unroll
-  for (int k = 0; k < kFolders; ++k) x[k] = __longlong_as_double((long long)w[k]);
-  sum = tree_sum<kFolders>(x);
+  for (int k = 0; k < H; ++k) x[k] = __longlong_as_double((long long)w[k]);
+  const double part = tree_sum<H>(x);
+  // lanes < 32 receive the sum of lane + 32 (rows 8..15 of the same slot)
+  const unsigned plo = (unsigned)__double2loint(part), phi = (unsigned)__double2hiint(part);
+  const auto lo = __builtin_amdgcn_permlane32_swap(plo, plo, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(phi, phi, false, false);
+  sum = part + __hiloint2double((int)hi[1], (int)lo[1]);
   return true;
 }
 
@@ -1058,6 +1077,8 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
       }
       pf_key[tid - 64] = m;
     }
+    // STAMPS: how long the look-ahead kept this wave (reported in the worker lane's "level-1" column)
+    if (STAMPS && !MANY && wave != 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t n = wall_clock64(); acc_l1 += n - t_mark; t_mark = n; }
 
     if (wave == 0) {
       // Addresses that depend on the lane are re-made here every round: hoisted out of the loop they would sit in
@@ -1090,6 +1111,11 @@ __device__ __forceinline__ void persistent_body(const PersistArgs& a) {
       // ---- level 2: every workgroup adds the parts ----
       double tot = 0.0;
       if (!MULTI) {
+        // A workgroup that is no folder has nothing to find before the folders have gathered their rows (a hop of
+        // ~1.5 us): polling the parts from the start only puts 240 workgroups' loads into the queues the 16 folders'
+        // polls and stores go through.  One point per thread (C2): 6.82 -> 6.55 us per round with 64 units (50: 6.63,
+        // 60 - 70: 6.55, 85: 6.9, 100: 7.1); several points per thread (C5): no gain, not delayed.
+        if (VGICP_L2_DELAY > 0 && !MANY && !folder) __builtin_amdgcn_s_sleep(VGICP_L2_DELAY);
         if (ok) ok = poll_and_sum<false>(parts, lane, a.spin_limit, tot);
       } else {
         // ---- several GPUs: workgroup 0 adds the parts to this rank's total and stores it into the mailbox
@@ -1296,51 +1322,59 @@ __global__ void pack_scan_kernel(const double* __restrict__ pts, const double* _
 }
 
 // The same packing for a scan that is still ARRIVING in page-locked host memory: the upload of vgicp_align /
-// vgicp_scan_upload without the runtime's copy engine.  Host threads (plain memcpy, no HIP call: CopyCrew,
-// vgicp_context.h) fill `apts` (n x 24 B) and `acov` (n x 72 B) in units of `unit` points and publish each unit by
-// storing `seq` into flags[16 * u] (one 64-byte line per flag, written after the unit's bytes).  This ONE launch reads
-// the staging memory over PCIe itself — 16-byte loads of consecutive lanes, a block's 96 x kPackArenaBlock bytes
-// through LDS — while the threads are still copying the units behind: 9.6 MB arrive in 0.19 - 0.20 ms = 49 GB/s
-// (tools/micro/stage_crew_probe.hip: a kernel gets 54 GB/s out of the link; staging + copy commands + pack took 0.45 ms).
+// vgicp_scan_upload without the runtime's copy engine.  Host threads (plain copies, no HIP call: CopyCrew,
+// vgicp_context.h) fill `apts` (n x 24 B) and `acov` in units of `unit` points and publish each unit by storing `seq`
+// into flags[16 * u] (one 64-byte line per flag, written after the unit's bytes).  This ONE launch reads the staging
+// memory over PCIe itself — 16-byte loads of consecutive lanes, a block's bytes through LDS — while the threads are
+// still copying the units behind (tools/micro/stage_crew_probe.hip: a kernel gets 54 GB/s out of the link; staging +
+// copy commands + pack took 0.45 ms).
+// Round 6: the link is what bounds the upload, so a unit whose covariances are ALL bitwise symmetric — every covariance
+// the reference produces is (src/CloudPreprocessor.cpp:119-123 apart from its indefinite corner) — crosses
+// it as six doubles per point (c00 c10 c20 c11 c21 c22: 48 instead of 72 bytes, 72 instead of 96 per point in all), and
+// the three mirrored entries are made here.  The host thread that copies a unit checks every covariance while it reads
+// it anyway and says which form it wrote in flags[16 * u + 1] (kArenaCompact / kArenaFull, stored before the flag); a
+// unit with ONE asymmetric covariance travels whole.  A unit's covariances start at acov + 72 * (first point) in both
+// forms.  What lands on the device is the caller's scan bit for bit either way.
 // Every block also leaves the AoS copy on the device (map insertion and download read it) and reports an asymmetric
-// covariance like pack_scan_kernel.  flags == nullptr: everything is there already (no waiting).
+// covariance like pack_scan_kernel.  wait == 0: everything is there already (the forms are still read from the flags).
 // A wait that exceeds spin_limit polls (each a PCIe round trip, >= 1 us) ends the block's workgroup: the host, which
-// knows how long its copy threads took, then repeats the packing without flags behind this launch.
+// knows how long its copy threads took, then repeats the packing without waiting behind this launch.
 constexpr int kPackArenaBlock = 256;
 __global__ __launch_bounds__(kPackArenaBlock) void pack_arena_kernel(
     const char* __restrict__ apts, const char* __restrict__ acov, uint32_t n, uint32_t unit, const uint32_t* flags,
-    uint32_t seq, uint32_t spin_limit, double* __restrict__ aos_pts, double* __restrict__ aos_cov,
+    uint32_t wait, uint32_t seq, uint32_t spin_limit, double* __restrict__ aos_pts, double* __restrict__ aos_cov,
     double* __restrict__ soa, uint64_t stride, uint32_t* asym) {
   typedef int v4i __attribute__((ext_vector_type(4)));
   constexpr uint32_t B = kPackArenaBlock;
   __shared__ __attribute__((aligned(16))) double lds[12 * B];
-  __shared__ uint32_t ok;
+  __shared__ __attribute__((aligned(16))) double lds_compact[6 * B];
+  __shared__ uint32_t ok, form_sh;
   const uint32_t t = threadIdx.x, blocks = (n + B - 1) / B;
   uint32_t have_unit = 0xFFFFFFFFu;
   for (uint32_t b = blockIdx.x; b < blocks; b += gridDim.x) {
     const uint32_t p0 = b * B, cnt = min(B, n - p0);
-    if (flags != nullptr) {
-      const uint32_t u = p0 / unit;   // unit is a multiple of the block: a block never straddles two units
-      if (u != have_unit) {
-        if (t == 0) {
-          uint32_t good = 1;
+    const uint32_t u = p0 / unit;   // unit is a multiple of the block: a block never straddles two units
+    if (u != have_unit) {
+      if (t == 0) {
+        uint32_t good = 1;
+        if (wait)
           for (uint32_t spins = 0; __hip_atomic_load(flags + 16 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq; ++spins) {
             if (spins >= spin_limit) { good = 0; break; }
             __builtin_amdgcn_s_sleep(20);
           }
-          __atomic_thread_fence(__ATOMIC_ACQUIRE);
-          ok = good;
-        }
-        __syncthreads();
-        if (!ok) return;   // uniform
-        have_unit = u;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        ok = good;
+        form_sh = good ? __hip_atomic_load(flags + 16 * u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : kArenaFull;
       }
+      __syncthreads();
+      if (!ok) return;   // uniform
+      have_unit = u;
     }
+    const bool compact = form_sh == kArenaCompact;   // uniform
     const v4i* sp = reinterpret_cast<const v4i*>(apts + (size_t)p0 * 24);
-    const v4i* sc = reinterpret_cast<const v4i*>(acov + (size_t)p0 * 72);
     v4i* lp = reinterpret_cast<v4i*>(lds);
     v4i* lc = reinterpret_cast<v4i*>(lds + 3 * B);
-    // an odd count (the scan's last block only) leaves half a 16-byte chunk at the end of the points AND of the
+    // an odd count (the scan's last block only) leaves half a 16-byte chunk at the end of the points AND of the full
     // covariances: read whole (the staging areas are padded), stored to the device copy as 8 bytes
     const uint32_t np = (cnt * 24 + 15) / 16, np_whole = (cnt * 24) / 16, nc = (cnt * 72 + 15) / 16, nc_whole = (cnt * 72) / 16;
     v4i* dp = reinterpret_cast<v4i*>(aos_pts + 3 * (size_t)p0);
@@ -1350,32 +1384,54 @@ __global__ __launch_bounds__(kPackArenaBlock) void pack_arena_kernel(
       lp[k] = w;
       if (k < np_whole) dp[k] = w;
     }
-    for (uint32_t k = t; k < nc; k += B) {
-      const v4i w = __builtin_nontemporal_load(sc + k);
-      lc[k] = w;
-      if (k < nc_whole) dc[k] = w;
+    if (!compact) {
+      const v4i* sc = reinterpret_cast<const v4i*>(acov + (size_t)p0 * 72);
+      for (uint32_t k = t; k < nc; k += B) {
+        const v4i w = __builtin_nontemporal_load(sc + k);
+        lc[k] = w;
+        if (k < nc_whole) dc[k] = w;
+      }
+    } else {
+      // the unit's compact records are contiguous from the unit's start: this block's begin (p0 - unit start) * 48 in
+      const uint32_t u0 = u * unit;
+      const v4i* sc = reinterpret_cast<const v4i*>(acov + (size_t)u0 * 72 + (size_t)(p0 - u0) * 48);
+      v4i* lq = reinterpret_cast<v4i*>(lds_compact);
+      for (uint32_t k = t; k < cnt * 3; k += B) lq[k] = __builtin_nontemporal_load(sc + k);   // 48 B = three chunks per point
     }
     __syncthreads();
     if (t == 0 && np != np_whole) {
       aos_pts[3 * (size_t)(p0 + cnt) - 1] = lds[3 * cnt - 1];
-      aos_cov[9 * (size_t)(p0 + cnt) - 1] = lds[3 * B + 9 * cnt - 1];
+      if (!compact) aos_cov[9 * (size_t)(p0 + cnt) - 1] = lds[3 * B + 9 * cnt - 1];
     }
     if (t < cnt) {
       const size_t i = p0 + t;
 #pragma unroll
       for (int k = 0; k < 3; ++k) soa[k * stride + i] = lds[3 * t + k];
       double c[9];
+      if (compact) {
+        const double a0 = lds_compact[6 * t], a1 = lds_compact[6 * t + 1], a2 = lds_compact[6 * t + 2],
+                     a3 = lds_compact[6 * t + 3], a4 = lds_compact[6 * t + 4], a5 = lds_compact[6 * t + 5];
+        c[0] = a0; c[1] = a1; c[2] = a2; c[3] = a1; c[4] = a3; c[5] = a4; c[6] = a2; c[7] = a4; c[8] = a5;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        c[k] = lds[3 * B + 9 * t + k];
-        soa[(3 + k) * stride + i] = c[k];
+        for (int k = 0; k < 9; ++k) lds[3 * B + 9 * t + k] = c[k];   // the whole record for the device copy below
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c[k] = lds[3 * B + 9 * t + k];
       }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) soa[(3 + k) * stride + i] = c[k];
       const bool same = __double_as_longlong(c[1]) == __double_as_longlong(c[3]) &&
                         __double_as_longlong(c[2]) == __double_as_longlong(c[6]) &&
                         __double_as_longlong(c[5]) == __double_as_longlong(c[7]);
       if (!same) *asym = seq;
     }
     __syncthreads();
+    if (compact) {   // the device's AoS copy of the covariances, whole records, coalesced out of LDS
+      const uint32_t words = cnt * 9;   // doubles
+      for (uint32_t k = t; k < words / 2; k += B) dc[k] = lc[k];
+      if (t == 0 && (words & 1u)) aos_cov[9 * (size_t)p0 + words - 1] = lds[3 * B + words - 1];
+      __syncthreads();
+    }
   }
 }
 
@@ -1823,7 +1879,7 @@ hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const doubl
 
 uint32_t pack_arena_unit() { return 8u * kPackArenaBlock; }   // 2 048 points = 196 KB per unit
 hipError_t launch_pack_arena(hipStream_t s, const void* arena_points, const void* arena_covs, uint32_t n,
-                             const uint32_t* flags, uint32_t seq, uint32_t spin_limit, double* aos_pts, double* aos_cov,
+                             const uint32_t* flags, bool wait, uint32_t seq, uint32_t spin_limit, double* aos_pts, double* aos_cov,
                              double* soa, uint64_t stride, uint32_t* asym) {
   if (n == 0) return hipSuccess;
   // few enough workgroups that the ones still waiting for their unit are a trickle of PCIe reads, enough of them that
@@ -1831,7 +1887,7 @@ hipError_t launch_pack_arena(hipStream_t s, const void* arena_points, const void
   const uint32_t grid = std::min<uint32_t>(blocks_for(n, kPackArenaBlock), 128u);
   ++g_kernel_launches; hipLaunchKernelGGL(pack_arena_kernel, dim3(grid), dim3(kPackArenaBlock), 0, s,
                                           static_cast<const char*>(arena_points), static_cast<const char*>(arena_covs), n,
-                                          pack_arena_unit(), flags, seq, spin_limit, aos_pts, aos_cov, soa, stride, asym);
+                                          pack_arena_unit(), flags, wait ? 1u : 0u, seq, spin_limit, aos_pts, aos_cov, soa, stride, asym);
   return hipGetLastError();
 }
 

@@ -186,6 +186,22 @@ int host_icp_align(
     });
 }
 
+// Developer aid (tools/probe_eager.py): switch the classes' host-time trace on / off; out (optional) receives
+// Trace::Slots seconds followed by Trace::Slots call counts (as doubles) and is then reset.
+void host_trace(int enable, double * out)
+{
+  auto & t = ESKF_LIO::shim::trace();
+  if (out) {
+    for (int k = 0; k < ESKF_LIO::shim::Trace::Slots; ++k) {
+      out[k] = t.seconds[k];
+      out[ESKF_LIO::shim::Trace::Slots + k] = static_cast<double>(t.calls[k]);
+      t.seconds[k] = 0.0;
+      t.calls[k] = 0;
+    }
+  }
+  t.on = enable != 0;
+}
+
 // CloudPreprocessor(config) — cloud_preprocessor.voxel_size, sensors.lidar.extrinsics as a 4x4;
 // host_copy: 0 = eager (the host cloud holds the prepared scan after process()), 1 = deferred, -1 = the default;
 // sampled_check != 0: CloudPreprocessorConfig::residentCheck = Sampled (the default hashes every byte)

@@ -195,14 +195,17 @@ public:
       }
     }
     int rc = VGICP_ERR_BAD_ARGUMENT;
-    if (ticket) {
-      rc = vgicp_scan_prepare_staged_async(
-        ctx_, ticket, states.size(), packed.data(), shim::poseData(T_il_), voxelSize_, knn_);
-    }
-    if (!ticket) {
-      rc = vgicp_scan_prepare_async(
-        ctx_, n, n ? reinterpret_cast<const double *>(cloud.points_.data()) : nullptr,
-        lidarMeas->pointTime.data(), states.size(), packed.data(), shim::poseData(T_il_), voxelSize_, knn_);
+    {
+      shim::TraceScope ts(shim::Trace::ProcessEnqueue);
+      if (ticket) {
+        rc = vgicp_scan_prepare_staged_async(
+          ctx_, ticket, states.size(), packed.data(), shim::poseData(T_il_), voxelSize_, knn_);
+      }
+      if (!ticket) {
+        rc = vgicp_scan_prepare_async(
+          ctx_, n, n ? reinterpret_cast<const double *>(cloud.points_.data()) : nullptr,
+          lidarMeas->pointTime.data(), states.size(), packed.data(), shim::poseData(T_il_), voxelSize_, knn_);
+      }
     }
     if (rc == VGICP_ERR_BAD_ARGUMENT && !states.empty() && n) {
       // where the reference's deskew would step off its state queue (undefined behaviour there)
@@ -217,15 +220,24 @@ public:
       return;
     }
     size_t kept = 0;
-    shim::check(ctx_, vgicp_scan_info(ctx_, &kept, nullptr, nullptr), "vgicp_scan_info");   // the frame's extra synchronisation
-    cloud.points_.resize(kept);
-    cloud.covariances_.resize(kept);
+    {
+      shim::TraceScope ts(shim::Trace::ProcessWait);
+      shim::check(ctx_, vgicp_scan_info(ctx_, &kept, nullptr, nullptr), "vgicp_scan_info");   // the frame's extra synchronisation
+    }
+    {
+      shim::TraceScope ts(shim::Trace::ProcessResize);
+      shim::adoptStorage(cloud.covariances_, shim::storagePool().covariances, kept);   // storage of an earlier frame's cloud
+      cloud.points_.resize(kept);
+      cloud.covariances_.resize(kept);
+    }
     if (kept) {
+      shim::TraceScope ts(shim::Trace::ProcessDownload);
       shim::check(
         ctx_, vgicp_scan_download(
           ctx_, kept, reinterpret_cast<double *>(cloud.points_.data()),
           reinterpret_cast<double *>(cloud.covariances_.data()), &kept), "vgicp_scan_download");
     }
+    shim::TraceScope ts(shim::Trace::ProcessStamp);
     shim::stampResident(ctx_, cloud, kept, true, residentCheck_);
   }
 

@@ -22,6 +22,12 @@
 
 #include <chrono>
 #include <cmath>
+#if defined(__x86_64__) && (defined(__GNUC__) || defined(__clang__))
+#include <immintrin.h>
+#endif
+#if defined(__linux__)
+#include <sys/mman.h>
+#endif
 #include <cstdint>
 #include <cstdlib>
 #include <fstream>
@@ -84,6 +90,96 @@ inline void check(vgicp_ctx * ctx, int rc, const char * what)
   }
 }
 
+// Developer aid: where a frame's host time goes inside the classes (tools/probe_eager.py through libvgicp_host.so).
+// Off unless shim::trace().on is set; a disabled scope costs one predictable branch.
+struct Trace
+{
+  enum Slot {ProcessEnqueue, ProcessWait, ProcessResize, ProcessDownload, ProcessStamp, AlignVerify, AlignCall,
+    UpdateVerify, UpdateRest, Slots};
+  bool on = false;
+  double seconds[Slots] = {0};
+  uint64_t calls[Slots] = {0};
+};
+inline Trace & trace()
+{
+  static Trace t;
+  return t;
+}
+struct TraceScope
+{
+  int slot;
+  std::chrono::steady_clock::time_point t0;
+  explicit TraceScope(int s)
+  : slot(trace().on ? s : -1)
+  {
+    if (slot >= 0) {t0 = std::chrono::steady_clock::now();}
+  }
+  ~TraceScope()
+  {
+    if (slot >= 0) {
+      trace().seconds[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      ++trace().calls[slot];
+    }
+  }
+};
+
+// Storage of clouds that died inside these classes (a cloud moved into updateLocalMap, src/Odometry.cpp:86, ends in the
+// map's hands) is kept for the clouds to come: process() needs 72 bytes per kept point for the covariances of every
+// frame, and a FRESH allocation of that size is what the C library maps anew and the kernel faults in page by page
+// (measured: 0.44 ms of a 1.1 ms frame were `covariances_.resize()`); storage that was used before costs nothing.
+// At most four vectors of each kind are kept; everything else is freed as before.
+struct StoragePool
+{
+  std::mutex mutex;
+  std::vector<std::vector<Vector3d>> points;
+  std::vector<std::vector<Matrix3d>> covariances;
+};
+inline StoragePool & storagePool()
+{
+  static StoragePool pool;
+  return pool;
+}
+// the cloud is about to be destroyed by its last owner: keep its buffers
+inline void recycleStorage(PointCloud & cloud)
+{
+  StoragePool & pool = storagePool();
+  std::lock_guard<std::mutex> lk(pool.mutex);
+  if (cloud.covariances_.capacity() && pool.covariances.size() < 4) {
+    cloud.covariances_.clear();
+    pool.covariances.emplace_back(std::move(cloud.covariances_));
+  }
+  if (cloud.points_.capacity() && pool.points.size() < 4) {
+    cloud.points_.clear();
+    pool.points.emplace_back(std::move(cloud.points_));
+  }
+}
+// make room for n elements in v, out of the pool when v has none of its own (v's contents are not kept)
+template<typename T>
+inline void adoptStorage(std::vector<T> & v, std::vector<std::vector<T>> & kept, size_t n)
+{
+  if (v.capacity() >= n) {return;}
+  {
+    StoragePool & pool = storagePool();
+    std::lock_guard<std::mutex> lk(pool.mutex);
+    for (size_t i = 0; i < kept.size(); ++i) {
+      if (kept[i].capacity() >= n) {
+        v.swap(kept[i]);
+        v.clear();
+        kept.erase(kept.begin() + static_cast<std::ptrdiff_t>(i));
+        return;
+      }
+    }
+  }
+  // nothing to reuse (the clouds of the last frames are still with the shadow grid's worker): a fresh allocation, and
+  // its pages brought in by ONE call instead of one fault each (Linux >= 5.14; ignored where it is not known)
+  v.reserve(n);
+#if defined(__linux__)
+  const uintptr_t lo = (reinterpret_cast<uintptr_t>(v.data()) + 4095u) & ~uintptr_t(4095u);
+  const uintptr_t hi = reinterpret_cast<uintptr_t>(v.data() + v.capacity()) & ~uintptr_t(4095u);
+  if (hi > lo + (256u << 10)) {(void)madvise(reinterpret_cast<void *>(lo), hi - lo, 23 /* MADV_POPULATE_WRITE */);}
+#endif
+}
+
 // One context per process, created on first use: device $VGICP_DEVICE (default 0), or — VGICP_DEVICES=0,1,2,3 — ONE
 // context that drives several devices from this thread (vgicp_create_multi: replicated map, point-sharded align;
 // an ordinal may repeat, "0,0", to split one device).  The reference's single caller thread (src/main.cpp:68-70)
@@ -140,7 +236,8 @@ struct ResidentStamp
   const void * covData = nullptr;
   size_t pointCount = 0, covCount = 0;
   uint64_t hash = 0, generation = 0;
-  bool sampled = false;      // the hash covers 64 elements of each buffer only (ResidentCheck::Sampled)
+  bool sampled = false;      // the hash covers 64 elements of each buffer only
+  bool wantSampled = false;  // what the configuration asked for (ResidentCheck::Sampled); `sampled` is also set for a deferred host copy
   size_t kept = 0;           // points of the resident scan, when known (0 while the preparation has not reported)
   bool hostIsCurrent = false;  // the host buffers hold the prepared scan (false: the raw sweep, the scan is on the device only)
 };
@@ -149,28 +246,64 @@ inline std::vector<ResidentStamp> & residentStamps()
   static std::vector<ResidentStamp> stamps;
   return stamps;
 }
+// Every byte of a buffer in one pass at the speed the caches deliver it: 16 interleaved lanes of 64-bit words, each a
+// pair of running sums (s1 += w; s2 += s1 — position-dependent, so a changed word, a swapped pair or a shifted run all
+// show), folded with odd multipliers at the end.  Not cryptographic: a change detector for buffers nobody attacks.
+// AVX2 when the CPU has it (four 4-lane vectors), the same lanes in plain C++ otherwise — the same value either way.
+#if defined(__x86_64__) && (defined(__GNUC__) || defined(__clang__))
+#define ESKF_LIO_SHIM_HASH_AVX2 1
+__attribute__((target("avx2"))) inline void lanesAvx2(const uint64_t * w, size_t blocks, uint64_t (&s1)[16], uint64_t (&s2)[16])
+{
+  __m256i a[4], b[4];
+  for (int v = 0; v < 4; ++v) {
+    a[v] = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s1 + 4 * v));
+    b[v] = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s2 + 4 * v));
+  }
+  for (size_t k = 0; k < blocks; ++k, w += 16) {
+    for (int v = 0; v < 4; ++v) {
+      a[v] = _mm256_add_epi64(a[v], _mm256_loadu_si256(reinterpret_cast<const __m256i *>(w + 4 * v)));
+      b[v] = _mm256_add_epi64(b[v], a[v]);
+    }
+  }
+  for (int v = 0; v < 4; ++v) {
+    _mm256_storeu_si256(reinterpret_cast<__m256i *>(s1 + 4 * v), a[v]);
+    _mm256_storeu_si256(reinterpret_cast<__m256i *>(s2 + 4 * v), b[v]);
+  }
+}
+#endif
+inline uint64_t bufferHash(const void * p, size_t bytes, uint64_t seed)
+{
+  uint64_t s1[16], s2[16];
+  for (int l = 0; l < 16; ++l) {s1[l] = seed + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(l + 1); s2[l] = 0;}
+  const uint64_t * w = static_cast<const uint64_t *>(p);
+  const size_t words = bytes / 8, blocks = words / 16;
+  size_t done = 0;
+#ifdef ESKF_LIO_SHIM_HASH_AVX2
+  static const bool wide = __builtin_cpu_supports("avx2");
+  if (wide) {lanesAvx2(w, blocks, s1, s2); done = blocks * 16;}
+#endif
+  for (size_t i = done; i < words; ++i) {   // without AVX2 everything, else the last partial block
+    const size_t l = i & 15u;
+    s1[l] += w[i];
+    s2[l] += s1[l];
+  }
+  uint64_t h = bytes * 0x100000001B3ull;
+  for (int l = 0; l < 16; ++l) {
+    h = (h ^ s1[l]) * 0x9FB21C651E98DF25ull;
+    h ^= h >> 29;
+    h = (h ^ s2[l]) * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 31;
+  }
+  return h;
+}
 inline uint64_t sampleHash(const PointCloud & cloud, bool sampled)
 {
-  const bool full = !sampled;
   const size_t n = cloud.points_.size(), m = cloud.covariances_.size();
-  if (full) {
-    // four independent multiply-xorshift lanes over 8-byte words: runs at the speed the caches deliver the buffers
-    uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
-    auto mixWords = [&h](const void * p, size_t bytes) {
-        const uint64_t * w = static_cast<const uint64_t *>(p);
-        const size_t words = bytes / 8;
-        size_t i = 0;
-        for (; i + 4 <= words; i += 4) {
-          for (int k = 0; k < 4; ++k) {
-            h[k] = (h[k] ^ w[i + k]) * 0x9FB21C651E98DF25ull;
-            h[k] ^= h[k] >> 29;
-          }
-        }
-        for (; i < words; ++i) {h[0] = (h[0] ^ w[i]) * 0x9FB21C651E98DF25ull; h[0] ^= h[0] >> 29;}
-      };
-    if (n) {mixWords(cloud.points_.data(), n * sizeof(Vector3d));}
-    if (m) {mixWords(cloud.covariances_.data(), m * sizeof(Matrix3d));}
-    return h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ (n * 0x100000001B3ull) ^ m;
+  if (!sampled) {
+    uint64_t h = n * 0x100000001B3ull ^ m;
+    if (n) {h = bufferHash(cloud.points_.data(), n * sizeof(Vector3d), h);}
+    if (m) {h = bufferHash(cloud.covariances_.data(), m * sizeof(Matrix3d), h);}
+    return h;
   }
   uint64_t h = 1469598103934665603ull;
   auto mix = [&h](const void * p, size_t bytes) {
@@ -209,7 +342,11 @@ inline void stampResident(
   st->covData = cloud.covariances_.data();
   st->pointCount = cloud.points_.size();
   st->covCount = cloud.covariances_.size();
-  st->sampled = how == ResidentCheck::Sampled;
+  // a host cloud that does NOT hold the prepared scan (HostCopy::Deferred: it still holds the raw sweep, and its contract
+  // says "materialize before you touch it") has no content the device's copy could be compared with: its stamp guards
+  // the object's identity (address, buffers, sizes, 64 samples), whatever the configuration asks for
+  st->wantSampled = how == ResidentCheck::Sampled;
+  st->sampled = st->wantSampled || !hostIsCurrent;
   st->hash = sampleHash(cloud, st->sampled);
   st->generation = scanGeneration(ctx);
   st->kept = kept;
@@ -254,7 +391,7 @@ inline void materialize(vgicp_ctx * ctx, PointCloud & cloud)
         ctx, n, reinterpret_cast<double *>(cloud.points_.data()),
         reinterpret_cast<double *>(cloud.covariances_.data()), &n), "vgicp_scan_download");
   }
-  stampResident(ctx, cloud, n, true, st->sampled ? ResidentCheck::Sampled : ResidentCheck::FullHash);
+  stampResident(ctx, cloud, n, true, st->wantSampled ? ResidentCheck::Sampled : ResidentCheck::FullHash);
 }
 }  // namespace shim
 
@@ -385,11 +522,23 @@ public:
   // reference: src/LocalMap.cpp:10-76. The cloud is moved into the world frame in place, as there.
   void updateLocalMap(PointCloudPtr cloud, const Isometry3d & transform, bool initialize = false)
   {
+    // a cloud that ends its life here (moved in by its only owner, src/Odometry.cpp:86, and not passed on to the shadow
+    // grid's worker) leaves its buffers to the frames to come
+    struct Recycler
+    {
+      PointCloudPtr & c;
+      ~Recycler() {if (c && c.use_count() == 1) {shim::recycleStorage(*c);}}
+    } recycler{cloud};
     // The cloud CloudPreprocessor::process prepared and ICP::align registered is still resident on the device
     // (src/Odometry.cpp:74,79,86 pass the same cloud along): with the grid on the device the insertion runs there
     // on that resident scan, enqueued only — no upload, nothing waited for.  The host cloud is moved into the world
     // frame as the reference does only when it holds the prepared scan (eager host copy).
-    shim::ResidentStamp * resident = deviceResident_ ? shim::residentStampOf(ctx_, *cloud) : nullptr;
+    shim::ResidentStamp * resident = nullptr;
+    {
+      shim::TraceScope ts(shim::Trace::UpdateVerify);
+      resident = deviceResident_ ? shim::residentStampOf(ctx_, *cloud) : nullptr;
+    }
+    shim::TraceScope tsRest(shim::Trace::UpdateRest);
     if (resident) {
       const bool hostIsCurrent = resident->hostIsCurrent;
       trajectory_.push_back(transform);
@@ -696,6 +845,7 @@ private:
         if (needsPointRemoval(it->first, op.position)) {it = voxelGrid_.erase(it);} else {++it;}
       }
     }
+    if (op.cloud && op.cloud.use_count() == 1) {shim::recycleStorage(*op.cloud);}   // its last owner: the buffers stay
     op.cloud.reset();
   }
   void shadowLoop()

@@ -84,8 +84,13 @@ public:
     // src/ErrorStateKF.cpp:130 hand it over untouched): no second upload of its 96 bytes per point, and the frame's
     // one synchronisation is this call's.  Any other cloud — or that one after somebody changed it — goes up as it is.
     int rc;
-    if (shim::ResidentStamp * resident = shim::residentStampOf(ctx, cloud)) {
-      (void)resident;
+    shim::ResidentStamp * resident = nullptr;
+    {
+      shim::TraceScope ts(shim::Trace::AlignVerify);
+      resident = shim::residentStampOf(ctx, cloud);
+    }
+    shim::TraceScope tsCall(shim::Trace::AlignCall);
+    if (resident) {
       rc = vgicp_align_resident(ctx, shim::poseData(guess), &params, pose, &stats);
       lastUsedResidentScan_ = true;
     } else {
