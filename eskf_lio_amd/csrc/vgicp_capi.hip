@@ -796,6 +796,9 @@ int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgi
   VG_CREATE(hipMemset(ctx->d_tiles, 0, preprocess_tile_bytes()));
   VG_CREATE(hipMemset(ctx->d_counters, 0, (kCounterWords + 4) * sizeof(uint32_t)));
   ctx->d_ins_counters = ctx->d_counters + kCounterWords;
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_fetch_hdr), 128, 0));
+  std::memset(ctx->h_fetch_hdr, 0, 128);
+  { void* dev = nullptr; VG_CREATE(hipHostGetDevicePointer(&dev, ctx->h_fetch_hdr, 0)); ctx->h_fetch_hdr_dev = static_cast<unsigned long long*>(dev); }
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_ins_counters), 4 * sizeof(uint32_t), 0));
   ctx->h_ins_counters[0] = ctx->h_ins_counters[1] = 0;
   if (const char* se = std::getenv("VGICP_STAGE_EVENTS"); se && se[0] == '1') {
@@ -955,7 +958,8 @@ int vgicp_destroy(vgicp_ctx* ctx) {
     if (ctx->ev_state_table[k]) (void)hipEventDestroy(ctx->ev_state_table[k]);
   }
   for (auto& e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
-  for (auto& e : ctx->ev_pipe) if (e) (void)hipEventDestroy(e);
+  if (ctx->h_fetch_hdr) (void)hipHostFree(ctx->h_fetch_hdr);
+  if (ctx->h_fetch) (void)hipHostFree(ctx->h_fetch);
   (void)hipFree(ctx->d_stage);
   (void)hipFree(ctx->d_cells);
   (void)hipFree(ctx->d_scan);
@@ -1809,6 +1813,7 @@ int enqueue_prepare(vgicp_ctx* ctx, double* d_pts, size_t n, double voxel_size, 
   a.soa = soa;
   a.soa_stride = soa_stride;
   a.counters = ctx->d_counters;
+  a.host_kept = ctx->h_fetch_hdr_dev;
   a.tiles = ctx->d_tiles;
   a.epoch = ctx->prep_epoch;
   a.debug = debug;
@@ -2529,6 +2534,120 @@ int vgicp_scan_prepare(vgicp_ctx* ctx, size_t n, const double* points, const dou
   return VGICP_OK;
 }
 
+// CloudPreprocessor::process with the host copy the reference leaves behind (src/CloudPreprocessor.cpp:8-23 ends with the
+// prepared scan IN the caller's cloud), for a preparation that was only enqueued (vgicp_scan_prepare_async):
+//   vgicp_scan_fetch_begin   enqueues ONE kernel behind the preparation that will write the prepared scan into page-locked
+//                            memory piece by piece, and returns as soon as the down-sampling has told the host how many
+//                            points it keeps (a posted write of run_scan_kernel, ~0.1 ms before the neighbour search and
+//                            the covariances are through): the caller sizes its vectors in that time;
+//   vgicp_scan_fetch_end     copies every piece out the moment its flag arrives, then brings the context up to date
+//                            (what vgicp_scan_info does) — no copy command, one synchronisation at the very end.
+// Against vgicp_scan_info + vgicp_scan_download (a synchronisation, two copy commands, a second synchronisation and a
+// 2.6 MB memcpy in a row: 0.25 - 0.33 ms for a 27 000-point scan) this is the transfer itself.
+namespace {
+constexpr uint32_t kFetchPiece = 64u << 10;
+constexpr double kFetchPatienceSeconds = 5.0;
+int ensure_fetch_stage(vgicp_ctx* ctx, size_t points) {
+  if (points <= ctx->fetch_cap_points && ctx->h_fetch) return VGICP_OK;
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_fetch) VG_HIP(ctx, hipHostFree(ctx->h_fetch));
+  ctx->h_fetch = nullptr;
+  ctx->fetch_cap_points = 0;
+  const size_t cap = std::max<size_t>(points + points / 4, 4096);
+  const size_t data = (((cap * 24u) + 255u) & ~size_t(255)) + cap * 72u + 256u;
+  const size_t flag_bytes = (data / kFetchPiece + 2) * 64;
+  VG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_fetch), flag_bytes + data, 0));
+  std::memset(ctx->h_fetch, 0, flag_bytes);
+  void* dev = nullptr;
+  VG_HIP(ctx, hipHostGetDevicePointer(&dev, ctx->h_fetch, 0));
+  ctx->h_fetch_dev = static_cast<char*>(dev);
+  ctx->fetch_cap_points = cap;
+  ctx->fetch_flag_bytes = flag_bytes;
+  return VGICP_OK;
+}
+}  // namespace
+
+int vgicp_scan_fetch_begin(vgicp_ctx* ctx, size_t* kept) {
+  if (!ctx || !kept) return VGICP_ERR_BAD_ARGUMENT;
+  *kept = 0;
+  if (ctx->multi || !ctx->scan_pending) {
+    // nothing pending (or a multi-device context, whose prepared scan is dealt out first): the two-step path
+    ctx->fetch_open = false;
+    return vgicp_scan_info(ctx, kept, nullptr, nullptr);
+  }
+  VG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_fetch_stage(ctx, ctx->n_upper);
+  if (rc != VGICP_OK) return rc;
+  if (++ctx->fetch_seq == 0) ++ctx->fetch_seq;
+  VG_HIP(ctx, launch_fetch(ctx->stream, ctx->d_scan_aos, ctx->d_scan_aos + 3 * ctx->scan_capacity, ctx->d_counters, ctx->prep_epoch,
+                           (uint32_t)std::min<size_t>(ctx->fetch_cap_points, ctx->n_upper),
+                           ctx->h_fetch_dev + ctx->fetch_flag_bytes, reinterpret_cast<uint32_t*>(ctx->h_fetch_dev),
+                           ctx->h_fetch_hdr_dev + 8, ctx->fetch_seq, kFetchPiece));
+  ctx->fetch_open = true;
+  // how many points the down-sampling kept (or the fetch kernel's first word: the preparation is through, refused or not)
+  const double t0 = now_seconds();
+  for (uint32_t spins = 0;; ++spins) {
+    const unsigned long long k = __atomic_load_n(ctx->h_fetch_hdr, __ATOMIC_ACQUIRE);
+    if ((uint32_t)(k >> 32) == ctx->prep_epoch) { ctx->fetch_kept = (uint32_t)k; break; }
+    const unsigned long long d = __atomic_load_n(ctx->h_fetch_hdr + 8, __ATOMIC_ACQUIRE);
+    if ((uint32_t)(d >> 32) == ctx->fetch_seq) {   // the fetch kernel has started: the preparation ended without a count
+      ctx->fetch_open = false;
+      return vgicp_scan_info(ctx, kept, nullptr, nullptr);   // reports why (a refused scan), or the count after all
+    }
+    __builtin_ia32_pause();
+    if ((spins & 4095u) == 4095u && now_seconds() - t0 > kFetchPatienceSeconds) {
+      ctx->fetch_open = false;
+      const int rc_info = vgicp_scan_info(ctx, kept, nullptr, nullptr);
+      return rc_info != VGICP_OK ? rc_info : fail(ctx, VGICP_ERR_TIMEOUT, "the preparation did not report its size within 5 s");
+    }
+  }
+  *kept = ctx->fetch_kept;
+  return VGICP_OK;
+}
+
+int vgicp_scan_fetch_end(vgicp_ctx* ctx, size_t capacity, double* points, double* covs, size_t* n) {
+  if (!ctx || !n) return VGICP_ERR_BAD_ARGUMENT;
+  *n = 0;
+  if (!ctx->fetch_open) return vgicp_scan_download(ctx, capacity, points, covs, n);
+  ctx->fetch_open = false;
+  const size_t kept = ctx->fetch_kept;
+  int rc_copy = VGICP_OK;
+  if (kept > 0 && (capacity < kept || !points || !covs)) {
+    rc_copy = fail(ctx, VGICP_ERR_BAD_ARGUMENT, "capacity smaller than the prepared scan (or a NULL output pointer)");
+  } else if (kept > 0) {
+    const size_t pb = kept * 24u, pb_pad = (pb + 255u) & ~size_t(255), total = pb_pad + kept * 72u;
+    const uint32_t pieces = (uint32_t)((total + kFetchPiece - 1) / kFetchPiece);
+    const uint32_t* flags = reinterpret_cast<const uint32_t*>(ctx->h_fetch);
+    const char* stage = ctx->h_fetch + ctx->fetch_flag_bytes;
+    const double t0 = now_seconds();
+    for (uint32_t piece = 0; piece < pieces && rc_copy == VGICP_OK; ++piece) {
+      for (uint32_t spins = 0; __atomic_load_n(flags + 16u * piece, __ATOMIC_ACQUIRE) != ctx->fetch_seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 4095u) == 4095u && now_seconds() - t0 > kFetchPatienceSeconds) {
+          rc_copy = fail(ctx, VGICP_ERR_TIMEOUT, "the prepared scan did not arrive within 5 s");
+          break;
+        }
+      }
+      if (rc_copy != VGICP_OK) break;
+      const size_t off = (size_t)piece * kFetchPiece, len = std::min<size_t>(kFetchPiece, total - off);
+      // a piece may hold the end of the points, the padding and the beginning of the covariances
+      if (off < pb) std::memcpy(reinterpret_cast<char*>(points) + off, stage + off, std::min(len, pb - off));
+      if (off + len > pb_pad) {
+        const size_t from = std::max(off, pb_pad);
+        std::memcpy(reinterpret_cast<char*>(covs) + (from - pb_pad), stage + from, off + len - from);
+      }
+    }
+  }
+  // the preparation's own verdict and counters, the pending map insertion's totals: as every synchronising entry point
+  const int rc = settle(ctx);
+  if (rc != VGICP_OK) return rc;
+  if (rc_copy != VGICP_OK) return rc_copy;
+  if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident");
+  if (ctx->n != kept) return fail(ctx, VGICP_ERR_HIP, "the preparation reported two different sizes");
+  *n = kept;
+  return VGICP_OK;
+}
+
 int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double* covs, size_t* n) {
   if (!ctx) return VGICP_ERR_BAD_ARGUMENT;
   if (ctx->multi) return vgicp_multi_api::scan_download(ctx, capacity, points, covs, n);
@@ -2543,44 +2662,6 @@ int vgicp_scan_download(vgicp_ctx* ctx, size_t capacity, double* points, double*
   VG_HIP(ctx, hipSetDevice(ctx->device));
   arena_reset(ctx);
   const size_t pb = (size_t)ctx->n * 3 * sizeof(double), cb = (size_t)ctx->n * 9 * sizeof(double);
-  if (pb + cb > kArenaMin && pb + cb <= kArenaBytes && !is_pagelocked(points) && !is_pagelocked(covs)) {
-    // the drop-in's eager host copy (CloudPreprocessor::process, every frame): the DMA engine moves piece k + 1 into
-    // the page-locked arena while this thread copies piece k out to the caller — the two halves of the staged copy
-    // overlap instead of following each other (2.6 MB: one synchronisation + one 2.6 MB memcpy less on the frame's path)
-    char* stage = arena_take(ctx, pb + cb);
-    if (stage) {
-      constexpr size_t kPiece = 384u << 10;
-      constexpr int kEvents = 8;
-      for (int k = 0; k < kEvents; ++k)
-        if (!ctx->ev_pipe[k]) VG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pipe[k], hipEventDisableTiming));
-      struct Piece { char* dst; const char* src; size_t bytes; };
-      std::vector<Piece> pieces;
-      const char* dev_p = reinterpret_cast<const char*>(ctx->d_scan_aos);
-      const char* dev_c = reinterpret_cast<const char*>(ctx->d_scan_aos + 3 * ctx->scan_capacity);
-      for (size_t off = 0; off < pb; off += kPiece) pieces.push_back({reinterpret_cast<char*>(points) + off, dev_p + off, std::min(kPiece, pb - off)});
-      for (size_t off = 0; off < cb; off += kPiece) pieces.push_back({reinterpret_cast<char*>(covs) + off, dev_c + off, std::min(kPiece, cb - off)});
-      size_t enq = 0, done = 0, at = 0;
-      std::vector<size_t> where(pieces.size());
-      while (done < pieces.size()) {
-        for (; enq < pieces.size() && enq < done + (size_t)kEvents; ++enq) {   // at most kEvents pieces in flight
-          where[enq] = at;
-          VG_HIP(ctx, hipMemcpyAsync(stage + at, pieces[enq].src, pieces[enq].bytes, hipMemcpyDeviceToHost, ctx->stream));
-          VG_HIP(ctx, hipEventRecord(ctx->ev_pipe[enq % kEvents], ctx->stream));
-          at += (pieces[enq].bytes + 255) & ~size_t(255);
-        }
-        // polled, not slept on: a piece is 15 us of DMA, and an event wait that goes to sleep costs more than that
-        for (;;) {
-          const hipError_t q = hipEventQuery(ctx->ev_pipe[done % kEvents]);
-          if (q == hipSuccess) break;
-          if (q != hipErrorNotReady) return fail_hip(ctx, q, "hipEventQuery(download piece)");
-          __builtin_ia32_pause();
-        }
-        std::memcpy(pieces[done].dst, stage + where[done], pieces[done].bytes);
-        ++done;
-      }
-      return VGICP_OK;
-    }
-  }
   VG_RC(user_d2h(ctx, points, ctx->d_scan_aos, pb));
   VG_RC(user_d2h(ctx, covs, ctx->d_scan_aos + 3 * ctx->scan_capacity, cb));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -347,7 +347,16 @@ struct vgicp_ctx {
   size_t upload_whole_hint = 0;             // a sub-context's shard: the size of the caller's WHOLE scan decides, not the shard's
   struct PendingOut { void* dst; const char* src; size_t bytes; };
   std::vector<PendingOut> pending_out;
-  hipEvent_t ev_pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // vgicp_scan_download's pieces
+  // vgicp_scan_fetch_*: the prepared scan written into page-locked memory by a kernel, piece by piece
+  unsigned long long* h_fetch_hdr = nullptr;      // pinned, two 64-byte lines: [0] epoch << 32 | kept (run_scan_kernel), [8] seq << 32 | refused (fetch_kernel)
+  unsigned long long* h_fetch_hdr_dev = nullptr;  // the same as the device addresses it
+  char* h_fetch = nullptr;           // pinned: [one 64-byte flag line per piece][points, padded to 256 bytes][covariances]
+  char* h_fetch_dev = nullptr;
+  size_t fetch_cap_points = 0;       // points the staging area can hold
+  size_t fetch_flag_bytes = 0;
+  uint32_t fetch_seq = 0;
+  bool fetch_open = false;           // a fetch kernel is enqueued behind the pending preparation
+  uint32_t fetch_kept = 0;
   // sweeps staged AHEAD of their preparation (vgicp_sweep_stage: the lidar callback's thread copies a sweep into
   // page-locked memory when it arrives; vgicp_scan_prepare_staged_async consumes it by ticket).  Guarded by
   // ahead_mutex: the one part of a context that another thread may enter while the owner thread is inside a call.

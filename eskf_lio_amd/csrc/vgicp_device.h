@@ -277,6 +277,8 @@ struct PrepareArgs {
   double* soa;                   // optional
   uint64_t soa_stride;
   uint32_t* counters;
+  unsigned long long* host_kept; // optional, page-locked host memory as the device addresses it: receives epoch << 32 | kept
+                                 // points as soon as the down-sampling knows it (vgicp_scan_fetch_begin waits for that)
   void* tiles;                   // preprocess_tile_bytes()
   uint32_t epoch;
   int debug;
@@ -295,6 +297,14 @@ struct PrepareArgs {
   // widens them (float -> double is exact).  src_step == 0: n x 3 doubles.
   uint32_t src_step, src_off[3];
 };
+// The prepared scan (AoS on the device: kept x 3 doubles, kept x 9 doubles; kept and the refusal flags read from the
+// counter block) written by a KERNEL into page-locked host memory in pieces of piece_bytes, every piece published by
+// storing seq into flags[16 * piece] — the download of vgicp_scan_fetch_end, the mirror image of pack_arena_kernel.
+// Layout of `stage`: the points, padded to a multiple of 256 bytes, then the covariances.  hdr_done receives
+// seq << 32 | 1 (refused / nothing prepared) or seq << 32 first thing.
+hipError_t launch_fetch(hipStream_t s, const double* aos_pts, const double* aos_cov, const uint32_t* counters, uint32_t epoch,
+                        uint32_t n_cap, char* stage, uint32_t* flags, unsigned long long* hdr_done, uint32_t seq,
+                        uint32_t piece_bytes);
 hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a);        // = head + tail
 // head: the kernels that read the raw sweep (deskew bounds from the times, prologue); tail: everything behind them.
 // A host that stages the sweep itself launches the head, finishes staging and launches the tail, so that the device

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
     const double* __restrict__ pts, const unsigned long long* __restrict__ codes, const uint32_t* __restrict__ idx,
     uint32_t n, double* __restrict__ sorted_pts, uint32_t* __restrict__ queries, uint32_t* __restrict__ keep_by_index,
     uint32_t* counters, TileSlot* tiles, uint32_t epoch, uint32_t scan_tiles, CellEntry* table, uint32_t mask,
-    uint32_t cell_blocks_x) {
+    uint32_t cell_blocks_x, unsigned long long* host_kept) {
   if (blockIdx.x >= scan_tiles) {  // (whole workgroups; before anything synchronises)
     const uint32_t v = blockIdx.x - scan_tiles;
     cell_build_body(codes, n, table, mask, v % cell_blocks_x, (int)(v / cell_blocks_x));
@@ -584,7 +584,10 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
     // scan): nothing this tile would store is trustworthy, and the indices it would store THROUGH are not even in
     // range.  No store at all; the tile that owns the scan's total leaves an empty scan behind, so that a kernel
     // enqueued behind the preparation (the align that does not wait for the host) finds nothing to read.
-    if (tid == 0 && (size_t)(tile + 1) * kScanTile >= n) counters[0] = counters[1] = 0u;
+    if (tid == 0 && (size_t)(tile + 1) * kScanTile >= n) {
+      counters[0] = counters[1] = 0u;
+      if (host_kept) __hip_atomic_store(host_kept, (unsigned long long)epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;
   }
   RunMin base_prefix = prefix_sh;
@@ -600,6 +603,9 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
     if (j + 1 == n) {
       counters[0] = v.count;
       counters[1] = v.runs;
+      // the host may be waiting for exactly this number (vgicp_scan_fetch_begin: it sizes its vectors while the
+      // neighbour search runs): one posted write into page-locked memory, tagged with the call's epoch
+      if (host_kept) __hip_atomic_store(host_kept, ((unsigned long long)epoch << 32) | v.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     queries[v.count - 1u] = (uint32_t)v.packed;
     keep_by_index[(uint32_t)(v.packed >> 32)] = 1u;
@@ -1304,6 +1310,37 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   }
 }
 
+// The prepared scan out to the host without a copy command and without a synchronisation: see launch_fetch
+// (vgicp_device.h).  A copy command costs ~20 - 40 us apiece on this platform and the host can neither start its own copy
+// before the command has completed nor learn the size without a round trip; a kernel's posted writes run at the link's
+// rate and the host reads every piece the moment its flag arrives.
+constexpr int kFetchBlock = 256;
+__global__ __launch_bounds__(kFetchBlock) void fetch_kernel(const double* __restrict__ aos_pts, const double* __restrict__ aos_cov,
+                                                            const uint32_t* __restrict__ counters, uint32_t epoch, uint32_t n_cap,
+                                                            char* __restrict__ stage, uint32_t* flags, unsigned long long* hdr_done,
+                                                            uint32_t seq, uint32_t piece_bytes) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const bool refused = counters[kBeyondGrid] == epoch || counters[kScanTimeout] == epoch;
+  const uint32_t kept = refused ? 0u : (counters[0] < n_cap ? counters[0] : n_cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(hdr_done, ((unsigned long long)seq << 32) | (refused ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const size_t pb = (size_t)kept * 24u, pb_pad = (pb + 255u) & ~size_t(255), total = pb_pad + (size_t)kept * 72u;
+  const uint32_t pieces = (uint32_t)((total + piece_bytes - 1) / piece_bytes);
+  const char* sp = reinterpret_cast<const char*>(aos_pts);
+  const char* sc = reinterpret_cast<const char*>(aos_cov);
+  for (uint32_t piece = blockIdx.x; piece < pieces; piece += gridDim.x) {
+    const size_t off = (size_t)piece * piece_bytes;
+    const size_t len = total - off < piece_bytes ? total - off : piece_bytes;
+    for (size_t k = (size_t)threadIdx.x * 16u; k < len; k += (size_t)kFetchBlock * 16u) {
+      const size_t pos = off + k;   // both parts start on a multiple of 16 bytes; a chunk never straddles them
+      const v4i w = pos < pb_pad ? *reinterpret_cast<const v4i*>(sp + pos) : *reinterpret_cast<const v4i*>(sc + (pos - pb_pad));
+      *reinterpret_cast<v4i*>(stage + pos) = w;
+    }
+    __threadfence_system();   // every thread: its stores have reached the host before the flag may
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + 16u * piece, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 // Eigen::JacobiSVD<Matrix3d>(A, ComputeFullU | ComputeFullV) in its published operation order (Eigen 3.4
 // src/SVD/JacobiSVD.h compute() / real_2x2_jacobi_svd(), src/Jacobi/Jacobi.h makeJacobi(), rotation product and
 // apply_rotation_in_the_plane()): what src/CloudPreprocessor.cpp:119-123 runs on every covariance.  Two-sided
@@ -1705,6 +1742,17 @@ uint32_t merge_sort_launches(uint32_t n) {
 }
 }  // namespace
 
+hipError_t launch_fetch(hipStream_t s, const double* aos_pts, const double* aos_cov, const uint32_t* counters, uint32_t epoch,
+                        uint32_t n_cap, char* stage, uint32_t* flags, unsigned long long* hdr_done, uint32_t seq,
+                        uint32_t piece_bytes) {
+  const size_t worst = (((size_t)n_cap * 24u + 255u) & ~size_t(255)) + (size_t)n_cap * 72u;
+  const uint32_t grid = (uint32_t)std::min<size_t>(std::max<size_t>((worst + piece_bytes - 1) / piece_bytes, 1), 48);
+  ++g_kernel_launches;
+  hipLaunchKernelGGL(fetch_kernel, dim3(grid), dim3(kFetchBlock), 0, s, aos_pts, aos_cov, counters, epoch, n_cap, stage, flags,
+                     hdr_done, seq, piece_bytes);
+  return hipGetLastError();
+}
+
 hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a) {
   const hipError_t e = launch_prepare_head(s, a);
   return e != hipSuccess ? e : launch_prepare_tail(s, a);
@@ -1841,7 +1889,8 @@ hipError_t launch_prepare_tail(hipStream_t s, const PrepareArgs& a) {
   // ---- runs, kept points, query list (one launch); output slots in scan order (one launch) ----
   const uint32_t scan_tiles = blocks_for(n, kScanTile), cell_blocks_x = blocks_for(n, kScanThreads);
   hipLaunchKernelGGL(run_scan_kernel, dim3(scan_tiles + cell_blocks_x * kLevels), dim3(kScanThreads), 0, s, a.pts, codes_out,
-                     idx_out, n, spts, queries, keep_i, a.counters, tiles_a, a.epoch, scan_tiles, table, mask, cell_blocks_x);
+                     idx_out, n, spts, queries, keep_i, a.counters, tiles_a, a.epoch, scan_tiles, table, mask, cell_blocks_x,
+                     a.host_kept);
   hipLaunchKernelGGL(keep_scan_kernel, dim3(blocks_for(n, kScanTile)), dim3(kScanThreads), 0, s, keep_i, n, rank_i,
                      a.counters, tiles_b, a.epoch);
   // ---- octree cells of all levels, the exact search (one wave per kept point; the grid covers every raw point,

@@ -219,10 +219,13 @@ public:
       shim::stampResident(ctx_, cloud, 0, false, residentCheck_);   // the host keeps the raw sweep; the prepared scan is on the device
       return;
     }
+    // The eager host copy: one kernel behind the preparation writes the prepared scan into page-locked memory; the
+    // count arrives first (the down-sampling knows it long before the neighbour search is through), the vectors are
+    // sized while the device still works, and the pieces are copied out as they land (vgicp_scan_fetch_*).
     size_t kept = 0;
     {
       shim::TraceScope ts(shim::Trace::ProcessWait);
-      shim::check(ctx_, vgicp_scan_info(ctx_, &kept, nullptr, nullptr), "vgicp_scan_info");   // the frame's extra synchronisation
+      shim::check(ctx_, vgicp_scan_fetch_begin(ctx_, &kept), "vgicp_scan_fetch_begin");
     }
     {
       shim::TraceScope ts(shim::Trace::ProcessResize);
@@ -230,12 +233,12 @@ public:
       cloud.points_.resize(kept);
       cloud.covariances_.resize(kept);
     }
-    if (kept) {
+    {
       shim::TraceScope ts(shim::Trace::ProcessDownload);
       shim::check(
-        ctx_, vgicp_scan_download(
-          ctx_, kept, reinterpret_cast<double *>(cloud.points_.data()),
-          reinterpret_cast<double *>(cloud.covariances_.data()), &kept), "vgicp_scan_download");
+        ctx_, vgicp_scan_fetch_end(
+          ctx_, kept, kept ? reinterpret_cast<double *>(cloud.points_.data()) : nullptr,
+          kept ? reinterpret_cast<double *>(cloud.covariances_.data()) : nullptr, &kept), "vgicp_scan_fetch_end");
     }
     shim::TraceScope ts(shim::Trace::ProcessStamp);
     shim::stampResident(ctx_, cloud, kept, true, residentCheck_);

@@ -334,6 +334,17 @@ int vgicp_scan_prepare_staged_async(vgicp_ctx* ctx, uint64_t ticket, size_t num_
 int vgicp_sweep_stage_cloud2(vgicp_ctx* ctx, size_t n, const void* data, size_t point_step, size_t off_x, size_t off_y,
                              size_t off_z, size_t off_time, uint64_t* ticket);
 int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], size_t max_points_per_voxel);
+/* The host copy CloudPreprocessor::process leaves behind (src/CloudPreprocessor.cpp:8-23 ends with the prepared scan in
+ * the caller's cloud) for a preparation that was only enqueued, without a copy command and without waiting twice:
+ *   vgicp_scan_fetch_begin   enqueues one kernel behind the pending preparation that writes the prepared scan into
+ *                            page-locked memory of the context piece by piece, and returns as soon as the down-sampling
+ *                            has reported how many points it keeps (*kept) — while the neighbour search and the
+ *                            covariances are still running: the caller sizes its vectors in that time;
+ *   vgicp_scan_fetch_end     copies the pieces into points (kept x 3) / covs (kept x 9, column-major) as they arrive and
+ *                            brings the context up to date as vgicp_scan_info does (a refused scan fails this call).
+ * Without a pending preparation (or on a multi-device context) the pair is vgicp_scan_info + vgicp_scan_download. */
+int vgicp_scan_fetch_begin(vgicp_ctx* ctx, size_t* kept);
+int vgicp_scan_fetch_end(vgicp_ctx* ctx, size_t capacity, double* points, double* covs, size_t* n);
 
 /* What the calls of THIS HOST THREAD into the module (whatever the context) have cost the host since this context's
  * counters were last reset (reset != 0 resets them):

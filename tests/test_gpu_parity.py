@@ -1131,6 +1131,52 @@ def test_sweep_staged_on_arrival_prepares_to_the_same_bits(oracle):
         assert len([c.sweep_stage(sweeps[1], times[1]) for _ in range(2)]) == 2
 
 
+def test_scan_fetch_returns_the_prepared_scan_without_a_copy_command(oracle):
+    """vgicp_scan_fetch_begin / _end (ABI 6): the host copy of an ENQUEUED preparation, written into page-locked memory by a
+    kernel behind it and copied out piece by piece — equal to vgicp_scan_info + vgicp_scan_download bit for bit (and so to
+    the oracle), for sizes below / at / beyond a 64 KB piece boundary, with and without the deskew, after a refused scan,
+    and the context is settled afterwards (align, insertion and a second frame work as after vgicp_scan_info)."""
+    from eskf_lio_amd import capi, synth
+    st = synth.make_imu_states(48, seed=5)
+    ext = synth.se3_to_SE3([0.01, -0.02, 0.03, 0.002, -0.001, 0.003])
+    with capi.Context(0) as a, capi.Context(0) as b:
+        for ctx in (a, b):
+            ctx.map_reset(0.3, 100_000)
+        for k, n in enumerate((700, 2_731, 9_000, 30_001, 61_234)):
+            raw = synth.make_lidar_scan(n, seed=60 + k)
+            tt = synth.make_point_times(n, st[1, 0] + 1e-4, st[-3, 0] + 0.4 / 400.0, seed=11 + k)
+            with_states = st if k % 2 == 0 else None
+            a.scan_prepare_async(raw, tt if with_states is not None else None, with_states, ext, 0.3, 30)
+            fp, fc = a.scan_fetch()
+            b.scan_prepare_async(raw, tt if with_states is not None else None, with_states, ext, 0.3, 30)
+            kept = b.scan_info()[0]
+            dp, dc = b.scan_download()
+            assert kept == len(fp) == len(dp) and np.array_equal(fp, dp) and np.array_equal(fc, dc), n
+            if k == 2:   # against the oracle chain once
+                moved, _ = oracle.transform(raw, np.tile(np.eye(3).reshape(9), (n, 1)), ext)
+                desk, _ = oracle.deskew(moved, tt, st)
+                rp, rc, _ = oracle.preprocess(desk, 0.3, 30)
+                assert np.array_equal(fp, rp) and np.array_equal(fc, rc)
+            # the context is up to date: the resident chain goes on from here
+            for ctx in (a, b):
+                if k:
+                    ctx.align_resident(np.eye(4), 5, 1e-6, 0.9999)
+                ctx.map_insert_resident_async(np.eye(4), 20)
+            assert a.map_size()[0] == b.map_size()[0]
+        # fetch without anything pending: the two-step path's answer
+        fp2, fc2 = a.scan_fetch()
+        assert np.array_equal(fp2, fp) and np.array_equal(fc2, fc)
+        # a refused scan (a point beyond the search grid): the fetch reports it like vgicp_scan_info, nothing hangs
+        bad = synth.make_lidar_scan(5_000, seed=3).copy()
+        bad[17, 0] = 1e9
+        a.scan_prepare_async(bad, None, None, None, 0.3, 30)
+        with pytest.raises(capi.VgicpError) as e:
+            a.scan_fetch()
+        assert e.value.code == capi.ERR_BAD_ARGUMENT
+        a.scan_prepare_async(raw, None, None, ext, 0.3, 30)          # and the context recovers
+        assert len(a.scan_fetch()[0]) > 0
+
+
 def test_wire_format_sweep_is_widened_on_the_device(oracle):
     """vgicp_sweep_stage_cloud2: the payload of a PointCloud2 handed over as the sensor wrote it (float32 x y z and a
     float64 timestamp inside records of point_step bytes, other fields and padding around them); the device picks the
