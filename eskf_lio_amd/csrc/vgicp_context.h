@@ -105,6 +105,7 @@ struct CopyCrew {
   // job number << 32 | units of that job completed: a completion that lands after its job was given up (deadline) finds
   // another job's number here and is dropped instead of being counted for the job that follows
   std::atomic<uint64_t> finished{0};
+  std::atomic<uint32_t> taken{0};      // units whose job fields a thread has read so far (see work())
   uint32_t job = 0;                    // jobs posted so far (the caller's thread only)
   bool quit = false;
   bool broken = false;                 // a helper missed finish()'s deadline: no helper is woken again (caller's thread only)
@@ -143,6 +144,10 @@ struct CopyCrew {
       const size_t p0 = (size_t)u * unit, cnt = std::min<size_t>(unit, n - p0);
       void (*j_copy)(void*, const void*, size_t) = copy;
       uint32_t (*j_copy_b_form)(void*, const void*, size_t) = copy_b_form;
+      // "I have read the job": a finish() that gives up on this thread writes the next job's fields afterwards, and
+      // this is the edge that orders those writes behind the reads above (a completed unit orders them through
+      // `finished`; a thread that never completes has nothing else to show)
+      taken.fetch_add(1, std::memory_order_release);
       j_copy(j_apts + p0 * j_size_a, j_pts + p0 * j_size_a, cnt * j_size_a);
       if (j_size_b && j_copy_b_form)
         __atomic_store_n(j_flags + 16 * (size_t)u + 1, j_copy_b_form(j_acov + p0 * j_size_b, j_cov + p0 * j_size_b, cnt), __ATOMIC_RELAXED);
@@ -209,7 +214,7 @@ struct CopyCrew {
       if ((spins & 255u) == 0) {
         const double t = now_seconds();
         if (t0 == 0.0) t0 = t;
-        else if (t - t0 > deadline_seconds) { ok = false; broken = true; break; }
+        else if (t - t0 > deadline_seconds) { ok = false; broken = true; (void)taken.load(std::memory_order_acquire); break; }
       }
     }
     next.store(((uint64_t)job << 32) | kClosed, std::memory_order_release);
