@@ -248,12 +248,15 @@ int ensure_scan(vgicp_ctx* ctx, size_t n) {
   if (n <= ctx->scan_capacity && ctx->d_scan) return VGICP_OK;
   if (ctx->d_scan) VG_HIP(ctx, hipFree(ctx->d_scan));
   if (ctx->d_scan_aos) VG_HIP(ctx, hipFree(ctx->d_scan_aos));
+  if (ctx->d_memo) VG_HIP(ctx, hipFree(ctx->d_memo));
   ctx->d_scan = ctx->d_scan_aos = nullptr;
+  ctx->d_memo = nullptr;
   ctx->scan_capacity = 0;
   size_t cap = std::max<size_t>(n + n / 4, 1024);
   cap = (cap + 63) & ~size_t(63);  // planes stay 512-byte aligned
   VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_scan), cap * kScanPlanes * sizeof(double)));
   VG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_scan_aos), cap * kScanPlanes * sizeof(double)));
+  VG_HIP(ctx, hipMalloc(&ctx->d_memo, cap * 16));
   ctx->scan_capacity = cap;
   return VGICP_OK;
 }
@@ -298,6 +301,14 @@ IterArgs base_args(const vgicp_ctx* ctx) {
   a.voxel_size = ctx->voxel_size;
   a.log = ctx->d_log;
   a.stamps = ctx->d_stamps;
+  a.memo = static_cast<int4*>(ctx->d_memo);
+  a.memo_valid = 0;   // the caller knows which launch of the align this is
+  a.scan_seq = ctx->scan_seq;
+  a.asym_dev = (ctx->scan_sym_known && !ctx->dev.no_sym) ? ctx->d_ins_counters + 2 : nullptr;
+  // the dense record copy (tables far beyond the caches' reach): used where it is current — the aligns that reach the
+  // loop after a persistent launch has rebuilt it, or run_align's own ensure_dense
+  a.dense = (ctx->d_dense && ctx->dense_version == ctx->map_version && ctx->slots >= ctx->dense_slots_threshold &&
+             ctx->dense_slots_threshold != 0) ? ctx->d_dense : nullptr;
   return a;
 }
 
@@ -345,6 +356,7 @@ int enqueue_launch(vgicp_ctx* ctx, const IterArgs& base, int j, uint32_t body_gr
   a.state_in = ctx->d_state + (j & 1);
   a.state_out = ctx->d_state + ((j + 1) & 1);
   a.rows = ctx->d_rows[j & 1];
+  a.memo_valid = j > 0 ? 1u : 0u;   // launch 0 of an align writes every point's memo
   if (use_comm) {
     a.prev = ctx->d_sums;
     a.prev_rows = j > 0 ? 1u : 0u;
@@ -645,6 +657,13 @@ int run_align(vgicp_ctx* ctx, const double* guess, const vgicp_params* params, d
   h0->done = (max_it == 0) ? 1 : 0;
   VG_HIP(ctx, hipMemcpyAsync(ctx->d_state, h0, sizeof(AlignState), hipMemcpyHostToDevice, ctx->stream));
 
+  // a table far beyond the caches' reach: the loop reads remembered records from the dense copy too (rebuilt here
+  // when the map changed since; storage was made with the table, nothing is allocated)
+  if (ctx->table && ctx->dense_slots_threshold != 0 && ctx->slots >= ctx->dense_slots_threshold && ctx->voxels > 0) {
+    bool usable = false;
+    rc = ensure_dense(ctx, &usable);
+    if (rc != VGICP_OK) return rc;
+  }
   const IterArgs base = base_args(ctx);
   const uint32_t grid = iterate_grid(ctx);
   const bool use_comm = ctx->comm != nullptr;
@@ -964,6 +983,7 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   (void)hipFree(ctx->d_cells);
   (void)hipFree(ctx->d_scan);
   (void)hipFree(ctx->d_scan_aos);
+  (void)hipFree(ctx->d_memo);
   (void)hipFree(ctx->d_state);
   (void)hipHostFree(ctx->h_state);
   (void)hipFree(ctx->d_rows_persist);
@@ -2997,6 +3017,7 @@ int align_host_summed(vgicp_ctx* const* subs, int n, const double guess[16], con
       a.rows = ctx->d_rows[j & 1];
       a.prev = ctx->d_sums;           // the row the host summed over the ranks
       a.prev_rows = j > 0 ? 1u : 0u;
+      a.memo_valid = j > 0 ? 1u : 0u;
       if (profile && r == 0) VG_HIP(ctx, hipEventRecord(ctx->ev_prof[2 * j], ctx->stream));
       if (closing) VG_HIP(ctx, launch_close(ctx->stream, a, ctx->iter_block));
       else {

@@ -276,6 +276,7 @@ struct vgicp_ctx {
   // resident scan
   double* d_scan_aos = nullptr;  // points (3n) then covs (9n)
   double* d_scan = nullptr;      // SoA planes
+  void* d_memo = nullptr;        // per point {key, slot}: the launch-per-round loop's memory between launches (IterArgs::memo)
   size_t scan_capacity = 0;      // points
   uint32_t n = 0;
   uint64_t stride = 0;

@@ -76,6 +76,14 @@ struct IterArgs {
   double* log;        // [max_iteration][kSlots]
   uint64_t* stamps;   // diagnostic aid (VGICP_DEBUG_STAMPS=1): phase times of workgroup 0 in 10 ns
                       // ticks, summed over launches; nullptr in normal operation
+  // round 6: what the persistent launch keeps on chip, kept in HBM between the launches of one align
+  int4* memo;               // [n] per point: voxel key of the last round + its record's slot (index in `dense` when that
+                            // is set) / kMemoMiss; written by the launch that finds a point's key changed (all points in
+                            // an align's first launch), nullptr = look every point up in every launch
+  uint32_t memo_valid;      // != 0: an earlier launch of THIS align filled the memos
+  uint32_t scan_seq;        // with asym_dev: *asym_dev != scan_seq = every covariance of the scan is bitwise symmetric
+  const uint32_t* asym_dev; // (nine planes are read instead of twelve); nullptr = unknown, read all
+  const VoxelRecord* dense; // dense copy of the FULL records (tables beyond the caches' reach), or nullptr
 };
 
 // Arguments of the persistent single-launch align (single GPU): every round of the loop runs inside

@@ -514,18 +514,36 @@ __device__ __forceinline__ void accumulate_match(const double* R, const double (
   acc(v[kCountSlot], 1.0);
 }
 
+constexpr uint32_t kMemoMiss = 0xFFFFFFFFu;  // memo.w of a point whose voxel is not in the map
+constexpr uint32_t kMemoNone = 0xFFFFFFFEu;  // nothing looked up
+
+// Payload of a record whose slot is known (an unchanged key that hit last round): one round trip.
+__device__ __forceinline__ void load_payload(const VoxelRecord* rec, double (&mu)[3], double (&S)[9]) {
+  const double2* pay = reinterpret_cast<const double2*>(rec->mean);
+  const double2 a0 = pay[0], a1 = pay[1], a2 = pay[2], a3 = pay[3], a4 = pay[4], a5 = pay[5];
+  mu[0] = a0.x; mu[1] = a0.y; mu[2] = a1.x;
+  S[0] = a1.y; S[1] = a2.x; S[2] = a2.y; S[3] = a3.x; S[4] = a3.y; S[5] = a4.x;
+  S[6] = a4.y; S[7] = a5.x; S[8] = a5.y;
+}
+
 // One VGICP round.  Launch j reads state j&1 and the rows launch j-1 wrote, writes state (j+1)&1
 // and its own rows; the host alternates the buffers; the kernel boundary is the only synchronisation
 // between workgroups.  Inside a workgroup wave 0 is the SOLVER (it owns no points); waves 1.. are
 // workers, BLOCK-64 points per workgroup pass:
-//   all      issue the loads of the previous rows, the state and (workers) the first point; fold rows
+//   all      issue the loads of the previous rows, the state and (workers) the first point AND ITS MEMO; fold rows
 //   solver   LDLT solve, exponential, compose, convergence -> new pose in LDS       } concurrently,
-//   workers  transform the point with the OLD pose, probe the table, start loading  } between two
-//            the voxel record it lands in                                           } barriers
-//   workers  transform with the NEW pose; the key almost never changes between rounds (steps are far
-//            smaller than a voxel), so the prefetched record is already in registers — the table's
-//            latency hides behind the solve; a changed key is simply probed again
+//   workers  fetch the payload of the voxel the memo names (nothing to compute)     } between two barriers
+//   workers  transform with the NEW pose; "still inside last round's voxel?" (same_voxel_coord, the persistent launch's
+//            test) — almost always yes: the payload is in registers, or the point is known to have no voxel and costs
+//            nothing; a changed key is probed and remembered
 //   workers  accumulate, grid-stride over further points, butterfly, one 256-byte row per workgroup.
+// Round 6 brought the loop to the persistent launch's data path (it is what an RCCL communicator, a multi-device
+// context after a give-up and every VGICP_FLAG_NO_PERSISTENT align run): a 16-byte MEMO per point in HBM {key, slot or
+// index in the dense record copy} — the map is immutable during an align (src/LocalMap.cpp:94-100), so an unchanged
+// key that missed costs 16 bytes instead of a 128-byte line, and one that hit goes straight to its payload (rounds
+// 1-5 transformed with the OLD pose, hashed and probed every point in every launch: 1.66 x the algorithmic bytes at C2);
+// nine instead of twelve planes of a scan whose covariances are all bitwise symmetric; the dense record copy of tables
+// beyond the caches' reach.  The arithmetic per match is unchanged, so the loop still returns the persistent launch's bits.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
   constexpr int kWaves = BLOCK / 64;
@@ -538,12 +556,20 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
   const bool worker = wave != 0;
   const uint32_t stride_pts = gridDim.x * kWorkers;
   const double inv_voxel = 1.0 / a.voxel_size;
+  const double same_margin = 0x1p-20 * a.voxel_size;  // same_voxel_coord
+  const bool cov_sym = a.asym_dev != nullptr && *a.asym_dev != a.scan_seq;  // uniform
+  const bool remembered = a.memo != nullptr && a.memo_valid != 0;           // uniform: an earlier launch of this align wrote the memos
+  const VoxelRecord* pay_base = a.dense ? a.dense : a.table;                // uniform: where a remembered record's payload is read from
   uint32_t i = worker ? blockIdx.x * kWorkers + (tid - 64) : a.n;
 
   double q[kScanPlanes];
 #pragma unroll
   for (int k = 0; k < kScanPlanes; ++k) q[k] = 0.0;
-  if (i < a.n) load_point(a.scan, a.stride, i, q);
+  int4 m = make_int4(0, 0, 0, (int32_t)kMemoNone);
+  if (i < a.n) {
+    load_point_sym(a.scan, a.stride, i, q, cov_sym);
+    if (remembered) m = a.memo[i];
+  }
 
   int it, max_it;
   double cos_thr, tsq_thr;
@@ -553,20 +579,15 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
   if (solving) __syncthreads();
   const uint64_t t_fold = a.stamps ? wall_clock64() : 0;
 
-  // speculative lookup with the old pose (workers) || solve (wave 0)
-  int32_t okx = 0, oky = 0, okz = 0;
-  bool hit = false;
+  // the payload the memo names (workers) || solve (wave 0)
   double mu[3] = {0.0, 0.0, 0.0}, S[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) S[k] = 0.0;
+  bool have_payload = false;
   if (worker) {
-    if (i < a.n) {
-      double p[3];
-      transform_point(head.total.R, head.total.t, q[0], q[1], q[2], p);
-      okx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
-      oky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
-      okz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
-      hit = find_and_load(a.table, a.mask, okx, oky, okz, mu, S);
+    if (i < a.n && remembered && (uint32_t)m.w < kMemoNone) {
+      load_payload(pay_base + (uint32_t)m.w, mu, S);
+      have_payload = true;
     }
   } else if (solving) {
     prologue_solve<BLOCK>(a, sh, head.total, lane, it, max_it, cos_thr, tsq_thr);
@@ -596,17 +617,43 @@ __global__ __launch_bounds__(BLOCK) void iterate_kernel(IterArgs a) {
     double C[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) C[k] = q[3 + k];
-    const uint32_t inext = i + stride_pts;
-    if (inext < a.n) load_point(a.scan, a.stride, inext, q);  // prefetch the next point under this one's gather
+    const uint32_t icur = i, inext = i + stride_pts;
+    const int4 mcur = m;
+    if (inext < a.n) {  // prefetch the next point (and its memo) under this one's gather
+      load_point_sym(a.scan, a.stride, inext, q, cov_sym);
+      if (remembered) m = a.memo[inext];
+    }
     i = inext;
 
     double p[3];
     transform_point(R, t, x, y, z, p);
-    const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
-    const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
-    const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
-    if (!first || kx != okx || ky != oky || kz != okz)
-      hit = find_and_load(a.table, a.mask, kx, ky, kz, mu, S);
+    bool hit;
+    // still inside last round's voxel?  (true implies an unchanged key; the key itself is made only otherwise)
+    const bool stayed = remembered && (uint32_t)mcur.w != kMemoNone &&
+                        (((int)same_voxel_coord(p[0], mcur.x, a.voxel_size, same_margin) &
+                          (int)same_voxel_coord(p[1], mcur.y, a.voxel_size, same_margin) &
+                          (int)same_voxel_coord(p[2], mcur.z, a.voxel_size, same_margin)) != 0);
+    if (stayed) {
+      hit = (uint32_t)mcur.w != kMemoMiss;
+      if (hit && !(first && have_payload)) load_payload(pay_base + (uint32_t)mcur.w, mu, S);
+    } else {
+      const int32_t kx = voxel_coord_fast(p[0], a.voxel_size, inv_voxel);
+      const int32_t ky = voxel_coord_fast(p[1], a.voxel_size, inv_voxel);
+      const int32_t kz = voxel_coord_fast(p[2], a.voxel_size, inv_voxel);
+      if (remembered && (uint32_t)mcur.w != kMemoNone && mcur.x == kx && mcur.y == ky && mcur.z == kz) {
+        hit = (uint32_t)mcur.w != kMemoMiss;   // a point right below a face: key unchanged after all
+        if (hit && !(first && have_payload)) load_payload(pay_base + (uint32_t)mcur.w, mu, S);
+      } else {
+        const VoxelRecord* rec = find_voxel(a.table, a.mask, kx, ky, kz);
+        hit = rec != nullptr;
+        if (a.memo) {
+          uint32_t where = kMemoMiss;
+          if (hit) where = a.dense ? reinterpret_cast<const uint32_t*>(&rec->reserved)[1] : (uint32_t)(rec - a.table);
+          a.memo[icur] = make_int4(kx, ky, kz, (int32_t)where);
+        }
+        if (hit) load_payload(rec, mu, S);
+      }
+    }
     if (hit) {
       if (first) accumulate_match<true>(R, p, C, mu, S, v);  // the thread's first point of the round
       else accumulate_match<false>(R, p, C, mu, S, v);
@@ -808,18 +855,6 @@ __device__ __forceinline__ uint64_t pinned_clock(double (&x)[N]) {
 #pragma unroll
   for (int k = 0; k < N; ++k) asm volatile("" : "+v"(x[k]));
   return t;
-}
-
-constexpr uint32_t kMemoMiss = 0xFFFFFFFFu;  // memo.w of a point whose voxel is not in the map
-constexpr uint32_t kMemoNone = 0xFFFFFFFEu;  // nothing looked up
-
-// Payload of a record whose slot is known (an unchanged key that hit last round): one round trip.
-__device__ __forceinline__ void load_payload(const VoxelRecord* rec, double (&mu)[3], double (&S)[9]) {
-  const double2* pay = reinterpret_cast<const double2*>(rec->mean);
-  const double2 a0 = pay[0], a1 = pay[1], a2 = pay[2], a3 = pay[3], a4 = pay[4], a5 = pay[5];
-  mu[0] = a0.x; mu[1] = a0.y; mu[2] = a1.x;
-  S[0] = a1.y; S[1] = a2.x; S[2] = a2.y; S[3] = a3.x; S[4] = a3.y; S[5] = a4.x;
-  S[6] = a4.y; S[7] = a5.x; S[8] = a5.y;
 }
 
 // MULTI: several GPUs (the rank totals cross xGMI through mailboxes); STAMPS: in-kernel phase clocks
