@@ -60,6 +60,7 @@ class FrameStats(C.Structure):
 
 OPTION_STAGE_EVENTS = 1
 OPTION_UPLOAD_STAGE_KB = 2   # scans up to this many KiB are staged through page-locked memory of the context; 0 = in place (vgicp_hip.h)
+OPTION_REFERENCE_ORDER = 3   # != 0: scan preparations emit the kept points in the reference's unordered_map order (vgicp_hip.h)
 COUNTER_UPLOAD_SLOW = 6
 
 

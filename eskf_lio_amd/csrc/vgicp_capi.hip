@@ -8,6 +8,8 @@
 // with VGICP_ERR_NO_DEVICE / VGICP_ERR_HIP.
 #include <immintrin.h>
 
+#include <array>
+#include <unordered_map>
 #include "vgicp_context.h"
 
 namespace vgicp {
@@ -1301,6 +1303,9 @@ int vgicp_set_option(vgicp_ctx* ctx, int option, int value) {
       if (value < 0) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "negative size");
       ctx->upload_stage_limit = (size_t)value << 10;
       return VGICP_OK;
+    case VGICP_OPTION_REFERENCE_ORDER:
+      ctx->reference_order = value != 0;
+      return VGICP_OK;
     default:
       return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "unknown option");
   }
@@ -1969,6 +1974,60 @@ int settle(vgicp_ctx* ctx) {
   return rc_scan != VGICP_OK ? rc_scan : rc_ins;
 }
 
+// VGICP_OPTION_REFERENCE_ORDER — the kept points in the sequence the reference emits them (src/CloudPreprocessor.cpp:85-99):
+// the iteration order of a std::unordered_map<Eigen::Vector3i, int, open3d::utility::hash_eigen<Eigen::Vector3i>> that was
+// filled in scan order.  Only the first point of a voxel creates a node, so the container sees the kept points' voxel
+// keys in ascending input index — the order the device emits — and its node order is libstdc++'s for that hash and that
+// insertion sequence (the reference's platform, Ubuntu 22.04 / GCC 11, ships the libstdc++ this module is built
+// against; the C++ standard leaves the order open).  The container itself is what is asked here: the same type with the
+// same hash, filled the same way, on the host (27 000 insertions: ~1.5 ms — a parity mode, not the fast path).
+struct VoxelKeyHostHash {   // open3d::utility::hash_eigen<Eigen::Vector3i>: boost-style combine of std::hash<int>
+  size_t operator()(const std::array<int32_t, 3>& k) const {
+    size_t seed = 0;
+    for (int n = 0; n < 3; ++n) seed ^= std::hash<int>()(k[n]) + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+    return seed;
+  }
+};
+// perm[o] = the ascending-order slot of the point the reference emits o-th.  pts: m x 3, the kept points in ascending input index.
+void reference_order_of(const double* pts, size_t m, double voxel_size, std::vector<uint32_t>* perm) {
+  std::unordered_map<std::array<int32_t, 3>, uint32_t, VoxelKeyHostHash> grid;
+  for (size_t i = 0; i < m; ++i) {
+    std::array<int32_t, 3> key;   // the preprocessor's getVoxelIndex: floor(p / voxel) as int (src/CloudPreprocessor.cpp:129-133)
+    for (int a = 0; a < 3; ++a) key[a] = static_cast<int32_t>(std::floor(pts[3 * i + a] / voxel_size));
+    if (grid.find(key) == grid.end()) grid[key] = (uint32_t)i;   // as the reference writes it (:88-91)
+  }
+  perm->clear();
+  perm->reserve(grid.size());
+  for (const auto& kv : grid) perm->push_back(kv.second);
+}
+// The resident scan (just prepared, stream synchronised, ctx->n kept points) is put into the reference's order in place.
+int reorder_resident_scan(vgicp_ctx* ctx, double voxel_size) {
+  const size_t m = ctx->n;
+  if (m < 2) return VGICP_OK;
+  std::vector<double> pts(3 * m);
+  VG_HIP(ctx, hipMemcpyAsync(pts.data(), ctx->d_scan_aos, m * 24, hipMemcpyDeviceToHost, ctx->stream));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<uint32_t> perm;
+  reference_order_of(pts.data(), m, voxel_size, &perm);
+  if (perm.size() != m) return fail(ctx, VGICP_ERR_HIP, "reference order: the kept points do not lie in distinct voxels");
+  const size_t pb = (m * 24 + 255) & ~size_t(255), cb = (m * 72 + 255) & ~size_t(255), ib = (m * 4 + 255) & ~size_t(255);
+  const int rc = ensure_stage(ctx, pb + cb + ib);
+  if (rc != VGICP_OK) return rc;
+  char* base = static_cast<char*>(ctx->d_stage);
+  double* t_pts = reinterpret_cast<double*>(base);
+  double* t_cov = reinterpret_cast<double*>(base + pb);
+  uint32_t* d_perm = reinterpret_cast<uint32_t*>(base + pb + cb);
+  double* aos_cov = ctx->d_scan_aos + 3 * ctx->scan_capacity;
+  VG_HIP(ctx, hipMemcpyAsync(d_perm, perm.data(), m * 4, hipMemcpyHostToDevice, ctx->stream));
+  VG_HIP(ctx, launch_gather_scan(ctx->stream, d_perm, (uint32_t)m, ctx->d_scan_aos, aos_cov, nullptr, t_pts, t_cov, nullptr));
+  VG_HIP(ctx, hipMemcpyAsync(ctx->d_scan_aos, t_pts, m * 24, hipMemcpyDeviceToDevice, ctx->stream));
+  VG_HIP(ctx, hipMemcpyAsync(aos_cov, t_cov, m * 72, hipMemcpyDeviceToDevice, ctx->stream));
+  // the planes the registration reads, from the reordered AoS copy (the symmetry word is not consulted for a prepared scan)
+  VG_HIP(ctx, launch_pack_scan(ctx->stream, ctx->d_scan_aos, aos_cov, (uint32_t)m, ctx->d_scan, ctx->stride, ctx->d_ins_counters + 3, 0));
+  VG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `perm` and `pts` die with this frame
+  return VGICP_OK;
+}
+
 int check_preprocess_args(vgicp_ctx* ctx, size_t n, double voxel_size, int knn) {
   if (!(voxel_size > 0.0)) return fail(ctx, VGICP_ERR_BAD_ARGUMENT, "voxel_size must be positive");
   if (knn < 1 || knn > preprocess_max_knn())
@@ -2025,6 +2084,19 @@ int vgicp_preprocess(vgicp_ctx* ctx, size_t n, const double* points, double voxe
   if (out_index) VG_RC(user_d2h(ctx, out_index, d_out_idx, (size_t)m * sizeof(uint64_t)));
   VG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   user_copies_finish(ctx);
+  if (ctx->reference_order && m > 1) {   // VGICP_OPTION_REFERENCE_ORDER: the host arrays, through copies
+    std::vector<uint32_t> perm;
+    reference_order_of(out_points, m, voxel_size, &perm);
+    if (perm.size() != m) return fail(ctx, VGICP_ERR_HIP, "reference order: the kept points do not lie in distinct voxels");
+    std::vector<double> p(out_points, out_points + 3 * (size_t)m), c(out_covs, out_covs + 9 * (size_t)m);
+    std::vector<uint64_t> ix;
+    if (out_index) ix.assign(out_index, out_index + m);
+    for (size_t o = 0; o < m; ++o) {
+      std::memcpy(out_points + 3 * o, p.data() + 3 * (size_t)perm[o], 24);
+      std::memcpy(out_covs + 9 * o, c.data() + 9 * (size_t)perm[o], 72);
+      if (out_index) out_index[o] = ix[perm[o]];
+    }
+  }
   return VGICP_OK;
 }
 
@@ -2359,6 +2431,13 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
   ctx->n = (uint32_t)n;          // an upper bound until the pending scan is settled
   ctx->scan_pending = true;
   ctx->scan_ready = true;
+  if (ctx->reference_order) {
+    // the parity mode: this preparation is waited for, and its result put into the reference's sequence, before anything
+    // else sees it (an "async" preparation is synchronous under this option)
+    rc = settle(ctx);
+    if (rc != VGICP_OK) return rc;
+    return reorder_resident_scan(ctx, voxel_size);
+  }
   return VGICP_OK;
 }
 }  // namespace

@@ -333,6 +333,7 @@ struct vgicp_ctx {
   uint32_t scan_seq = 0;             // uploads so far; pack_scan_kernel marks an asymmetric covariance with it
   bool scan_sym_known = false;       // the resident scan went through pack_scan_kernel (not a scan prepared on the device)
   int64_t prep_deskewed = 0;
+  bool reference_order = false;      // VGICP_OPTION_REFERENCE_ORDER: prepared scans come in the reference's unordered_map order
   bool prep_with_deskew = false;
   double prep_voxel = 0.0;           // > 0: the resident scan was down-sampled on the device to one point per voxel of this size
   // the deskew's state table on its way to the device: pinned, two slots in turn (an enqueue-only preparation returns

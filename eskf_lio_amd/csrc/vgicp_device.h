@@ -183,6 +183,9 @@ hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, c
 // Test hook: solve + exponential + convergence test of one round on given normal equations (one wave).
 hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosine_threshold,
                              double translation_sq_threshold, int force_pivoted, double* out20);
+// out[o] = in[perm[o]], o < m, for a scan's AoS arrays (idx / out_idx optional): VGICP_OPTION_REFERENCE_ORDER
+hipError_t launch_gather_scan(hipStream_t s, const uint32_t* perm, uint32_t m, const double* pts, const double* covs,
+                              const unsigned long long* idx, double* out_pts, double* out_covs, unsigned long long* out_idx);
 // asym: one device word that receives seq when a covariance is not bitwise symmetric (PersistArgs::asym_dev)
 hipError_t launch_pack_scan(hipStream_t s, const double* points_aos, const double* covs_aos,
                             uint32_t n, double* soa, uint64_t stride, uint32_t* asym, uint32_t seq);

@@ -1336,6 +1336,22 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(const double* __restric
   }
 }
 
+// out[o] = in[perm[o]] for the AoS arrays of a scan (points 3, covariances 9, optionally the input indices): the
+// reordering of VGICP_OPTION_REFERENCE_ORDER (one thread per kept point; the planes are re-made by pack_scan_kernel).
+__global__ void gather_scan_kernel(const uint32_t* __restrict__ perm, uint32_t m, const double* __restrict__ pts,
+                                   const double* __restrict__ covs, const unsigned long long* __restrict__ idx,
+                                   double* __restrict__ out_pts, double* __restrict__ out_covs,
+                                   unsigned long long* __restrict__ out_idx) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= m) return;
+  const uint32_t from = perm[o];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out_pts[3 * (size_t)o + k] = pts[3 * (size_t)from + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) out_covs[9 * (size_t)o + k] = covs[9 * (size_t)from + k];
+  if (idx) out_idx[o] = idx[from];
+}
+
 // AoS (the caller's Eigen memory) -> 12 SoA planes.
 __global__ void pack_scan_kernel(const double* __restrict__ pts, const double* __restrict__ covs,
                                  uint32_t n, double* __restrict__ soa, uint64_t stride, uint32_t* asym, uint32_t seq) {
@@ -1901,6 +1917,14 @@ hipError_t launch_solve_step(hipStream_t s, const double* packed27, double cosin
 hipError_t launch_fold_rows(hipStream_t s, const double* rows, uint32_t nrows, const AlignState* state,
                             double* sums) {
   ++g_kernel_launches; hipLaunchKernelGGL(fold_rows_kernel, dim3(1), dim3(1024), 0, s, rows, nrows, state, sums);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_scan(hipStream_t s, const uint32_t* perm, uint32_t m, const double* pts, const double* covs,
+                              const unsigned long long* idx, double* out_pts, double* out_covs, unsigned long long* out_idx) {
+  if (m == 0) return hipSuccess;
+  ++g_kernel_launches; hipLaunchKernelGGL(gather_scan_kernel, dim3(blocks_for(m, 256)), dim3(256), 0, s, perm, m, pts, covs, idx,
+                                          out_pts, out_covs, out_idx);
   return hipGetLastError();
 }
 

@@ -59,6 +59,11 @@ struct CloudPreprocessorConfig
   // to uploading the cloud, as the reference reads the host cloud every time; Sampled (~0.1 ms per frame cheaper) sees
   // resizes, reallocations and edits of 64 sampled elements only
   shim::ResidentCheck residentCheck = shim::ResidentCheck::FullHash;
+  // true: the prepared cloud's points come in the sequence the REFERENCE emits them (the iteration order of its
+  // unordered_map, src/CloudPreprocessor.cpp:85-99) instead of ascending input index: a frame chain then reproduces the
+  // reference's chain, not only its per-call results (VGICP_OPTION_REFERENCE_ORDER; ~1.5 ms per frame on the host, and
+  // process() waits for the device).  YAML key cloud_preprocessor.reference_order: true
+  bool referenceOrder = false;
   static HostCopy defaultHostCopy()
   {
     const char * env = std::getenv("VGICP_HOST_COPY");
@@ -112,6 +117,9 @@ public:
   : voxelSize_(config.voxelSize), knn_(config.knn), T_il_(shim::poseFromData(config.T_il)),
     hostCopy_(config.hostCopy), residentCheck_(config.residentCheck), ctx_(ctx ? ctx : shim::defaultContext())
   {
+    if (config.referenceOrder) {
+      shim::check(ctx_, vgicp_set_option(ctx_, VGICP_OPTION_REFERENCE_ORDER, 1), "vgicp_set_option");
+    }
   }
 
 #if defined(ESKF_LIO_SHIM_HAVE_YAML)
@@ -129,6 +137,11 @@ public:
       const auto mode = config["cloud_preprocessor"]["host_copy"].as<std::string>();
       hostCopy_ = (mode == "deferred") ? CloudPreprocessorConfig::HostCopy::Deferred :
         CloudPreprocessorConfig::HostCopy::Eager;
+    }
+    if (config["cloud_preprocessor"]["reference_order"].IsDefined() &&
+      config["cloud_preprocessor"]["reference_order"].as<bool>())
+    {
+      shim::check(ctx_, vgicp_set_option(ctx_, VGICP_OPTION_REFERENCE_ORDER, 1), "vgicp_set_option");
     }
     if (config["cloud_preprocessor"]["resident_check"].IsDefined()) {   // optional key, not in the reference's file
       residentCheck_ = config["cloud_preprocessor"]["resident_check"].as<std::string>() == "sampled" ?

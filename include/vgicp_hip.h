@@ -369,6 +369,15 @@ int vgicp_get_frame_stats(vgicp_ctx* ctx, vgicp_frame_stats* out, int reset);
  * VGICP_UPLOAD_STAGE_LIMIT=bytes in the environment sets the default).  0: every scan is handed to the runtime in
  * place, which registers the caller's pages with the driver — for callers that never free those buffers. */
 #define VGICP_OPTION_UPLOAD_STAGE_KB 2
+/* value != 0: every scan preparation (vgicp_preprocess, vgicp_scan_prepare*) emits its kept points in the sequence the
+ * REFERENCE emits them — the iteration order of its std::unordered_map<Eigen::Vector3i, int, hash_eigen> filled in scan
+ * order (src/CloudPreprocessor.cpp:85-99; libstdc++'s node order, i.e. the order on the reference's platform) — instead
+ * of ascending input index.  The kept set and every covariance are the same; what changes is what an order-dependent
+ * consumer makes of them: Voxel::addPoint's running mean (include/ESKF_LIO/LocalMap.hpp:79-87) and the order the
+ * registration's sums are taken in.  With it a frame chain on this module reproduces the reference's chain, not only
+ * its per-call results.  A parity mode: the container is replayed on the host (~1.5 ms per 27 000
+ * kept points) and an enqueued preparation is waited for; off by default. */
+#define VGICP_OPTION_REFERENCE_ORDER 3
 int vgicp_set_option(vgicp_ctx* ctx, int option, int value);
 
 /* Copies the resident scan (vgicp_scan_upload / vgicp_scan_prepare) to the host: points n x 3, covs n x 9

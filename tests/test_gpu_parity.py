@@ -1754,6 +1754,60 @@ def test_preprocess_feeds_the_registration(gpu_ctx, oracle):
     assert et < 0.05 and er < 0.01                                 # and it recovers the motion
 
 
+def test_reference_order_option_reproduces_the_references_sequence_and_chain(oracle):
+    """VGICP_OPTION_REFERENCE_ORDER (round 6): the kept points in the iteration order of the reference's
+    std::unordered_map (src/CloudPreprocessor.cpp:85-99) instead of ascending input index — the last documented deviation
+    of a frame CHAIN from the reference's (Voxel::addPoint's running mean depends on the sequence,
+    include/ESKF_LIO/LocalMap.hpp:79-87).  (1) Every preparation entry point returns oracle_preprocess_ordered(...,
+    ORACLE_ORDER_REFERENCE_HASH) bit for bit: points, covariances AND their order; (2) a 12-frame chain prepare -> align
+    -> insert on the device, all in that order, against the oracle's chain in that order: the same round counts and
+    correspondence counts every frame, poses to rounding (1e-9; the two chains in DIFFERENT orders are 3e-5 m apart,
+    tests/test_oracle.py), the same voxel set with means to rounding at the end."""
+    from eskf_lio_amd import capi, synth
+    world = synth.make_lidar_scan(9_000, seed=0x46524D, extent=12.0)
+    with capi.Context(0) as ctx:
+        ctx.set_option(capi.OPTION_REFERENCE_ORDER, 1)
+        rp, rc, ri = oracle.preprocess_ordered(world, 0.3, 30, oracle.ORDER_REFERENCE_HASH)
+        assert not np.array_equal(ri, np.sort(ri))                    # it IS another order
+        gp, gc, gi = ctx.preprocess(world, 0.3, 30)                    # the host-returning entry point
+        assert np.array_equal(gi, ri) and np.array_equal(gp, rp) and np.array_equal(gc, rc)
+        ctx.map_reset(0.3, 0)
+        kept, _ = ctx.scan_prepare(world, None, None, None, 0.3, 30)   # the resident one
+        dp, dc = ctx.scan_download()
+        assert kept == len(rp) and np.array_equal(dp, rp) and np.array_equal(dc, rc)
+        ctx.scan_prepare_async(world, None, None, None, 0.3, 30)       # and the enqueued one (waited for under the option)
+        fp, fc = ctx.scan_fetch()
+        assert np.array_equal(fp, rp) and np.array_equal(fc, rc)
+        # the chain
+        frames, cap = 12, 20
+        truth = [synth.se3_to_SE3([0.05 * f, 0.02 * f, 0.0, 0.0, 0.0, 0.004 * f]) for f in range(frames + 1)]
+        rng = np.random.default_rng(12)
+        omap = oracle.OracleMap(0.3, cap)
+        ctx.map_reset(0.3, 0)
+        pose_o, pose_g = np.eye(4), np.eye(4)
+        for f in range(frames + 1):
+            Tinv = synth.invert_pose(truth[f])
+            sweep = np.ascontiguousarray((world + rng.normal(scale=0.005, size=world.shape)) @ Tinv[:3, :3].T + Tinv[:3, 3])
+            p, c, _ = oracle.preprocess_ordered(sweep, 0.3, 30, oracle.ORDER_REFERENCE_HASH)
+            ctx.scan_prepare_async(sweep, None, None, None, 0.3, 30)
+            if f > 0:
+                ro = omap.align(p, c, pose_o, 30, 1e-6, 0.9999)
+                rg = ctx.align_resident(pose_g, 30, 1e-6, 0.9999)
+                assert rg.iterations == ro.iterations and np.array_equal(rg.corr_count[:rg.iterations], ro.corr_count[:ro.iterations]), f
+                dt, dr = pose_error(rg.pose, ro.pose)
+                assert dt < 1e-9 and dr < 1e-9, (f, dt, dr)
+                pose_o, pose_g = ro.pose, rg.pose
+            omap.insert(*oracle.transform(p, c, pose_o))
+            ctx.map_insert_resident(pose_g, cap)
+        keys, means, covs, counts = ctx.map_export()
+        ok, om, oc, on = omap.export()
+        a = {tuple(k): i for i, k in enumerate(keys.tolist())}
+        assert len(a) == len(ok) and all(tuple(k) in a for k in ok.tolist())
+        order = np.array([a[tuple(k)] for k in ok.tolist()])
+        assert np.array_equal(counts[order], on)
+        assert np.abs(means[order] - om).max() < 1e-9 and np.abs(covs[order] - oc).max() < 1e-9
+
+
 @pytest.mark.parametrize("map_voxel,scan_voxel,cap", [(0.3, 0.3, 20), (0.3, 0.1, 5), (0.3, 0.1, 100), (1.0, 0.1, 100)])
 def test_resident_insertion_without_the_sort_is_bit_exact(oracle, monkeypatch, map_voxel, scan_voxel, cap):
     """LocalMap::updateLocalMap (src/LocalMap.cpp:44-72) on a scan the device down-sampled itself: a map voxel receives
