@@ -64,6 +64,12 @@ constexpr int kPool = 256;             // cells waiting per query
 #define VGICP_LEAF_POINTS 512
 #endif
 constexpr uint32_t kLeafPoints = VGICP_LEAF_POINTS;
+// The neighbour search keeps its candidates unordered and makes the order once (round 6, knn_search_kernel);
+// -DVGICP_KNN_EAGER builds rounds 2-5's sorted k-list with one insertion per candidate instead (A/B: 104.9 -> 101.3 us
+// per 60 000-point sweep, the same bits; tools/soak_preprocess.py: 817 random scans against the oracle, no mismatch).
+#ifndef VGICP_KNN_EAGER
+#define VGICP_KNN_LAZY 1
+#endif
 constexpr uint32_t kHomePoints = 128;  // the query's own cell is measured whole when it holds at most this many
 constexpr int kCovBlock = 128;
 constexpr unsigned long long kEmptyCell = ~0ull;
@@ -811,6 +817,10 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   __shared__ unsigned long long pool_key[kSearchBlock / 64][kPool];
   __shared__ uint32_t pool_start[kSearchBlock / 64][kPool];
   __shared__ uint32_t pool_end[kSearchBlock / 64][kPool];
+#ifdef VGICP_KNN_LAZY
+  __shared__ double cand_d[kSearchBlock / 64][64];     // the candidates still in the race (at most 64), unordered
+  __shared__ uint32_t cand_i[kSearchBlock / 64][64];
+#endif
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous
@@ -864,7 +874,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
 #ifdef VGICP_PREP_TRACE
   uint32_t opens = 0, home_batches = 0;
 #endif
-  const unsigned long long list_lanes = K >= 64 ? ~0ull : (1ull << K) - 1ull;
+  [[maybe_unused]] const unsigned long long list_lanes = K >= 64 ? ~0ull : (1ull << K) - 1ull;
 
   // squared distance to sorted point j and, from the same record, its original index
   auto dist2 = [&](uint32_t j, uint32_t& id) {
@@ -900,6 +910,114 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   // of the sorted order around the query (inside home when there is one): real points and usually near ones. The
   // search skips the points it has measured here when it meets them again (sorted positions skip_start ..
   // skip_start + skip_count - 1).  (-DVGICP_KNN_SEEDS_ONLY keeps the opening of rounds 2-5 for A/B runs: K seeds.)
+#ifdef VGICP_KNN_LAZY
+  // ---- round 6: the candidates are kept UNORDERED until the end ---------------------------------------------------
+  // What the search needs while it runs is one number, an upper bound of the K-th distance so far (it filters points
+  // and prunes cells); the ORDER of the K nearest is needed once, at the end.  Rounds 2-5 kept a sorted list and paid
+  // ~15 instructions per candidate that passed (27 per query) plus an all-pairs ranking of the 64-point opening window
+  // (~200).  Here the candidates that pass the bound are appended to a buffer of at most 64 (lane l mirrors entry l),
+  // and after every batch that brought any the bound is tightened by a RADIX SELECT over single-precision keys rounded
+  // UP (20 wave ballots: one vector compare each, the counting on the scalar unit) and the buffer compacted to the
+  // entries below it; the exact order by (distance, index) is made once from the ~K survivors.  Exact: a point is only
+  // ever dropped for lying above a bound that at least K seen points lie under.
+  double* cdv = cand_d[wave];
+  uint32_t* civ = cand_i[wave];
+  const uint32_t span_lo = has_home ? home_start : 0u, span_hi = has_home ? home_end : n;
+  const uint32_t W = span_hi - span_lo < 64u ? span_hi - span_lo : 64u;   // >= K: home holds K points, and K <= n
+  uint32_t w0 = qj > W / 2 ? qj - W / 2 : 0;
+  if (w0 < span_lo) w0 = span_lo;
+  if (w0 + W > span_hi) w0 = span_hi - W;
+  uint32_t skip_start = w0, skip_count = W;
+  double ld = INFINITY;           // lane < cnt: entry `lane` of the buffer
+  uint32_t li = 0xFFFFFFFFu;
+  uint32_t cnt = 0;               // uniform
+  double kth = INFINITY;          // uniform: an upper bound of the K-th smallest distance among the points seen so far
+  // K-th smallest single-precision key (distances rounded UP; non-negative floats order as unsigned integers) among the
+  // cnt entries, to 20 leading bits, rounded up: the new bound.  Entries above it leave the buffer.
+  auto tighten = [&]() {
+    const uint32_t fkey = (uint32_t)lane < cnt ? __builtin_bit_cast(uint32_t, __double2float_ru(ld)) : 0xFFFFFFFFu;
+    uint32_t prefix = 0;
+#pragma unroll
+    for (int bit = 30; bit >= 11; --bit) {
+      const uint32_t trial = prefix | (1u << bit);
+      const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(fkey < trial));
+      if (below < (uint32_t)K) prefix = trial;   // the K-th key has this bit set
+    }
+    const uint32_t top = prefix | 0x7FFu;
+    const bool keep = fkey <= top;
+    const unsigned long long who = __ballot(keep);
+    const uint32_t kept = (uint32_t)__builtin_popcountll(who);
+    if (kept < cnt) {
+      const uint32_t at = (uint32_t)__builtin_popcountll(who & lanes_below);
+      wave_sync();   // every lane holds its entry in registers: the slots can be rewritten
+      if (keep) { cdv[at] = ld; civ[at] = li; }
+      wave_sync();
+      cnt = kept;
+      if ((uint32_t)lane < cnt) { ld = cdv[lane]; li = civ[lane]; }
+    }
+    kth = top >= 0x7F800000u ? INFINITY : (double)__builtin_bit_cast(float, top);
+    if (cnt > 56u) {
+      // hardly any room left (dozens of points within a 2^-12 band of the K-th distance): keep exactly the K nearest by
+      // (distance, index) — all pairs, the one place besides the end where the order is made
+      uint32_t rank = 0;
+      const unsigned long long key = (unsigned long long)__double_as_longlong(ld);
+      for (uint32_t e = 0; e < cnt; ++e) {
+        const unsigned long long ke = (unsigned long long)__double_as_longlong(cdv[e]);
+        const uint32_t ie = civ[e];
+        rank += ((ke < key) | ((ke == key) & (ie < li))) ? 1u : 0u;
+      }
+      const bool stay = (uint32_t)lane < cnt && rank < (uint32_t)K;
+      wave_sync();
+      if (stay) { cdv[rank] = ld; civ[rank] = li; }
+      wave_sync();
+      cnt = (uint32_t)K;
+      if ((uint32_t)lane < cnt) { ld = cdv[lane]; li = civ[lane]; }
+      kth = readlane_f64(ld, K - 1);
+    }
+  };
+  {
+    const bool mine = (uint32_t)lane < W;
+    uint32_t id = 0xFFFFFFFFu;
+    double d = INFINITY;
+    if (mine) d = dist2(w0 + (uint32_t)lane, id);
+    if (!(d < INFINITY)) d = INFINITY;  // a NaN / infinite point is a placeholder that everything finite displaces
+    ld = d;
+    li = id;
+    cdv[lane] = d;
+    civ[lane] = id;
+    wave_sync();
+    cnt = W;
+    if (cnt > (uint32_t)K) tighten();
+    else if (cnt == (uint32_t)K) {   // exactly K points in reach so far: their largest distance is the bound
+      double mx = (uint32_t)lane < cnt ? ld : 0.0;
+      for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+      kth = uniform_f64(mx);
+    }
+  }
+  uint32_t kth_id = 0xFFFFFFFFu;   // (ties at the bound are admitted: the order is settled at the end)
+  double bound = kth;
+  // every lane brings one candidate (valid, d, id, j); the ones at or below the bound join the buffer
+  auto offer = [&](bool valid, double d, uint32_t id, uint32_t j) {
+    ++batches;
+    bool pass = valid & (j - skip_start >= skip_count) & (d <= kth);
+    unsigned long long todo = __ballot(pass);
+    while (todo) {
+      const uint32_t room = 64u - cnt;
+      const uint32_t ahead = (uint32_t)__builtin_popcountll(todo & lanes_below);
+      const bool now = pass && ahead < room;
+      if (now) { cdv[cnt + ahead] = d; civ[cnt + ahead] = id; }
+      const uint32_t took = (uint32_t)__builtin_popcountll(__ballot(now));
+      inserts += took;
+      cnt += took;
+      wave_sync();
+      if ((uint32_t)lane < cnt) { ld = cdv[lane]; li = civ[lane]; }
+      if (cnt > (uint32_t)K) tighten();
+      pass = pass && !now && (d <= kth);
+      todo = __ballot(pass);
+    }
+  };
+  (void)kth_id;
+#else
 #ifndef VGICP_KNN_SEEDS_ONLY
   // The opening window: up to 64 consecutive points of the sorted order around the query (inside home when there is
   // one), one per lane.  All of them are ranked against each other at once -- every lane counts the keys below its
@@ -1042,6 +1160,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       kth_id = (uint32_t)__builtin_amdgcn_readlane((int)li, K - 1);
     }
   };
+#endif  // VGICP_KNN_LAZY
   if (has_home) {
     // the rest of home, then home as a whole is what the search skips; all K are now within home's diagonal
 #ifndef VGICP_KNN_SEEDS_ONLY
@@ -1276,7 +1395,22 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   if (lane == 0 && spills && debug) atomicAdd(&counters[2], 1u);
   const uint32_t qi = uniform_u32(sorted_idx[qj]);
   const uint32_t o = uniform_u32(slot_of_index[qi]);
+#ifdef VGICP_KNN_LAZY
+  {
+    // the order, once: rank of every survivor by (distance, index) among the survivors (all distinct by index)
+    wave_sync();
+    uint32_t rank = 0;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(ld);
+    for (uint32_t e = 0; e < cnt; ++e) {
+      const unsigned long long ke = (unsigned long long)__double_as_longlong(cdv[e]);
+      const uint32_t ie = civ[e];
+      rank += ((ke < key) | ((ke == key) & (ie < li))) ? 1u : 0u;
+    }
+    if ((uint32_t)lane < cnt && rank < (uint32_t)K) nbr[(size_t)o * kMaxKnn + rank] = li;
+  }
+#else
   if (lane < kMaxKnn) nbr[(size_t)o * kMaxKnn + lane] = li;  // original indices: the list carries nothing else
+#endif
   if (lane == 0) {
     out_pts[3 * (size_t)o] = qx; out_pts[3 * (size_t)o + 1] = qy; out_pts[3 * (size_t)o + 2] = qz;
     if (soa) { soa[o] = qx; soa[soa_stride + o] = qy; soa[2 * soa_stride + o] = qz; }  // the planes the registration reads
