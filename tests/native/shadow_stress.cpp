@@ -65,6 +65,11 @@ int main(int argc, char** argv) {
     T.matrix()(1, 3) = 0.1 * f;
     for (int which = 0; which < 2; ++which) {
       auto cloud = std::make_shared<PointCloud>();
+      // round 6: the clouds' storage comes out of the pool that clouds dying inside the classes fill — here the shadow
+      // grid's worker on another thread (what CloudPreprocessor::process does before it sizes a cloud)
+      shim::adoptStorage(cloud->covariances_, shim::storagePool().covariances, 1500);
+      shim::adoptStorage(cloud->points_, shim::storagePool().points, 1500);
+      if (!cloud->covariances_.empty() || !cloud->points_.empty()) { std::printf("adopted storage is not empty\n"); return 1; }
       std::mt19937_64 gen(1000 + f);
       std::uniform_real_distribution<double> v(-8.0, 8.0);
       for (int i = 0; i < 1500; ++i) {
