@@ -1,0 +1,65 @@
+// CPU check of the drop-in's "is this host cloud still the resident scan" hash (include/eskf_lio_shim/LocalMap.hpp,
+// shim::bufferHash / sampleHash): the AVX2 lanes and the plain ones give the same value, every single-bit edit of a
+// buffer changes it, so do a swap of two words inside one lane and a shifted run; ResidentCheck::Sampled sees an edit of a
+// sampled element and misses one of an unsampled element (the documented price of that mode), FullHash sees both.
+// Links nothing of the module (the C ABI is stubbed out: the header only needs the declarations).
+#define ESKF_LIO_SHIM_FORCE_POD 1
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "eskf_lio_shim/LocalMap.hpp"
+
+using namespace ESKF_LIO;
+
+static uint64_t plain_lanes(const void* p, size_t bytes, uint64_t seed) {
+  uint64_t s1[16], s2[16];
+  for (int l = 0; l < 16; ++l) { s1[l] = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(l + 1); s2[l] = 0; }
+  const uint64_t* w = static_cast<const uint64_t*>(p);
+  for (size_t i = 0; i < bytes / 8; ++i) { const size_t l = i & 15u; s1[l] += w[i]; s2[l] += s1[l]; }
+  uint64_t h = bytes * 0x100000001B3ull;
+  for (int l = 0; l < 16; ++l) {
+    h = (h ^ s1[l]) * 0x9FB21C651E98DF25ull; h ^= h >> 29;
+    h = (h ^ s2[l]) * 0xC2B2AE3D27D4EB4Full; h ^= h >> 31;
+  }
+  return h;
+}
+
+int main() {
+  for (size_t words : {size_t(1), size_t(15), size_t(16), size_t(17), size_t(333), size_t(27000 * 12)}) {
+    std::vector<uint64_t> buf(words);
+    for (size_t i = 0; i < words; ++i) buf[i] = (i + 1) * 0x9E3779B97F4A7C15ull ^ (i << 7);
+    const uint64_t h0 = shim::bufferHash(buf.data(), words * 8, 42);
+    if (h0 != plain_lanes(buf.data(), words * 8, 42)) { std::printf("AVX2 and plain lanes differ at %zu words\n", words); return 1; }
+    const size_t step = words > 4000 ? 997 : 1;
+    for (size_t i = 0; i < words; i += step) {
+      buf[i] ^= 1ull << (i % 64);
+      if (shim::bufferHash(buf.data(), words * 8, 42) == h0) { std::printf("a single-bit edit of word %zu of %zu is not seen\n", i, words); return 1; }
+      buf[i] ^= 1ull << (i % 64);
+    }
+    if (words > 40) {
+      std::swap(buf[5], buf[21]);     // two words of one lane
+      if (shim::bufferHash(buf.data(), words * 8, 42) == h0) { std::printf("a swap inside one lane is not seen\n"); return 1; }
+      std::swap(buf[5], buf[21]);
+      std::vector<uint64_t> shifted(buf.begin() + 1, buf.end());
+      shifted.push_back(buf[0]);      // the same words, rotated by one
+      if (shim::bufferHash(shifted.data(), words * 8, 42) == h0) { std::printf("a rotated buffer is not seen\n"); return 1; }
+    }
+  }
+  PointCloud cloud;
+  cloud.points_.resize(5000);
+  cloud.covariances_.resize(5000);
+  for (size_t i = 0; i < 5000; ++i) {
+    for (int a = 0; a < 3; ++a) cloud.points_[i].v[a] = 0.001 * (double)(3 * i + a);
+    for (int k = 0; k < 9; ++k) cloud.covariances_[i].m[k] = 1.0 + 1e-6 * (double)(9 * i + k);
+  }
+  const uint64_t full = shim::sampleHash(cloud, false), sampled = shim::sampleHash(cloud, true);
+  cloud.points_[0].v[0] += 1e-3;   // element 0 is sampled
+  if (shim::sampleHash(cloud, false) == full || shim::sampleHash(cloud, true) == sampled) { std::printf("an edit of a sampled element is not seen\n"); return 1; }
+  cloud.points_[0].v[0] -= 1e-3;
+  cloud.covariances_[1].m[4] += 1e-9;   // element 1 of 5 000 is not
+  if (shim::sampleHash(cloud, false) == full) { std::printf("FullHash misses an edit of an unsampled element\n"); return 1; }
+  if (shim::sampleHash(cloud, true) != sampled) { std::printf("Sampled was expected to miss this edit (the test's premise)\n"); return 1; }
+  std::printf("ok\n");
+  return 0;
+}

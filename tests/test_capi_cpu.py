@@ -257,6 +257,20 @@ def test_copy_crew_survives_helpers_that_come_late(tmp_path):
     assert run.returncode == 0 and "ok 20000 jobs" in run.stdout and "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
 
 
+def test_dropin_resident_check_hash_on_the_cpu(tmp_path):
+    """The drop-in classes read the DEVICE copy of a cloud only while a hash over every byte of the host cloud still
+    matches (shim::ResidentCheck::FullHash, the default since round 6; reference: src/Registration.cpp:11 and
+    src/LocalMap.cpp:45-58 always read the host cloud).  tests/native/shim_hash.cpp: the AVX2 lanes equal the plain
+    ones, every single-bit edit / in-lane swap / rotation of a buffer changes the value, FullHash sees an edit of an
+    element the 64-sample check (ResidentCheck::Sampled, the opt-in) misses."""
+    exe = tmp_path / "shim_hash"
+    out = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
+                          os.path.join(ROOT, "tests", "native", "shim_hash.cpp")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout[-500:] + run.stderr[-500:]
+
+
 def test_shadow_grid_of_the_dropin_map_on_the_cpu(tmp_path):
     """The drop-in LocalMap's defaults keep the grid on the device and a host-side SHADOW of it (a worker thread) for
     save() (include/eskf_lio_shim/LocalMap.hpp; reference src/LocalMap.cpp:10-76,156-167).  tests/native/shadow_stress.cpp
