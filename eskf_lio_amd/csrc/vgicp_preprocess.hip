@@ -59,9 +59,10 @@ constexpr int kPool = 256;             // cells waiting per query
 // where a dense surface is seen from a sparse place (a query metres from a wall) the small threshold made the search
 // take a hundred tiny cells one by one, and the kernel ended on a handful of such queries running alone
 // (frame sweep, 29 151 queries: 128 -> 203 us, longest query 168 us; 256 -> 160 / 126; 512 -> 148 / 99; 1024 -> 153 / 98;
-// 64 -> +13 % on 128.  profiles/r10_knn_leaf.txt)
+// 64 -> +13 % on 128.  profiles/r10_knn_leaf.txt).  Round 6, with the candidates kept unordered (a point that passes costs
+// an append, not an insertion): 256 -> 115 us, 512 -> 95.5, **1024 -> 89.8**, 1536 -> 90.4, 2048 -> 91.5, 4096 -> 95.0.
 #ifndef VGICP_LEAF_POINTS
-#define VGICP_LEAF_POINTS 512
+#define VGICP_LEAF_POINTS 1024
 #endif
 constexpr uint32_t kLeafPoints = VGICP_LEAF_POINTS;
 // The neighbour search keeps its candidates unordered and makes the order once (round 6, knn_search_kernel);
@@ -70,7 +71,16 @@ constexpr uint32_t kLeafPoints = VGICP_LEAF_POINTS;
 #ifndef VGICP_KNN_EAGER
 #define VGICP_KNN_LAZY 1
 #endif
-constexpr uint32_t kHomePoints = 128;  // the query's own cell is measured whole when it holds at most this many
+#ifndef VGICP_KNN_TIGHTEN_AT
+#define VGICP_KNN_TIGHTEN_AT 40   // entries in the candidate buffer (of 64) at which the bound is tightened
+#endif
+#ifndef VGICP_KNN_SELECT_LOW
+#define VGICP_KNN_SELECT_LOW 15   // the select resolves bits 30 .. this one of the single-precision key (16 steps)
+#endif
+#ifndef VGICP_HOME_POINTS
+#define VGICP_HOME_POINTS 128
+#endif
+constexpr uint32_t kHomePoints = VGICP_HOME_POINTS;  // the query's own cell is measured whole when it holds at most this many
 constexpr int kCovBlock = 128;
 constexpr unsigned long long kEmptyCell = ~0ull;
 constexpr unsigned long long kKeyMask = (1ull << 60) - 1;
@@ -917,7 +927,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   // ~15 instructions per candidate that passed (27 per query) plus an all-pairs ranking of the 64-point opening window
   // (~200).  Here the candidates that pass the bound are appended to a buffer of at most 64 (lane l mirrors entry l),
   // and after every batch that brought any the bound is tightened by a RADIX SELECT over single-precision keys rounded
-  // UP (20 wave ballots: one vector compare each, the counting on the scalar unit) and the buffer compacted to the
+  // UP (16 wave ballots: one vector compare each, the counting on the scalar unit) and the buffer compacted to the
   // entries below it; the exact order by (distance, index) is made once from the ~K survivors.  Exact: a point is only
   // ever dropped for lying above a bound that at least K seen points lie under.
   double* cdv = cand_d[wave];
@@ -933,17 +943,17 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   uint32_t cnt = 0;               // uniform
   double kth = INFINITY;          // uniform: an upper bound of the K-th smallest distance among the points seen so far
   // K-th smallest single-precision key (distances rounded UP; non-negative floats order as unsigned integers) among the
-  // cnt entries, to 20 leading bits, rounded up: the new bound.  Entries above it leave the buffer.
+  // cnt entries, to its 16 leading bits (VGICP_KNN_SELECT_LOW), rounded up: the new bound.  Entries above it leave the buffer.
   auto tighten = [&]() {
     const uint32_t fkey = (uint32_t)lane < cnt ? __builtin_bit_cast(uint32_t, __double2float_ru(ld)) : 0xFFFFFFFFu;
     uint32_t prefix = 0;
 #pragma unroll
-    for (int bit = 30; bit >= 11; --bit) {
+    for (int bit = 30; bit >= VGICP_KNN_SELECT_LOW; --bit) {
       const uint32_t trial = prefix | (1u << bit);
       const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(fkey < trial));
       if (below < (uint32_t)K) prefix = trial;   // the K-th key has this bit set
     }
-    const uint32_t top = prefix | 0x7FFu;
+    const uint32_t top = prefix | ((1u << VGICP_KNN_SELECT_LOW) - 1u);
     const bool keep = fkey <= top;
     const unsigned long long who = __ballot(keep);
     const uint32_t kept = (uint32_t)__builtin_popcountll(who);
@@ -1009,9 +1019,15 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
       const uint32_t took = (uint32_t)__builtin_popcountll(__ballot(now));
       inserts += took;
       cnt += took;
-      wave_sync();
-      if ((uint32_t)lane < cnt) { ld = cdv[lane]; li = civ[lane]; }
-      if (cnt > (uint32_t)K) tighten();
+      // ... but not after every batch: a select costs ~35 vector instructions, a candidate that slips in under a stale
+      // bound ~2.  The bound is tightened when the buffer holds VGICP_KNN_TIGHTEN_AT entries, or when candidates of this
+      // batch are still waiting for room (A/B on the 60 000-point frame sweep: after every batch 100.4 us; at 40 / 48 /
+      // 56 / 64 entries 95.8 / 96.6 / 95.1 / 96.3; at 40 with 16 instead of 20 bits of the key: 94.7)
+      if (cnt > (uint32_t)K && (cnt >= (uint32_t)VGICP_KNN_TIGHTEN_AT || (todo & ~__ballot(now)) != 0ull)) {
+        wave_sync();   // (the lanes' mirror of the buffer is brought up to date only where somebody reads it)
+        if ((uint32_t)lane < cnt) { ld = cdv[lane]; li = civ[lane]; }
+        tighten();
+      }
       pass = pass && !now && (d <= kth);
       todo = __ballot(pass);
     }
@@ -1399,6 +1415,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   {
     // the order, once: rank of every survivor by (distance, index) among the survivors (all distinct by index)
     wave_sync();
+    if ((uint32_t)lane < cnt) { ld = cdv[lane]; li = civ[lane]; }
     uint32_t rank = 0;
     const unsigned long long key = (unsigned long long)__double_as_longlong(ld);
     for (uint32_t e = 0; e < cnt; ++e) {
