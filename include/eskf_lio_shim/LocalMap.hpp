@@ -217,16 +217,17 @@ inline vgicp_ctx * defaultContext()
 // CloudPreprocessor::process leaves the prepared scan on the device and stamps the host cloud; ICP::align and
 // LocalMap::updateLocalMap (src/Odometry.cpp:74,79,86 hand the SAME cloud from one to the next) recognise the stamp
 // and work on the resident scan instead of uploading the cloud again.  The stamp is the cloud's address, its
-// buffers' addresses and sizes, a hash over 64 evenly spaced elements (first and last included) and the library's
+// buffers' addresses and sizes, a hash over the buffers' contents and the library's
 // scan generation (VGICP_COUNTER_SCAN_GENERATION: anything else that replaced the resident scan voids it).  A
 // cloud that was resized, reallocated or edited in place — ANY byte of either buffer: by default every byte is hashed
-// (ResidentCheck::FullHash, ~25 GB/s out of the caches: 0.05 - 0.1 ms per check of a 27 000-point prepared cloud) —
+// (ResidentCheck::FullHash, ~35 GB/s out of the caches: 0.07 ms per check of a 27 000-point prepared cloud) —
 // falls back to the upload path, which is what the reference does with every cloud (src/Registration.cpp:11,
 // src/LocalMap.cpp:45-58 always read the host cloud).  ResidentCheck::Sampled hashes 64 evenly spaced elements of each
 // buffer instead (first and last included): ~1 us, but an edit of an UNSAMPLED element in place is not seen — only for
 // callers that never edit a prepared cloud in place, or call shim::forget(cloud) when they do.  Chosen through the
-// configuration structs (CloudPreprocessorConfig / RegistrationConfig / LocalMapConfig ::residentCheck, YAML key
-// cloud_preprocessor.resident_check: sampled), never through the environment; a stamp remembers how it was made.
+// configuration (CloudPreprocessorConfig::residentCheck — the class that makes the stamp —, YAML key
+// cloud_preprocessor.resident_check: sampled), never through the environment; a stamp remembers how it was made, and
+// ICP::align / LocalMap::updateLocalMap check it the way it was made.
 enum class ResidentCheck {FullHash, Sampled};
 struct ResidentStamp
 {
