@@ -266,7 +266,10 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
         from eskf_lio_amd import host
         chain_poses = [r.pose for r in results]
 
-        def dropin(host_copy, device_resident, on_arrival=False, keep_raw_points=True):
+        def dropin(host_copy, device_resident, on_arrival=False, keep_raw_points=True, sensor_rate=False):
+            # sensor_rate: between two frames (outside the timed part) the map's shadow-grid worker is allowed to catch
+            # up, as it does at a LiDAR's 10 Hz: the clouds it has finished with leave their storage to the next frame's
+            # process(), which a back-to-back loop (frames every 0.8 ms against 3 ms of shadow work each) never sees
             pre = host.CloudPreprocessor(h, ext, host_copy)
             icp = host.ICP(30, 1e-6, 0.9999)
             cfg = dict(translation_sq_threshold=-1.0, cosine_threshold=2.0, remove_distant_points=False,
@@ -290,12 +293,16 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
                 pose = got["pose"]
                 poses.append(pose)
                 resident += int(got["used_resident"])
+                if sensor_rate:
+                    lmap.drain()                                   # waits for the shadow grid's worker (untimed)
             voxels = len(lmap)
             return wall / frames * 1e3, poses, resident, voxels
         dropin("deferred", True)                                       # warm-up
         ms_def, poses_def, res_def, vox_def = dropin("deferred", True)
         dropin("eager", True)                                          # warm-up
         ms_eag, poses_eag, res_eag, _ = dropin("eager", True)          # THE CLASSES' DEFAULTS since round 5
+        dropin("eager", True, sensor_rate=True)
+        ms_eag_rate, _, _, _ = dropin("eager", True, sensor_rate=True)
         dropin("eager", False)                                         # warm-up (first-use allocations: page-locked arena, table growth)
         ms_host, poses_host, res_host, _ = dropin("eager", False)      # host-authoritative map (the defaults of rounds 1-4)
         dropin("deferred", True, on_arrival=True)
@@ -303,6 +310,7 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
         out["dropin_ms_per_frame"] = ms_def
         out["dropin_ms_per_frame_sweeps_staged_on_arrival"] = ms_arr
         out["dropin_eager_ms_per_frame"] = ms_eag
+        out["dropin_eager_at_sensor_rate_ms_per_frame"] = ms_eag_rate
         out["dropin_host_authoritative_ms_per_frame"] = ms_host
         out["dropin"] = {
             "what": "the frames above through ESKF_LIO::CloudPreprocessor::process / ICP::align / LocalMap::updateLocalMap "
@@ -310,7 +318,11 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
                     "CloudPreprocessorConfig::HostCopy::Deferred (the scan never returns to the host); dropin_eager: the "
                     "classes' DEFAULTS since round 5 (host copy of the prepared scan as the reference leaves it; the grid the "
                     "registration reads on the device; a host-side shadow grid, kept by a worker thread, holds every raw point "
-                    "for save()); dropin_host_authoritative: the defaults of rounds 1-4 (host map authoritative, device mirror fed batches)",
+                    "for save()) in a back-to-back loop; dropin_eager_at_sensor_rate: the same three calls per frame with the shadow "
+                    "grid's worker allowed to catch up BETWEEN frames (untimed), as at a LiDAR's 10 Hz, so that the storage of the "
+                    "clouds it has finished with is there for the next process() — about the same figure: process() is bound by "
+                    "the device (the whole preparation, then the scan over the link) either way; "
+                    "dropin_host_authoritative: the defaults of rounds 1-4 (host map authoritative, device mirror fed batches)",
             "ratio_to_the_abi_chain": ms_def / out["ms_per_frame"],
             "aligns_that_found_the_scan_resident": f"{res_def} of {frames} (deferred), {res_eag} of {frames} (defaults), {res_host} of {frames} (host-authoritative)",
             "host_authoritative_pose_delta_max": float(max(np.abs(a - b).max() for a, b in zip(poses_host, chain_poses))),

@@ -33,7 +33,7 @@ EXPORTS = (
     "vgicp_align", "vgicp_scan_upload", "vgicp_align_resident",
     "vgicp_accumulate", "vgicp_solve_step", "vgicp_match", "vgicp_voxel_index", "vgicp_preprocess", "vgicp_deskew",
     "vgicp_scan_prepare", "vgicp_scan_download",
-    "vgicp_peer_status", "vgicp_scan_prepare_async", "vgicp_sweep_stage", "vgicp_sweep_stage_cloud2", "vgicp_sweep_unstage", "vgicp_scan_fetch_begin", "vgicp_scan_fetch_end", "vgicp_scan_prepare_staged_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
+    "vgicp_peer_status", "vgicp_scan_prepare_async", "vgicp_sweep_stage", "vgicp_sweep_stage_cloud2", "vgicp_sweep_unstage", "vgicp_scan_fetch_begin", "vgicp_scan_fetch_end", "vgicp_scan_fetch_sums", "vgicp_scan_prepare_staged_async", "vgicp_scan_info", "vgicp_map_insert_resident_async", "vgicp_get_frame_stats",
     "vgicp_set_option", "vgicp_host_register", "vgicp_host_unregister",
     "vgicp_comm_unique_id", "vgicp_comm_init", "vgicp_comm_destroy",
     "vgicp_peer_export", "vgicp_peer_connect", "vgicp_peer_disconnect",
@@ -119,6 +119,7 @@ def load_library() -> C.CDLL:
     lib.vgicp_sweep_unstage.argtypes = [vp, C.c_uint64]
     lib.vgicp_scan_fetch_begin.argtypes = [vp, C.POINTER(sz)]
     lib.vgicp_scan_fetch_end.argtypes = [vp, sz, dp, dp, C.POINTER(sz)]
+    lib.vgicp_scan_fetch_sums.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.vgicp_peer_status.argtypes = [vp]
     lib.vgicp_peer_status.restype = C.c_char_p
     lib.vgicp_scan_prepare_staged_async.argtypes = [vp, C.c_uint64, sz, dp, dp, C.c_double, C.c_int]
@@ -508,6 +509,12 @@ class Context:
                                                   _dp(covs) if kept.value else None, C.byref(n)))
         assert n.value == kept.value
         return pts, covs
+
+    def scan_fetch_sums(self) -> np.ndarray:
+        """vgicp_scan_fetch_sums: the device-made checksums of the last scan_fetch -> uint64[2][2][16] (array, A / B, lane)."""
+        out = np.zeros(64, dtype=np.uint64)
+        self._check(self._lib.vgicp_scan_fetch_sums(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out.reshape(2, 2, 16)
 
     def sweep_unstage(self, ticket: int) -> None:
         """vgicp_sweep_unstage: drop a staged sweep that will not be prepared (its slot is free again)."""

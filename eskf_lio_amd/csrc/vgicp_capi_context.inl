@@ -72,8 +72,10 @@ int vgicp_internal::create_context(int device_id, uint32_t max_persist_grid, vgi
   VG_CREATE(hipMemset(ctx->d_tiles, 0, preprocess_tile_bytes()));
   VG_CREATE(hipMemset(ctx->d_counters, 0, (kCounterWords + 4) * sizeof(uint32_t)));
   ctx->d_ins_counters = ctx->d_counters + kCounterWords;
-  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_fetch_hdr), 128, 0));
-  std::memset(ctx->h_fetch_hdr, 0, 128);
+  VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_fetch_hdr), 640, 0));
+  std::memset(ctx->h_fetch_hdr, 0, 640);
+  VG_CREATE(hipMalloc(reinterpret_cast<void**>(&ctx->d_fetch_sums), 65 * sizeof(unsigned long long)));
+  VG_CREATE(hipMemset(ctx->d_fetch_sums, 0, 65 * sizeof(unsigned long long)));
   { void* dev = nullptr; VG_CREATE(hipHostGetDevicePointer(&dev, ctx->h_fetch_hdr, 0)); ctx->h_fetch_hdr_dev = static_cast<unsigned long long*>(dev); }
   VG_CREATE(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_ins_counters), 4 * sizeof(uint32_t), 0));
   ctx->h_ins_counters[0] = ctx->h_ins_counters[1] = 0;
@@ -235,6 +237,7 @@ int vgicp_destroy(vgicp_ctx* ctx) {
   }
   for (auto& e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
   if (ctx->h_fetch_hdr) (void)hipHostFree(ctx->h_fetch_hdr);
+  (void)hipFree(ctx->d_fetch_sums);
   if (ctx->h_fetch) (void)hipHostFree(ctx->h_fetch);
   (void)hipFree(ctx->d_stage);
   (void)hipFree(ctx->d_cells);

@@ -692,6 +692,7 @@ int scan_prepare_enqueue(vgicp_ctx* ctx, size_t n, const double* points, const d
                  (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, (now_seconds() - tr2) * 1e3);
   if (ctx->stage_events) { VG_HIP(ctx, hipEventRecord(ctx->ev_stage[1], ctx->stream)); ctx->ev_stage_set[1] = true; }
   ctx->n_upper = (uint32_t)n;
+  ctx->fetch_sums_valid = false;
   ctx->scan_sym_known = false;   // covariances made on the device: all twelve planes are read
   ctx->n = (uint32_t)n;          // an upper bound until the pending scan is settled
   ctx->scan_pending = true;
@@ -934,6 +935,7 @@ int ensure_fetch_stage(vgicp_ctx* ctx, size_t points) {
 int vgicp_scan_fetch_begin(vgicp_ctx* ctx, size_t* kept) {
   if (!ctx || !kept) return VGICP_ERR_BAD_ARGUMENT;
   *kept = 0;
+  ctx->fetch_sums_valid = false;
   if (ctx->multi || !ctx->scan_pending) {
     // nothing pending (or a multi-device context, whose prepared scan is dealt out first): the two-step path
     ctx->fetch_open = false;
@@ -946,7 +948,7 @@ int vgicp_scan_fetch_begin(vgicp_ctx* ctx, size_t* kept) {
   VG_HIP(ctx, launch_fetch(ctx->stream, ctx->d_scan_aos, ctx->d_scan_aos + 3 * ctx->scan_capacity, ctx->d_counters, ctx->prep_epoch,
                            (uint32_t)std::min<size_t>(ctx->fetch_cap_points, ctx->n_upper),
                            ctx->h_fetch_dev + ctx->fetch_flag_bytes, reinterpret_cast<uint32_t*>(ctx->h_fetch_dev),
-                           ctx->h_fetch_hdr_dev + 8, ctx->fetch_seq, kFetchPiece));
+                           ctx->h_fetch_hdr_dev + 8, ctx->fetch_seq, kFetchPiece, ctx->d_fetch_sums, ctx->h_fetch_hdr_dev + 16));
   ctx->fetch_open = true;
   // how many points the down-sampling kept (or the fetch kernel's first word: the preparation is through, refused or not)
   const double t0 = now_seconds();
@@ -1009,6 +1011,15 @@ int vgicp_scan_fetch_end(vgicp_ctx* ctx, size_t capacity, double* points, double
   if (!ctx->scan_ready) return fail(ctx, VGICP_ERR_NOT_READY, "no scan resident");
   if (ctx->n != kept) return fail(ctx, VGICP_ERR_HIP, "the preparation reported two different sizes");
   *n = kept;
+  ctx->fetch_sums_valid = true;   // the kernel has ended (settle synchronised): its last block posted the sums
+  return VGICP_OK;
+}
+
+int vgicp_scan_fetch_sums(vgicp_ctx* ctx, uint64_t sums[64]) {
+  if (!ctx || !sums) return VGICP_ERR_BAD_ARGUMENT;
+  if (ctx->multi || !ctx->fetch_sums_valid)
+    return fail(ctx, VGICP_ERR_NOT_READY, "no checksums: the last host copy did not come through vgicp_scan_fetch_begin / _end's kernel");
+  std::memcpy(sums, ctx->h_fetch_hdr + 16, 64 * sizeof(uint64_t));
   return VGICP_OK;
 }
 

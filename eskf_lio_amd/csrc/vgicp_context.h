@@ -355,13 +355,15 @@ struct vgicp_ctx {
   struct PendingOut { void* dst; const char* src; size_t bytes; };
   std::vector<PendingOut> pending_out;
   // vgicp_scan_fetch_*: the prepared scan written into page-locked memory by a kernel, piece by piece
-  unsigned long long* h_fetch_hdr = nullptr;      // pinned, two 64-byte lines: [0] epoch << 32 | kept (run_scan_kernel), [8] seq << 32 | refused (fetch_kernel)
+  unsigned long long* h_fetch_hdr = nullptr;      // pinned: word 0 epoch << 32 | kept (run_scan_kernel), word 8 seq << 32 | refused (fetch_kernel), words 16 .. 79 the checksums
   unsigned long long* h_fetch_hdr_dev = nullptr;  // the same as the device addresses it
   char* h_fetch = nullptr;           // pinned: [one 64-byte flag line per piece][points, padded to 256 bytes][covariances]
   char* h_fetch_dev = nullptr;
   size_t fetch_cap_points = 0;       // points the staging area can hold
   size_t fetch_flag_bytes = 0;
   uint32_t fetch_seq = 0;
+  unsigned long long* d_fetch_sums = nullptr;   // device, 65 words, zero between launches (fetch_kernel's checksums + ticket)
+  bool fetch_sums_valid = false;     // the page-locked copy (h_fetch_hdr + 16 .. + 80) holds the sums of the last completed fetch
   bool fetch_open = false;           // a fetch kernel is enqueued behind the pending preparation
   uint32_t fetch_kept = 0;
   // sweeps staged AHEAD of their preparation (vgicp_sweep_stage: the lidar callback's thread copies a sweep into

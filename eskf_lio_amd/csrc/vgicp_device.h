@@ -312,10 +312,11 @@ struct PrepareArgs {
 // counter block) written by a KERNEL into page-locked host memory in pieces of piece_bytes, every piece published by
 // storing seq into flags[16 * piece] — the download of vgicp_scan_fetch_end, the mirror image of pack_arena_kernel.
 // Layout of `stage`: the points, padded to a multiple of 256 bytes, then the covariances.  hdr_done receives
-// seq << 32 | 1 (refused / nothing prepared) or seq << 32 first thing.
+// seq << 32 | 1 (refused / nothing prepared) or seq << 32 first thing.  sums (device, 65 words, zero on entry and on
+// exit) / host_sums (page-locked, 64 words): position-weighted word sums of what was copied, see fetch_kernel.
 hipError_t launch_fetch(hipStream_t s, const double* aos_pts, const double* aos_cov, const uint32_t* counters, uint32_t epoch,
                         uint32_t n_cap, char* stage, uint32_t* flags, unsigned long long* hdr_done, uint32_t seq,
-                        uint32_t piece_bytes);
+                        uint32_t piece_bytes, unsigned long long* sums, unsigned long long* host_sums);
 hipError_t launch_prepare(hipStream_t s, const PrepareArgs& a);        // = head + tail
 // head: the kernels that read the raw sweep (deskew bounds from the times, prologue); tail: everything behind them.
 // A host that stages the sweep itself launches the head, finishes staging and launches the tail, so that the device

@@ -1466,30 +1466,94 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
 // before the command has completed nor learn the size without a round trip; a kernel's posted writes run at the link's
 // rate and the host reads every piece the moment its flag arrives.
 constexpr int kFetchBlock = 256;
+// sums (device, 64 words + a ticket word, zero between launches): [buffer 0 = points, 1 = covariances][A = 0 / B = 1][16 lanes].
+// The 8-byte words of each array are dealt to 16 lanes by their index (lane = index mod 16, k = index / 16): A_lane = sum of
+// the lane's words, B_lane = sum of (m_lane - k) x word with m_lane = the lane's word count, both mod 2^64 — what a host
+// that runs  s1 += w; s2 += s1  over the lane's words ends with, up to its start values (the drop-in's change detector,
+// include/eskf_lio_shim/LocalMap.hpp: bufferHash).  The last block to finish posts the 64 sums to the host and zeroes them.
 __global__ __launch_bounds__(kFetchBlock) void fetch_kernel(const double* __restrict__ aos_pts, const double* __restrict__ aos_cov,
                                                             const uint32_t* __restrict__ counters, uint32_t epoch, uint32_t n_cap,
                                                             char* __restrict__ stage, uint32_t* flags, unsigned long long* hdr_done,
-                                                            uint32_t seq, uint32_t piece_bytes) {
+                                                            uint32_t seq, uint32_t piece_bytes, unsigned long long* sums,
+                                                            unsigned long long* host_sums) {
   typedef int v4i __attribute__((ext_vector_type(4)));
+  __shared__ unsigned long long part[kFetchBlock / 64][64];
   const bool refused = counters[kBeyondGrid] == epoch || counters[kScanTimeout] == epoch;
   const uint32_t kept = refused ? 0u : (counters[0] < n_cap ? counters[0] : n_cap);
   if (blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(hdr_done, ((unsigned long long)seq << 32) | (refused ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const size_t pb = (size_t)kept * 24u, pb_pad = (pb + 255u) & ~size_t(255), total = pb_pad + (size_t)kept * 72u;
+  const size_t pb = (size_t)kept * 24u, pb_pad = (pb + 255u) & ~size_t(255), cb = (size_t)kept * 72u, total = pb_pad + cb;
   const uint32_t pieces = (uint32_t)((total + piece_bytes - 1) / piece_bytes);
   const char* sp = reinterpret_cast<const char*>(aos_pts);
   const char* sc = reinterpret_cast<const char*>(aos_cov);
+  // this thread's chunks are 16 bytes at multiples of 16 x 256 from 16 x threadIdx.x, both parts start on a multiple of
+  // 256 bytes: its two words always fall into lanes 2 (t & 7) and 2 (t & 7) + 1 of either array
+  unsigned long long a0[2] = {0, 0}, a1[2] = {0, 0}, b0[2] = {0, 0}, b1[2] = {0, 0};   // [array]: A / B of the even and the odd lane
+  const unsigned long long words_p = pb / 8u, words_c = cb / 8u;
+  const uint32_t lane_even = 2u * (threadIdx.x & 7u);
   for (uint32_t piece = blockIdx.x; piece < pieces; piece += gridDim.x) {
     const size_t off = (size_t)piece * piece_bytes;
     const size_t len = total - off < piece_bytes ? total - off : piece_bytes;
     for (size_t k = (size_t)threadIdx.x * 16u; k < len; k += (size_t)kFetchBlock * 16u) {
       const size_t pos = off + k;   // both parts start on a multiple of 16 bytes; a chunk never straddles them
-      const v4i w = pos < pb_pad ? *reinterpret_cast<const v4i*>(sp + pos) : *reinterpret_cast<const v4i*>(sc + (pos - pb_pad));
+      const bool in_points = pos < pb_pad;
+      const v4i w = in_points ? *reinterpret_cast<const v4i*>(sp + pos) : *reinterpret_cast<const v4i*>(sc + (pos - pb_pad));
       *reinterpret_cast<v4i*>(stage + pos) = w;
+      // the sums: word index inside its array, the lane's word count, the weight m - k
+      const int arr = in_points ? 0 : 1;
+      const unsigned long long words = in_points ? words_p : words_c;
+      const unsigned long long i0 = (in_points ? pos : pos - pb_pad) / 8u;
+      const unsigned long long w0 = ((unsigned long long)(uint32_t)w.y << 32) | (uint32_t)w.x;
+      const unsigned long long w1 = ((unsigned long long)(uint32_t)w.w << 32) | (uint32_t)w.z;
+      if (i0 < words) {
+        const unsigned long long m = (words - lane_even + 15u) >> 4;
+        a0[arr] += w0;
+        b0[arr] += (m - (i0 >> 4)) * w0;
+      }
+      if (i0 + 1u < words) {
+        const unsigned long long m = (words - (lane_even + 1u) + 15u) >> 4;
+        a1[arr] += w1;
+        b1[arr] += (m - ((i0 + 1u) >> 4)) * w1;
+      }
     }
     __threadfence_system();   // every thread: its stores have reached the host before the flag may
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flags + 16u * piece, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (sums == nullptr) return;
+  // fold the eight values a thread holds over the threads that share its lanes (t & 7 equal), then one atomic per sum
+  // and block; the block whose ticket is the last one posts the totals
+  unsigned long long v[8] = {a0[0], b0[0], a1[0], b1[0], a0[1], b0[1], a1[1], b1[1]};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    unsigned long long x = v[q];
+    x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);   // lanes with the same t & 7 inside the wave
+    v[q] = x;
+  }
+  const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
+  if (wl < 8u) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) part[wave][8 * q + wl] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64u) {
+    unsigned long long x = 0;
+    for (uint32_t wv = 0; wv < kFetchBlock / 64; ++wv) x += part[wv][threadIdx.x];
+    // part index 8 q + r: q = (array, odd lane?, B?) as in v[], r = t & 7  ->  sums[array][A/B][lane]
+    const uint32_t q = threadIdx.x >> 3, r = threadIdx.x & 7u;
+    const uint32_t arr = q >> 2, odd = (q >> 1) & 1u, isb = q & 1u;
+    if (x) atomicAdd(&sums[arr * 32u + isb * 16u + 2u * r + odd], x);
+  }
+  __threadfence();
+  __syncthreads();
+  __shared__ uint32_t last_sh;
+  if (threadIdx.x == 0) last_sh = atomicAdd(reinterpret_cast<unsigned int*>(sums + 64), 1u) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (last_sh && threadIdx.x < 64u) {
+    const unsigned long long x = __hip_atomic_load(&sums[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(host_sums + threadIdx.x, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    sums[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(sums + 64) = 0u;
   }
 }
 // Eigen::JacobiSVD<Matrix3d>(A, ComputeFullU | ComputeFullV) in its published operation order (Eigen 3.4
@@ -1895,12 +1959,12 @@ uint32_t merge_sort_launches(uint32_t n) {
 
 hipError_t launch_fetch(hipStream_t s, const double* aos_pts, const double* aos_cov, const uint32_t* counters, uint32_t epoch,
                         uint32_t n_cap, char* stage, uint32_t* flags, unsigned long long* hdr_done, uint32_t seq,
-                        uint32_t piece_bytes) {
+                        uint32_t piece_bytes, unsigned long long* sums, unsigned long long* host_sums) {
   const size_t worst = (((size_t)n_cap * 24u + 255u) & ~size_t(255)) + (size_t)n_cap * 72u;
   const uint32_t grid = (uint32_t)std::min<size_t>(std::max<size_t>((worst + piece_bytes - 1) / piece_bytes, 1), 48);
   ++g_kernel_launches;
   hipLaunchKernelGGL(fetch_kernel, dim3(grid), dim3(kFetchBlock), 0, s, aos_pts, aos_cov, counters, epoch, n_cap, stage, flags,
-                     hdr_done, seq, piece_bytes);
+                     hdr_done, seq, piece_bytes, sums, host_sums);
   return hipGetLastError();
 }
 

@@ -40,6 +40,8 @@ def load_library() -> C.CDLL:
     lib.host_localmap_destroy.argtypes = [vp]
     lib.host_localmap_size.restype = sz
     lib.host_localmap_size.argtypes = [vp]
+    lib.host_localmap_drain.restype = sz
+    lib.host_localmap_drain.argtypes = [vp]
     lib.host_localmap_update.argtypes = [vp, sz, dp, dp, dp, C.c_int]
     lib.host_localmap_match.argtypes = [vp, sz, dp, dp, dp, dp, dp, dp, C.POINTER(sz)]
     lib.host_localmap_export.restype = sz
@@ -121,6 +123,10 @@ class LocalMap:
 
     def __len__(self):
         return self._lib.host_localmap_size(self._h)
+
+    def drain(self) -> int:
+        """Waits for the shadow grid's worker (LocalMap::grid()); the host grid's voxel count."""
+        return self._lib.host_localmap_drain(self._h)
 
     def updateLocalMap(self, points, covs, transform, initialize: bool = False):
         """Returns the cloud moved into the world frame (the reference mutates it in place)."""

@@ -88,6 +88,9 @@ LocalMap * host_localmap_create(double voxel_size, size_t max_points_per_voxel)
 
 void host_localmap_destroy(LocalMap * map) {delete map;}
 size_t host_localmap_size(const LocalMap * map) {return map->size();}
+// waits until the shadow grid's worker has filed every cloud handed to it (what LocalMap::grid() / save() do first);
+// returns the host grid's voxel count
+size_t host_localmap_drain(const LocalMap * map) {return map->grid().size();}
 
 // updateLocalMap(cloud, transform, initialize); the transformed cloud is written back to
 // points/covs, as the reference mutates the shared cloud in place (src/LocalMap.cpp:15).

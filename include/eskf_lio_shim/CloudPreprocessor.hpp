@@ -253,8 +253,13 @@ public:
           ctx_, kept, kept ? reinterpret_cast<double *>(cloud.points_.data()) : nullptr,
           kept ? reinterpret_cast<double *>(cloud.covariances_.data()) : nullptr, &kept), "vgicp_scan_fetch_end");
     }
+    // the stamp: the full hash of what was just delivered comes from the device's own sums over the bytes it wrote (no
+    // second pass over 96 bytes per point here); the CHECKS in align / updateLocalMap still hash the host cloud itself
     shim::TraceScope ts(shim::Trace::ProcessStamp);
-    shim::stampResident(ctx_, cloud, kept, true, residentCheck_);
+    uint64_t sums[64], known = 0;
+    const bool summed = residentCheck_ == shim::ResidentCheck::FullHash && vgicp_scan_fetch_sums(ctx_, sums) == VGICP_OK;
+    if (summed) {known = shim::fullHashFromSums(sums, kept);}
+    shim::stampResident(ctx_, cloud, kept, true, residentCheck_, summed ? &known : nullptr);
   }
 
   void voxelDownsampleAndEstimateCovariances(PointCloud & cloud) const

@@ -139,21 +139,32 @@ inline StoragePool & storagePool()
   static StoragePool pool;
   return pool;
 }
-// the cloud is about to be destroyed by its last owner: keep its buffers
+// the cloud is about to be destroyed by its last owner: keep its buffers (four of a kind at most: a fifth replaces the
+// smallest one kept when it is larger)
+template<typename T>
+inline void keepStorage(std::vector<T> & v, std::vector<std::vector<T>> & kept)
+{
+  if (!v.capacity()) {return;}
+  v.clear();
+  if (kept.size() < 4) {
+    kept.emplace_back(std::move(v));
+    return;
+  }
+  size_t smallest = 0;
+  for (size_t i = 1; i < kept.size(); ++i) {
+    if (kept[i].capacity() < kept[smallest].capacity()) {smallest = i;}
+  }
+  if (kept[smallest].capacity() < v.capacity()) {kept[smallest].swap(v);}
+}
 inline void recycleStorage(PointCloud & cloud)
 {
   StoragePool & pool = storagePool();
   std::lock_guard<std::mutex> lk(pool.mutex);
-  if (cloud.covariances_.capacity() && pool.covariances.size() < 4) {
-    cloud.covariances_.clear();
-    pool.covariances.emplace_back(std::move(cloud.covariances_));
-  }
-  if (cloud.points_.capacity() && pool.points.size() < 4) {
-    cloud.points_.clear();
-    pool.points.emplace_back(std::move(cloud.points_));
-  }
+  keepStorage(cloud.covariances_, pool.covariances);
+  keepStorage(cloud.points_, pool.points);
 }
-// make room for n elements in v, out of the pool when v has none of its own (v's contents are not kept)
+// make room for n elements in v, out of the pool when v has none of its own (v's contents are not kept): the smallest
+// kept buffer that is large enough
 template<typename T>
 inline void adoptStorage(std::vector<T> & v, std::vector<std::vector<T>> & kept, size_t n)
 {
@@ -161,18 +172,22 @@ inline void adoptStorage(std::vector<T> & v, std::vector<std::vector<T>> & kept,
   {
     StoragePool & pool = storagePool();
     std::lock_guard<std::mutex> lk(pool.mutex);
+    size_t best = kept.size();
     for (size_t i = 0; i < kept.size(); ++i) {
-      if (kept[i].capacity() >= n) {
-        v.swap(kept[i]);
-        v.clear();
-        kept.erase(kept.begin() + static_cast<std::ptrdiff_t>(i));
-        return;
-      }
+      if (kept[i].capacity() >= n && (best == kept.size() || kept[i].capacity() < kept[best].capacity())) {best = i;}
+    }
+    if (best != kept.size()) {
+      v.swap(kept[best]);
+      v.clear();
+      kept.erase(kept.begin() + static_cast<std::ptrdiff_t>(best));
+      return;
     }
   }
-  // nothing to reuse (the clouds of the last frames are still with the shadow grid's worker): a fresh allocation, and
-  // its pages brought in by ONE call instead of one fault each (Linux >= 5.14; ignored where it is not known)
-  v.reserve(n);
+  // nothing to reuse (the clouds of the last frames are still with the shadow grid's worker, or were smaller): a fresh
+  // allocation with room for the next frames' sizes (a scan's kept count moves by a few per cent from frame to frame:
+  // an exact fit would send every other frame here), its pages brought in by ONE call instead of one fault each
+  // (Linux >= 5.14; ignored where it is not known)
+  v.reserve(n + n / 4 + 64);
 #if defined(__linux__)
   const uintptr_t lo = (reinterpret_cast<uintptr_t>(v.data()) + 4095u) & ~uintptr_t(4095u);
   const uintptr_t hi = reinterpret_cast<uintptr_t>(v.data() + v.capacity()) & ~uintptr_t(4095u);
@@ -297,6 +312,32 @@ inline uint64_t bufferHash(const void * p, size_t bytes, uint64_t seed)
   }
   return h;
 }
+// The same value from sums the DEVICE made while it wrote the buffer (vgicp_scan_fetch_sums): a lane that starts at c
+// and adds m words ends with s1 = c + A and s2 = m c + B, A the sum of its words and B the sum of (m - k) x word.
+inline uint64_t bufferHashFromSums(const uint64_t * A, const uint64_t * B, size_t bytes, uint64_t seed)
+{
+  const size_t words = bytes / 8;
+  uint64_t h = bytes * 0x100000001B3ull;
+  for (size_t l = 0; l < 16; ++l) {
+    const uint64_t c = seed + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(l + 1);
+    const uint64_t m = (words - l + 15u) >> 4;
+    h = (h ^ (c + A[l])) * 0x9FB21C651E98DF25ull;
+    h ^= h >> 29;
+    h = (h ^ (m * c + B[l])) * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 31;
+  }
+  return h;
+}
+// sampleHash(cloud, false) of a cloud of n points and n covariances whose bytes the fetch kernel summed
+inline uint64_t fullHashFromSums(const uint64_t (&sums)[64], size_t n)
+{
+  uint64_t h = n * 0x100000001B3ull ^ n;
+  if (n) {
+    h = bufferHashFromSums(sums, sums + 16, n * sizeof(Vector3d), h);
+    h = bufferHashFromSums(sums + 32, sums + 48, n * sizeof(Matrix3d), h);
+  }
+  return h;
+}
 inline uint64_t sampleHash(const PointCloud & cloud, bool sampled)
 {
   const size_t n = cloud.points_.size(), m = cloud.covariances_.size();
@@ -330,7 +371,7 @@ inline ResidentStamp * findStamp(vgicp_ctx * ctx)
 }
 inline void stampResident(
   vgicp_ctx * ctx, const PointCloud & cloud, size_t kept, bool hostIsCurrent,
-  ResidentCheck how = ResidentCheck::FullHash)
+  ResidentCheck how = ResidentCheck::FullHash, const uint64_t * knownFullHash = nullptr)
 {
   ResidentStamp * st = findStamp(ctx);
   if (!st) {
@@ -348,7 +389,8 @@ inline void stampResident(
   // the object's identity (address, buffers, sizes, 64 samples), whatever the configuration asks for
   st->wantSampled = how == ResidentCheck::Sampled;
   st->sampled = st->wantSampled || !hostIsCurrent;
-  st->hash = sampleHash(cloud, st->sampled);
+  // knownFullHash: the full hash of exactly these bytes, made elsewhere (by the device as it delivered them)
+  st->hash = knownFullHash && !st->sampled ? *knownFullHash : sampleHash(cloud, st->sampled);
   st->generation = scanGeneration(ctx);
   st->kept = kept;
   st->hostIsCurrent = hostIsCurrent;

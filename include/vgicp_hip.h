@@ -345,6 +345,14 @@ int vgicp_map_insert_resident_async(vgicp_ctx* ctx, const double transform[16], 
  * Without a pending preparation (or on a multi-device context) the pair is vgicp_scan_info + vgicp_scan_download. */
 int vgicp_scan_fetch_begin(vgicp_ctx* ctx, size_t* kept);
 int vgicp_scan_fetch_end(vgicp_ctx* ctx, size_t capacity, double* points, double* covs, size_t* n);
+/* Checksums of what the last vgicp_scan_fetch_end delivered, made BY THE DEVICE while it wrote the pieces — for a caller
+ * that wants a fingerprint of the two arrays without reading 96 bytes per point again (the shim's "is this host cloud
+ * still the resident scan" stamp).  The 8-byte words of each array are dealt to 16 lanes by their index (lane = index
+ * mod 16, k = index / 16); sums[32 a + lane] = the sum of the lane's words, sums[32 a + 16 + lane] = the sum of
+ * (m_lane - k) x word with m_lane the lane's word count, both mod 2^64; a = 0 the points, 1 the covariances.  That is
+ * what the loop  s1 += w; s2 += s1  over a lane's words ends with, up to its start values.  VGICP_ERR_NOT_READY when
+ * the last host copy did not come through the fetch kernel (nothing pending, a multi-device context). */
+int vgicp_scan_fetch_sums(vgicp_ctx* ctx, uint64_t sums[64]);
 
 /* What the calls of THIS HOST THREAD into the module (whatever the context) have cost the host since this context's
  * counters were last reset (reset != 0 resets them):

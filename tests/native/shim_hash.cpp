@@ -46,6 +46,27 @@ int main() {
       if (shim::bufferHash(shifted.data(), words * 8, 42) == h0) { std::printf("a rotated buffer is not seen\n"); return 1; }
     }
   }
+  // the same value from per-lane sums (what the fetch kernel posts): A = sum of the lane's words, B = sum of (m - k) x word
+  for (size_t n : {size_t(0), size_t(1), size_t(2), size_t(5), size_t(16), size_t(4999), size_t(10131)}) {
+    PointCloud c;
+    c.points_.resize(n);
+    c.covariances_.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      for (int a = 0; a < 3; ++a) c.points_[i].v[a] = -7.5 + 0.37 * (double)(3 * i + a);
+      for (int k = 0; k < 9; ++k) c.covariances_[i].m[k] = 1e-3 * (double)((9 * i + k) % 101) - 0.02;
+    }
+    uint64_t sums[64] = {0};
+    const uint64_t* arrays[2] = {reinterpret_cast<const uint64_t*>(c.points_.data()), reinterpret_cast<const uint64_t*>(c.covariances_.data())};
+    const size_t words[2] = {3 * n, 9 * n};
+    for (int a = 0; a < 2; ++a) {
+      for (size_t i = 0; i < words[a]; ++i) {
+        const size_t l = i & 15u, m = (words[a] - l + 15u) >> 4;
+        sums[32 * a + l] += arrays[a][i];
+        sums[32 * a + 16 + l] += (uint64_t)(m - (i >> 4)) * arrays[a][i];
+      }
+    }
+    if (shim::fullHashFromSums(sums, n) != shim::sampleHash(c, false)) { std::printf("the hash from per-lane sums differs at %zu points\n", n); return 1; }
+  }
   PointCloud cloud;
   cloud.points_.resize(5000);
   cloud.covariances_.resize(5000);

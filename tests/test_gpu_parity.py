@@ -1152,6 +1152,17 @@ def test_scan_fetch_returns_the_prepared_scan_without_a_copy_command(oracle):
             kept = b.scan_info()[0]
             dp, dc = b.scan_download()
             assert kept == len(fp) == len(dp) and np.array_equal(fp, dp) and np.array_equal(fc, dc), n
+            # vgicp_scan_fetch_sums: the checksums the kernel made while writing equal the ones of the delivered bytes
+            sums = a.scan_fetch_sums()
+            for arr, buf in enumerate((fp, fc)):
+                w = np.ascontiguousarray(buf).view(np.uint64).reshape(-1)
+                idx = np.arange(len(w), dtype=np.uint64)
+                for lane in range(16):
+                    wl = w[lane::16]
+                    m = np.uint64(len(wl))
+                    with np.errstate(over="ignore"):
+                        assert sums[arr, 0, lane] == wl.sum(dtype=np.uint64), (n, arr, lane)
+                        assert sums[arr, 1, lane] == ((m - (idx[lane::16] >> np.uint64(4))) * wl).sum(dtype=np.uint64), (n, arr, lane)
             if k == 2:   # against the oracle chain once
                 moved, _ = oracle.transform(raw, np.tile(np.eye(3).reshape(9), (n, 1)), ext)
                 desk, _ = oracle.deskew(moved, tt, st)
@@ -1166,6 +1177,9 @@ def test_scan_fetch_returns_the_prepared_scan_without_a_copy_command(oracle):
         # fetch without anything pending: the two-step path's answer
         fp2, fc2 = a.scan_fetch()
         assert np.array_equal(fp2, fp) and np.array_equal(fc2, fc)
+        with pytest.raises(capi.VgicpError) as e:      # ... which no kernel summed
+            a.scan_fetch_sums()
+        assert e.value.code == capi.ERR_NOT_READY
         # a refused scan (a point beyond the search grid): the fetch reports it like vgicp_scan_info, nothing hangs
         bad = synth.make_lidar_scan(5_000, seed=3).copy()
         bad[17, 0] = 1e9

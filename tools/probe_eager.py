@@ -2,7 +2,10 @@
 """Where the host time of a frame goes inside the drop-in classes (CloudPreprocessor::process -> ICP::align ->
 LocalMap::updateLocalMap), per host-copy mode and resident check.
 
-    python tools/probe_eager.py [frames] [sweep points]
+    python tools/probe_eager.py [frames] [sweep points] [drain]
+
+"drain": the shadow grid's worker is waited for between frames, outside the timed region (a sensor's pace, where a frame
+never meets the previous one's host work) — without it the frames run back to back.
 """
 import ctypes as C
 import os
@@ -17,6 +20,7 @@ from eskf_lio_amd import host, synth  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 points = int(sys.argv[2]) if len(sys.argv) > 2 else 60_000
+drain = len(sys.argv) > 3 and sys.argv[3] == "drain"
 SLOTS = ("process: enqueue", "process: wait (scan_info)", "process: resize", "process: download", "process: stamp",
          "align: verify", "align: call", "update: verify", "update: rest")
 lib = host.load_library()
@@ -47,6 +51,8 @@ def run(host_copy, check):
         fr.run(pre, icp, lmap, pose, move_cloud=True)
         wall += time.perf_counter() - t0
         pose = fr.end()["pose"]
+        if drain:
+            lmap.drain()
     return wall / frames * 1e3
 
 
