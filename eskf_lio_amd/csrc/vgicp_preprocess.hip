@@ -38,10 +38,13 @@
 #include <cstring>
 #include <string.h>
 
+#ifdef VGICP_SORT_ROCPRIM
 #include <rocprim/rocprim.hpp>
+#endif
 
 #include "vgicp_device.h"
 #include "vgicp_device_fn.h"
+#include "vgicp_sort.h"
 
 namespace vgicp {
 namespace {
@@ -1878,20 +1881,19 @@ inline uint32_t blocks_for(uint64_t work, uint32_t block) { return (uint32_t)((w
 __host__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 __host__ inline uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
-// The one sort: (Morton code, index) pairs, stable. A scan is 10^4 .. 10^6 points; at these sizes a launch costs as
-// much as the work it does, so the sort is rocPRIM's stable merge sort with 2 048-item blocks (512 threads x 4):
-// 100 000 points are 49 sorted blocks and six merge passes; hipCUB's radix-sort front end picks the same merge sort
-// with 1 024-item blocks and seven passes at this size (-22 us; 1 024 / 4 096 / 8 192-item blocks: -17 / -10 / +55 us).
-// Which block size rocPRIM's merge sort runs with.  Its cost at these sizes is the number of launches, and that steps at
-// powers of two of the block count (rocprofv3, sort launches of one preparation, us; profiles/r10_knn_leaf.txt):
+// The one sort: (Morton code, index) pairs, stable — vgicp_sort.h (every wave sorts 256 pairs in registers, then groups
+// of four runs are merged per launch: five launches, 34 us for a sweep of 60 000 points).  Until round 6 this was
+// rocPRIM's merge sort, one launch per doubling of the run length (42.5 us there; launches of one preparation's sort,
+// us, profiles/r10_knn_leaf.txt):
 //   points           28k   33k   60k   65k   66k  100k  130k  150k  250k  300k
 //   2 048 per block  35.5  50.8  50.9  51.3  48.7  50.1  52.7  70.8 108.1 115.8
 //   4 096 per block  43.8  42.3  43.7  43.1  59.1  60.2  62.0  60.5  93.9 119.3
-// so sweeps of 32 769 - 65 536 and of 131 073 - 262 144 points take the larger blocks.
+// -DVGICP_SORT_ROCPRIM builds that one again (A/B measurements only).
+#ifdef VGICP_SORT_ROCPRIM
 inline bool sort_in_large_blocks(uint32_t n) { return (n > 32768u && n <= 65536u) || (n > 131072u && n <= 262144u); }
-inline hipError_t sort_codes(void* temp, size_t& temp_bytes, const unsigned long long* codes_in,
-                             unsigned long long* codes_out, const uint32_t* idx_in, uint32_t* idx_out, uint32_t n,
-                             hipStream_t s) {
+inline hipError_t sort_codes_rocprim(void* temp, size_t& temp_bytes, const unsigned long long* codes_in,
+                                     unsigned long long* codes_out, const uint32_t* idx_in, uint32_t* idx_out, uint32_t n,
+                                     hipStream_t s) {
   if (sort_in_large_blocks(n)) {
     using Large = rocprim::merge_sort_config<512, 1024, 4>;
     return rocprim::merge_sort<Large>(temp, temp_bytes, codes_in, codes_out, idx_in, idx_out, (size_t)n,
@@ -1901,6 +1903,7 @@ inline hipError_t sort_codes(void* temp, size_t& temp_bytes, const unsigned long
   return rocprim::merge_sort<Config>(temp, temp_bytes, codes_in, codes_out, idx_in, idx_out, (size_t)n,
                                      rocprim::less<unsigned long long>(), s);
 }
+#endif
 
 struct Layout {
   size_t codes_in, codes_out, idx_in, idx_out, spts, keep_i, rank_i, queries, nbr, cub, total;
@@ -1910,7 +1913,11 @@ struct Layout {
 __host__ inline Layout layout_for(uint32_t n) {
   Layout L;
   size_t sort_pairs = 0;
-  (void)sort_codes(nullptr, sort_pairs, nullptr, nullptr, nullptr, nullptr, n, nullptr);
+#ifdef VGICP_SORT_ROCPRIM
+  (void)sort_codes_rocprim(nullptr, sort_pairs, nullptr, nullptr, nullptr, nullptr, n, nullptr);
+#else
+  sort_pairs = sortk::split_bytes(n, sizeof(unsigned long long));   // the runs' splitters; the pairs alternate between the in and out buffers
+#endif
   L.cub_bytes = sort_pairs;
   size_t off = 0;
   L.codes_in = off; off += align256((size_t)n * 8);
@@ -1948,12 +1955,15 @@ size_t preprocess_tile_bytes() {   // tile slots of the two scans + the prologue
 }
 
 namespace {
-// launches of rocPRIM's merge sort (2 048- or 4 096-item blocks, sort_in_large_blocks): one block sort and one
-// merge launch per doubling of the sorted run length
+// launches of the sort
 uint32_t merge_sort_launches(uint32_t n) {
+#ifdef VGICP_SORT_ROCPRIM
   uint32_t launches = 1;
   for (uint64_t run = sort_in_large_blocks(n) ? 4096 : 2048; run < n; run <<= 1) ++launches;
   return launches;
+#else
+  return sortk::launches_for(n);
+#endif
 }
 }  // namespace
 
@@ -2096,8 +2106,12 @@ hipError_t launch_prepare_tail(hipStream_t s, const PrepareArgs& a) {
   unsigned long long* tiles_b = B.tiles_b;
 
   // ---- the one sort ----
+#ifdef VGICP_SORT_ROCPRIM
   size_t cub_bytes = B.cub_bytes;
-  hipError_t e = sort_codes(B.cub, cub_bytes, codes_in, codes_out, idx_in, idx_out, n, s);
+  hipError_t e = sort_codes_rocprim(B.cub, cub_bytes, codes_in, codes_out, idx_in, idx_out, n, s);
+#else
+  hipError_t e = sortk::sort_pairs(codes_in, idx_in, codes_out, idx_out, B.cub, n, s);   // the inputs are scratch from here on
+#endif
   if (e != hipSuccess) return e;
   g_kernel_launches += merge_sort_launches(n);
 

@@ -1131,6 +1131,19 @@ def test_sweep_staged_on_arrival_prepares_to_the_same_bits(oracle):
         assert len([c.sweep_stage(sweeps[1], times[1]) for _ in range(2)]) == 2
 
 
+def test_the_preparations_sort_equals_a_stable_sort():
+    """eskf_lio_amd/csrc/vgicp_sort.h (tile sort in LDS + whole groups of runs merged per launch) against std::stable_sort
+    over (key, index) pairs: sizes around every boundary of the plan, voxel-code-like keys with long runs of equal values,
+    all-equal / sorted / reversed / random 63-bit keys, nothing written past the end (tests/native/sort_check.hip, built
+    by `make sort_check`)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "eskf_lio_amd", "lib", "sort_check")
+    assert os.path.exists(exe), "eskf_lio_amd/lib/sort_check is missing: run __graft_entry__.build() (make -C eskf_lio_amd/csrc sort_check)"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
 def test_scan_fetch_returns_the_prepared_scan_without_a_copy_command(oracle):
     """vgicp_scan_fetch_begin / _end (ABI 6): the host copy of an ENQUEUED preparation, written into page-locked memory by a
     kernel behind it and copied out piece by piece — equal to vgicp_scan_info + vgicp_scan_download bit for bit (and so to
