@@ -40,6 +40,8 @@ def load_library() -> C.CDLL:
     lib.host_localmap_destroy.argtypes = [vp]
     lib.host_localmap_size.restype = sz
     lib.host_localmap_size.argtypes = [vp]
+    lib.host_hash_helpers.restype = None
+    lib.host_hash_helpers.argtypes = [C.c_int]
     lib.host_localmap_drain.restype = sz
     lib.host_localmap_drain.argtypes = [vp]
     lib.host_localmap_update.argtypes = [vp, sz, dp, dp, dp, C.c_int]

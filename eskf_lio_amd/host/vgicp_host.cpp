@@ -87,6 +87,8 @@ LocalMap * host_localmap_create(double voxel_size, size_t max_points_per_voxel)
 }
 
 void host_localmap_destroy(LocalMap * map) {delete map;}
+// helper threads of the drop-in's full-hash check (CloudPreprocessorConfig::residentCheckThreads; 0 = the caller alone)
+void host_hash_helpers(int n) {ESKF_LIO::shim::HashCrew::instance().setHelpers(n);}
 size_t host_localmap_size(const LocalMap * map) {return map->size();}
 // waits until the shadow grid's worker has filed every cloud handed to it (what LocalMap::grid() / save() do first);
 // returns the host grid's voxel count

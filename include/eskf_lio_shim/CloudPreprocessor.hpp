@@ -59,6 +59,10 @@ struct CloudPreprocessorConfig
   // to uploading the cloud, as the reference reads the host cloud every time; Sampled (~0.1 ms per frame cheaper) sees
   // resizes, reallocations and edits of 64 sampled elements only
   shim::ResidentCheck residentCheck = shim::ResidentCheck::FullHash;
+  // helper threads of the FullHash check (shim::HashCrew, shared by every object of the process: the last configuration
+  // made wins): they hash beside the caller, and in ICP::align while the caller waits for the device.  0: the caller
+  // alone (one core, ~70 us per check and 35 000 points); at most 3.  YAML key cloud_preprocessor.resident_check_threads
+  int residentCheckThreads = 2;
   // true: the prepared cloud's points come in the sequence the REFERENCE emits them (the iteration order of its
   // unordered_map, src/CloudPreprocessor.cpp:85-99) instead of ascending input index: a frame chain then reproduces the
   // reference's chain, not only its per-call results (VGICP_OPTION_REFERENCE_ORDER; ~1.5 ms per frame on the host, and
@@ -120,6 +124,7 @@ public:
     if (config.referenceOrder) {
       shim::check(ctx_, vgicp_set_option(ctx_, VGICP_OPTION_REFERENCE_ORDER, 1), "vgicp_set_option");
     }
+    shim::HashCrew::instance().setHelpers(config.residentCheckThreads);
   }
 
 #if defined(ESKF_LIO_SHIM_HAVE_YAML)
@@ -142,6 +147,9 @@ public:
       config["cloud_preprocessor"]["reference_order"].as<bool>())
     {
       shim::check(ctx_, vgicp_set_option(ctx_, VGICP_OPTION_REFERENCE_ORDER, 1), "vgicp_set_option");
+    }
+    if (config["cloud_preprocessor"]["resident_check_threads"].IsDefined()) {   // optional key, not in the reference's file
+      shim::HashCrew::instance().setHelpers(config["cloud_preprocessor"]["resident_check_threads"].as<int>());
     }
     if (config["cloud_preprocessor"]["resident_check"].IsDefined()) {   // optional key, not in the reference's file
       residentCheck_ = config["cloud_preprocessor"]["resident_check"].as<std::string>() == "sampled" ?

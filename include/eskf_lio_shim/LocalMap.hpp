@@ -37,6 +37,7 @@
 #include <string>
 #include <tuple>
 #include <unordered_map>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -287,18 +288,55 @@ __attribute__((target("avx2"))) inline void lanesAvx2(const uint64_t * w, size_t
   }
 }
 #endif
-inline uint64_t bufferHash(const void * p, size_t bytes, uint64_t seed)
+// The sums of a run of full 16-word blocks, from zero: A[l] = the lane's words added up, B[l] = its running sums added
+// up (= sum of (blocks - k) x word k).  Runs that follow one another combine (blocks' weights shift by what comes after),
+// so a buffer can be summed in pieces, on several cores (HashCrew below) or by the device (vgicp_scan_fetch_sums).
+struct HashChunk
 {
-  uint64_t s1[16], s2[16];
-  for (int l = 0; l < 16; ++l) {s1[l] = seed + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(l + 1); s2[l] = 0;}
-  const uint64_t * w = static_cast<const uint64_t *>(p);
-  const size_t words = bytes / 8, blocks = words / 16;
+  const uint64_t * w = nullptr;
+  size_t blocks = 0;
+  uint64_t A[16], B[16];
+};
+inline void laneSums(HashChunk & c)
+{
+  for (int l = 0; l < 16; ++l) {c.A[l] = 0; c.B[l] = 0;}
   size_t done = 0;
 #ifdef ESKF_LIO_SHIM_HASH_AVX2
   static const bool wide = __builtin_cpu_supports("avx2");
-  if (wide) {lanesAvx2(w, blocks, s1, s2); done = blocks * 16;}
+  if (wide) {lanesAvx2(c.w, c.blocks, c.A, c.B); done = c.blocks;}
 #endif
-  for (size_t i = done; i < words; ++i) {   // without AVX2 everything, else the last partial block
+  for (size_t k = done; k < c.blocks; ++k) {
+    for (size_t l = 0; l < 16; ++l) {
+      c.A[l] += c.w[16 * k + l];
+      c.B[l] += c.A[l];
+    }
+  }
+}
+// consecutive chunks of one buffer -> the sums of all their blocks
+inline void combineChunks(const HashChunk * chunks, int count, uint64_t (&A)[16], uint64_t (&B)[16])
+{
+  for (int l = 0; l < 16; ++l) {A[l] = 0; B[l] = 0;}
+  size_t after = 0;
+  for (int i = count - 1; i >= 0; --i) {
+    for (int l = 0; l < 16; ++l) {
+      A[l] += chunks[i].A[l];
+      B[l] += chunks[i].B[l] + static_cast<uint64_t>(after) * chunks[i].A[l];
+    }
+    after += chunks[i].blocks;
+  }
+}
+// the hash of a buffer whose full blocks were summed (A, B): the lanes' start values, the last partial block, the fold
+inline uint64_t finishBufferHash(const void * p, size_t bytes, uint64_t seed, const uint64_t (&A)[16], const uint64_t (&B)[16])
+{
+  const uint64_t * w = static_cast<const uint64_t *>(p);
+  const size_t words = bytes / 8, blocks = words / 16;
+  uint64_t s1[16], s2[16];
+  for (int l = 0; l < 16; ++l) {
+    const uint64_t c = seed + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(l + 1);
+    s1[l] = c + A[l];
+    s2[l] = static_cast<uint64_t>(blocks) * c + B[l];
+  }
+  for (size_t i = blocks * 16; i < words; ++i) {
     const size_t l = i & 15u;
     s1[l] += w[i];
     s2[l] += s1[l];
@@ -309,6 +347,176 @@ inline uint64_t bufferHash(const void * p, size_t bytes, uint64_t seed)
     h ^= h >> 29;
     h = (h ^ s2[l]) * 0xC2B2AE3D27D4EB4Full;
     h ^= h >> 31;
+  }
+  return h;
+}
+inline uint64_t bufferHash(const void * p, size_t bytes, uint64_t seed)
+{
+  HashChunk c;
+  c.w = static_cast<const uint64_t *>(p);
+  c.blocks = bytes / 8 / 16;
+  laneSums(c);
+  return finishBufferHash(p, bytes, seed, c.A, c.B);
+}
+// A few helper threads that sum chunks beside the caller (or instead of it, while the caller waits for the device): the
+// full-hash check reads 96 bytes per point twice a frame, ~70 us each on one core for a 35 000-point scan.  Chunks are
+// taken from one atomic word that carries the job's number (a helper that comes late for a job finds the word closed
+// or the next job's number and takes nothing); finish() takes what is left itself, so a job ends even when no helper
+// ever runs.  Helpers spin for ~100 us after a job (a frame's second check follows its first closely), then sleep.
+class HashCrew
+{
+public:
+  static HashCrew & instance()
+  {
+    static HashCrew crew;
+    return crew;
+  }
+  // how many helper threads jobs may use (0: the caller alone); threads are started when first needed
+  void setHelpers(int n) {wanted_.store(n < 0 ? 0 : (n > 3 ? 3 : n), std::memory_order_relaxed);}
+  int helpers() const {return wanted_.load(std::memory_order_relaxed);}
+  // the chunks' laneSums start on the helpers; finish() must follow (same thread), the chunks stay where they are until then
+  void begin(HashChunk * chunks, int count)
+  {
+    const int want = helpers();
+    if (want > static_cast<int>(threads_.size())) {
+      std::lock_guard<std::mutex> lk(mutex_);
+      while (static_cast<int>(threads_.size()) < want) {threads_.emplace_back([this] {loop();});}
+    }
+    chunks_.store(chunks, std::memory_order_relaxed);   // (a helper late for the last job may look: its exchange then fails)
+    count_.store(count, std::memory_order_relaxed);
+    done_.store(0, std::memory_order_relaxed);
+    job_ = (job_ + 1u) & 0x7FFFFFFFu;
+    ticket_.store(static_cast<uint64_t>(job_) << 32, std::memory_order_seq_cst);     // open, chunk 0 next
+    if (want > 0 && sleepers_.load(std::memory_order_seq_cst) > 0) {
+      {std::lock_guard<std::mutex> lk(mutex_);}
+      wake_.notify_all();
+    }
+  }
+  void finish()
+  {
+    while (takeOne()) {}
+    ticket_.store((static_cast<uint64_t>(job_) << 32) | kClosed, std::memory_order_seq_cst);
+    // chunks a helper has taken are being summed (no lock, no device in there): they arrive
+    for (uint32_t spins = 0; done_.load(std::memory_order_acquire) != count_.load(std::memory_order_relaxed); ++spins) {
+      if (spins < 4096u) {pauseCpu();} else {std::this_thread::yield();}
+    }
+  }
+  ~HashCrew()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mutex_);
+      quit_.store(true, std::memory_order_seq_cst);
+    }
+    wake_.notify_all();
+    for (auto & t : threads_) {t.join();}
+  }
+
+private:
+  static constexpr uint64_t kClosed = 0xFFFFFFFFull;
+  static void pauseCpu()
+  {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  // one chunk of the open job, if there is one left: summed here
+  bool takeOne()
+  {
+    for (;;) {
+      uint64_t t = ticket_.load(std::memory_order_acquire);
+      const uint64_t index = t & 0xFFFFFFFFull;
+      if (index == kClosed) {return false;}
+      HashChunk * chunks = chunks_.load(std::memory_order_relaxed);   // this job's, if the exchange below succeeds (the word
+      const int count = count_.load(std::memory_order_relaxed);       //  only changes job when closed)
+      if (index >= static_cast<uint64_t>(count)) {return false;}
+      if (!ticket_.compare_exchange_weak(t, t + 1u, std::memory_order_acq_rel, std::memory_order_acquire)) {continue;}
+      laneSums(chunks[index]);
+      done_.fetch_add(1, std::memory_order_release);
+      return true;
+    }
+  }
+  void loop()
+  {
+    for (;;) {
+      if (takeOne()) {continue;}
+      // nothing to take: watch the word for a while, then sleep until begin() says so
+      const uint64_t seen = ticket_.load(std::memory_order_acquire);
+      const auto t0 = std::chrono::steady_clock::now();
+      bool changed = false;
+      for (uint32_t spins = 0; !changed; ++spins) {
+        pauseCpu();
+        changed = ticket_.load(std::memory_order_acquire) != seen || quit_.load(std::memory_order_relaxed);
+        if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) {break;}
+      }
+      if (quit_.load(std::memory_order_seq_cst)) {return;}
+      if (changed) {continue;}
+      std::unique_lock<std::mutex> lk(mutex_);
+      sleepers_.fetch_add(1, std::memory_order_seq_cst);
+      wake_.wait(lk, [&] {return quit_.load(std::memory_order_seq_cst) || ticket_.load(std::memory_order_seq_cst) != seen;});
+      sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+      if (quit_.load(std::memory_order_seq_cst)) {return;}
+    }
+  }
+  std::mutex mutex_;
+  std::condition_variable wake_;
+  std::vector<std::thread> threads_;
+  std::atomic<uint64_t> ticket_{kClosed};
+  std::atomic<int> done_{0}, sleepers_{0}, wanted_{2};
+  std::atomic<bool> quit_{false};
+  std::atomic<HashChunk *> chunks_{nullptr};
+  std::atomic<int> count_{0};
+  uint32_t job_ = 0;
+};
+// sampleHash(cloud, false) in pieces: the chunks of both buffers (points first), summed anywhere, then folded
+struct FullHashJob
+{
+  static constexpr int kMaxChunks = 16;
+  HashChunk chunks[kMaxChunks];
+  int count = 0, pointChunks = 0;
+  const PointCloud * cloud = nullptr;
+};
+inline void planFullHash(const PointCloud & cloud, FullHashJob & job, int workers)
+{
+  job.cloud = &cloud;
+  job.count = 0;
+  const size_t bytesP = cloud.points_.size() * sizeof(Vector3d), bytesC = cloud.covariances_.size() * sizeof(Matrix3d);
+  const size_t blocksP = bytesP / 128, blocksC = bytesC / 128;
+  // pieces of at least 64 KB, about two per worker so that whoever is faster takes more
+  const size_t total = blocksP + blocksC;
+  size_t pieces = static_cast<size_t>(workers < 1 ? 1 : workers) * 2;
+  const size_t most = total / 512 ? total / 512 : 1;
+  pieces = pieces > most ? most : pieces;
+  pieces = pieces > static_cast<size_t>(FullHashJob::kMaxChunks - 2) ? static_cast<size_t>(FullHashJob::kMaxChunks - 2) : pieces;
+  const size_t per = (total + pieces - 1) / pieces;
+  auto cut = [&](const void * p, size_t blocks) {
+      const uint64_t * w = static_cast<const uint64_t *>(p);
+      size_t at = 0;
+      do {
+        const size_t take = blocks - at < per + per / 4 ? blocks - at : per;   // no sliver at the end
+        HashChunk & c = job.chunks[job.count++];
+        c.w = w + 16 * at;
+        c.blocks = take;
+        at += take;
+      } while (at < blocks && job.count < FullHashJob::kMaxChunks - 1);
+      if (at < blocks) {job.chunks[job.count - 1].blocks += blocks - at;}
+    };
+  if (bytesP) {cut(cloud.points_.data(), blocksP);}
+  job.pointChunks = job.count;
+  if (bytesC) {cut(cloud.covariances_.data(), blocksC);}
+}
+inline uint64_t foldFullHash(const FullHashJob & job)
+{
+  const PointCloud & cloud = *job.cloud;
+  const size_t n = cloud.points_.size(), m = cloud.covariances_.size();
+  uint64_t h = n * 0x100000001B3ull ^ m;
+  uint64_t A[16], B[16];
+  if (n) {
+    combineChunks(job.chunks, job.pointChunks, A, B);
+    h = finishBufferHash(cloud.points_.data(), n * sizeof(Vector3d), h, A, B);
+  }
+  if (m) {
+    combineChunks(job.chunks + job.pointChunks, job.count - job.pointChunks, A, B);
+    h = finishBufferHash(cloud.covariances_.data(), m * sizeof(Matrix3d), h, A, B);
   }
   return h;
 }
@@ -342,10 +550,17 @@ inline uint64_t sampleHash(const PointCloud & cloud, bool sampled)
 {
   const size_t n = cloud.points_.size(), m = cloud.covariances_.size();
   if (!sampled) {
-    uint64_t h = n * 0x100000001B3ull ^ m;
-    if (n) {h = bufferHash(cloud.points_.data(), n * sizeof(Vector3d), h);}
-    if (m) {h = bufferHash(cloud.covariances_.data(), m * sizeof(Matrix3d), h);}
-    return h;
+    HashCrew & crew = HashCrew::instance();
+    FullHashJob job;
+    const bool shared = crew.helpers() > 0 && (n * sizeof(Vector3d) + m * sizeof(Matrix3d)) >= (256u << 10);
+    planFullHash(cloud, job, shared ? crew.helpers() + 1 : 1);
+    if (shared) {
+      crew.begin(job.chunks, job.count);
+      crew.finish();
+    } else {
+      for (int i = 0; i < job.count; ++i) {laneSums(job.chunks[i]);}
+    }
+    return foldFullHash(job);
   }
   uint64_t h = 1469598103934665603ull;
   auto mix = [&h](const void * p, size_t bytes) {
@@ -395,8 +610,9 @@ inline void stampResident(
   st->kept = kept;
   st->hostIsCurrent = hostIsCurrent;
 }
-// The stamp of `cloud` if it still is the resident scan of ctx, else nullptr.
-inline ResidentStamp * residentStampOf(vgicp_ctx * ctx, const PointCloud & cloud)
+// The stamp of `cloud` if object, buffers, sizes and the context's scan generation still are what was stamped (the
+// cheap part of the check: the contents are NOT looked at), else nullptr.
+inline ResidentStamp * residentIdentityOf(vgicp_ctx * ctx, const PointCloud & cloud)
 {
   ResidentStamp * st = findStamp(ctx);
   if (!st || st->cloud != &cloud || st->pointData != cloud.points_.data() ||
@@ -405,8 +621,13 @@ inline ResidentStamp * residentStampOf(vgicp_ctx * ctx, const PointCloud & cloud
   {
     return nullptr;
   }
-  if (st->generation != scanGeneration(ctx) || st->hash != sampleHash(cloud, st->sampled)) {return nullptr;}
-  return st;
+  return st->generation == scanGeneration(ctx) ? st : nullptr;
+}
+// The stamp of `cloud` if it still is the resident scan of ctx, else nullptr.
+inline ResidentStamp * residentStampOf(vgicp_ctx * ctx, const PointCloud & cloud)
+{
+  ResidentStamp * st = residentIdentityOf(ctx, cloud);
+  return st && st->hash == sampleHash(cloud, st->sampled) ? st : nullptr;
 }
 inline void forget(vgicp_ctx * ctx)
 {

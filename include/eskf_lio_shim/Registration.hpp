@@ -83,14 +83,42 @@ public:
     // The cloud CloudPreprocessor::process just prepared is resident on the device already (src/Odometry.cpp:74 ->
     // src/ErrorStateKF.cpp:130 hand it over untouched): no second upload of its 96 bytes per point, and the frame's
     // one synchronisation is this call's.  Any other cloud — or that one after somebody changed it — goes up as it is.
-    int rc;
+    int rc = VGICP_OK;
     shim::ResidentStamp * resident = nullptr;
+    bool done = false;
     {
       shim::TraceScope ts(shim::Trace::AlignVerify);
-      resident = shim::residentStampOf(ctx, cloud);
+      resident = shim::residentIdentityOf(ctx, cloud);
+    }
+    shim::HashCrew & crew = shim::HashCrew::instance();
+    if (resident && !resident->sampled && crew.helpers() > 0 &&
+      cloud.points_.size() * (sizeof(Vector3d) + sizeof(Matrix3d)) >= (256u << 10))
+    {
+      // The full-hash check of a large cloud and the registration at the same time: helper threads read the host cloud
+      // while this thread waits for the device, which registers its own copy.  The result counts only if the hash then
+      // matches the stamp; a cloud edited since is registered again below from the host data, as the reference would
+      // (vgicp_align_resident changes neither the resident scan nor the map).
+      shim::FullHashJob job;
+      shim::planFullHash(cloud, job, crew.helpers());
+      crew.begin(job.chunks, job.count);
+      {
+        shim::TraceScope tsCall(shim::Trace::AlignCall);
+        rc = vgicp_align_resident(ctx, shim::poseData(guess), &params, pose, &stats);
+      }
+      {
+        shim::TraceScope ts(shim::Trace::AlignVerify);
+        crew.finish();
+        done = shim::foldFullHash(job) == resident->hash;
+      }
+      if (!done) {resident = nullptr;}
+    } else if (resident) {
+      shim::TraceScope ts(shim::Trace::AlignVerify);
+      if (resident->hash != shim::sampleHash(cloud, resident->sampled)) {resident = nullptr;}
     }
     shim::TraceScope tsCall(shim::Trace::AlignCall);
-    if (resident) {
+    if (done) {
+      lastUsedResidentScan_ = true;
+    } else if (resident) {
       rc = vgicp_align_resident(ctx, shim::poseData(guess), &params, pose, &stats);
       lastUsedResidentScan_ = true;
     } else {

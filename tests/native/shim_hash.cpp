@@ -2,9 +2,12 @@
 // shim::bufferHash / sampleHash): the AVX2 lanes and the plain ones give the same value, every single-bit edit of a
 // buffer changes it, so do a swap of two words inside one lane and a shifted run; ResidentCheck::Sampled sees an edit of a
 // sampled element and misses one of an unsampled element (the documented price of that mode), FullHash sees both.
+// The same hash from pieces summed by helper threads (shim::HashCrew) equals the one-thread value for changing sizes and
+// helper counts (also under ThreadSanitizer).
 // Links nothing of the module (the C ABI is stubbed out: the header only needs the declarations).
 #define ESKF_LIO_SHIM_FORCE_POD 1
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -25,7 +28,7 @@ static uint64_t plain_lanes(const void* p, size_t bytes, uint64_t seed) {
   return h;
 }
 
-int main() {
+int main(int argc, char** argv) {
   for (size_t words : {size_t(1), size_t(15), size_t(16), size_t(17), size_t(333), size_t(27000 * 12)}) {
     std::vector<uint64_t> buf(words);
     for (size_t i = 0; i < words; ++i) buf[i] = (i + 1) * 0x9E3779B97F4A7C15ull ^ (i << 7);
@@ -81,6 +84,34 @@ int main() {
   cloud.covariances_[1].m[4] += 1e-9;   // element 1 of 5 000 is not
   if (shim::sampleHash(cloud, false) == full) { std::printf("FullHash misses an edit of an unsampled element\n"); return 1; }
   if (shim::sampleHash(cloud, true) != sampled) { std::printf("Sampled was expected to miss this edit (the test's premise)\n"); return 1; }
+  // the same value from pieces summed on helper threads (shim::HashCrew), for changing sizes and helper counts, with the
+  // caller taking part (sampleHash) and with the caller away (begin ... finish, as ICP::align runs it beside the device call)
+  {
+    shim::HashCrew & crew = shim::HashCrew::instance();
+    const int rounds = argc > 1 ? std::atoi(argv[1]) : 3000;
+    for (int k = 0; k < rounds; ++k) {
+      const size_t n = 2500 + (size_t)(k * 37 % 9000);
+      PointCloud c;
+      c.points_.resize(n);
+      c.covariances_.resize(n);
+      for (size_t i = 0; i < n; i += 1 + n / 300) {
+        c.points_[i].v[k % 3] = 0.25 * (double)(i + (size_t)k);
+        c.covariances_[i].m[k % 9] = 1e-3 * (double)(i ^ (size_t)k);
+      }
+      crew.setHelpers(0);
+      const uint64_t alone = shim::sampleHash(c, false);
+      crew.setHelpers(1 + k % 3);
+      if (shim::sampleHash(c, false) != alone) { std::printf("round %d: the crew's hash differs (caller taking part)\n", k); return 1; }
+      shim::FullHashJob job;
+      shim::planFullHash(c, job, crew.helpers());
+      crew.begin(job.chunks, job.count);
+      if (k % 5 == 0) { volatile uint64_t spin = 0; for (int q = 0; q < 20000; ++q) spin += (uint64_t)q; }   // "the device call"
+      crew.finish();
+      if (shim::foldFullHash(job) != alone) { std::printf("round %d: the crew's hash differs (caller away)\n", k); return 1; }
+      c.covariances_[n / 2].m[4] += 1e-9;
+      if (shim::sampleHash(c, false) == alone) { std::printf("round %d: an edit is not seen through the crew\n", k); return 1; }
+    }
+  }
   std::printf("ok\n");
   return 0;
 }

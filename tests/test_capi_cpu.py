@@ -264,11 +264,20 @@ def test_dropin_resident_check_hash_on_the_cpu(tmp_path):
     ones, every single-bit edit / in-lane swap / rotation of a buffer changes the value, FullHash sees an edit of an
     element the 64-sample check (ResidentCheck::Sampled, the opt-in) misses."""
     exe = tmp_path / "shim_hash"
-    out = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
+    out = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
                           os.path.join(ROOT, "tests", "native", "shim_hash.cpp")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
-    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout[-500:] + run.stderr[-500:]
+    # the helper threads of the check (shim::HashCrew) under ThreadSanitizer: a job's set-up against helpers still
+    # looking at the last one, chunks handed out once, sums published before finish() returns
+    tsan = tmp_path / "shim_hash_tsan"
+    out = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include"),
+                          "-o", str(tsan), os.path.join(ROOT, "tests", "native", "shim_hash.cpp")], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for this compiler: " + out.stderr[-200:])
+    run = subprocess.run([str(tsan), "400"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and run.stdout.strip() == "ok" and "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
 
 
 def test_shadow_grid_of_the_dropin_map_on_the_cpu(tmp_path):

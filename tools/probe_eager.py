@@ -2,7 +2,7 @@
 """Where the host time of a frame goes inside the drop-in classes (CloudPreprocessor::process -> ICP::align ->
 LocalMap::updateLocalMap), per host-copy mode and resident check.
 
-    python tools/probe_eager.py [frames] [sweep points] [drain]
+    python tools/probe_eager.py [frames] [sweep points] [drain|-] [hash helper threads]
 
 "drain": the shadow grid's worker is waited for between frames, outside the timed region (a sensor's pace, where a frame
 never meets the previous one's host work) — without it the frames run back to back.
@@ -21,10 +21,12 @@ from eskf_lio_amd import host, synth  # noqa: E402
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 points = int(sys.argv[2]) if len(sys.argv) > 2 else 60_000
 drain = len(sys.argv) > 3 and sys.argv[3] == "drain"
+helpers = int(sys.argv[4]) if len(sys.argv) > 4 else None
 SLOTS = ("process: enqueue", "process: wait (scan_info)", "process: resize", "process: download", "process: stamp",
          "align: verify", "align: call", "update: verify", "update: rest")
 lib = host.load_library()
 lib.host_trace.argtypes = [C.c_int, C.POINTER(C.c_double)]
+lib.host_hash_helpers.argtypes = [C.c_int]
 
 h, cap = 0.3, 20
 st = synth.make_imu_states(48, seed=5)
@@ -35,6 +37,8 @@ tt = synth.make_point_times(points, st[1, 0] + 1e-4, st[-3, 0] + 0.4 / 400.0, se
 
 def run(host_copy, check):
     pre = host.CloudPreprocessor(h, ext, host_copy, resident_check=check)
+    if helpers is not None:
+        lib.host_hash_helpers(helpers)     # the constructor set the configuration's default (2)
     icp = host.ICP(30, 1e-6, 0.9999)
     cfg = dict(translation_sq_threshold=-1.0, cosine_threshold=2.0, remove_distant_points=False, distance_threshold=1e9,
                removing_period=1e9, device_resident=True, keep_raw_points=True)
