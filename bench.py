@@ -250,9 +250,10 @@ def frame_chain_leg(device: int, frames: int = 30, sweep_points: int = 60_000, c
                 "poses_bit_equal": bool(all(np.array_equal(a.pose, b.pose) for a, b in zip(results, results_arr))),
                 "copies_per_frame": fs_arr.copies / frames, "kernel_launches_per_frame": fs_arr.kernel_launches / frames},
             "kernel_launches_per_frame": fs.kernel_launches / frames,
-            "kernel_launches_note": "counted by the library; rocPRIM's merge sort (the scan preparation's one sort) is counted "
-                                    "as one block sort + one launch per doubling of the run length, rocprofv3 sees two more "
-                                    "at this size (profiles/*_frame_kernel_stats.csv)",
+            "kernel_launches_note": "counted by the library: prologue, the preparation's hand-written sort (one tile sort + one "
+                                    "merge launch per factor of four in run length: five at this size), two scans, split, "
+                                    "search, covariances, the align's one launch, two for the insertion "
+                                    "(profiles/*_frame_kernel_stats.csv shows the same kernels)",
             "copies_per_frame": fs.copies / frames,
             "host_syncs_per_frame": fs.host_syncs / frames,
             "align_rounds_per_frame": float(np.mean([r.iterations for r in results])),

@@ -15,6 +15,11 @@ bash tools/prep_pmc.sh > gpurun_out/$T/prep_pmc.txt 2>&1
 VGICP_DEBUG_STAMPS=1 timeout 300 python3 tools/probe.py C2 50 2>&1 | grep -E "eager|stamps" > gpurun_out/$T/c2_stamps.txt
 VGICP_DEBUG_STAMPS=1 timeout 300 python3 tools/probe.py C5 10 2>&1 | grep -E "eager|stamps" >> gpurun_out/$T/c2_stamps.txt
 timeout 300 python3 tools/probe_eager.py 30 60000 2>&1 | grep -v "ICP not" > gpurun_out/$T/dropin_host_time.txt
+for h in 0 2; do echo "hash helper threads: $h (back to back, then with the shadow grid's worker drained between frames)" >> gpurun_out/$T/dropin_host_time.txt
+  timeout 300 python3 tools/probe_eager.py 30 60000 - $h 2>&1 | grep "eager    full" >> gpurun_out/$T/dropin_host_time.txt
+  timeout 300 python3 tools/probe_eager.py 30 60000 drain $h 2>&1 | grep "eager    full" >> gpurun_out/$T/dropin_host_time.txt; done
+# the hand-written sort alone: against std::stable_sort, then per-kernel times
+( timeout 300 eskf_lio_amd/lib/sort_check; bash tools/ab_sort.sh sort_check 60000 100000 1000000 ) > gpurun_out/$T/sort_standalone.txt 2>&1
 timeout 600 bash tools/ab_upload_bench.sh > gpurun_out/$T/upload_switches.txt 2>&1
 # soaks
 timeout 200 python3 tools/soak_upload.py 45 > gpurun_out/$T/soak_upload.txt 2>&1
