@@ -39,4 +39,4 @@ with capi.Context(0) as a, capi.Context(0) as b:
     slow = a.counter(capi.COUNTER_UPLOAD_SLOW)
 print(f"staged upload soak: {n_runs} aligns of 1 .. 300 000 points in {seconds:.0f} s, every one bit-equal to the in-place upload; "
       f"uploads repeated because the copy threads were held up: {slow}; slowest staged align {worst * 1e3:.2f} ms; "
-      f"VGICP_UPLOAD_THREADS = {os.environ.get('VGICP_UPLOAD_THREADS', '2 (default)')}")
+      f"VGICP_UPLOAD_THREADS = {os.environ.get('VGICP_UPLOAD_THREADS', '3 (default)')}")
