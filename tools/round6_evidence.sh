@@ -25,5 +25,6 @@ timeout 600 bash tools/ab_upload_bench.sh > gpurun_out/$T/upload_switches.txt 2>
 timeout 200 python3 tools/soak_upload.py 45 > gpurun_out/$T/soak_upload.txt 2>&1
 timeout 300 python3 tools/soak_exchange.py 60 > gpurun_out/$T/soak_exchange.txt 2>&1
 timeout 300 python3 tools/soak_preprocess.py 90 11 > gpurun_out/$T/soak_preprocess.txt 2>&1
+timeout 200 python3 tools/soak_dropin.py 60 2>&1 | grep -v 'ICP not' | tail -n 3 > gpurun_out/$T/soak_dropin.txt
 python3 -m pytest tests/test_replay.py -m gpu -q -k street -s 2>&1 | grep -v amdgpu | tail -12 > gpurun_out/$T/street.txt
 tail -n 3 gpurun_out/$T/soak_upload.txt gpurun_out/$T/soak_exchange.txt gpurun_out/$T/soak_preprocess.txt gpurun_out/$T/street.txt
