@@ -444,8 +444,11 @@ struct RunMinOp {
 // write-through stores of the aggregate, s_waitcnt vmcnt(0), write-through store of the flag (= the call's epoch, so
 // the slots need no clearing between calls); the consumer polls the flag and then reads the aggregate write-through.
 constexpr int kScanThreads = 256;
-constexpr int kScanItems = 8;
-constexpr uint32_t kScanTile = kScanThreads * kScanItems;
+// consecutive items per thread: 4 (tiles of 1 024) while the scan has room in the tile slots, 8 (tiles of 2 048) beyond
+// 4 M points.  At scan sizes a tile more is a workgroup more on an idle CU, and four items are half the chain of
+// eight (run_scan_kernel at 60 000 points: 20.2 us with 8, 17.6 with 4, 16.7 with 2; keep_scan_kernel 5.5 / 5.1 / 5.1).
+constexpr int kScanItemsSmall = 4, kScanItemsLarge = 8;
+inline int scan_items_for(uint32_t n) { return (uint64_t)n <= (uint64_t)kMaxScanTiles * kScanThreads * kScanItemsSmall ? kScanItemsSmall : kScanItemsLarge; }
 constexpr uint32_t kScanSpinLimit = 1u << 22;
 
 struct TileSlot {  // 32 bytes
@@ -502,6 +505,7 @@ __device__ __forceinline__ RunMin runmin_wave_scan(RunMin v, uint32_t lane) {
 // the table cost 13 us between the scans and the search).
 __device__ __forceinline__ void cell_build_body(const unsigned long long* __restrict__ codes, uint32_t n, CellEntry* table,
                                                 uint32_t mask, uint32_t block_x, int level);
+template <int kScanItems>
 __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
     const double* __restrict__ pts, const unsigned long long* __restrict__ codes, const uint32_t* __restrict__ idx,
     uint32_t n, double* __restrict__ sorted_pts, uint32_t* __restrict__ queries, uint32_t* __restrict__ keep_by_index,
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
     cell_build_body(codes, n, table, mask, v % cell_blocks_x, (int)(v / cell_blocks_x));
     return;
   }
+  constexpr uint32_t kScanTile = kScanThreads * kScanItems;
   __shared__ uint32_t tile_sh;
   __shared__ RunMin wave_tot[kScanThreads / 64];
   __shared__ RunMin prefix_sh;
@@ -522,11 +527,30 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
   __syncthreads();
   const uint32_t tile = tile_sh;
   const uint32_t j0 = tile * kScanTile + tid * kScanItems;  // this thread's kScanItems consecutive sorted positions
+  // Every load below is unconditional, from a clamped place, and masked afterwards: a load under a condition becomes a
+  // branch, and the eight items' chains (index -> point -> store) then run one after the other — thirty tiles are one
+  // wave per SIMD, nothing else hides a round trip (round 6: 24 -> see profiles; the sort's header has the same note).
   unsigned long long c[kScanItems + 2];                     // codes j0 - 1 .. j0 + kScanItems
 #pragma unroll
   for (int k = 0; k < kScanItems + 2; ++k) {
     const long long j = (long long)j0 + k - 1;
-    c[k] = (j >= 0 && j < (long long)n) ? codes[j] : 0ull;
+    const bool there = j >= 0 && j < (long long)n;
+    const unsigned long long got = codes[there ? j : 0];
+    c[k] = there ? got : 0ull;
+  }
+  uint32_t src[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const uint32_t j = j0 + (uint32_t)k;
+    src[k] = idx[j < n ? j : 0u];
+  }
+  double px[kScanItems], py[kScanItems], pz[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const size_t i = j0 + (uint32_t)k < n ? src[k] : 0u;
+    px[k] = pts[3 * i];
+    py[k] = pts[3 * i + 1];
+    pz[k] = pts[3 * i + 2];
   }
   RunMin e[kScanItems];
 #pragma unroll
@@ -535,15 +559,17 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
     e[k] = runmin_identity();
     if (j < n) {
       const unsigned long long cur = c[k + 1], prev = c[k];
-      const uint32_t i = idx[j];
+      const uint32_t i = src[k];
       double2* rec = reinterpret_cast<double2*>(sorted_pts + 4 * (size_t)j);
-      rec[0] = make_double2(pts[3 * (size_t)i], pts[3 * (size_t)i + 1]);
-      rec[1] = make_double2(pts[3 * (size_t)i + 2], __longlong_as_double((long long)i));
-      uint32_t runs = 0;
-#pragma unroll 1
-      for (int l = 0; l < kLevels; ++l) {
-        if (j != 0 && (cur >> (3 * l)) == (prev >> (3 * l))) break;
-        ++runs;
+      rec[0] = make_double2(px[k], py[k]);
+      rec[1] = make_double2(pz[k], __longlong_as_double((long long)i));
+      // cells this point opens: the levels, from the finest, on which its code differs from its predecessor's — all
+      // levels up to the one that holds the highest differing bit
+      const unsigned long long diff = cur ^ prev;
+      uint32_t runs = (uint32_t)kLevels;
+      if (j != 0) {
+        const uint32_t upto = diff ? (63u - (uint32_t)__builtin_clzll(diff)) / 3u + 1u : 0u;
+        runs = upto < (uint32_t)kLevels ? upto : (uint32_t)kLevels;
       }
       e[k].packed = ((unsigned long long)i << 32) | j;
       e[k].count = (j == 0 || (cur >> (3 * kFineShift)) != (prev >> (3 * kFineShift))) ? 1u : 0u;
@@ -634,9 +660,11 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
 // Exclusive prefix sum of the kept flags over SCAN order: every kept point's output slot (ascending original
 // index). Same single-launch scheme; a tile's aggregate travels as one 8-byte granule {epoch, sum}: the data is
 // the signal.
+template <int kScanItems>
 __global__ __launch_bounds__(kScanThreads) void keep_scan_kernel(const uint32_t* __restrict__ keep_by_index, uint32_t n,
                                                                  uint32_t* __restrict__ rank_of_index, uint32_t* counters,
                                                                  unsigned long long* tiles, uint32_t epoch) {
+  constexpr uint32_t kScanTile = kScanThreads * kScanItems;
   __shared__ uint32_t tile_sh;
   __shared__ uint32_t wave_tot[kScanThreads / 64];
   __shared__ uint32_t prefix_sh;
@@ -648,7 +676,11 @@ __global__ __launch_bounds__(kScanThreads) void keep_scan_kernel(const uint32_t*
   const uint32_t i0 = tile * kScanTile + tid * kScanItems;
   uint32_t f[kScanItems];
 #pragma unroll
-  for (int k = 0; k < kScanItems; ++k) f[k] = (i0 + (uint32_t)k < n) ? keep_by_index[i0 + (uint32_t)k] : 0u;
+  for (int k = 0; k < kScanItems; ++k) {   // (unconditional loads from a clamped place: see run_scan_kernel)
+    const bool there = i0 + (uint32_t)k < n;
+    const uint32_t got = keep_by_index[there ? i0 + (uint32_t)k : 0u];
+    f[k] = there ? got : 0u;
+  }
   uint32_t sum = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) sum += f[k];
@@ -719,9 +751,11 @@ __device__ __forceinline__ void cell_build_body(const unsigned long long* __rest
   // thread doing those two dozen atomic round trips in sequence set the pace
   const uint32_t j = block_x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const unsigned long long c = codes[j] >> (3 * l);
-  const bool opens = j == 0 || c != (codes[j - 1] >> (3 * l));
-  const bool closes = j + 1 == n || c != (codes[j + 1] >> (3 * l));
+  // (the three codes are requested together: a load behind `||` is a branch and a round trip of its own)
+  const unsigned long long c_here = codes[j], c_before = codes[j ? j - 1 : 0u], c_after = codes[j + 1 < n ? j + 1 : j];
+  const unsigned long long c = c_here >> (3 * l);
+  const bool opens = j == 0 || c != (c_before >> (3 * l));
+  const bool closes = j + 1 == n || c != (c_after >> (3 * l));
   if (!opens && !closes) return;
   CellEntry* e = claim_cell(table, mask, cell_key(c, l));
   if (opens) e->start = j;
@@ -2025,7 +2059,7 @@ bool prepare_bounds_fused(uint32_t n, uint32_t states, bool ordered_states) {
 hipError_t launch_prepare_head(hipStream_t s, const PrepareArgs& a) {
   const uint32_t n = a.n;
   if (n == 0) return hipSuccess;
-  if ((uint64_t)blocks_for(n, kScanTile) > kMaxScanTiles) return hipErrorInvalidValue;
+  if ((uint64_t)blocks_for(n, kScanThreads * (uint32_t)scan_items_for(n)) > kMaxScanTiles) return hipErrorInvalidValue;
   const PrepareBuffers B = prepare_buffers(a);
   unsigned long long* codes_in = B.codes_in;
   uint32_t *idx_in = B.idx_in, *keep_i = B.keep_i;
@@ -2116,12 +2150,21 @@ hipError_t launch_prepare_tail(hipStream_t s, const PrepareArgs& a) {
   g_kernel_launches += merge_sort_launches(n);
 
   // ---- runs, kept points, query list (one launch); output slots in scan order (one launch) ----
-  const uint32_t scan_tiles = blocks_for(n, kScanTile), cell_blocks_x = blocks_for(n, kScanThreads);
-  hipLaunchKernelGGL(run_scan_kernel, dim3(scan_tiles + cell_blocks_x * kLevels), dim3(kScanThreads), 0, s, a.pts, codes_out,
-                     idx_out, n, spts, queries, keep_i, a.counters, tiles_a, a.epoch, scan_tiles, table, mask, cell_blocks_x,
-                     a.host_kept);
-  hipLaunchKernelGGL(keep_scan_kernel, dim3(blocks_for(n, kScanTile)), dim3(kScanThreads), 0, s, keep_i, n, rank_i,
-                     a.counters, tiles_b, a.epoch);
+  const uint32_t items = (uint32_t)scan_items_for(n);
+  const uint32_t scan_tiles = blocks_for(n, kScanThreads * items), cell_blocks_x = blocks_for(n, kScanThreads);
+  if (items == (uint32_t)kScanItemsSmall) {
+    hipLaunchKernelGGL(run_scan_kernel<kScanItemsSmall>, dim3(scan_tiles + cell_blocks_x * kLevels), dim3(kScanThreads), 0, s, a.pts,
+                       codes_out, idx_out, n, spts, queries, keep_i, a.counters, tiles_a, a.epoch, scan_tiles, table, mask,
+                       cell_blocks_x, a.host_kept);
+    hipLaunchKernelGGL(keep_scan_kernel<kScanItemsSmall>, dim3(scan_tiles), dim3(kScanThreads), 0, s, keep_i, n, rank_i, a.counters,
+                       tiles_b, a.epoch);
+  } else {
+    hipLaunchKernelGGL(run_scan_kernel<kScanItemsLarge>, dim3(scan_tiles + cell_blocks_x * kLevels), dim3(kScanThreads), 0, s, a.pts,
+                       codes_out, idx_out, n, spts, queries, keep_i, a.counters, tiles_a, a.epoch, scan_tiles, table, mask,
+                       cell_blocks_x, a.host_kept);
+    hipLaunchKernelGGL(keep_scan_kernel<kScanItemsLarge>, dim3(scan_tiles), dim3(kScanThreads), 0, s, keep_i, n, rank_i, a.counters,
+                       tiles_b, a.epoch);
+  }
   // ---- octree cells of all levels, the exact search (one wave per kept point; the grid covers every raw point,
   //      the waves beyond the kept count leave at once), covariances ----
   // the sort is done: its input buffers hold the two query lists now
