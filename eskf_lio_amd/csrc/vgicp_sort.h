@@ -72,11 +72,22 @@ __global__ __launch_bounds__(kTileThreads) void tile_sort_kernel(const K* __rest
   const uint32_t base = (blockIdx.x * (kTileThreads / 64u) + (threadIdx.x >> 6)) * kTile;   // wave-uniform
   if (base >= n) return;
   Pair<K> e[4];
+  if (base + kTile <= n) {                        // (wave-uniform) a full tile: four consecutive pairs per lane
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint32_t g = base + 4u * lane + (uint32_t)r;
-    e[r].k = g < n ? keys_in[g] : ~K(0);          // beyond the end: after every pair of the scan
-    e[r].v = g < n ? idx_in[g] : 0xFFFFFFFFu;
+    for (int r = 0; r < 4; ++r) {
+      e[r].k = keys_in[base + 4u * lane + (uint32_t)r];
+      e[r].v = idx_in[base + 4u * lane + (uint32_t)r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                 // unconditional loads from a clamped place, masked afterwards
+      const uint32_t g = base + 4u * lane + (uint32_t)r;
+      const bool there = g < n;
+      const K k = keys_in[there ? g : 0u];
+      const uint32_t v = idx_in[there ? g : 0u];
+      e[r].k = there ? k : ~K(0);                  // beyond the end: after every pair of the scan
+      e[r].v = there ? v : 0xFFFFFFFFu;
+    }
   }
 #pragma unroll
   for (uint32_t size = 2; size <= kTile; size <<= 1) {
