@@ -16,7 +16,7 @@
 //      order gives every kept point its output slot (ascending index)
 //   3. a hash table of (level, cell) -> [start, end) over the sorted order is built for all levels:
 //      an octree whose nodes are contiguous runs of the sorted points (by the workgroups behind the scan's tiles
-//      in the same launch); query_split_kernel then puts the queries of sparse neighbourhoods -- the expensive
+//      in the same launch); query_split_body (keep_and_split_kernel) then puts the queries of sparse neighbourhoods -- the expensive
 //      ones -- at the head of the search's launch
 //   4. ONE WAVE per kept point (control flow is uniform, lanes share the work): the k-list starts
 //      full with sorted-order neighbours of the query; the finest own cell with >= k points ("home")
@@ -660,24 +660,29 @@ __global__ __launch_bounds__(kScanThreads) void run_scan_kernel(
 // Exclusive prefix sum of the kept flags over SCAN order: every kept point's output slot (ascending original
 // index). Same single-launch scheme; a tile's aggregate travels as one 8-byte granule {epoch, sum}: the data is
 // the signal.
+// (round 6) Run by SUB-BLOCKS of 256 threads inside the 1 024-thread workgroups of keep_and_split_kernel: `sub` is the
+// sub-block, `tid` the thread inside it; every thread of the workgroup calls this (the barriers are the workgroup's), a
+// sub-block whose ticket lies beyond the scan's tiles only keeps the others company.
 template <int kScanItems>
-__global__ __launch_bounds__(kScanThreads) void keep_scan_kernel(const uint32_t* __restrict__ keep_by_index, uint32_t n,
-                                                                 uint32_t* __restrict__ rank_of_index, uint32_t* counters,
-                                                                 unsigned long long* tiles, uint32_t epoch) {
+__device__ __forceinline__ void keep_scan_body(const uint32_t* __restrict__ keep_by_index, uint32_t n,
+                                               uint32_t* __restrict__ rank_of_index, uint32_t* counters,
+                                               unsigned long long* tiles, uint32_t epoch, uint32_t scan_tiles) {
   constexpr uint32_t kScanTile = kScanThreads * kScanItems;
-  __shared__ uint32_t tile_sh;
-  __shared__ uint32_t wave_tot[kScanThreads / 64];
-  __shared__ uint32_t prefix_sh;
-  __shared__ uint32_t abort_sh;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (tid == 0) tile_sh = atomicAdd(&counters[kTicketB], 1u);
+  constexpr int kSubs = 4;   // kSplitBlock / kScanThreads
+  __shared__ uint32_t tile_sh[kSubs];
+  __shared__ uint32_t wave_tot[kSubs][kScanThreads / 64];
+  __shared__ uint32_t prefix_sh[kSubs];
+  __shared__ uint32_t abort_sh[kSubs];
+  const uint32_t sub = threadIdx.x / kScanThreads, tid = threadIdx.x % kScanThreads, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) tile_sh[sub] = atomicAdd(&counters[kTicketB], 1u);
   __syncthreads();
-  const uint32_t tile = tile_sh;
+  const uint32_t tile = tile_sh[sub];
+  const bool idle = tile >= scan_tiles;   // (sub-block-uniform)
   const uint32_t i0 = tile * kScanTile + tid * kScanItems;
   uint32_t f[kScanItems];
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {   // (unconditional loads from a clamped place: see run_scan_kernel)
-    const bool there = i0 + (uint32_t)k < n;
+    const bool there = !idle && i0 + (uint32_t)k < n;
     const uint32_t got = keep_by_index[there ? i0 + (uint32_t)k : 0u];
     f[k] = there ? got : 0u;
   }
@@ -690,43 +695,45 @@ __global__ __launch_bounds__(kScanThreads) void keep_scan_kernel(const uint32_t*
     const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
     if ((int)lane >= d) incl += o;
   }
-  if (lane == 63u) wave_tot[wave] = incl;
+  if (lane == 63u) wave_tot[sub][wave] = incl;
   __syncthreads();
   if (wave == 0) {
-    uint32_t agg = 0;
-#pragma unroll
-    for (int w = 0; w < kScanThreads / 64; ++w) agg += wave_tot[w];
-    if (lane == 0u) st_through64(tiles + tile, ((unsigned long long)epoch << 32) | agg);
     uint32_t pre = 0;
     bool late = false;
-    for (uint32_t base = 0; base < tile; base += 64u) {
-      const uint32_t t = base + lane;
-      uint32_t v = 0;
-      if (t < tile) {
-        uint32_t spins = 0;
-        unsigned long long w = ld_through64(tiles + t);
-        while ((uint32_t)(w >> 32) != epoch) {
-          if (++spins > kScanSpinLimit) { late = true; break; }
-          __builtin_amdgcn_s_sleep(2);
-          w = ld_through64(tiles + t);
-        }
-        v = (uint32_t)w;
-      }
+    if (!idle) {
+      uint32_t agg = 0;
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-      pre += v;
+      for (int w = 0; w < kScanThreads / 64; ++w) agg += wave_tot[sub][w];
+      if (lane == 0u) st_through64(tiles + tile, ((unsigned long long)epoch << 32) | agg);
+      for (uint32_t base = 0; base < tile; base += 64u) {
+        const uint32_t t = base + lane;
+        uint32_t v = 0;
+        if (t < tile) {
+          uint32_t spins = 0;
+          unsigned long long w = ld_through64(tiles + t);
+          while ((uint32_t)(w >> 32) != epoch) {
+            if (++spins > kScanSpinLimit) { late = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+            w = ld_through64(tiles + t);
+          }
+          v = (uint32_t)w;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+        pre += v;
+      }
     }
     const bool gave_up = __any(late);
     if (gave_up && lane == 0u) counters[kScanTimeout] = epoch;
     if (lane == 0u) {
-      prefix_sh = pre;
-      abort_sh = gave_up ? 1u : 0u;
+      prefix_sh[sub] = pre;
+      abort_sh[sub] = gave_up ? 1u : 0u;
     }
   }
   __syncthreads();
-  if (abort_sh != 0u) return;  // a prefix made of stale slots: no output slot is written (every reader checks the timeout word)
-  uint32_t run = prefix_sh + (incl - sum);
-  for (uint32_t w = 0; w < wave; ++w) run += wave_tot[w];
+  if (idle || abort_sh[sub] != 0u) return;  // a prefix made of stale slots: no output slot is written (every reader checks the timeout word)
+  uint32_t run = prefix_sh[sub] + (incl - sum);
+  for (uint32_t w = 0; w < wave; ++w) run += wave_tot[sub][w];
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     if (i0 + (uint32_t)k < n) rank_of_index[i0 + (uint32_t)k] = run;
@@ -805,15 +812,15 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 constexpr int kHeavyLevel = VGICP_HEAVY_LEVEL;
 constexpr uint32_t kHeavyBelow = VGICP_HEAVY_BELOW;
 constexpr int kSplitBlock = 1024;  // one atomic per list and workgroup: same-address atomics cost ~20 ns apiece
-__global__ __launch_bounds__(kSplitBlock) void query_split_kernel(const double* __restrict__ spts, uint32_t n, double h,
-                                                                 const CellEntry* __restrict__ table, uint32_t mask,
-                                                                 const uint32_t* __restrict__ queries, uint32_t epoch,
-                                                                 uint32_t* __restrict__ heavy, uint32_t* __restrict__ light,
-                                                                 uint32_t* counters) {
+__device__ __forceinline__ void query_split_body(uint32_t block, const double* __restrict__ spts, uint32_t n, double h,
+                                                 const CellEntry* __restrict__ table, uint32_t mask,
+                                                 const uint32_t* __restrict__ queries, uint32_t epoch,
+                                                 uint32_t* __restrict__ heavy, uint32_t* __restrict__ light,
+                                                 uint32_t* counters) {
   __shared__ uint32_t wave_heavy[kSplitBlock / 64], wave_light[kSplitBlock / 64], base_sh[2];
   const uint32_t m = counters[0];
   if (counters[kBeyondGrid] == epoch || counters[kScanTimeout] == epoch) return;
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = block * blockDim.x + threadIdx.x;
   const bool valid = r < m && r < n;
   uint32_t qj = 0;
   bool is_heavy = false;
@@ -852,6 +859,23 @@ __global__ __launch_bounds__(kSplitBlock) void query_split_kernel(const double* 
   }
 }
 
+// The two small passes between the scans and the search in ONE launch (round 6; they need the first scan's results and
+// nothing of each other): the first keep_blocks workgroups give every kept point its output slot (keep_scan_body, four
+// tiles of 256 threads per workgroup), the others sort the queries into the two start lists (query_split_body).  As
+// launches of their own they took 5.0 + 5.6 us and a launch boundary.
+static_assert(kSplitBlock == 4 * kScanThreads, "keep_scan_body runs four sub-blocks per workgroup");
+template <int kScanItems>
+__global__ __launch_bounds__(kSplitBlock) void keep_and_split_kernel(const uint32_t* __restrict__ keep_by_index, uint32_t n,
+                                                                    uint32_t* __restrict__ rank_of_index, uint32_t* counters,
+                                                                    unsigned long long* tiles, uint32_t epoch, uint32_t scan_tiles,
+                                                                    uint32_t keep_blocks, const double* __restrict__ spts, double h,
+                                                                    const CellEntry* __restrict__ table, uint32_t mask,
+                                                                    const uint32_t* __restrict__ queries, uint32_t* __restrict__ heavy,
+                                                                    uint32_t* __restrict__ light) {
+  if (blockIdx.x < keep_blocks) keep_scan_body<kScanItems>(keep_by_index, n, rank_of_index, counters, tiles, epoch, scan_tiles);
+  else query_split_body(blockIdx.x - keep_blocks, spts, n, h, table, mask, queries, epoch, heavy, light, counters);
+}
+
 // Exact k nearest neighbours of one kept point per wave; writes the neighbours' original indices (ascending
 // distance, ties by index) to nbr[slot * kMaxKnn + k] and the point itself to the output.
 __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
@@ -877,7 +901,7 @@ __global__ __launch_bounds__(kSearchBlock) void knn_search_kernel(
   // so does everyone when the scan was refused (a point beyond the search grid) or a device-wide scan timed out
   const uint32_t m = uniform_u32(counters[0]);
   if (uniform_u32(counters[kBeyondGrid]) == epoch || uniform_u32(counters[kScanTimeout]) == epoch) return;
-  // the queries of sparse neighbourhoods first (query_split_kernel), one per wave in dispatch order; then the others,
+  // the queries of sparse neighbourhoods first (query_split_body), one per wave in dispatch order; then the others,
   // every XCD one contiguous eighth of their list
   const uint32_t n_heavy = uniform_u32(counters[kHeavyQueries]);
   const uint32_t n_light = m - n_heavy;
@@ -2152,33 +2176,34 @@ hipError_t launch_prepare_tail(hipStream_t s, const PrepareArgs& a) {
   // ---- runs, kept points, query list (one launch); output slots in scan order (one launch) ----
   const uint32_t items = (uint32_t)scan_items_for(n);
   const uint32_t scan_tiles = blocks_for(n, kScanThreads * items), cell_blocks_x = blocks_for(n, kScanThreads);
+  // the sort is done: its input buffers hold the two query lists now
+  uint32_t* q_heavy = idx_in;
+  uint32_t* q_light = reinterpret_cast<uint32_t*>(codes_in);
+  const uint32_t keep_blocks = (scan_tiles + 3u) / 4u, split_blocks = blocks_for(n, kSplitBlock);
   if (items == (uint32_t)kScanItemsSmall) {
     hipLaunchKernelGGL(run_scan_kernel<kScanItemsSmall>, dim3(scan_tiles + cell_blocks_x * kLevels), dim3(kScanThreads), 0, s, a.pts,
                        codes_out, idx_out, n, spts, queries, keep_i, a.counters, tiles_a, a.epoch, scan_tiles, table, mask,
                        cell_blocks_x, a.host_kept);
-    hipLaunchKernelGGL(keep_scan_kernel<kScanItemsSmall>, dim3(scan_tiles), dim3(kScanThreads), 0, s, keep_i, n, rank_i, a.counters,
-                       tiles_b, a.epoch);
+    hipLaunchKernelGGL(keep_and_split_kernel<kScanItemsSmall>, dim3(keep_blocks + split_blocks), dim3(kSplitBlock), 0, s, keep_i, n,
+                       rank_i, a.counters, tiles_b, a.epoch, scan_tiles, keep_blocks, spts, a.voxel_size, table, mask, queries, q_heavy,
+                       q_light);
   } else {
     hipLaunchKernelGGL(run_scan_kernel<kScanItemsLarge>, dim3(scan_tiles + cell_blocks_x * kLevels), dim3(kScanThreads), 0, s, a.pts,
                        codes_out, idx_out, n, spts, queries, keep_i, a.counters, tiles_a, a.epoch, scan_tiles, table, mask,
                        cell_blocks_x, a.host_kept);
-    hipLaunchKernelGGL(keep_scan_kernel<kScanItemsLarge>, dim3(scan_tiles), dim3(kScanThreads), 0, s, keep_i, n, rank_i, a.counters,
-                       tiles_b, a.epoch);
+    hipLaunchKernelGGL(keep_and_split_kernel<kScanItemsLarge>, dim3(keep_blocks + split_blocks), dim3(kSplitBlock), 0, s, keep_i, n,
+                       rank_i, a.counters, tiles_b, a.epoch, scan_tiles, keep_blocks, spts, a.voxel_size, table, mask, queries, q_heavy,
+                       q_light);
   }
   // ---- octree cells of all levels, the exact search (one wave per kept point; the grid covers every raw point,
   //      the waves beyond the kept count leave at once), covariances ----
-  // the sort is done: its input buffers hold the two query lists now
-  uint32_t* q_heavy = idx_in;
-  uint32_t* q_light = reinterpret_cast<uint32_t*>(codes_in);
-  hipLaunchKernelGGL(query_split_kernel, dim3(blocks_for(n, kSplitBlock)), dim3(kSplitBlock), 0, s, spts, n, a.voxel_size, table, mask, queries,
-                     a.epoch, q_heavy, q_light, a.counters);
   hipLaunchKernelGGL(knn_search_kernel, dim3(8 * (blocks_for((n + 7) / 8, kSearchBlock / 64) + 2)), dim3(kSearchBlock), 0, s, spts,
                      idx_out, n, a.voxel_size, a.knn, table, mask, q_heavy, q_light, rank_i, a.epoch, nbr, a.out_pts, a.out_idx, a.soa,
                      a.soa_stride, a.counters, a.debug);
   const int found = a.knn < (int)n ? a.knn : (int)n;
   hipLaunchKernelGGL(cov_kernel, dim3(blocks_for(n, kCovBlock)), dim3(kCovBlock), 0, s, a.pts, nbr, found, a.out_covs, a.soa,
                      a.soa_stride, a.counters, a.epoch);
-  g_kernel_launches += 5;
+  g_kernel_launches += 4;
   return hipGetLastError();
 }
 
