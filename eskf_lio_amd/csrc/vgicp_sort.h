@@ -143,7 +143,9 @@ __global__ __launch_bounds__(kMergeThreads) void rank_merge_kernel(const K* __re
   const uint32_t i = wave_first + lane;
   const bool valid = i < n;
   const uint32_t last_lane = (n - wave_first < 64u ? n - wave_first : 64u) - 1u;
-  const K key = valid ? keys_in[i] : ~K(0);
+  const K got_key = keys_in[valid ? i : 0u];                    // (unconditional, clamped: see below)
+  const uint32_t my_idx = idx_in[valid ? i : 0u];               // asked for now, needed at the very end
+  const K key = valid ? got_key : ~K(0);
   const K k_first = read_lane(key, 0u), k_last = read_lane(key, last_lane);
   const uint32_t r = wave_first >> run_log2;                    // the wave's run (64 divides run) ...
   const uint32_t first = r - r % (uint32_t)G;                   // ... and the first run of its group
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(kMergeThreads) void rank_merge_kernel(const K* __re
   if (!valid) return;
   const unsigned long long to = group_start + rank;
   keys_out[to] = key;
-  idx_out[to] = idx_in[i];
+  idx_out[to] = my_idx;
   if (split_out) {                                               // the merged run's splitters: S = G run / 64
     constexpr uint32_t g_log2 = G == 2 ? 1u : G == 4 ? 2u : G == 8 ? 3u : 4u;
     const uint32_t s_log2 = run_log2 + g_log2 - 6u;
