@@ -280,6 +280,19 @@ def test_dropin_resident_check_hash_on_the_cpu(tmp_path):
     assert run.returncode == 0 and run.stdout.strip() == "ok" and "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
 
 
+def test_sort_plan_of_the_preparation_on_the_cpu(tmp_path):
+    """Host logic of the hand-written sort (eskf_lio_amd/csrc/vgicp_sort.h: which groups of runs the merge levels take,
+    how many launches that is, how much room the splitters need) for sizes up to 20 M pairs: tests/native/sort_plan.hip,
+    compiled by hipcc (it cross-compiles without a GPU) and run on the CPU — no device call.  The sort itself is checked on
+    the GPU against std::stable_sort (tests/native/sort_check.hip, test_gpu_parity.py)."""
+    exe = tmp_path / "sort_plan"
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "--offload-arch=gfx950", "-o", str(exe),
+                          os.path.join(ROOT, "tests", "native", "sort_plan.hip")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.startswith("ok"), run.stdout[-500:] + run.stderr[-500:]
+
+
 def test_shadow_grid_of_the_dropin_map_on_the_cpu(tmp_path):
     """The drop-in LocalMap's defaults keep the grid on the device and a host-side SHADOW of it (a worker thread) for
     save() (include/eskf_lio_shim/LocalMap.hpp; reference src/LocalMap.cpp:10-76,156-167).  tests/native/shadow_stress.cpp
