@@ -448,7 +448,14 @@ constexpr int kScanThreads = 256;
 // 4 M points.  At scan sizes a tile more is a workgroup more on an idle CU, and four items are half the chain of
 // eight (run_scan_kernel at 60 000 points: 20.2 us with 8, 17.6 with 4, 16.7 with 2; keep_scan_kernel 5.5 / 5.1 / 5.1).
 constexpr int kScanItemsSmall = 4, kScanItemsLarge = 8;
-inline int scan_items_for(uint32_t n) { return (uint64_t)n <= (uint64_t)kMaxScanTiles * kScanThreads * kScanItemsSmall ? kScanItemsSmall : kScanItemsLarge; }
+inline int scan_items_for(uint32_t n) {
+#ifdef VGICP_SCAN_ITEMS_LARGE_ONLY   // developer builds: the > 4 M-point variant at test sizes (tools/ab_build.sh items8 -DVGICP_SCAN_ITEMS_LARGE_ONLY)
+  (void)n;
+  return kScanItemsLarge;
+#else
+  return (uint64_t)n <= (uint64_t)kMaxScanTiles * kScanThreads * kScanItemsSmall ? kScanItemsSmall : kScanItemsLarge;
+#endif
+}
 constexpr uint32_t kScanSpinLimit = 1u << 22;
 
 struct TileSlot {  // 32 bytes
