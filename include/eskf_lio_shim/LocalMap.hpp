@@ -96,7 +96,7 @@ inline void check(vgicp_ctx * ctx, int rc, const char * what)
 struct Trace
 {
   enum Slot {ProcessEnqueue, ProcessWait, ProcessResize, ProcessDownload, ProcessStamp, AlignVerify, AlignCall,
-    UpdateVerify, UpdateRest, Slots};
+    UpdateVerify, UpdateRest, UpdateInsert, UpdateShadow, Slots};   // (the last two are parts of UpdateRest)
   bool on = false;
   double seconds[Slots] = {0};
   uint64_t calls[Slots] = {0};
@@ -809,9 +809,12 @@ public:
       const bool insert = initialize || !hasPrevTransform_ || needsMapUpdate(transform);
       bool evicted = false;
       if (insert) {
-        shim::check(
-          ctx_, vgicp_map_insert_resident_async(ctx_, shim::poseData(transform), maxNumPointsPerVoxel_),
-          "vgicp_map_insert_resident_async");
+        {
+          shim::TraceScope tsInsert(shim::Trace::UpdateInsert);
+          shim::check(
+            ctx_, vgicp_map_insert_resident_async(ctx_, shim::poseData(transform), maxNumPointsPerVoxel_),
+            "vgicp_map_insert_resident_async");
+        }
         if (removeDistantPoints_ && now() - currentRemoveTime_ > removePeriod_) {
           evicted = true;
           const Vector3d position = transform.translation();
@@ -841,6 +844,7 @@ public:
         op.insert = insert;
         op.evict = evicted;
         op.position = transform.translation();
+        shim::TraceScope tsShadow(shim::Trace::UpdateShadow);
         shadowPush(std::move(op));
       } else {
         if (hostIsCurrent) {cloud->Transform(transform.matrix());}   // in place, as src/LocalMap.cpp:15 (the stamp is void now)

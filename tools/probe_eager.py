@@ -23,7 +23,7 @@ points = int(sys.argv[2]) if len(sys.argv) > 2 else 60_000
 drain = len(sys.argv) > 3 and sys.argv[3] == "drain"
 helpers = int(sys.argv[4]) if len(sys.argv) > 4 else None
 SLOTS = ("process: enqueue", "process: wait (scan_info)", "process: resize", "process: download", "process: stamp",
-         "align: verify", "align: call", "update: verify", "update: rest")
+         "align: verify", "align: call", "update: verify", "update: rest", "(of it: insert call", "shadow push)")
 lib = host.load_library()
 lib.host_trace.argtypes = [C.c_int, C.POINTER(C.c_double)]
 lib.host_hash_helpers.argtypes = [C.c_int]
